@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the MI355X-native Faster-R-CNN/FPN detection hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "images/sec ResNet-101-FPN @ 800x1333", configs[2]): one image per
+step through region_proposal -> roi_pooling -> prediction (+ anchor generation, fg softmax, level
+assignment) at the ResNet-101-FPN shapes: 267 069 anchors, 1000 proposals, P2..P5 x 256 channels,
+21 classes.  The dense conv parts of the model (backbone, neck, RPN head, RoI head) are NOT part of
+this path: their outputs are the synthetic inputs, resident in HBM before the
+timed region.  One process per GPU; images shard by rank (weak scaling: one image per GPU per step);
+with N > 1 every step ends with one RCCL all-gather of the fixed-size detection records.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the
+fused RoI crop+pool kernel, HBM bound) and `cpu_baseline` (the C restatement of the reference path
+timed on this box's host cores; kind "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+IMAGE_SHAPE = (800, 1333)
+NUM_CLASSES = 21
+NUM_PROPOSALS = 1000
+CHANNELS = 256
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+
+
+def algorithmic_roi_bytes(sorted_rois, levels, level_shapes, image_shape, channels, pool=7, elem=4):
+    """B_roi = sum_r U_r*C*s + R*P*P*C*s + R*16, U_r = unique feature cells tapped by
+    RoI r on its level (first/last in-bounds sample coordinate of the 2P x 2P grid, FPN normalisation
+    of model/roi_pooling.py:30-35 + TF crop_and_resize)."""
+    crop = 2 * pool
+    H_img, W_img = np.float32(image_shape[0]), np.float32(image_shape[1])
+    total_cells = 0
+    taps = 0
+    for r, l in zip(sorted_rois, levels):
+        Hk, Wk = level_shapes[int(l)]
+        spans = []
+        for lo, hi, img, dim in ((r[1], r[3], H_img, Hk), (r[0], r[2], W_img, Wk)):
+            lo_n, hi_n = np.float32(lo) / img, np.float32(hi) / img
+            lim = np.float32(dim - 1)
+            scale = (hi_n - lo_n) * lim / np.float32(crop - 1)
+            coords = lo_n * lim + np.arange(crop, dtype=np.float32) * scale
+            ok = coords[(coords >= 0) & (coords <= lim)]
+            if ok.size == 0:
+                spans.append(0)
+            else:
+                first, last = ok.min(), ok.max()
+                spans.append(int(min(np.ceil(last), dim - 1) - max(np.floor(first), 0) + 1))
+        total_cells += spans[0] * spans[1]
+        taps += crop * crop * 4
+    R = len(sorted_rois)
+    out_bytes = R * pool * pool * channels * elem
+    return dict(B_roi=total_cells * channels * elem + out_bytes + R * 16,
+                B_taps=taps * channels * elem + out_bytes, out=out_bytes, unique_cells=total_cells)
+
+
+def cpu_baseline(host, image_shape, budget_s=20.0, max_images=8):
+    """The reference path as the TF-eager CPU code runs it (C restatement, oracle/oracle.c): heap NMS
+    over all anchors, un-fused 14x14 crop -> max-pool, sequential per-class loop.  Bounded sample."""
+    from oracle import c_oracle as co
+    threads = max(1, min(os.cpu_count() or 1, co.max_threads()))
+    K = NUM_PROPOSALS
+    t_all = []
+    n_img = 0
+    t_start = time.perf_counter()
+    scratch = np.empty((K, 14, 14, CHANNELS), np.float32)
+    while n_img < max_images and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        anchors = co.fpn_anchors(image_shape)
+        fg = co.rpn_fg_fpn(host['rpn_logits'])
+        rois, idx = co.region_proposal(host['rpn_deltas'], anchors, fg, image_shape, K, 0.7)
+        lv, perm, cnt = co.assign_levels(rois)
+        srois = rois[perm]
+        slv = lv[perm]
+        for l in range(4):
+            sel = srois[slv == l + 2]
+            if sel.shape[0]:
+                co.roi_pool(host['feats'][l], sel, image_shape=image_shape, pool=7, threads=threads,
+                            scratch=scratch[:sel.shape[0]])
+        k = rois.shape[0]
+        co.post_ops(host['cls_scores'][:k], host['cls_deltas'][:k], srois, image_shape, [0, 0, 0, 0],
+                    [.1, .1, .2, .2], 50, 50, 0.3, 0.0, 16, NUM_CLASSES)
+        t_all.append(time.perf_counter() - t0)
+        n_img += 1
+    t = float(np.median(t_all))
+    return dict(value=1.0 / t, unit='img/s', cores=threads, kind='port',
+                sample='%d images of the same 800x1333 FPN hot-path workload, median; C restatement of the '
+                       'reference path (heap NMS over 267069 anchors single-threaded, un-fused crop 14x14 + '
+                       'max-pool on %d OpenMP threads, sequential class loop)' % (n_img, threads),
+                ms_per_image=t * 1e3)
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch of the RoI kernel from the committed rocprofv3 --pmc run (profiles/)."""
+    p = os.path.join(ROOT, 'profiles', 'roi_pool_traffic.json')
+    try:
+        d = json.load(open(p))
+        if d.get('workload') == workload_key:
+            return d.get('hbm_bytes_per_launch')
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--scores', choices=['distinct', 'clustered'], default='distinct',
+                    help='RPN score distribution (SURVEY 8d: distinct; clustered = trained-like)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' %
+                             (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from tf_eager_object_detection_amd import _lib, parallel
+    from tf_eager_object_detection_amd import synthetic as syn
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, synthetic_fpn_inputs
+    _lib.lib()     # fail loudly without the HIP library
+
+    host, dev = synthetic_fpn_inputs(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, seed=1234 + rank,
+                                     score_kind=args.scores)
+    hot = FpnHotPath(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS)
+    max_det = hot.cfg['max_per_image']
+
+    ev_roi = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+
+    def one_step(i=None):
+        hot.stage_proposals(dev['rpn_logits'], dev['rpn_deltas'])
+        if i is not None:
+            ev_roi[i][0].record()
+        hot.stage_roi(dev['feats'])
+        if i is not None:
+            ev_roi[i][1].record()
+        boxes, labels, scores, count = hot.stage_detect(dev['cls_scores'], dev['cls_deltas'])
+        rec = parallel.pack_detections(boxes, labels, scores, count, max_det)
+        return parallel.all_gather_detections(rec) if world > 1 else rec
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if int(hot.nms_done.item()) != 1:
+        raise SystemExit('NMS did not complete inside the blind chunks -- result would be invalid')
+
+    if rank == 0:
+        roi_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_roi]))
+        k = int(hot.roi_count.item())
+        srois = hot.sorted_rois[:k].cpu().numpy()
+        lv = hot.roi_level[:k].cpu().numpy()
+        algo = algorithmic_roi_bytes(srois, lv, syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS)
+        achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
+        workload = 'fpn_hot_path_800x1333_r101fpn_%s' % args.scores
+        result = {
+            'metric': 'images/sec', 'value': args.steps * world / elapsed, 'unit': 'img/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ResNet-101-FPN @ 800x1333 detection hot path: anchors(267069) -> fg softmax '
+                                   '-> RegionProposal (decode+clip+NMS over all anchors, 1000 proposals) -> '
+                                   'assign_levels -> RoI crop14x14+maxpool over P2..P5x256 -> post_ops (21 classes); '
+                                   'conv backbone/heads out of scope (their outputs are synthetic inputs in HBM)',
+                       'images_per_step_per_gpu': 1, 'global_batch': world, 'rpn_scores': args.scores,
+                       'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(workload),
+                         'kernel_ms': roi_ms, 'algorithmic_bytes': algo['B_roi'],
+                         'bytes_all_taps': algo['B_taps'], 'bytes_output': algo['out']},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

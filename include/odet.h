@@ -1,0 +1,209 @@
+/* odet.h -- C ABI of libodet_hip.so: the MI355X (gfx950) detection hot path.
+ *
+ * Drop-in boundary for the Faster-R-CNN / FPN inference hot path of
+ * irvingzhang0512/tf_eager_object_detection.  The reference has no FFI of its own (it is
+ * 100 % Python over TensorFlow ops); each entry point below replaces the TensorFlow work
+ * behind one reference function, cited as file:line relative to the reference checkout.
+ * The Python package tf_eager_object_detection_amd re-creates the reference's call surface
+ * on top of these symbols with ctypes (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *  - extern "C", plain pointers + sizes, no C++/torch types.  All array pointers are DEVICE
+ *    pointers (HBM) unless the parameter is documented "host".  The caller owns every
+ *    buffer; the library allocates nothing.  Scratch memory is a caller-provided workspace
+ *    sized by the matching *_workspace_bytes() query.
+ *  - `stream` is a hipStream_t passed as void* (0 = null stream).  Calls only enqueue work;
+ *    the few that must read a device-side count to decide how much more work to enqueue say
+ *    so ("host-syncs on `stream`").
+ *  - Boxes are float32 [x1,y1,x2,y2] rows; feature maps are NHWC float32 with batch = 1.
+ *  - Return value: 0 = ok, negative = error (ODET_E_*); odet_last_error() gives the text for
+ *    the calling thread.  Nothing throws across the ABI.
+ *  - Arithmetic is float32 in the reference's operation order, no FMA contraction; exp/log
+ *    are correctly rounded float32.  Ties in NMS / top-k: (score desc, index asc).
+ */
+#ifndef ODET_H_
+#define ODET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODET_VERSION 100
+
+#define ODET_OK 0
+#define ODET_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
+#define ODET_E_WORKSPACE (-2) /* workspace too small */
+#define ODET_E_HIP (-3)       /* a HIP runtime call failed */
+#define ODET_E_LIMIT (-4)     /* size exceeds a documented kernel limit */
+
+typedef void* odet_stream_t;
+
+int odet_version(void);
+const char* odet_last_error(void);
+
+/* ---- anchors ------------------------------------------------------------------------ */
+
+/* utils/anchor_generator.py:46-60 generate_by_anchor_base_tf.
+ * out[(y*fw+x)*A+a] = base[a] + (x*stride, y*stride, x*stride, y*stride).
+ * anchor_base: device [A,4]; out: device [fh*fw*A,4]. */
+int odet_anchors_shift(const float* anchor_base, int A, int feat_stride, int fh, int fw,
+                       float* out, odet_stream_t stream);
+
+#define ODET_MAX_LEVELS 8
+#define ODET_MAX_ANCHORS_PER_CELL 32
+/* utils/anchor_generator.py:137-178 make_anchors for ALL pyramid levels in one launch
+ * (caller loop: model/fpn/base_fpn_model.py:163-186 _get_anchors).
+ * Host arrays: fh/fw/stride [num_levels]; wh [num_levels*A*2] = per level, per anchor
+ * (w, h) in float32 exactly as enum_scales/enum_ratios produce them (the Python layer
+ * evaluates that A-element table with IEEE float32 ops).  out: device [sum fh*fw*A, 4],
+ * levels concatenated in order, location-major / anchor-minor inside a level. */
+int odet_anchors_fpn(int num_levels, int A, const int* fh, const int* fw, const int* stride,
+                     const float* wh, float* out, odet_stream_t stream);
+
+/* ---- box transforms ------------------------------------------------------------------ */
+
+/* utils/bbox_transform.py:32-55 decode_bbox_with_mean_and_std.  means/stds: host [4].
+ * If clip_h > 0 the result is also clipped to [0, clip_w-1] x [0, clip_h-1] as
+ * utils/bbox_tf.py:70-74 does with min_value 0 (fusion used by region_proposal.py:59-63).
+ * delta_stride: floats between consecutive delta rows (4 for a dense [n,4] array). */
+int odet_decode(const float* anchors, const float* deltas, int64_t delta_stride, int n,
+                const float* means, const float* stds, int clip_h, int clip_w, float* out,
+                odet_stream_t stream);
+
+/* utils/bbox_transform.py:4-29 encode_bbox_with_mean_and_std. */
+int odet_encode(const float* src, const float* dst, int n, const float* means, const float* stds,
+                float* out, odet_stream_t stream);
+
+/* utils/bbox_tf.py:59-78 bboxes_clip_filter with min_edge=None: clip only. */
+int odet_clip(const float* boxes, int n, float min_value, int max_h, int max_w, float* out,
+              odet_stream_t stream);
+
+size_t odet_compact_workspace_bytes(int n);
+/* utils/bbox_tf.py:59-84 bboxes_clip_filter with min_edge: clip, keep rows with both
+ * (+1) edges >= min_edge, ascending index order.  out_boxes [n,4], out_idx int64 [n],
+ * out_count device int32[1]. */
+int odet_clip_filter(const float* boxes, int n, float min_value, int max_h, int max_w,
+                     float min_edge, float* out_boxes, int64_t* out_idx, int32_t* out_count,
+                     void* workspace, size_t workspace_bytes, odet_stream_t stream);
+
+/* utils/bbox_tf.py:87-101 bboxes_range_filter: indices of boxes fully inside the image. */
+int odet_range_filter(const float* boxes, int n, int max_h, int max_w, int64_t* out_idx,
+                      int32_t* out_count, void* workspace, size_t workspace_bytes,
+                      odet_stream_t stream);
+
+/* model/prediction.py:136 tf.where(score > thr): ascending indices of values[i*stride] > thr. */
+int odet_where_greater(const float* values, int64_t stride, int n, float thr, int64_t* out_idx,
+                       int32_t* out_count, void* workspace, size_t workspace_bytes,
+                       odet_stream_t stream);
+
+/* utils/bbox_tf.py:37-56 pairwise_iou (+1 convention, 0 where intersection == 0).
+ * out: device [n,m] row-major. */
+int odet_pairwise_iou(const float* boxes1, int n, const float* boxes2, int m, float* out,
+                      odet_stream_t stream);
+
+/* rows gather: out[i,:] = src[idx[i],:] for i < count (count_dev overrides n when non-null).
+ * idx_is_64 selects int64 / int32 indices.  row_floats floats per row. */
+int odet_gather_rows(const float* src, const void* idx, int idx_is_64, int n,
+                     const int32_t* count_dev, int row_floats, float* out, odet_stream_t stream);
+
+/* ---- RPN score glue ------------------------------------------------------------------ */
+
+#define ODET_RPN_LAYOUT_FPN 0   /* model/fpn/base_fpn_model.py:223,429: [n,2] (bg,fg) pairs */
+#define ODET_RPN_LAYOUT_FRCNN 1 /* model/faster_rcnn/base_faster_rcnn_model.py:149-152:
+                                   per location [A bg | A fg] */
+/* fg probability = softmax(bg,fg)[1] with tf.nn.softmax arithmetic.  logits: [nloc, 2*A]
+ * (FRCNN) or [n,2] with A ignored (FPN, nloc = n).  out: [nloc*A] resp. [n]. */
+int odet_rpn_fg_softmax(const float* logits, int nloc, int A, int layout, float* out,
+                        odet_stream_t stream);
+
+/* ---- NMS / region proposal ----------------------------------------------------------- */
+
+size_t odet_nms_workspace_bytes(int n, int max_output);
+/* tf.image.non_max_suppression (NonMaxSuppressionV3, score_threshold=-inf) as called at
+ * model/region_proposal.py:74-76 and model/prediction.py:146: exact greedy NMS over all n
+ * boxes, IoU without +1, strict '>', stop at max_output.  out_idx int32 [max_output]
+ * (original indices in keep order), out_boxes (nullable) [max_output,4] gathered rows,
+ * out_count device int32[1].
+ * Candidates are consumed in score order in chunks of 4096.  `blind_chunks` (>= 1) chunks are
+ * enqueued unconditionally (a chunk after completion is a no-op on the device).
+ *  - out_done == NULL  (exact mode): if more chunks may be needed the call host-syncs on
+ *    `stream` once per further chunk until the device reports completion.  Always exact.
+ *  - out_done != NULL  (sync-free mode, graph-capturable): exactly blind_chunks chunks run;
+ *    *out_done (device int32) = 1 when the result is complete, 0 when max_output was not
+ *    reached within blind_chunks*4096 candidates (caller re-runs in exact mode). */
+int odet_nms(const float* boxes, const float* scores, int n, int max_output, float iou_threshold,
+             int32_t* out_idx, float* out_boxes, int32_t* out_count, int blind_chunks,
+             int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream);
+
+size_t odet_region_proposal_workspace_bytes(int n, int max_output);
+/* model/region_proposal.py:55-81 RegionProposal.call: decode (means/stds host [4]) -> clip
+ * to the image -> NMS over ALL n anchors -> gather.  out_rois [max_output,4], out_idx
+ * (nullable) int32 [max_output], out_count device int32[1]; blind_chunks / out_done as in
+ * odet_nms. */
+int odet_region_proposal(const float* deltas, const float* anchors, const float* scores, int n,
+                         int image_h, int image_w, const float* means, const float* stds,
+                         int max_output, float iou_threshold, float* out_rois, int32_t* out_idx,
+                         int32_t* out_count, int blind_chunks, int32_t* out_done, void* workspace,
+                         size_t workspace_bytes, odet_stream_t stream);
+
+/* ---- FPN level assignment ------------------------------------------------------------ */
+
+#define ODET_ASSIGN_MAX_ROIS 8192
+/* model/fpn/base_fpn_model.py:303-324 _assign_levels.  rois [n,4] (count_dev overrides n
+ * when non-null; n is then the capacity).  Outputs: out_rois [n,4] level-sorted (stable),
+ * out_level int32 [n] (level - min_level of each SORTED row), out_perm int64 [n] (original
+ * row of each sorted row), out_counts int32 [max_level-min_level+1]. */
+int odet_assign_levels(const float* rois, int n, const int32_t* count_dev, int min_level,
+                       int max_level, float* out_rois, int32_t* out_level, int64_t* out_perm,
+                       int32_t* out_counts, odet_stream_t stream);
+
+/* ---- RoI feature extraction ---------------------------------------------------------- */
+
+#define ODET_ROI_NORM_STRIDE 0   /* model/roi_pooling.py:63-74: (roi/stride)/(dim-1) */
+#define ODET_ROI_NORM_IMAGE 1    /* model/roi_pooling.py:25-35: roi/image_size (FPN) */
+#define ODET_ROI_NORM_TP_ALIGN 2 /* model/roi_pooling.py:93-137,174-177: tensorpack RoIAlign */
+#define ODET_ROI_NORM_TP_ALIGN_NOPAD 3 /* same with pad_border=False (roi_pooling.py:93,97) */
+#define ODET_ROI_POOL_NONE 0     /* crop P x P            (roi_pooling.py:85-90) */
+#define ODET_ROI_POOL_MAX2 1     /* crop 2P x 2P + 2x2 max (roi_pooling.py:36-42,75-84) */
+#define ODET_ROI_POOL_AVG2 2     /* crop 2P x 2P + 2x2 avg (roi_pooling.py:149-154) */
+
+typedef struct {
+  const float* data; /* device NHWC [1,H,W,C] */
+  int32_t H, W;
+  float stride; /* used by NORM_STRIDE / NORM_TP_ALIGN */
+} odet_level_t;
+
+/* tf.image.crop_and_resize (bilinear, extrapolation 0) + optional 2x2 pool, fused, over up
+ * to ODET_MAX_LEVELS feature maps in one launch.  levels: host array; roi_level: device
+ * int32 [n] index into levels for each RoI (nullable = all 0); count_dev (nullable)
+ * overrides n.  C % 4 == 0.  out [n,P,P,C]. */
+int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                  const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode,
+                  int image_h, int image_w, int pool_size, int pool_mode, float* out,
+                  odet_stream_t stream);
+
+/* ---- detection post-processing ------------------------------------------------------- */
+
+#define ODET_POSTOPS_MAX_ROIS 4096
+#define ODET_POSTOPS_MAX_CANDIDATES 8192 /* (num_classes-1) * max_per_class */
+size_t odet_post_ops_workspace_bytes(int num_classes, int max_per_class);
+/* model/prediction.py:103-163 post_ops_prediction, all classes in one launch + one merge
+ * launch.  scores [R,Ccls] softmax, deltas [R,Ccls,4], rois [R,4] (count_dev overrides R).
+ * Loops classes 1..num_classes-1 (num_classes <= Ccls).  means/stds host [4].
+ * Outputs (capacity max_per_image): out_boxes [.,4], out_labels int32, out_scores in
+ * (score desc, class asc, NMS order) order, out_count device int32[1]
+ * (0 == the reference returns (None, None, None)). */
+int odet_post_ops(const float* scores, const float* deltas, const float* rois, int R,
+                  const int32_t* count_dev, int Ccls, int num_classes, int image_h, int image_w,
+                  const float* means, const float* stds, int max_per_class, int max_per_image,
+                  float nms_iou_threshold, float score_threshold, float min_edge,
+                  float* out_boxes, int32_t* out_labels, float* out_scores, int32_t* out_count,
+                  void* workspace, size_t workspace_bytes, odet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODET_H_ */

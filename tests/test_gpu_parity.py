@@ -1,0 +1,406 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, called through the C ABI
+(ctypes -> libodet_hip.so), against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): anchor / kept-box / filter INDICES bit-exact; box coordinates,
+scores and RoI features within 1e-4 (fp32).  The IEEE-only kernels (anchors, clip, bilinear
+crops, max-pool) are additionally required to be bit-identical.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from oracle import oracle_np as on
+from tf_eager_object_detection_amd import ops
+from tf_eager_object_detection_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star: bbox coordinates and scores within 1e-4 fp32
+M0 = [0, 0, 0, 0]
+S1 = [1, 1, 1, 1]
+S2 = [0.1, 0.1, 0.2, 0.2]
+
+
+def g(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def h(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size:
+        scale = np.maximum(1.0, np.abs(b))
+        assert np.max(np.abs(a - b) / scale) <= tol, float(np.max(np.abs(a - b)))
+
+
+# ------------------------------------------------------------------------------- anchors ------
+def test_anchors_shift_bit_exact():
+    from tf_eager_object_detection_amd.utils.anchor_generator import generate_anchor_base, generate_by_anchor_base_tf
+    for scales, (fh, fw) in (((8, 16, 32), (38, 50)), ((8, 16, 32), (50, 84)), ((4, 8, 16, 32), (2, 3))):
+        base = generate_anchor_base(16, [0.5, 1, 2], np.array(scales)).astype(np.float32)
+        got = h(generate_by_anchor_base_tf(base, 16, fh, fw))
+        np.testing.assert_array_equal(got, on.generate_by_anchor_base_tf(base, 16, fh, fw))
+    assert h(generate_by_anchor_base_tf(base, 16, 50, 84)).shape[0] == 50 * 84 * 12
+
+
+@pytest.mark.parametrize('shape', [(800, 1333), (1333, 1333), (600, 800), (37, 53)])
+def test_fpn_anchors_bit_exact(shape):
+    from tf_eager_object_detection_amd.utils.anchor_generator import make_anchors, make_fpn_anchors
+    got = h(make_fpn_anchors(shape, syn.FPN_STRIDES, syn.FPN_BASE_SIZES, syn.FPN_SCALES, syn.FPN_RATIOS))
+    want = co.fpn_anchors(shape)
+    assert got.shape[0] == syn.num_fpn_anchors(shape)
+    np.testing.assert_array_equal(got, want)
+    one = h(make_anchors(64, (1., 2.), (0.5, 1.0, 2.0), 4.0, 5.0, 8))
+    np.testing.assert_array_equal(one, on.make_anchors(64, (1., 2.), (0.5, 1.0, 2.0), 4.0, 5.0, 8))
+
+
+# ------------------------------------------------------------------------- box transforms -----
+def test_decode_encode_clip():
+    from tf_eager_object_detection_amd.utils.bbox_transform import (decode_bbox_with_mean_and_std,
+                                                                    encode_bbox_with_mean_and_std)
+    rng = np.random.default_rng(11)
+    anchors = co.fpn_anchors((600, 800))
+    n = anchors.shape[0]
+    for sigma, stds in ((0.1, S1), (0.01, S1), (1.0, S2)):
+        d = syn.rpn_deltas(n, rng, sigma) if sigma < 1 else rng.normal(0, 1, (n, 4)).astype(np.float32)
+        got = h(decode_bbox_with_mean_and_std(g(anchors), g(d), M0, stds))
+        want = co.decode(anchors, d, M0, stds)
+        close(got, want)
+        assert np.mean(got == want) > 0.9999          # correctly rounded exp on both sides
+    gt = anchors + rng.uniform(-3, 3, anchors.shape).astype(np.float32)
+    gt[:, 2:] = np.maximum(gt[:, 2:], gt[:, :2] + 1)
+    close(h(encode_bbox_with_mean_and_std(g(anchors), g(gt), M0, S2)), co.encode(anchors, gt, M0, S2))
+    # KA5
+    z = h(decode_bbox_with_mean_and_std(g(anchors[:100]), g(np.zeros((100, 4), np.float32)), M0, S1))
+    np.testing.assert_array_equal(z, anchors[:100] + np.float32([0, 0, 1, 1]))
+    # fused decode+clip == decode then clip
+    d = syn.rpn_deltas(n, rng, 0.3)
+    fused = h(ops.decode(g(anchors), g(d), M0, S1, clip_shape=(600, 800)))
+    want, _ = co.clip_filter(co.decode(anchors, d, M0, S1), 0, 600, 800)
+    close(fused, want)
+    assert fused.min() >= 0 and fused[:, 0::2].max() <= 799 and fused[:, 1::2].max() <= 599
+
+
+def test_filters_index_exact():
+    from tf_eager_object_detection_amd.utils.bbox_tf import bboxes_clip_filter, bboxes_range_filter
+    rng = np.random.default_rng(12)
+    anchors = co.fpn_anchors((600, 800))
+    boxes = co.decode(anchors, syn.rpn_deltas(anchors.shape[0], rng, 0.2), M0, S1)
+    gb, gi = bboxes_clip_filter(g(boxes), 0, 600, 800, 16)
+    wb, wi = co.clip_filter(boxes, 0, 600, 800, 16)
+    assert gi.dtype == torch.int64
+    np.testing.assert_array_equal(h(gi), wi)
+    np.testing.assert_array_equal(h(gb), wb)
+    cb, ci = bboxes_clip_filter(g(boxes), 0, 600, 800)
+    np.testing.assert_array_equal(h(cb), co.clip_filter(boxes, 0, 600, 800)[0])
+    np.testing.assert_array_equal(h(ci), np.arange(boxes.shape[0]))
+    np.testing.assert_array_equal(h(bboxes_range_filter(g(anchors), 600, 800)), co.range_filter(anchors, 600, 800))
+    # empty result and tiny inputs
+    tiny = np.float32([[0, 0, 3, 3], [5, 5, 6, 6]])
+    b, i = bboxes_clip_filter(g(tiny), 0, 600, 800, 16)
+    assert b.shape == (0, 4) and i.shape == (0,)
+    # strided where(score > thr) (prediction.py:136)
+    S = syn.class_scores(777, 21, rng)
+    idx, cnt = ops.where_greater(g(S)[:, 5], 0.05)
+    np.testing.assert_array_equal(h(idx[:int(cnt.item())]), np.nonzero(S[:, 5] > np.float32(0.05))[0])
+
+
+def test_pairwise_iou():
+    from tf_eager_object_detection_amd.utils.bbox_tf import pairwise_iou
+    rng = np.random.default_rng(13)
+    a = syn.random_boxes(1000, (600, 800), rng)
+    b = syn.random_boxes(37, (600, 800), rng)
+    b[3] = a[5]
+    close(h(pairwise_iou(g(a), g(b))), co.pairwise_iou(a, b), 1e-6)
+    anchors = co.fpn_anchors((800, 1333))
+    big = h(pairwise_iou(g(anchors), g(b)))
+    close(big, co.pairwise_iou(anchors, b), 1e-6)
+    assert pairwise_iou(g(a[:0]), g(b)).shape == (0, 37)
+
+
+def test_rpn_fg_softmax():
+    rng = np.random.default_rng(14)
+    lg = rng.normal(0, 3, (267069, 2)).astype(np.float32)
+    close(h(ops.rpn_fg_softmax(g(lg), 3, ops.RPN_LAYOUT_FPN)), co.rpn_fg_fpn(lg), 1e-6)
+    lg = rng.normal(0, 3, (4200, 18)).astype(np.float32)
+    close(h(ops.rpn_fg_softmax(g(lg), 9, ops.RPN_LAYOUT_FRCNN)), co.rpn_fg_frcnn(lg, 9), 1e-6)
+    # KA12
+    one = np.float32([[1.0, 2.0, 3.0, 0.5, 2.0, 7.0]])
+    np.testing.assert_allclose(h(ops.rpn_fg_softmax(g(one), 3, ops.RPN_LAYOUT_FRCNN)), on.rpn_fg_scores_frcnn(one, 3),
+                               atol=1e-7)
+
+
+# ----------------------------------------------------------------------------------- NMS ------
+def _nms_gpu(boxes, scores, k, thr):
+    idx, cnt = ops.nms(g(boxes), g(scores), k, thr)
+    return h(idx[:int(cnt.item())])
+
+
+def test_nms_known_answers():
+    box = np.float32([[0, 0, 10, 10]])
+    assert _nms_gpu(np.repeat(box, 4, 0), np.float32([.1, .9, .5, .3]), 10, 0.5).tolist() == [1]
+    b = np.float32([[0, 0, 10, 10], [0, 0, 10, 5]])
+    assert _nms_gpu(b, np.float32([.9, .8]), 10, 0.5).tolist() == [0, 1]       # IoU == thr: strict >
+    assert _nms_gpu(b, np.float32([.9, .8]), 10, 0.49).tolist() == [0]
+    z = np.float32([[0, 0, 10, 10], [5, 5, 5, 9], [5, 5, 5, 9]])
+    assert _nms_gpu(z, np.float32([.9, .8, .7]), 10, 0.1).tolist() == [0, 1, 2]  # zero area
+    far = np.float32([[i * 100, 0, i * 100 + 10, 10] for i in range(6)])
+    assert _nms_gpu(far, np.float32([.5, .9, .9, .1, .7, .9]), 4, 0.5).tolist() == [1, 2, 5, 4]
+    assert _nms_gpu(b[:, [2, 3, 0, 1]], np.float32([.9, .8]), 10, 0.49).tolist() == [0]
+    assert _nms_gpu(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 5, 0.5).size == 0
+    # NaN / -inf scores are never candidates (score > lowest-float is false)
+    s = np.float32([0.5, np.nan, -np.inf, 0.7])
+    assert _nms_gpu(far[:4], s, 4, 0.5).tolist() == [3, 0]
+
+
+@pytest.mark.parametrize('n,k,thr,kind', [
+    (1, 1, 0.7, 'distinct'), (63, 300, 0.7, 'distinct'), (64, 10, 0.3, 'tied'), (65, 65, 0.5, 'distinct'),
+    (4096, 300, 0.7, 'tied'), (4097, 4097, 0.7, 'distinct'), (5000, 2000, 0.7, 'clustered'),
+    (20000, 1000, 0.7, 'clustered'), (20000, 20000, 0.5, 'tied'), (37800, 300, 0.7, 'clustered'),
+])
+def test_nms_index_exact(n, k, thr, kind):
+    rng = np.random.default_rng(n + k)
+    boxes = syn.random_boxes(n, (800, 1333), rng, 16, 400)
+    if kind == 'distinct':
+        scores = syn.scores_distinct(n, rng)
+    elif kind == 'tied':
+        scores = syn.scores_tied(n, rng, 2)
+    else:
+        scores = syn.scores_clustered(boxes, (800, 1333), rng)
+    want, stats = co.nms(boxes, scores, k, thr, True)
+    got = _nms_gpu(boxes, scores, k, thr)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_nms_dense_suppression_many_chunks():
+    # nearly identical boxes: almost everything is suppressed, the scan has to walk many 4096-chunks
+    rng = np.random.default_rng(5)
+    n = 30000
+    base = np.float32([100, 100, 300, 260])
+    boxes = base + rng.uniform(-3, 3, (n, 4)).astype(np.float32)
+    boxes[::1000] += np.float32([500, 300, 500, 300])           # a few far-away survivors
+    scores = syn.scores_distinct(n, rng)
+    want, stats = co.nms(boxes, scores, 100, 0.5, True)
+    assert stats[0] > 8192                                      # really needs > 2 chunks
+    np.testing.assert_array_equal(_nms_gpu(boxes, scores, 100, 0.5), want)
+
+
+def test_nms_sync_free_mode_reports_completion():
+    rng = np.random.default_rng(6)
+    n = 20000
+    boxes = syn.random_boxes(n, (800, 1333), rng, 16, 300)
+    scores = syn.scores_distinct(n, rng)
+    done = torch.zeros(1, dtype=torch.int32, device='cuda')
+    idx, cnt = ops.nms(g(boxes), g(scores), 300, 0.7, blind_chunks=2, done=done)
+    assert int(done.item()) == 1
+    np.testing.assert_array_equal(h(idx[:int(cnt.item())]), co.nms(boxes, scores, 300, 0.7))
+    # ask for more than two chunks can deliver -> done == 0, prefix still exact
+    done.zero_()
+    idx, cnt = ops.nms(g(boxes), g(scores), 20000, 0.7, blind_chunks=1, done=done)
+    assert int(done.item()) == 0
+    m = int(cnt.item())
+    np.testing.assert_array_equal(h(idx[:m]), co.nms(boxes, scores, 20000, 0.7)[:m])
+
+
+@pytest.mark.parametrize('shape,k,kind', [((800, 1333), 1000, 'distinct'), ((800, 1333), 1000, 'clustered'),
+                                          ((800, 1333), 2000, 'clustered'), ((1333, 1333), 1000, 'tied')])
+def test_region_proposal_full_size(shape, k, kind):
+    """model/region_proposal.py at BASELINE sizes: 267 069 / 446 118 anchors, NMS over all of them."""
+    from tf_eager_object_detection_amd.model.region_proposal import RegionProposal
+    rng = np.random.default_rng(1234)
+    anchors = co.fpn_anchors(shape)
+    n = anchors.shape[0]
+    deltas = syn.rpn_deltas(n, rng, 0.1)
+    scores = {'distinct': syn.scores_distinct, 'tied': lambda n_, r: syn.scores_tied(n_, r, 4)}.get(kind, None)
+    scores = scores(n, rng) if scores else syn.scores_clustered(anchors, shape, rng)
+    layer = RegionProposal(num_anchors=3, num_post_nms_test=k, num_post_nms_train=2000, nms_iou_threshold=0.7,
+                           target_means=M0, target_stds=S1)
+    inputs = (g(deltas), g(anchors), g(scores), list(shape))
+    rois_p, idx_p, cnt = layer.padded(inputs, training=False)
+    want_rois, want_idx, stats = co.region_proposal(deltas, anchors, scores, shape, k, 0.7, return_stats=True)
+    m = int(cnt.item())
+    np.testing.assert_array_equal(h(idx_p[:m]), want_idx)          # kept anchor indices: bit-exact
+    close(h(rois_p[:m]), want_rois)
+    rois = layer(inputs, training=False)
+    assert rois.shape == (len(want_idx), 4)
+    close(h(rois), want_rois)
+
+
+# ------------------------------------------------------------------------------ RoI pooling ----
+def _feat(hw, c, rng):
+    return rng.standard_normal((1, hw[0], hw[1], c), dtype=np.float32)
+
+
+def test_roi_pooling_layers_match_oracle_bit_exact():
+    from tf_eager_object_detection_amd.model.roi_pooling import (RoiPoolingCropAndResize, RoiPoolingCropAndResize2,
+                                                                 RoiPoolingRoiAlign, crop_and_resize, roi_align)
+    rng = np.random.default_rng(21)
+    feat = _feat((38, 50), 64, rng)
+    rois = syn.random_boxes(200, (600, 800), rng, 8, 700)
+    rois[0] = [0, 0, 799, 599]
+    rois[1] = [-50, -30, 120, 90]            # partly outside -> extrapolated zeros
+    rois[2] = [300, 300, 300, 300]           # degenerate
+    rois[3] = [700, 500, 1200, 900]          # beyond the map
+    fg, rg = g(feat), g(rois)
+    for flag in (True, False):
+        got = h(RoiPoolingCropAndResize(7, flag)((fg, rg, 16)))
+        want = co.roi_pool(feat, rois, stride=16, pool=7, max_pool=flag)
+        np.testing.assert_array_equal(got, want)
+    got = h(RoiPoolingCropAndResize2(7)((fg, rg, [600, 800])))
+    np.testing.assert_array_equal(got, co.roi_pool(feat, rois, image_shape=(600, 800), pool=7))
+    got = h(RoiPoolingRoiAlign(7)((fg, rg, 16)))
+    close(got, co.roi_align(feat, rois, 16, 7), 1e-5)
+    # free functions (feature-map coordinates)
+    fb = rois / np.float32(16)
+    close(h(roi_align(fg, g(fb), 7)), on.roi_align(feat, fb, 7), 1e-5)
+    close(h(crop_and_resize(fg, g(fb[:20]), torch.zeros(20, dtype=torch.int32), 14)),
+          on.crop_and_resize_tp(feat, fb[:20], np.zeros(20, np.int32), 14), 1e-5)
+    close(h(crop_and_resize(fg, g(fb[:20]), torch.zeros(20, dtype=torch.int32), 6, pad_border=False)),
+          on.crop_and_resize_tp(feat, fb[:20], np.zeros(20, np.int32), 6, pad_border=False), 1e-5)
+    # KA8: identity crop through the P x P (no pool) path: box = whole map
+    ident = h(ops.roi_pool([g(feat[:, :7, :7])], g(np.float32([[0, 0, 6, 6]])), None, ops.ROI_NORM_STRIDE, 7,
+                           ops.ROI_POOL_NONE, strides=[1.0]))
+    np.testing.assert_array_equal(ident[0], feat[0, :7, :7])
+    assert RoiPoolingCropAndResize(7)((fg, g(rois[:0]), 16)).shape == (0, 7, 7, 64)
+
+
+@pytest.mark.parametrize('C', [4, 256, 512, 1024])
+def test_roi_pool_channel_counts(C):
+    rng = np.random.default_rng(C)
+    feat = _feat((20, 30), C, rng)
+    rois = syn.random_boxes(40, (320, 480), rng, 8, 300)
+    got = h(ops.roi_pool([g(feat)], g(rois), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_MAX2, strides=[16.0]))
+    np.testing.assert_array_equal(got, co.roi_pool(feat, rois, stride=16, pool=7, max_pool=True))
+
+
+def test_fpn_roi_path_full_size():
+    """assign_levels + multi-level RoI kernel at config-3 size: 1000 RoIs, P2..P5 x 256 channels."""
+    from tf_eager_object_detection_amd.model.roi_pooling import roi_pooling_fpn_levels
+    rng = np.random.default_rng(1234)
+    shape = (800, 1333)
+    shapes = syn.fpn_level_shapes(shape)[:4]
+    feats = syn.features(shapes, 256, rng)
+    rois = syn.random_boxes(1000, shape, rng, 16, 800)
+    rois[:5] = [[0, 0, 112, 112], [0, 0, 224, 224], [0, 0, 448, 448], [10, 10, 10, 200], [0, 0, 1332, 799]]
+    sorted_rois, lvl, perm, counts = ops.assign_levels(g(rois), 2, 5)
+    wl, wperm, wcnt = co.assign_levels(rois)
+    np.testing.assert_array_equal(h(perm), wperm)                       # bit-exact indices
+    np.testing.assert_array_equal(h(counts), wcnt)
+    np.testing.assert_array_equal(h(lvl) + 2, wl[wperm])
+    np.testing.assert_array_equal(h(sorted_rois), rois[wperm])
+    out = h(roi_pooling_fpn_levels([g(f) for f in feats], sorted_rois, lvl, shape, 7))
+    rois_list, _, _ = on.assign_levels(rois)
+    want = np.concatenate([co.roi_pool(f, r, image_shape=shape, pool=7, threads=8)
+                           for f, r in zip(feats, rois_list) if r.shape[0]], axis=0)
+    np.testing.assert_array_equal(out, want)                            # IEEE-only kernel: bit-identical
+
+
+def test_assign_levels_boundaries_and_count_dev():
+    def sq(s):
+        return [0, 0, s, s]
+    r = np.float32([sq(112), sq(224), sq(448), sq(10), sq(2000), [5, 5, 5, 50], [50, 5, 5, 5], sq(223.9), sq(111.9)])
+    s, lvl, perm, counts = ops.assign_levels(g(r), 2, 5)
+    assert h(perm).tolist() == [3, 5, 6, 8, 0, 7, 1, 2, 4] and h(counts).tolist() == [4, 2, 1, 2]
+    cnt = torch.tensor([4], dtype=torch.int32, device='cuda')
+    s, lvl, perm, counts = ops.assign_levels(g(r), 2, 5, count_dev=cnt)
+    assert h(counts).tolist() == [1, 1, 1, 1] and h(perm)[:4].tolist() == [3, 0, 1, 2]
+    rng = np.random.default_rng(3)
+    big = syn.random_boxes(8192, (800, 1333), rng, 4, 1200)
+    _, _, perm, counts = ops.assign_levels(g(big), 2, 5)
+    wl, wperm, wcnt = co.assign_levels(big)
+    np.testing.assert_array_equal(h(perm), wperm)
+
+
+# ------------------------------------------------------------------------------- post-ops -----
+def _check_post(got, want):
+    gb, gl, gs = got
+    wb, wl, ws = want
+    if wb is None:
+        assert gb is None and gl is None and gs is None
+        return
+    assert gl.dtype == torch.int32
+    np.testing.assert_array_equal(h(gl), wl)                     # labels exact (same order: score desc)
+    close(h(gs), ws, 1e-6)
+    close(h(gb), wb)
+
+
+@pytest.mark.parametrize('R,ncls,mpc,mpi,sthr', [(300, 21, 50, 50, 0.0), (1000, 21, 50, 50, 0.0),
+                                                 (1000, 81, 100, 300, 0.0), (1000, 21, 50, 150, 0.05),
+                                                 (7, 21, 50, 50, 0.0), (1000, 81, 100, 100, 0.05)])
+def test_post_ops_prediction(R, ncls, mpc, mpi, sthr):
+    from tf_eager_object_detection_amd.model.prediction import post_ops_prediction
+    rng = np.random.default_rng(R + ncls)
+    shape = (800, 1333)
+    S = syn.class_scores(R, ncls, rng)
+    D = syn.class_deltas(R, ncls, rng)
+    rois = syn.random_boxes(R, shape, rng, 16, 600)
+    got = post_ops_prediction(g(S), g(D), g(rois), list(shape), M0, S2, mpc, mpi, 0.3, sthr, 16, num_classes=ncls)
+    want = co.post_ops(S, D, rois, shape, M0, S2, mpc, mpi, 0.3, sthr, 16, ncls)
+    _check_post(got, want)
+
+
+def test_post_ops_edge_cases():
+    from tf_eager_object_detection_amd.model.prediction import post_ops_prediction
+    rng = np.random.default_rng(8)
+    shape = (600, 800)
+    R = 64
+    S = syn.class_scores(R, 81, rng)
+    D = syn.class_deltas(R, 81, rng)
+    rois = syn.random_boxes(R, shape, rng, 16, 400)
+    # nothing survives -> (None, None, None) (prediction.py:153-154)
+    assert post_ops_prediction(g(S), g(D), g(rois), list(shape), M0, S2, 5, 5, 0.3, 1.5, 16) == (None, None, None)
+    # default num_classes=21 on 81 columns only visits classes 1..20 (reference quirk)
+    got = post_ops_prediction(g(S), g(D), g(rois), list(shape), M0, S2, 50, 150, 0.3, 0.0, 16)
+    _check_post(got, co.post_ops(S, D, rois, shape, M0, S2, 50, 150, 0.3, 0.0, 16, 21))
+    assert int(got[1].max()) <= 20
+    # target_means / target_stds None -> defaults (prediction.py:128-131)
+    got = post_ops_prediction(g(S), g(D), g(rois), list(shape), None, None, 50, 150, 0.3, 0.0, 16)
+    _check_post(got, co.post_ops(S, D, rois, shape, None, None, 50, 150, 0.3, 0.0, 16, 21))
+    # min-edge filter removes everything small
+    small = np.float32([[10, 10, 14, 14]] * R)
+    Dz = np.zeros_like(D)
+    assert post_ops_prediction(g(S), g(Dz), g(small), list(shape), M0, S2, 5, 5, 0.3, 0.0, 16) == (None, None, None)
+    # tied scores: every RoI identical score per class -> lower RoI index wins
+    St = np.full((R, 21), 1.0 / 21, np.float32)
+    got = post_ops_prediction(g(St), g(D[:, :21]), g(rois), list(shape), M0, S2, 50, 150, 0.3, 0.0, 16)
+    _check_post(got, co.post_ops(St, D[:, :21], rois, shape, M0, S2, 50, 150, 0.3, 0.0, 16, 21))
+
+
+def test_predict_after_roi_matches_oracle():
+    from tf_eager_object_detection_amd.model.prediction import predict_after_roi
+    rng = np.random.default_rng(9)
+    R = 200
+    S = syn.class_scores(R, 21, rng, 3.0)
+    D = syn.class_deltas(R, 21, rng)
+    rois = syn.random_boxes(R, (600, 800), rng, 16, 400)
+    gb, gl, gs = predict_after_roi(g(S), g(D), g(rois), [600, 800], M0, S2, 5, 20, 0.3, 0.3)
+    wb, wl, ws = on.predict_after_roi(S, D, rois, (600, 800), M0, S2, 5, 20, 0.3, 0.3)
+    np.testing.assert_array_equal(h(gl), wl)
+    close(h(gs), ws, 1e-6)
+    close(h(gb), wb)
+
+
+# ---------------------------------------------------------------------- size-independent ------
+def test_properties_at_full_size():
+    """Checks that do not need the oracle: NMS output is sorted by score, pairwise non-overlapping
+    above thr, maximal (every rejected top candidate overlaps a kept one), idempotent."""
+    rng = np.random.default_rng(77)
+    n = 267069
+    boxes = syn.random_boxes(n, (800, 1333), rng, 8, 600)
+    scores = syn.scores_clustered(boxes, (800, 1333), rng)
+    idx, cnt = ops.nms(g(boxes), g(scores), 1000, 0.7)
+    k = h(idx[:int(cnt.item())]).astype(np.int64)
+    assert len(k) == 1000 and len(np.unique(k)) == 1000
+    assert np.all(np.diff(scores[k]) <= 0)
+    kb = boxes[k]
+    iou = co.pairwise_iou(kb - np.float32([0, 0, 1, 1]), kb - np.float32([0, 0, 1, 1]))   # (+1 cancels)
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= 0.7 + 1e-6
+    # idempotence: NMS of the kept set keeps everything, same order
+    idx2, cnt2 = ops.nms(g(kb), g(scores[k]), 1000, 0.7)
+    assert h(idx2[:int(cnt2.item())]).tolist() == list(range(1000))

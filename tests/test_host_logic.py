@@ -1,0 +1,110 @@
+"""CPU tests of the product's host side: the numpy-level anchor tables against the reference's
+golden vectors, the C-ABI library (loads, exports every symbol include/odet.h declares, ctypes
+table in sync with the header) and the fail-loudly rule (no CPU path)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_product_anchor_base_matches_reference_golden(golden):
+    from tf_eager_object_detection_amd.utils.anchor_generator import generate_anchor_base
+    for i in range(5):
+        got = generate_anchor_base(float(golden['ab%d_base' % i]), golden['ab%d_ratios' % i],
+                                   golden['ab%d_scales' % i])
+        np.testing.assert_array_equal(got, golden['ab%d_out' % i])
+    assert generate_anchor_base().shape == (9, 4)
+
+
+def test_product_anchor_by_base_np_matches_reference_golden(golden):
+    from tf_eager_object_detection_amd.utils.anchor_generator import generate_anchor_base, generate_by_anchor_base_np
+    base = generate_anchor_base(16, [0.5, 1, 2], [8, 16, 32])
+    for i in range(3):
+        h, w, st = golden['np%d_hws' % i]
+        np.testing.assert_array_equal(generate_by_anchor_base_np(base, int(st), int(h), int(w)),
+                                      golden['np%d_out' % i])
+
+
+def test_wh_table_is_float32_and_swapped():
+    from tf_eager_object_detection_amd.utils.anchor_generator import _wh_table
+    wh = _wh_table(32, (1.,), (0.5, 1.0, 2.0))
+    assert wh.dtype == np.float32 and wh.shape == (3, 2)
+    # ratio 0.5 -> w = 32*sqrt(.5) = 22.627, h = 32/sqrt(.5) = 45.25  (w/h = ratio)
+    np.testing.assert_allclose(wh[0], [22.627417, 45.254833], rtol=1e-6)
+    np.testing.assert_array_equal(wh[1], np.float32([32, 32]))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'odet.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(odet_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    from tf_eager_object_detection_amd import _lib
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for name in syms:
+        assert hasattr(handle, name), 'libodet_hip.so does not export %s' % name
+    assert handle.odet_version() == 100
+
+
+def test_ctypes_table_matches_header():
+    from tf_eager_object_detection_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _header_symbols()
+    text = open(os.path.join(ROOT, 'include', 'odet.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r'\b%s\s*\(([^;]*?)\)\s*;' % name, text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ('', 'void') else len(params.split(','))
+        assert n == len(args), '%s: header has %d parameters, ctypes table %d' % (name, n, len(args))
+
+
+def test_argument_errors_are_reported_through_the_abi():
+    from tf_eager_object_detection_amd import _lib
+    L = _lib.lib()
+    rc = L.odet_roi_pool(None, 1, 256, None, None, 4, None, 0, 0, 0, 7, 1, None, None)
+    assert rc == -1 and b'null pointer' in L.odet_last_error()
+    rc = L.odet_anchors_fpn(99, 3, None, None, None, None, None, None)
+    assert rc == -1
+    assert L.odet_nms_workspace_bytes(267069, 1000) > 267069 * 16
+    assert L.odet_post_ops_workspace_bytes(21, 50) > 20 * 50 * 20
+
+
+def test_no_cpu_fallback():
+    from tf_eager_object_detection_amd import _lib
+    from tf_eager_object_detection_amd.utils.bbox_transform import decode_bbox_with_mean_and_std
+    from tf_eager_object_detection_amd.model.region_proposal import RegionProposal
+    a = torch.zeros(4, 4)
+    with pytest.raises(_lib.OdetError):
+        decode_bbox_with_mean_and_std(a, a, [0, 0, 0, 0], [1, 1, 1, 1])
+    with pytest.raises(_lib.OdetError):
+        RegionProposal()((a, a, torch.zeros(4), [32, 32]), training=False)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'tf_eager_object_detection_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'oracle/' not in src and 'liboracle' not in src, f
+
+
+def test_synthetic_shapes():
+    from tf_eager_object_detection_amd import synthetic as syn
+    assert syn.num_fpn_anchors((800, 1333)) == 267069
+    assert syn.num_fpn_anchors((1333, 1333)) == 446118
+    assert syn.fpn_level_shapes((800, 1333)) == [(200, 334), (100, 167), (50, 84), (25, 42), (13, 21)]
+    rng = np.random.default_rng(0)
+    s = syn.scores_distinct(1000, rng)
+    assert len(np.unique(s)) == 1000 and s.dtype == np.float32

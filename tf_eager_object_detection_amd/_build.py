@@ -1,0 +1,65 @@
+"""Builds libodet_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so is
+git-ignored but travels to the GPU box inside the gpurun snapshot."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(PKG), 'include')
+OBJ_DIR = os.path.join(CSRC, '_obj')
+LIB = os.path.join(PKG, 'libodet_hip.so')
+SOURCES = ['boxes.hip', 'sort.hip', 'nms.hip', 'roi.hip', 'postops.hip']
+HEADERS = [os.path.join(CSRC, 'odet_internal.h'), os.path.join(INCLUDE, 'odet.h')]
+
+# -ffp-contract=off: the parity contract is "one IEEE float32 operation per reference
+# operation"; an FMA would change low bits of box coordinates and bilinear taps.
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+               '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-variable']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return 'hipcc'
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, src + '.o')
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
+            cmd = [hipcc] + HIPCC_FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed on %s' % src)
+    if force or procs or _stale(LIB, objs):
+        tmp = LIB + '.tmp.%d' % os.getpid()
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', tmp]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

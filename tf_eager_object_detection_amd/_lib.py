@@ -1,0 +1,126 @@
+"""ctypes binding of libodet_hip.so (include/odet.h).
+
+PyTorch is only plumbing here: it owns device memory and the HIP stream; every detection op
+is a hand-written HIP kernel behind the C ABI.  There is NO CPU fallback: if the library is
+missing, or a tensor is not on the GPU, the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libodet_hip.so')
+
+_lib = None
+
+_vp, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+
+class OdetLevel(C.Structure):
+    """odet_level_t"""
+    _fields_ = [('data', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32), ('stride', C.c_float)]
+
+
+# name -> (restype, argtypes); mirrors include/odet.h one to one
+SIGNATURES = {
+    'odet_version': (_i, []),
+    'odet_last_error': (C.c_char_p, []),
+    'odet_anchors_shift': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'odet_anchors_fpn': (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'odet_decode': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    'odet_encode': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'odet_clip': (_i, [_vp, _i, _f, _i, _i, _vp, _vp]),
+    'odet_compact_workspace_bytes': (_sz, [_i]),
+    'odet_clip_filter': (_i, [_vp, _i, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'odet_range_filter': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'odet_where_greater': (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    'odet_pairwise_iou': (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    'odet_gather_rows': (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    'odet_rpn_fg_softmax': (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    'odet_nms_workspace_bytes': (_sz, [_i, _i]),
+    'odet_nms': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    'odet_region_proposal_workspace_bytes': (_sz, [_i, _i]),
+    'odet_region_proposal': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _sz,
+                                   _vp]),
+    'odet_assign_levels': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'odet_roi_pool': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'odet_post_ops_workspace_bytes': (_sz, [_i, _i]),
+    'odet_post_ops': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f,
+                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class OdetError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libodet_hip.so once.  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OdetError(
+                'libodet_hip.so is missing (%s). Build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` or `python -m tf_eager_object_detection_amd._build`; there is no CPU fallback.'
+                % LIB_PATH)
+        # torch is imported first on purpose: its bundled libamdhip64.so (SONAME libamdhip64.so.7)
+        # is then the one HIP runtime of the process and this library binds to it.
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.odet_version() != 100:
+            raise OdetError('libodet_hip.so version mismatch: %d' % handle.odet_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OdetError('odet error %d: %s' % (rc, lib().odet_last_error().decode('utf-8', 'replace')))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dptr(t, dtype=None, name='tensor'):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %s' % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise OdetError('%s must live on the GPU: tf_eager_object_detection_amd has no CPU path' % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def f32c(t, name='tensor'):
+    """float32 contiguous view/copy of a GPU tensor (the reference casts with tf.to_float)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor, got %s' % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise OdetError('%s must live on the GPU: tf_eager_object_detection_amd has no CPU path' % name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def host4(values, name):
+    """Python sequence of 4 floats -> C float[4] (means / stds are host data in the reference)."""
+    if values is None:
+        raise ValueError('%s is None' % name)
+    vals = [float(v) for v in values]
+    if len(vals) != 4:
+        raise ValueError('%s must have 4 elements' % name)
+    return (C.c_float * 4)(*vals)
+
+
+def workspace(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)

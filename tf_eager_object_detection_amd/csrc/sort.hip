@@ -1,0 +1,174 @@
+// Stable LSD radix sort of (score, index) pairs, descending score / ascending index on ties.
+//
+// Feeds the exact greedy NMS (model/region_proposal.py:74 runs tf.image.non_max_suppression
+// over ALL anchors: 267 069 at 800x1333 FPN).  TF pops a max-heap; a stable descending sort
+// gives the same visiting order with the declared tie rule (score desc, index asc).
+//
+// Key: ~asc(score) so that an ascending LSD sort yields descending scores.  Scores TF would
+// never push (NaN, or <= lowest float: "score > score_threshold" is false) get key 0xFFFFFFFF
+// and sort to the end; *n_valid_dev counts the rest.
+//
+// 4 passes x 8-bit digits.  Per pass: block histogram -> one-workgroup scan -> stable scatter
+// (wave64 ballot multi-split: 8 ballots give each lane the set of lanes sharing its digit).
+#include "odet_internal.h"
+
+#define RS_BLOCK 256
+#define RS_ITEMS 8
+#define RS_TILE (RS_BLOCK * RS_ITEMS)
+#define RS_WAVES (RS_BLOCK / 64)
+#define RS_RADIX 256
+
+size_t odet_sort_hist_entries(int n) {
+  size_t nblocks = ((size_t)(n > 0 ? n : 1) + RS_TILE - 1) / RS_TILE;
+  return nblocks * RS_RADIX;
+}
+
+__global__ void __launch_bounds__(256) k_make_keys(const float* __restrict__ scores, int n, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals, int32_t* __restrict__ n_valid) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  bool valid = false;
+  if (i < n) {
+    float s = scores[i];
+    valid = s > -3.402823466e+38f;   // NonMaxSuppressionV3: score > score_threshold (= lowest); NaN fails
+    keys[i] = valid ? ~d_float_asc_key(s) : 0xFFFFFFFFu;
+    vals[i] = (uint32_t)i;
+  }
+  unsigned long long b = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
+}
+
+// element order inside a block: wave-contiguous: e = blockStart + (wave*ITEMS + item)*64 + lane
+__device__ __forceinline__ int rs_elem(int item) {
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  return blockIdx.x * RS_TILE + (w * RS_ITEMS + item) * 64 + lane;
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift,
+                                                      uint32_t* __restrict__ hist, int nblocks) {
+  __shared__ uint32_t h[RS_RADIX];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int e = rs_elem(it);
+    if (e < n) atomicAdd(&h[(keys[e] >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];   // digit-major
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of `count` entries in place, one workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) k_rs_scan(uint32_t* __restrict__ hist, int count) {
+  __shared__ uint32_t wsum[17];
+  int per = (count + 1023) / 1024;
+  int lo = threadIdx.x * per;
+  uint32_t s = 0;
+  for (int k = 0; k < per; ++k)
+    if (lo + k < count) s += hist[lo + k];
+  uint32_t inc = wave_incl_scan_u32(s);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int k = 0; k < 16; ++k) { uint32_t t = wsum[k]; wsum[k] = run; run += t; }
+  }
+  __syncthreads();
+  uint32_t ex = wsum[w] + inc - s;
+  for (int k = 0; k < per; ++k)
+    if (lo + k < count) { uint32_t t = hist[lo + k]; hist[lo + k] = ex; ex += t; }
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restrict__ keys_in,
+                                                         const uint32_t* __restrict__ vals_in, int n, int shift,
+                                                         const uint32_t* __restrict__ hist, int nblocks,
+                                                         uint32_t* __restrict__ keys_out,
+                                                         uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t cnt[RS_WAVES][RS_RADIX];
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = threadIdx.x; k < RS_WAVES * RS_RADIX; k += RS_BLOCK) (&cnt[0][0])[k] = 0;
+  __syncthreads();
+
+  uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int e = rs_elem(it);
+    bool in = e < n;
+    key[it] = in ? keys_in[e] : 0xFFFFFFFFu;
+    val[it] = in ? vals_in[e] : 0u;
+    uint32_t d = (key[it] >> shift) & 0xFF;
+    // lanes of this wave holding the same digit (out-of-range lanes excluded)
+    unsigned long long same = __ballot(in);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      unsigned long long bal = __ballot((d >> b) & 1);
+      same &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    uint32_t before = (uint32_t)__popcll(same & lt_mask);
+    volatile uint32_t* slot = &cnt[w][d];
+    uint32_t old = *slot;                     // same value for every lane sharing d
+    rank[it] = old + before;
+    if (in && before == 0) *slot = old + (uint32_t)__popcll(same);   // leader updates
+  }
+  __syncthreads();
+  // digit `threadIdx.x`: turn per-wave counts into per-wave bases (+ global block offset)
+  {
+    uint32_t g = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; ++k) {
+      uint32_t t = cnt[k][threadIdx.x];
+      cnt[k][threadIdx.x] = g;
+      g += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int e = rs_elem(it);
+    if (e < n) {
+      uint32_t d = (key[it] >> shift) & 0xFF;
+      uint32_t pos = cnt[w][d] + rank[it];
+      keys_out[pos] = key[it];
+      vals_out[pos] = val[it];
+    }
+  }
+}
+
+// Sorts indices 0..n-1 by (score desc, index asc).  keys_a/vals_a/keys_b/vals_b: n uint32
+// each; hist: odet_sort_hist_entries(n) uint32.  *sorted_vals points at the buffer holding
+// the result (vals_a after an even number of passes).
+int odet_sort_pairs_desc(const float* scores, int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
+                         uint32_t* vals_b, uint32_t* hist, int32_t* n_valid_dev, uint32_t** sorted_vals,
+                         hipStream_t st) {
+  ODET_HIP(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_make_keys, dim3((n + 255) / 256), dim3(256), 0, st, scores, n, keys_a, vals_a, n_valid_dev);
+  ODET_LAUNCH_CHECK();
+  int nblocks = (n + RS_TILE - 1) / RS_TILE;
+  uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+  for (int pass = 0; pass < 4; ++pass) {
+    int shift = pass * 8;
+    hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, n, shift, hist, nblocks);
+    ODET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, hist, nblocks * RS_RADIX);
+    ODET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, vin, n, shift, hist, nblocks, kout,
+                       vout);
+    ODET_LAUNCH_CHECK();
+    uint32_t* t;
+    t = kin; kin = kout; kout = t;
+    t = vin; vin = vout; vout = t;
+  }
+  *sorted_vals = vin;   // == vals_a after 4 passes
+  return ODET_OK;
+}

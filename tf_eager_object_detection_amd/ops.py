@@ -1,0 +1,300 @@
+"""Functional torch-tensor front-end of the C ABI (one function per odet_* entry point).
+
+Inputs and outputs are GPU tensors; shapes that depend on data (NMS survivors, filters) come
+back padded together with a device-side count.  The reference-surface modules in
+``model/`` and ``utils/`` slice them to the reference's dynamic shapes (one host sync, as the
+reference itself does at region_proposal.py:78 / prediction.py:147); ``pipeline.py`` keeps
+everything padded and sync-free.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+# constants of include/odet.h
+RPN_LAYOUT_FPN, RPN_LAYOUT_FRCNN = 0, 1
+ROI_NORM_STRIDE, ROI_NORM_IMAGE, ROI_NORM_TP_ALIGN = 0, 1, 2
+ROI_POOL_NONE, ROI_POOL_MAX2, ROI_POOL_AVG2 = 0, 1, 2
+ASSIGN_MAX_ROIS = 8192
+POSTOPS_MAX_ROIS = 4096
+POSTOPS_MAX_CANDIDATES = 8192
+MAX_LEVELS = 8
+
+
+def _boxes(t, name):
+    t = L.f32c(t, name)
+    if t.dim() != 2 or t.shape[1] != 4:
+        raise ValueError('%s must have shape [N,4], got %s' % (name, tuple(t.shape)))
+    return t
+
+
+def anchors_shift(anchor_base, feat_stride, height, width):
+    base = _boxes(anchor_base, 'anchor_base')
+    fh, fw = int(height), int(width)
+    out = torch.empty((fh * fw * base.shape[0], 4), dtype=torch.float32, device=base.device)
+    L.check(L.lib().odet_anchors_shift(L.dptr(base), base.shape[0], int(feat_stride), fh, fw, L.dptr(out), L.stream()))
+    return out
+
+
+def anchors_fpn(fh_list, fw_list, stride_list, wh_table, device):
+    """wh_table: float32 numpy [num_levels, A, 2] of (w, h) per level / anchor."""
+    nl = len(fh_list)
+    wh = np.ascontiguousarray(wh_table, dtype=np.float32)
+    A = wh.shape[1]
+    fh = (C.c_int * nl)(*[int(v) for v in fh_list])
+    fw = (C.c_int * nl)(*[int(v) for v in fw_list])
+    st = (C.c_int * nl)(*[int(v) for v in stride_list])
+    total = sum(int(a) * int(b) for a, b in zip(fh_list, fw_list)) * A
+    out = torch.empty((total, 4), dtype=torch.float32, device=device)
+    L.check(L.lib().odet_anchors_fpn(nl, A, fh, fw, st, wh.ctypes.data_as(C.c_void_p), L.dptr(out), L.stream()))
+    return out
+
+
+def decode(anchors, deltas, means, stds, clip_shape=None, out=None):
+    anchors = _boxes(anchors, 'anchors')
+    deltas = L.f32c(deltas, 'deltas')
+    n = anchors.shape[0]
+    if deltas.numel() != n * 4:
+        raise ValueError('deltas must hold %d x 4 values, got shape %s' % (n, tuple(deltas.shape)))
+    if out is None:
+        out = torch.empty((n, 4), dtype=torch.float32, device=anchors.device)
+    ch, cw = (0, 0) if clip_shape is None else (int(clip_shape[0]), int(clip_shape[1]))
+    L.check(L.lib().odet_decode(L.dptr(anchors), L.dptr(deltas), 4, n, L.host4(means, 'target_means'),
+                                L.host4(stds, 'target_stds'), ch, cw, L.dptr(out), L.stream()))
+    return out
+
+
+def encode(src, dst, means, stds):
+    src = _boxes(src, 'src_bbox')
+    dst = _boxes(dst, 'dst_bbox')
+    if src.shape != dst.shape:
+        raise ValueError('src_bbox and dst_bbox shapes differ: %s vs %s' % (tuple(src.shape), tuple(dst.shape)))
+    out = torch.empty_like(src)
+    L.check(L.lib().odet_encode(L.dptr(src), L.dptr(dst), src.shape[0], L.host4(means, 'target_means'),
+                                L.host4(stds, 'target_stds'), L.dptr(out), L.stream()))
+    return out
+
+
+def clip(boxes, min_value, max_height, max_width):
+    boxes = _boxes(boxes, 'boxes')
+    out = torch.empty_like(boxes)
+    L.check(L.lib().odet_clip(L.dptr(boxes), boxes.shape[0], float(min_value), int(max_height), int(max_width),
+                              L.dptr(out), L.stream()))
+    return out
+
+
+def _count_tensor(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def clip_filter(boxes, min_value, max_height, max_width, min_edge):
+    """-> (boxes [n,4] padded, idx int64 [n] padded, count int32[1] on device)"""
+    boxes = _boxes(boxes, 'boxes')
+    n = boxes.shape[0]
+    ob = torch.empty_like(boxes)
+    oi = torch.empty(n, dtype=torch.int64, device=boxes.device)
+    cnt = _count_tensor(boxes.device)
+    nb = L.lib().odet_compact_workspace_bytes(n)
+    ws = L.workspace(nb, boxes.device)
+    L.check(L.lib().odet_clip_filter(L.dptr(boxes), n, float(min_value), int(max_height), int(max_width),
+                                     float(min_edge), L.dptr(ob), L.dptr(oi), L.dptr(cnt), L.dptr(ws), nb, L.stream()))
+    return ob, oi, cnt
+
+
+def range_filter(boxes, max_height, max_width):
+    boxes = _boxes(boxes, 'anchors')
+    n = boxes.shape[0]
+    oi = torch.empty(n, dtype=torch.int64, device=boxes.device)
+    cnt = _count_tensor(boxes.device)
+    nb = L.lib().odet_compact_workspace_bytes(n)
+    ws = L.workspace(nb, boxes.device)
+    L.check(L.lib().odet_range_filter(L.dptr(boxes), n, int(max_height), int(max_width), L.dptr(oi), L.dptr(cnt),
+                                      L.dptr(ws), nb, L.stream()))
+    return oi, cnt
+
+
+def where_greater(values, threshold):
+    """tf.where(values > threshold)[:, 0] for a 1-D (possibly strided) float32 GPU tensor."""
+    if values.dim() != 1:
+        raise ValueError('values must be 1-D')
+    if values.dtype != torch.float32 or not values.is_cuda:
+        values = L.f32c(values, 'values')
+    n = values.shape[0]
+    stride = values.stride(0) if n > 1 else 1
+    if stride < 1:
+        values = values.contiguous()
+        stride = 1
+    oi = torch.empty(n, dtype=torch.int64, device=values.device)
+    cnt = _count_tensor(values.device)
+    nb = L.lib().odet_compact_workspace_bytes(n)
+    ws = L.workspace(nb, values.device)
+    L.check(L.lib().odet_where_greater(C.c_void_p(values.data_ptr()), stride, n, float(threshold), L.dptr(oi),
+                                       L.dptr(cnt), L.dptr(ws), nb, L.stream()))
+    return oi, cnt
+
+
+def pairwise_iou(b1, b2):
+    b1 = _boxes(b1, 'boxlist1')
+    b2 = _boxes(b2, 'boxlist2')
+    out = torch.empty((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=b1.device)
+    L.check(L.lib().odet_pairwise_iou(L.dptr(b1), b1.shape[0], L.dptr(b2), b2.shape[0], L.dptr(out), L.stream()))
+    return out
+
+
+def gather_rows(src, idx, count_dev=None):
+    src = L.f32c(src, 'src')
+    row = int(np.prod(src.shape[1:])) if src.dim() > 1 else 1
+    if idx.dtype not in (torch.int32, torch.int64):
+        raise TypeError('idx must be int32 or int64')
+    idx = idx.contiguous()
+    n = idx.shape[0]
+    out = torch.empty((n,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    L.check(L.lib().odet_gather_rows(L.dptr(src), L.dptr(idx), 1 if idx.dtype == torch.int64 else 0, n,
+                                     L.dptr(count_dev), row, L.dptr(out), L.stream()))
+    return out
+
+
+def rpn_fg_softmax(logits, num_anchors, layout):
+    logits = L.f32c(logits, 'rpn_score')
+    if layout == RPN_LAYOUT_FPN:
+        if logits.numel() % 2:
+            raise ValueError('FPN rpn scores must reshape to [-1, 2]')
+        n = logits.numel() // 2
+        out = torch.empty(n, dtype=torch.float32, device=logits.device)
+        L.check(L.lib().odet_rpn_fg_softmax(L.dptr(logits), n, 1, layout, L.dptr(out), L.stream()))
+    else:
+        A = int(num_anchors)
+        if logits.numel() % (2 * A):
+            raise ValueError('rpn scores must reshape to [-1, 2*num_anchors]')
+        nloc = logits.numel() // (2 * A)
+        out = torch.empty(nloc * A, dtype=torch.float32, device=logits.device)
+        L.check(L.lib().odet_rpn_fg_softmax(L.dptr(logits), nloc, A, layout, L.dptr(out), L.stream()))
+    return out
+
+
+def nms(boxes, scores, max_output_size, iou_threshold, with_boxes=False, blind_chunks=1, done=None):
+    """-> (idx int32 [K] padded, count int32[1]) (+ gathered boxes [K,4]).  ``done`` (int32[1]
+    GPU tensor) switches to the sync-free mode of odet_nms."""
+    boxes = _boxes(boxes, 'boxes')
+    scores = L.f32c(scores, 'scores').reshape(-1)
+    n = boxes.shape[0]
+    if scores.shape[0] != n:
+        raise ValueError('scores has %d entries for %d boxes' % (scores.shape[0], n))
+    K = max(min(int(max_output_size), n), 0)
+    idx = torch.empty(max(K, 1), dtype=torch.int32, device=boxes.device)
+    ob = torch.empty((max(K, 1), 4), dtype=torch.float32, device=boxes.device) if with_boxes else None
+    cnt = _count_tensor(boxes.device)
+    nb = L.lib().odet_nms_workspace_bytes(n, K)
+    ws = L.workspace(nb, boxes.device)
+    L.check(L.lib().odet_nms(L.dptr(boxes), L.dptr(scores), n, K, float(iou_threshold), L.dptr(idx), L.dptr(ob),
+                             L.dptr(cnt), int(blind_chunks), L.dptr(done), L.dptr(ws), nb, L.stream()))
+    return (idx, cnt, ob) if with_boxes else (idx, cnt)
+
+
+def region_proposal(deltas, anchors, scores, image_shape, num_post_nms, iou_threshold, means, stds,
+                    workspace=None, blind_chunks=1, done=None, out=None):
+    """-> (rois [K,4] padded, idx int32 [K] padded, count int32[1]).  ``done`` (int32[1] GPU
+    tensor) switches to the sync-free mode of odet_region_proposal."""
+    anchors = _boxes(anchors, 'anchors')
+    deltas = L.f32c(deltas, 'bboxes_txtytwth')
+    scores = L.f32c(scores, 'scores').reshape(-1)
+    n = anchors.shape[0]
+    if deltas.numel() != n * 4 or scores.shape[0] != n:
+        # the reference would raise InvalidArgumentError from TF on mismatched N
+        raise ValueError('RegionProposal: %d anchors but deltas %s / scores %s'
+                         % (n, tuple(deltas.shape), tuple(scores.shape)))
+    K = max(min(int(num_post_nms), n), 0)
+    if out is not None:
+        rois, idx, cnt = out
+    else:
+        rois = torch.empty((max(K, 1), 4), dtype=torch.float32, device=anchors.device)
+        idx = torch.empty(max(K, 1), dtype=torch.int32, device=anchors.device)
+        cnt = _count_tensor(anchors.device)
+    nb = L.lib().odet_region_proposal_workspace_bytes(n, K)
+    ws = workspace if workspace is not None and workspace.numel() >= nb else L.workspace(nb, anchors.device)
+    L.check(L.lib().odet_region_proposal(L.dptr(deltas), L.dptr(anchors), L.dptr(scores), n, int(image_shape[0]),
+                                         int(image_shape[1]), L.host4(means, 'target_means'),
+                                         L.host4(stds, 'target_stds'), K, float(iou_threshold), L.dptr(rois),
+                                         L.dptr(idx), L.dptr(cnt), int(blind_chunks), L.dptr(done), L.dptr(ws),
+                                         ws.numel(), L.stream()))
+    return rois, idx, cnt
+
+
+def assign_levels(rois, min_level, max_level, count_dev=None):
+    """-> (sorted rois [n,4], level int32 [n] (0-based), perm int64 [n], counts int32 [L])"""
+    rois = _boxes(rois, 'all_rois')
+    n = rois.shape[0]
+    nl = int(max_level) - int(min_level) + 1
+    out = torch.empty_like(rois)
+    lvl = torch.empty(max(n, 1), dtype=torch.int32, device=rois.device)
+    perm = torch.empty(max(n, 1), dtype=torch.int64, device=rois.device)
+    counts = torch.zeros(nl, dtype=torch.int32, device=rois.device)
+    L.check(L.lib().odet_assign_levels(L.dptr(rois), n, L.dptr(count_dev), int(min_level), int(max_level),
+                                       L.dptr(out), L.dptr(lvl), L.dptr(perm), L.dptr(counts), L.stream()))
+    return out, lvl[:n], perm[:n], counts
+
+
+def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, strides=None, image_shape=None,
+             count_dev=None, out=None):
+    """feature_maps: list of NHWC float32 GPU tensors [1,H,W,C] (one per level)."""
+    rois = _boxes(rois, 'rois')
+    n = rois.shape[0]
+    nl = len(feature_maps)
+    if nl < 1 or nl > MAX_LEVELS:
+        raise ValueError('between 1 and %d feature maps expected' % MAX_LEVELS)
+    levels = (L.OdetLevel * nl)()
+    keep = []
+    Cc = None
+    for i, fm in enumerate(feature_maps):
+        fm = L.f32c(fm, 'shared_layers')
+        if fm.dim() != 4 or fm.shape[0] != 1:
+            raise ValueError('feature map must be NHWC with batch 1, got %s' % (tuple(fm.shape),))
+        if Cc is None:
+            Cc = fm.shape[3]
+        elif fm.shape[3] != Cc:
+            raise ValueError('all levels must share the channel count')
+        keep.append(fm)
+        levels[i].data = fm.data_ptr()
+        levels[i].H = fm.shape[1]
+        levels[i].W = fm.shape[2]
+        levels[i].stride = float(strides[i]) if strides is not None else 0.0
+    P = int(pool_size)
+    if out is None:
+        out = torch.empty((n, P, P, Cc), dtype=torch.float32, device=rois.device)
+    ih, iw = (0, 0) if image_shape is None else (int(image_shape[0]), int(image_shape[1]))
+    if roi_level is not None and roi_level.dtype != torch.int32:
+        roi_level = roi_level.to(torch.int32)
+    L.check(L.lib().odet_roi_pool(levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
+                                  int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream()))
+    return out
+
+
+def post_ops(scores, deltas, rois, image_shape, means, stds, max_per_class, max_per_image, nms_iou_threshold,
+             score_threshold, min_edge, num_classes, count_dev=None):
+    """-> (boxes [M,4], labels int32 [M], scores [M]) padded to max_per_image, count int32[1]"""
+    scores = L.f32c(scores, 'roi_scores_softmax')
+    if scores.dim() != 2:
+        raise ValueError('roi_scores_softmax must be [num_rois, num_classes]')
+    R, Ccls = scores.shape
+    deltas = L.f32c(deltas, 'roi_txtytwth')
+    if deltas.numel() != R * Ccls * 4:
+        raise ValueError('roi_txtytwth must hold [num_rois, num_classes, 4] values')
+    rois = _boxes(rois, 'rois')
+    if rois.shape[0] != R:
+        raise ValueError('rois has %d rows for %d score rows' % (rois.shape[0], R))
+    M = max(int(max_per_image), 1)
+    ob = torch.empty((M, 4), dtype=torch.float32, device=scores.device)
+    ol = torch.empty(M, dtype=torch.int32, device=scores.device)
+    os_ = torch.empty(M, dtype=torch.float32, device=scores.device)
+    cnt = _count_tensor(scores.device)
+    nb = L.lib().odet_post_ops_workspace_bytes(int(num_classes), int(max_per_class))
+    ws = L.workspace(nb, scores.device)
+    L.check(L.lib().odet_post_ops(L.dptr(scores), L.dptr(deltas), L.dptr(rois), R, L.dptr(count_dev), Ccls,
+                                  int(num_classes), int(image_shape[0]), int(image_shape[1]),
+                                  L.host4(means, 'target_means'), L.host4(stds, 'target_stds'),
+                                  int(max_per_class), int(max_per_image), float(nms_iou_threshold),
+                                  float(score_threshold), float(min_edge), L.dptr(ob), L.dptr(ol), L.dptr(os_),
+                                  L.dptr(cnt), L.dptr(ws), nb, L.stream()))
+    return ob, ol, os_, cnt

@@ -1,0 +1,60 @@
+"""Image-parallel multi-GPU harness: one process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI on ROCm; "gloo" for the CPU tests), images sharded round-robin over ranks,
+ONE all-gather of fixed-size detection records per batch.
+
+The reference has no multi-GPU code at all (README "multi gpu support" is an unchecked TODO;
+batch is hard-wired to 1: model/roi_pooling.py:28,66,152).  The path shards naturally by image
+-- no stage has cross-image state -- so there is no data-path collective inside an image; the
+only exchange is the final record all-gather, which is latency-bound (<= 7.2 KB per image).
+
+Record layout per image: float32 [max_det, 6] = (x1, y1, x2, y2, score, label), padded rows have
+score = -1; plus the valid count.  Packed as one float32 [max_det*6 + 1] vector so a batch costs
+exactly one collective.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_images(num_images, rank, world_size):
+    """Image indices owned by `rank`: r, r+G, r+2G, ... (weak scaling: per-GPU work is fixed when the
+    global batch grows with the number of GPUs)."""
+    return list(range(rank, num_images, world_size))
+
+
+def pack_detections(boxes, labels, scores, count, max_det):
+    """Padded post-ops outputs (+ device count) -> float32 [max_det*6+1] record vector, no host sync."""
+    dev = boxes.device
+    rec = torch.empty(max_det * 6 + 1, dtype=torch.float32, device=dev)
+    body = rec[:max_det * 6].view(max_det, 6)
+    m = min(max_det, boxes.shape[0])
+    valid = (torch.arange(max_det, device=dev) < count.to(torch.int64)).to(torch.float32)[:, None]
+    body.zero_()
+    body[:m, 0:4] = boxes[:m]
+    body[:m, 4] = scores[:m]
+    body[:m, 5] = labels[:m].to(torch.float32)
+    body.mul_(valid)
+    body[:, 4] = body[:, 4] * valid[:, 0] - (1.0 - valid[:, 0])        # padded rows: score = -1
+    rec[max_det * 6] = count.to(torch.float32).reshape(())
+    return rec
+
+
+def unpack_detections(rec, max_det):
+    """record vector -> (boxes [M,4], labels int32 [M], scores [M]) with M = stored count (host sync)."""
+    m = int(rec[max_det * 6].item())
+    body = rec[:max_det * 6].view(max_det, 6)[:m]
+    return body[:, 0:4], body[:, 5].to(torch.int32), body[:, 4]
+
+
+def all_gather_detections(rec, group=None):
+    """One collective per batch: every rank receives every rank's record vector -> [world, len]."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return rec[None]
+    out = torch.empty((world, rec.numel()), dtype=rec.dtype, device=rec.device)
+    if rec.is_cuda:
+        dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
+    else:
+        parts = [torch.empty_like(rec) for _ in range(world)]     # gloo: list form
+        dist.all_gather(parts, rec.contiguous(), group=group)
+        out = torch.stack(parts, 0)
+    return out

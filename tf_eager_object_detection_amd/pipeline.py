@@ -1,0 +1,128 @@
+"""Static-shape, sync-free FPN detection hot path (MI355X-first arrangement of the reference's
+BaseFPN.call inference branch, model/fpn/base_fpn_model.py:208-276, minus the dense conv parts).
+
+The reference-surface modules return dynamically shaped tensors and therefore sync with the host
+once per stage (as the TF-eager reference does).  A production loop does not want that: here all
+buffers are allocated once at their maximum size, data-dependent counts stay in device memory and
+are consumed by the next kernel, and nothing between the RPN head's output and the final padded
+detections touches the host -- so the whole stage sequence can be replayed from a HIP graph.
+
+    stage_proposals : anchors (all levels, 1 launch) -> fg softmax -> decode+clip -> radix sort ->
+                      bit-matrix NMS -> level assignment (stable partition)
+    stage_roi       : fused crop_and_resize(14x14)+maxpool over P2..P5, level-sorted RoIs
+    stage_detect    : per-class filter/decode/clip/NMS (one workgroup per class) -> top-k merge
+"""
+import numpy as np
+import torch
+
+from . import ops
+from . import synthetic as syn
+from .utils.anchor_generator import make_fpn_anchors
+
+
+class FpnHotPath:
+    def __init__(self, image_shape, num_classes=21, num_proposals=1000, channels=256, pool_size=7,
+                 rpn_nms_iou=0.7, rpn_means=(0, 0, 0, 0), rpn_stds=(1, 1, 1, 1),
+                 roi_means=(0, 0, 0, 0), roi_stds=(0.1, 0.1, 0.2, 0.2), max_per_class=50, max_per_image=50,
+                 nms_iou=0.3, score_threshold=0.0, min_level=2, max_level=5, strides=syn.FPN_STRIDES,
+                 base_sizes=syn.FPN_BASE_SIZES, ratios=syn.FPN_RATIOS, scales=syn.FPN_SCALES,
+                 blind_chunks=2, device=None):
+        self.image_shape = [int(image_shape[0]), int(image_shape[1])]
+        self.num_classes = num_classes
+        self.K = num_proposals
+        self.C = channels
+        self.P = pool_size
+        self.cfg = dict(rpn_nms_iou=rpn_nms_iou, rpn_means=list(rpn_means), rpn_stds=list(rpn_stds),
+                        roi_means=list(roi_means), roi_stds=list(roi_stds), max_per_class=max_per_class,
+                        max_per_image=max_per_image, nms_iou=nms_iou, score_threshold=score_threshold)
+        self.min_level, self.max_level = min_level, max_level
+        self.strides, self.base_sizes, self.ratios, self.scales = strides, base_sizes, ratios, scales
+        self.blind_chunks = blind_chunks
+        self.device = device or torch.device('cuda', torch.cuda.current_device())
+        self.N = syn.num_fpn_anchors(self.image_shape, strides, len(ratios) * len(scales))
+        dev = self.device
+        K = self.K
+        # persistent buffers (allocated once; 288 GB of HBM makes this a non-issue)
+        nb = ops.L.lib().odet_region_proposal_workspace_bytes(self.N, K)
+        self.ws_rpn = torch.empty(nb, dtype=torch.uint8, device=dev)
+        self.rois = torch.zeros((K, 4), dtype=torch.float32, device=dev)
+        self.roi_idx = torch.zeros(K, dtype=torch.int32, device=dev)
+        self.roi_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nms_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.roi_features = torch.zeros((K, pool_size, pool_size, channels), dtype=torch.float32, device=dev)
+
+    # ---- stage 1: RPN outputs -> level-sorted proposals -------------------------------------
+    def stage_proposals(self, rpn_logits, rpn_deltas):
+        """rpn_logits [N,2] (bg,fg) as RpnHead emits them (base_fpn_model.py:429), rpn_deltas [N,4]."""
+        anchors = make_fpn_anchors(self.image_shape, self.strides, self.base_sizes, self.scales, self.ratios)
+        scores = ops.rpn_fg_softmax(rpn_logits, 1, ops.RPN_LAYOUT_FPN)                  # :223
+        ops.region_proposal(rpn_deltas, anchors, scores, self.image_shape, self.K, self.cfg['rpn_nms_iou'],
+                            self.cfg['rpn_means'], self.cfg['rpn_stds'], workspace=self.ws_rpn,
+                            blind_chunks=self.blind_chunks, done=self.nms_done,
+                            out=(self.rois, self.roi_idx, self.roi_count))              # :224
+        self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts = ops.assign_levels(
+            self.rois, self.min_level, self.max_level, count_dev=self.roi_count)        # :256 / :303-324
+        return self.sorted_rois, self.roi_level, self.roi_count
+
+    # ---- stage 2: RoI features ---------------------------------------------------------------
+    def stage_roi(self, p_list):
+        """p_list: P2..P5 NHWC feature maps.  -> [K,P,P,C] (rows >= count are zero)."""
+        nl = self.max_level - self.min_level + 1
+        return ops.roi_pool(list(p_list[:nl]), self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P,
+                            ops.ROI_POOL_MAX2, image_shape=self.image_shape, count_dev=self.roi_count,
+                            out=self.roi_features)                                      # :257 / :152-161
+
+    # ---- stage 3: RoI-head outputs -> detections ---------------------------------------------
+    def stage_detect(self, cls_softmax, cls_deltas):
+        """cls_softmax [K,Ccls], cls_deltas [K,Ccls,4] for the level-sorted RoIs (rows >= count ignored)."""
+        c = self.cfg
+        return ops.post_ops(cls_softmax, cls_deltas, self.sorted_rois, self.image_shape, c['roi_means'],
+                            c['roi_stds'], c['max_per_class'], c['max_per_image'], c['nms_iou'],
+                            c['score_threshold'], 16, self.num_classes, count_dev=self.roi_count)   # :267-275
+
+    def step(self, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
+        """One image through the whole hot path (the RoI head that sits between stage 2 and 3 in the
+        model is not part of this path; its outputs are inputs here)."""
+        self.stage_proposals(rpn_logits, rpn_deltas)
+        feats = self.stage_roi(p_list)
+        boxes, labels, scores, count = self.stage_detect(cls_softmax, cls_deltas)
+        return feats, boxes, labels, scores, count
+
+
+def synthetic_fpn_inputs(image_shape, num_classes=21, num_proposals=1000, channels=256, seed=1234,
+                         score_kind='distinct', device='cuda'):
+    """Seeded synthetic inputs of SURVEY.md section 8(d) for one image, as numpy + GPU tensors."""
+    rng = np.random.default_rng(seed)
+    shapes = syn.fpn_level_shapes(image_shape)
+    n = syn.num_fpn_anchors(image_shape)
+    feats = syn.features(shapes[:4], channels, rng)
+    deltas = syn.rpn_deltas(n, rng, 0.1)
+    if score_kind == 'distinct':
+        prob = syn.scores_distinct(n, rng)
+    else:
+        from .utils.anchor_generator import _wh_table  # anchors on the host only to place the clusters
+        anchors = _host_fpn_anchors(image_shape)
+        prob = syn.scores_clustered(anchors, image_shape, rng)
+    logits = syn.logits_from_prob(prob, rng)
+    cls_scores = syn.class_scores(num_proposals, num_classes, rng)
+    cls_deltas = syn.class_deltas(num_proposals, num_classes, rng)
+    host = dict(feats=feats, rpn_deltas=deltas, rpn_logits=logits, cls_scores=cls_scores, cls_deltas=cls_deltas)
+    dev = {k: ([torch.from_numpy(x).to(device) for x in v] if isinstance(v, list) else torch.from_numpy(v).to(device))
+           for k, v in host.items()}
+    return host, dev
+
+
+def _host_fpn_anchors(image_shape):
+    """numpy FPN anchors (only used to build clustered synthetic scores)."""
+    from .utils.anchor_generator import _wh_table
+    out = []
+    for (fh, fw), s, b in zip(syn.fpn_level_shapes(image_shape), syn.FPN_STRIDES, syn.FPN_BASE_SIZES):
+        wh = _wh_table(b, syn.FPN_SCALES, syn.FPN_RATIOS)
+        xs = np.arange(fw, dtype=np.float32) * np.float32(s)
+        ys = np.arange(fh, dtype=np.float32) * np.float32(s)
+        cx = np.tile(xs, fh)[:, None]
+        cy = np.repeat(ys, fw)[:, None]
+        hw = np.float32(0.5) * wh[None, :, 0]
+        hh = np.float32(0.5) * wh[None, :, 1]
+        out.append(np.stack([cx - hw, cy - hh, cx + hw, cy + hh], axis=2).reshape(-1, 4))
+    return np.concatenate(out, axis=0).astype(np.float32)
