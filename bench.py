@@ -159,8 +159,8 @@ def main():
         hot.stage_roi(dev['feats'])
         if i is not None:
             ev_roi[i][1].record()
-        boxes, labels, scores, count = hot.stage_detect(dev['cls_scores'], dev['cls_deltas'])
-        rec = parallel.pack_detections(boxes, labels, scores, count, max_det)
+        hot.stage_detect(dev['cls_scores'], dev['cls_deltas'])
+        rec = hot.stage_record()
         return parallel.all_gather_detections(rec) if world > 1 else rec
 
     def fence():

@@ -203,6 +203,16 @@ int odet_post_ops(const float* scores, const float* deltas, const float* rois, i
                   float* out_boxes, int32_t* out_labels, float* out_scores, int32_t* out_count,
                   void* workspace, size_t workspace_bytes, odet_stream_t stream);
 
+/* ---- multi-GPU detection records ------------------------------------------------------ */
+
+/* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of
+ * one image into the fixed-size record exchanged by the image-parallel all-gather:
+ * out_record float32 [max_det*6 + 1] = max_det rows (x1,y1,x2,y2,score,label), padded rows
+ * zero with score -1, then the count.  capacity = rows available in boxes/labels/scores. */
+int odet_pack_detections(const float* boxes, const int32_t* labels, const float* scores,
+                         const int32_t* count_dev, int capacity, int max_det, float* out_record,
+                         odet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,7 +77,8 @@ def test_decode_encode_clip():
     close(h(encode_bbox_with_mean_and_std(g(anchors), g(gt), M0, S2)), co.encode(anchors, gt, M0, S2))
     # KA5
     z = h(decode_bbox_with_mean_and_std(g(anchors[:100]), g(np.zeros((100, 4), np.float32)), M0, S1))
-    np.testing.assert_array_equal(z, anchors[:100] + np.float32([0, 0, 1, 1]))
+    np.testing.assert_allclose(z, anchors[:100] + np.float32([0, 0, 1, 1]), rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(z, co.decode(anchors[:100], np.zeros((100, 4), np.float32), M0, S1))
     # fused decode+clip == decode then clip
     d = syn.rpn_deltas(n, rng, 0.3)
     fused = h(ops.decode(g(anchors), g(d), M0, S1, clip_shape=(600, 800)))

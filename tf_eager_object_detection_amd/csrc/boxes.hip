@@ -375,8 +375,8 @@ extern "C" int odet_where_greater(const float* values, int64_t stride, int n, fl
 // coalesced; boxes1[i] is a wave-uniform (scalar) load.
 __global__ void __launch_bounds__(256) k_pairwise_iou(const float4* __restrict__ b1, int n, const float4* __restrict__ b2,
                                                       int m, float* __restrict__ out) {
-  int j = blockIdx.x * 64 + (threadIdx.x & 63);
-  int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+  int j = blockIdx.y * 64 + (threadIdx.x & 63);
+  int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n || j >= m) return;
   float4 p = b1[i], q = b2[j];
   float a1 = (p.w - p.y + 1.0f) * (p.z - p.x + 1.0f);            // bbox_tf.py:14-15
@@ -393,8 +393,8 @@ extern "C" int odet_pairwise_iou(const float* boxes1, int n, const float* boxes2
   ODET_REQUIRE(n >= 0 && m >= 0, "odet_pairwise_iou: negative size");
   if (n == 0 || m == 0) return ODET_OK;
   ODET_REQUIRE(boxes1 && boxes2 && out, "odet_pairwise_iou: null pointer");
-  ODET_REQUIRE((n + 3) / 4 <= 65535, "odet_pairwise_iou: n too large for one launch (max 262140)");
-  hipLaunchKernelGGL(k_pairwise_iou, dim3((m + 63) / 64, (n + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+  ODET_REQUIRE((m + 63) / 64 <= 65535, "odet_pairwise_iou: m too large for one launch (max 4194240)");
+  hipLaunchKernelGGL(k_pairwise_iou, dim3((n + 3) / 4, (m + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const float4*)boxes1, n, (const float4*)boxes2, m, out);
   ODET_LAUNCH_CHECK();
   return ODET_OK;

@@ -6,15 +6,17 @@
 // the candidates in descending-score order until max_output are kept, so the GPU version is:
 //
 //   1. stable radix sort of all n (score, index) pairs                       (sort.hip)
-//   2. per chunk of NMS_CHUNK = 4096 sorted candidates, until K kept or exhausted:
+//   2. per chunk of sorted candidates (first chunk ~1.5*K, later ones 4096), until K kept or
+//      the candidates are exhausted:
 //      a. k_nms_gather : boxes of the chunk in sorted order, corners normalised
 //      b. k_nms_cross  : (chunks > 0) candidates vs. boxes kept by earlier chunks -> bitmask
-//      c. k_nms_mask   : upper-triangular 4096x4096 suppression bit matrix, one wave per
+//      c. k_nms_mask   : upper-triangular suppression bit matrix of the chunk, one wave per
 //                        64x64 tile (whole chip busy), 64-bit word per (row, column block)
 //      d. k_nms_scan   : ONE workgroup walks the chunk in 64-candidate blocks: wave 0 resolves a
 //                        block serially on the scalar unit (ctz over the alive mask, diagonal
 //                        rows via v_readlane), then four waves OR the kept rows (prefetched
 //                        one block ahead into registers) into the removed-bit vector in LDS.
+//                        Outputs are written by all threads after the walk.
 //
 // The decision for every candidate is the same predicate TF evaluates (d_iou_gt), so kept
 // indices are identical to the serial algorithm, including the early stop at max_output.
@@ -23,30 +25,22 @@
 #define NMS_CHUNK 4096
 #define NMS_WORDS (NMS_CHUNK / 64)   // 64 u64 words per mask row
 
-struct NmsState {
-  int32_t n_valid;   // candidates TF would push into its heap
-  int32_t kept;      // boxes kept so far
-  int32_t pos;       // sorted candidates consumed so far
-  int32_t done;      // kept == K or pos == n_valid
-  int32_t chunk_m;   // size of the current chunk
+struct NmsState {      // zeroed by one memset per call
+  int32_t n_invalid;   // scores TF would not push into its heap (NaN, <= lowest float)
+  int32_t kept;        // boxes kept so far
+  int32_t pos;         // sorted candidates consumed so far
+  int32_t done;        // kept == K or pos == n_valid
+  int32_t chunk_m;     // size of the current chunk
   int32_t pad[3];
 };
 
-__global__ void k_nms_init(NmsState* st, int32_t* out_count) {
-  st->kept = 0;
-  st->pos = 0;
-  st->done = (st->n_valid == 0) ? 1 : 0;
-  st->chunk_m = 0;
-  *out_count = 0;
-}
-
 // a. gather the chunk's boxes in sorted order (corner-normalised) --------------------------
-__global__ void __launch_bounds__(256) k_nms_gather(NmsState* st, const float4* __restrict__ boxes,
+__global__ void __launch_bounds__(256) k_nms_gather(NmsState* st, int n, int cap, const float4* __restrict__ boxes,
                                                     const uint32_t* __restrict__ sorted_idx,
                                                     float4* __restrict__ sboxes) {
-  int pos = st->pos, nv = st->n_valid;
-  int m = st->done ? 0 : min(NMS_CHUNK, nv - pos);
-  int i = blockIdx.x * 256 + threadIdx.x;
+  const int pos = st->pos, nv = n - st->n_invalid;
+  const int m = st->done ? 0 : min(cap, nv - pos);
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) st->chunk_m = m;
   if (i < m) sboxes[i] = d_norm_box(boxes[sorted_idx[pos + i]]);
 }
@@ -57,10 +51,11 @@ __global__ void __launch_bounds__(256) k_nms_cross(const NmsState* st, const flo
                                                    unsigned long long* __restrict__ removed_init) {
   __shared__ float4 kb[256];
   __shared__ float ka[256];
-  int m = st->chunk_m, nk = st->kept;
-  int j = blockIdx.x * 256 + threadIdx.x;
-  float4 b = (j < m) ? sboxes[j] : make_float4(0, 0, 0, 0);
-  float area = d_box_area(b);
+  const int m = st->chunk_m, nk = st->kept;
+  if (blockIdx.x * 256 >= m) return;          // nothing to do for this block (also: finished NMS)
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const float4 b = (j < m) ? sboxes[j] : make_float4(0, 0, 0, 0);
+  const float area = d_box_area(b);
   bool sup = false;
   for (int k0 = 0; k0 < nk; k0 += 256) {
     __syncthreads();
@@ -70,7 +65,7 @@ __global__ void __launch_bounds__(256) k_nms_cross(const NmsState* st, const flo
       ka[threadIdx.x] = d_box_area(t);
     }
     __syncthreads();
-    int lim = min(256, nk - k0);
+    const int lim = min(256, nk - k0);
     for (int k = 0; k < lim; ++k) sup = sup || d_iou_gt(b, area, kb[k], ka[k], thr);
   }
   unsigned long long bal = __ballot(sup && j < m);
@@ -83,31 +78,30 @@ __global__ void __launch_bounds__(256) k_nms_cross(const NmsState* st, const flo
 __global__ void __launch_bounds__(64) k_nms_mask(const NmsState* st, const float4* __restrict__ sboxes, float thr,
                                                  unsigned long long* __restrict__ mask,
                                                  unsigned long long* __restrict__ diag) {
-  int cb = blockIdx.x, rb = blockIdx.y;
+  const int cb = blockIdx.x, rb = blockIdx.y;
   if (cb < rb) return;
-  int m = st->chunk_m;
+  const int m = st->chunk_m;
   if (rb * 64 >= m) return;
   __shared__ float4 cbox[64];
   __shared__ float carea[64];
-  int lane = threadIdx.x;
-  int col = cb * 64 + lane;
-  float4 c = (col < m) ? sboxes[col] : make_float4(0, 0, 0, 0);   // zero area never suppresses
+  const int lane = threadIdx.x;
+  const int col = cb * 64 + lane;
+  const float4 c = (col < m) ? sboxes[col] : make_float4(0, 0, 0, 0);   // zero area never suppresses
   cbox[lane] = c;
   carea[lane] = d_box_area(c);
   __syncthreads();
-  int row = rb * 64 + lane;
-  float4 r = (row < m) ? sboxes[row] : make_float4(0, 0, 0, 0);
-  float ra = d_box_area(r);
+  const int row = rb * 64 + lane;
+  const float4 r = (row < m) ? sboxes[row] : make_float4(0, 0, 0, 0);
+  const float ra = d_box_area(r);
   unsigned long long bits = 0;
-  int jstart = (cb == rb) ? 0 : 0;
 #pragma unroll 8
-  for (int j = jstart; j < 64; ++j) {
+  for (int j = 0; j < 64; ++j) {
     bool s = d_iou_gt(r, ra, cbox[j], carea[j], thr);
     bits |= s ? (1ull << j) : 0ull;
   }
   if (cb == rb) {
     // only later candidates (j > lane) can be suppressed by this row
-    unsigned long long later = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+    const unsigned long long later = (lane == 63) ? 0ull : (~0ull << (lane + 1));
     bits &= later;
     if (row < m) diag[row] = bits;
   }
@@ -115,9 +109,15 @@ __global__ void __launch_bounds__(64) k_nms_mask(const NmsState* st, const float
 }
 
 // d. serial scan ------------------------------------------------------------------------------
+// LDS: two staging buffers of one 64-candidate block each (64 rows x 64 words + 64 diagonal words).
+// Iteration b: (1) issue the global loads of block b+1 (they fly during the resolve), (2) wave 0
+// resolves block b from LDS only, (3) all waves OR the kept rows of block b (LDS) into `removed`,
+// (4) the loaded rows of block b+1 are written to the other staging buffer.
 #define SCAN_THREADS 256
 #define SCAN_WAVES 4
 #define SCAN_ROWS 16   // rows of a 64-candidate block owned by each wave
+#define SCAN_STAGE_WORDS (64 * NMS_WORDS + 64)
+#define SCAN_DYN_LDS (2 * SCAN_STAGE_WORDS * 8)
 
 __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -126,97 +126,132 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(
-    NmsState* st, const unsigned long long* __restrict__ mask, const unsigned long long* __restrict__ diag,
+    NmsState* st, int n, const unsigned long long* __restrict__ mask, const unsigned long long* __restrict__ diag,
     const unsigned long long* __restrict__ removed_init, int use_init, const float4* __restrict__ sboxes,
     const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ boxes, int K,
     int32_t* __restrict__ out_idx, float4* __restrict__ out_boxes, float4* __restrict__ kept_boxes,
-    int32_t* __restrict__ out_count) {
+    int32_t* __restrict__ out_count, int32_t* __restrict__ out_done) {
+  extern __shared__ __align__(16) unsigned long long stage[];   // [2][SCAN_STAGE_WORDS]
   __shared__ unsigned long long removed[NMS_WORDS];
+  __shared__ unsigned long long keptbits[NMS_WORDS];
+  __shared__ int keptpre[NMS_WORDS + 1];
   __shared__ unsigned long long s_kept64;
   __shared__ int s_nkept;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int m = st->chunk_m;
   const int pos0 = st->pos;
+  const int nk0 = st->kept;
   const int nblk = (m + 63) >> 6;
   if (threadIdx.x < NMS_WORDS) {
     unsigned long long r = use_init ? removed_init[threadIdx.x] : 0ull;
     // candidates beyond m do not exist
-    int lo = threadIdx.x * 64;
+    const int lo = threadIdx.x * 64;
     if (lo + 64 > m) r |= (lo >= m) ? ~0ull : (~0ull << (m - lo));
     removed[threadIdx.x] = r;
+    keptbits[threadIdx.x] = 0ull;
   }
-  if (threadIdx.x == 0) { s_nkept = st->kept; s_kept64 = 0; }
-  __syncthreads();
+  if (threadIdx.x == 0) { s_nkept = nk0; s_kept64 = 0; }
 
-  unsigned long long rows[SCAN_ROWS], nrows[SCAN_ROWS];
-  unsigned long long d = 0, nd = 0;
+  unsigned long long nrows[SCAN_ROWS];
+  unsigned long long nd = 0;
+  // block 0 -> staging buffer 0
   if (nblk > 0) {
 #pragma unroll
     for (int q = 0; q < SCAN_ROWS; ++q) {
-      int r = w * SCAN_ROWS + q;
-      rows[q] = (r < m) ? mask[(size_t)r * NMS_WORDS + lane] : 0ull;
+      const int r = w * SCAN_ROWS + q;
+      stage[(size_t)r * NMS_WORDS + lane] = (r < m) ? mask[(size_t)r * NMS_WORDS + lane] : 0ull;
     }
-    if (w == 0) d = (lane < m) ? diag[lane] : 0ull;
+    if (w == 0) stage[64 * NMS_WORDS + lane] = (lane < m) ? diag[lane] : 0ull;
   }
+  __syncthreads();
 
+  const unsigned long long lt_lane = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int b = 0; b < nblk; ++b) {
-    // prefetch the next block's rows / diagonal (independent of any decision)
-    if (b + 1 < nblk) {
+    unsigned long long* cur = stage + (size_t)(b & 1) * SCAN_STAGE_WORDS;
+    unsigned long long* nxt = stage + (size_t)((b + 1) & 1) * SCAN_STAGE_WORDS;
+    const bool more = (b + 1 < nblk);
+    // (1) loads of the next block (independent of any decision)
+    if (more) {
 #pragma unroll
       for (int q = 0; q < SCAN_ROWS; ++q) {
-        int r = (b + 1) * 64 + w * SCAN_ROWS + q;
+        const int r = (b + 1) * 64 + w * SCAN_ROWS + q;
         nrows[q] = (r < m) ? mask[(size_t)r * NMS_WORDS + lane] : 0ull;
       }
-      if (w == 0) { int r = (b + 1) * 64 + lane; nd = (r < m) ? diag[r] : 0ull; }
+      if (w == 0) { const int r = (b + 1) * 64 + lane; nd = (r < m) ? diag[r] : 0ull; }
     }
+    // (2) resolve this block: only candidates that actually suppress a still-alive later candidate
+    //     need a serial step; everything else that is alive is kept.
     if (w == 0) {
-      // serial resolve of this block on the scalar unit
       unsigned long long alive = ~rfl64(removed[b]);
-      int cnt = __builtin_amdgcn_readfirstlane(s_nkept);
-      const int cnt0 = cnt;
-      unsigned long long kept = 0;
-      uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
-      while (alive != 0 && cnt < K) {
-        int i = __builtin_ctzll(alive);
-        kept |= 1ull << i;
-        ++cnt;
-        uint32_t rlo = __builtin_amdgcn_readlane(dlo, i);
-        uint32_t rhi = __builtin_amdgcn_readlane(dhi, i);
+      const int cnt0 = __builtin_amdgcn_readfirstlane(s_nkept);
+      const unsigned long long d = cur[64 * NMS_WORDS + lane];
+      const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
+      for (;;) {
+        const bool is_s = ((alive >> lane) & 1ull) && ((d & alive) != 0ull);
+        const unsigned long long supp = __ballot(is_s);
+        if (supp == 0) break;
+        const int i = __builtin_ctzll(supp);
+        const uint32_t rlo = __builtin_amdgcn_readlane(dlo, i);
+        const uint32_t rhi = __builtin_amdgcn_readlane(dhi, i);
         alive &= ~(((unsigned long long)rhi << 32) | rlo);
-        alive &= ~(1ull << i);
       }
-      if ((kept >> lane) & 1ull) {
-        unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        int p = cnt0 + (int)__popcll(kept & lt);
-        int c = b * 64 + lane;
-        uint32_t oi = sorted_idx[pos0 + c];
-        out_idx[p] = (int32_t)oi;
-        if (out_boxes) out_boxes[p] = boxes[oi];
-        kept_boxes[p] = sboxes[c];
-      }
-      if (lane == 0) { s_kept64 = kept; s_nkept = cnt; }
+      // stop at max_output: keep only the first (K - cnt0) survivors
+      const int room = K - cnt0;
+      const int npop = (int)__popcll(alive);
+      unsigned long long kept = alive;
+      if (npop > room)
+        kept = __ballot(((alive >> lane) & 1ull) && (int)__popcll(alive & lt_lane) < room);
+      if (lane == 0) { s_kept64 = kept; s_nkept = cnt0 + min(npop, room); keptbits[b] = kept; }
     }
     __syncthreads();
+    // (3) OR the kept rows into the removed vector
     const unsigned long long kept = rfl64(s_kept64);
     const int nk = __builtin_amdgcn_readfirstlane(s_nkept);
     unsigned long long acc = 0;
 #pragma unroll
-    for (int q = 0; q < SCAN_ROWS; ++q)
-      if ((kept >> (w * SCAN_ROWS + q)) & 1ull) acc |= rows[q];
+    for (int q = 0; q < SCAN_ROWS; ++q) {
+      const int r = w * SCAN_ROWS + q;
+      if ((kept >> r) & 1ull) acc |= cur[(size_t)r * NMS_WORDS + lane];
+    }
     if (lane > b && acc) atomicOr(&removed[lane], acc);
+    // (4) stage the next block
+    if (more) {
 #pragma unroll
-    for (int q = 0; q < SCAN_ROWS; ++q) rows[q] = nrows[q];
-    d = nd;
+      for (int q = 0; q < SCAN_ROWS; ++q) nxt[(size_t)(w * SCAN_ROWS + q) * NMS_WORDS + lane] = nrows[q];
+      if (w == 0) nxt[64 * NMS_WORDS + lane] = nd;
+    }
     __syncthreads();
     if (nk >= K) break;
   }
+
+  // outputs: kept candidates in score order
   if (threadIdx.x == 0) {
-    int nk = s_nkept;
-    int np = pos0 + m;
+    int run = nk0;
+    for (int k = 0; k < NMS_WORDS; ++k) { keptpre[k] = run; run += (int)__popcll(keptbits[k]); }
+    keptpre[NMS_WORDS] = run;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < m; c += SCAN_THREADS) {
+    const unsigned long long kb = keptbits[c >> 6];
+    const int bit = c & 63;
+    if ((kb >> bit) & 1ull) {
+      const unsigned long long lt = (bit == 0) ? 0ull : (~0ull >> (64 - bit));
+      const int p = keptpre[c >> 6] + (int)__popcll(kb & lt);
+      const uint32_t oi = sorted_idx[pos0 + c];
+      out_idx[p] = (int32_t)oi;
+      if (out_boxes) out_boxes[p] = boxes[oi];
+      kept_boxes[p] = sboxes[c];
+    }
+  }
+  if (threadIdx.x == 0) {
+    const int nk = keptpre[NMS_WORDS];
+    const int np = pos0 + m;
+    const int done = (nk >= K || np >= n - st->n_invalid) ? 1 : 0;
     st->kept = nk;
     st->pos = np;
-    st->done = (nk >= K || np >= st->n_valid) ? 1 : 0;
+    st->done = done;
     *out_count = nk;
+    if (out_done) *out_done = done;
   }
 }
 
@@ -253,17 +288,24 @@ static size_t nms_carve(int n, int max_out, void* ws, size_t ws_bytes, NmsWorksp
 }
 
 extern "C" size_t odet_nms_workspace_bytes(int n, int max_output) {
-  char dummy;
-  return nms_carve(n, max_output, nullptr, 0, nullptr) + sizeof(dummy) * 0;
+  return nms_carve(n, max_output, nullptr, 0, nullptr);
 }
 
-__global__ void k_nms_export_done(const NmsState* st, int32_t* out_done) { *out_done = st->done; }
+// Size of the first chunk: with few overlaps K kept boxes need barely more than K candidates, so
+// the first bit matrix is sized ~1.5 K instead of 4096 (7x fewer IoU tiles for K = 1000).
+static int first_chunk_cap(int n, int K) {
+  long long c = ((long long)K * 3 / 2 + 63) / 64 * 64;
+  if (c < 256) c = 256;
+  if (c > NMS_CHUNK) c = NMS_CHUNK;
+  if (c > ((long long)n + 63) / 64 * 64) c = ((long long)n + 63) / 64 * 64;
+  return (int)c;
+}
 
 // blind_chunks >= 1 chunks are enqueued without looking at the device state (a chunk whose
 // predecessor already finished exits at once).  out_done == nullptr: exact mode -- afterwards the
 // host reads the state (one sync per further chunk) until the device reports done.
 // out_done != nullptr: sync-free mode -- exactly blind_chunks chunks, *out_done tells the caller
-// whether the result is complete (it always is when blind_chunks*4096 >= n).
+// whether the result is complete.
 static int nms_run(const float* boxes, const float* scores, int n, int K, float thr, int32_t* out_idx,
                    float* out_boxes, int32_t* out_count, int blind_chunks, int32_t* out_done, void* ws,
                    size_t ws_bytes, hipStream_t st) {
@@ -272,16 +314,19 @@ static int nms_run(const float* boxes, const float* scores, int n, int K, float 
   if (!ws || ws_bytes < need)
     return odet_set_error(ODET_E_WORKSPACE, "odet_nms: workspace too small (%zu < %zu)", ws_bytes, need);
   nms_carve(n, K, ws, ws_bytes, &w);
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODET_HIP(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_DYN_LDS));
+    attr_set = true;
+  }
+  ODET_HIP(hipMemsetAsync(w.state, 0, sizeof(NmsState), st));
   uint32_t* sorted = nullptr;
-  int rc = odet_sort_pairs_desc(scores, n, w.keys_a, w.vals_a, w.keys_b, w.vals_b, w.hist, &w.state->n_valid,
+  int rc = odet_sort_pairs_desc(scores, n, w.keys_a, w.vals_a, w.keys_b, w.vals_b, w.hist, &w.state->n_invalid,
                                 &sorted, st);
   if (rc != ODET_OK) return rc;
-  hipLaunchKernelGGL(k_nms_init, dim3(1), dim3(1), 0, st, w.state, out_count);
-  ODET_LAUNCH_CHECK();
-  const int max_chunks = (n + NMS_CHUNK - 1) / NMS_CHUNK;
-  const int nb = (std::min(n, NMS_CHUNK) + 63) / 64;
   if (blind_chunks < 1) blind_chunks = 1;
-  for (int c = 0; c < max_chunks; ++c) {
+  int consumed = 0;   // upper bound of candidates handed to chunks so far
+  for (int c = 0; consumed < n; ++c) {
     if (c >= blind_chunks) {
       if (out_done) break;
       // exact mode: need the device's verdict to know whether another chunk is required
@@ -290,24 +335,32 @@ static int nms_run(const float* boxes, const float* scores, int n, int K, float 
       ODET_HIP(hipStreamSynchronize(st));
       if (h.done) break;
     }
-    hipLaunchKernelGGL(k_nms_gather, dim3((std::min(n, NMS_CHUNK) + 255) / 256), dim3(256), 0, st, w.state,
+    const int cap = (c == 0) ? first_chunk_cap(n, K) : std::min(NMS_CHUNK, (n - consumed + 63) / 64 * 64);
+    const int nb = (cap + 63) / 64;
+    hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, w.state, n, cap,
                        (const float4*)boxes, sorted, w.sboxes);
     ODET_LAUNCH_CHECK();
     if (c > 0) {
-      hipLaunchKernelGGL(k_nms_cross, dim3(NMS_CHUNK / 256), dim3(256), 0, st, w.state, w.sboxes, w.kept_boxes, thr,
-                         w.removed_init);
+      hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, w.state, w.sboxes, w.kept_boxes,
+                         thr, w.removed_init);
       ODET_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, st, w.state, w.sboxes, thr, w.mask, w.diag);
     ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(SCAN_THREADS), 0, st, w.state, w.mask, w.diag, w.removed_init,
-                       c > 0 ? 1 : 0, w.sboxes, sorted, (const float4*)boxes, K, out_idx, (float4*)out_boxes,
-                       w.kept_boxes, out_count);
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(SCAN_THREADS), SCAN_DYN_LDS, st, w.state, n, w.mask, w.diag,
+                       w.removed_init, c > 0 ? 1 : 0, w.sboxes, sorted, (const float4*)boxes, K, out_idx,
+                       (float4*)out_boxes, w.kept_boxes, out_count, out_done);
     ODET_LAUNCH_CHECK();
+    consumed += cap;
   }
+  return ODET_OK;
+}
+
+static int nms_trivial(int32_t* out_count, int32_t* out_done, hipStream_t st) {
+  ODET_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), st));
   if (out_done) {
-    hipLaunchKernelGGL(k_nms_export_done, dim3(1), dim3(1), 0, st, w.state, out_done);
-    ODET_LAUNCH_CHECK();
+    ODET_HIP(hipMemsetAsync(out_done, 0, sizeof(int32_t), st));
+    ODET_HIP(hipMemsetAsync(out_done, 1, 1, st));   // little-endian int32 1
   }
   return ODET_OK;
 }
@@ -317,11 +370,7 @@ extern "C" int odet_nms(const float* boxes, const float* scores, int n, int max_
                         int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
   ODET_REQUIRE(n >= 0 && max_output >= 0, "odet_nms: negative size");
   ODET_REQUIRE(out_count, "odet_nms: null out_count");
-  if (n == 0 || max_output == 0) {
-    ODET_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), (hipStream_t)stream));
-    if (out_done) ODET_HIP(hipMemsetAsync(out_done, 1, 1, (hipStream_t)stream));
-    return ODET_OK;
-  }
+  if (n == 0 || max_output == 0) return nms_trivial(out_count, out_done, (hipStream_t)stream);
   ODET_REQUIRE(boxes && scores && out_idx, "odet_nms: null pointer");
   return nms_run(boxes, scores, n, max_output, iou_threshold, out_idx, out_boxes, out_count, blind_chunks, out_done,
                  workspace, workspace_bytes, (hipStream_t)stream);
@@ -341,11 +390,7 @@ extern "C" int odet_region_proposal(const float* deltas, const float* anchors, c
   ODET_REQUIRE(n >= 0 && max_output >= 0, "odet_region_proposal: negative size");
   ODET_REQUIRE(out_count, "odet_region_proposal: null out_count");
   ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_region_proposal: bad image shape");
-  if (n == 0 || max_output == 0) {
-    ODET_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), (hipStream_t)stream));
-    if (out_done) ODET_HIP(hipMemsetAsync(out_done, 1, 1, (hipStream_t)stream));
-    return ODET_OK;
-  }
+  if (n == 0 || max_output == 0) return nms_trivial(out_count, out_done, (hipStream_t)stream);
   ODET_REQUIRE(deltas && anchors && scores && means && stds && out_rois, "odet_region_proposal: null pointer");
   size_t need = odet_region_proposal_workspace_bytes(n, max_output);
   if (!workspace || workspace_bytes < need)
@@ -353,17 +398,13 @@ extern "C" int odet_region_proposal(const float* deltas, const float* anchors, c
                           workspace_bytes, need);
   OdetArena ar{(char*)workspace, workspace_bytes, 0};
   float* boxes = ar.take<float>((size_t)n * 4);
+  int32_t* idx_buf = out_idx;
+  if (!idx_buf) idx_buf = ar.take<int32_t>((size_t)max_output);
   size_t off = odet_align_up(ar.off, 256);
   // region_proposal.py:59 decode + :63 clip (min_edge=None), fused
   int rc = odet_decode(anchors, deltas, 4, n, means, stds, image_h, image_w, boxes, stream);
   if (rc != ODET_OK) return rc;
   // region_proposal.py:73-76 NMS over all n, :81 gather
-  int32_t* idx = out_idx ? out_idx : nullptr;
-  int32_t* idx_buf = idx;
-  if (!idx_buf) {
-    idx_buf = reinterpret_cast<int32_t*>((char*)workspace + off);
-    off = odet_align_up(off + sizeof(int32_t) * (size_t)max_output, 256);
-  }
   return nms_run(boxes, scores, n, max_output, iou_threshold, idx_buf, out_rois, out_count, blind_chunks, out_done,
                  (char*)workspace + off, workspace_bytes - off, (hipStream_t)stream);
 }

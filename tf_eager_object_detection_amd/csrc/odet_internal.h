@@ -99,7 +99,7 @@ struct Float4Host { float v[4]; };
 
 // shared between translation units
 int odet_sort_pairs_desc(const float* scores, int n, uint32_t* keys_a, uint32_t* vals_a,
-                         uint32_t* keys_b, uint32_t* vals_b, uint32_t* hist, int32_t* n_valid_dev,
+                         uint32_t* keys_b, uint32_t* vals_b, uint32_t* hist, int32_t* n_invalid_dev,
                          uint32_t** sorted_vals, hipStream_t stream);
 size_t odet_sort_hist_entries(int n);
 

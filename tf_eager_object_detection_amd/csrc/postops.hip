@@ -247,3 +247,36 @@ extern "C" int odet_post_ops(const float* scores, const float* deltas, const flo
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
+
+// ---------------------------------------------------------------------- detection records --
+// Fixed-size record of one image for the image-parallel all-gather: float32 [max_det, 6] rows
+// (x1, y1, x2, y2, score, label), padded rows are zero with score = -1, then one float holding
+// the count.  One launch, no host sync.
+__global__ void __launch_bounds__(256) k_pack_detections(const float4* __restrict__ boxes,
+                                                         const int32_t* __restrict__ labels,
+                                                         const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ count, int cap, int max_det,
+                                                         float* __restrict__ rec) {
+  const int m = min(min(*count, cap), max_det);
+  for (int i = threadIdx.x; i < max_det; i += 256) {
+    float* r = rec + (size_t)i * 6;
+    if (i < m) {
+      float4 b = boxes[i];
+      r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w; r[4] = scores[i]; r[5] = (float)labels[i];
+    } else {
+      r[0] = 0.0f; r[1] = 0.0f; r[2] = 0.0f; r[3] = 0.0f; r[4] = -1.0f; r[5] = 0.0f;
+    }
+  }
+  if (threadIdx.x == 0) rec[(size_t)max_det * 6] = (float)m;
+}
+
+extern "C" int odet_pack_detections(const float* boxes, const int32_t* labels, const float* scores,
+                                    const int32_t* count_dev, int capacity, int max_det, float* out_record,
+                                    odet_stream_t stream) {
+  ODET_REQUIRE(boxes && labels && scores && count_dev && out_record, "odet_pack_detections: null pointer");
+  ODET_REQUIRE(capacity >= 0 && max_det > 0, "odet_pack_detections: bad sizes");
+  hipLaunchKernelGGL(k_pack_detections, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float4*)boxes, labels,
+                     scores, count_dev, capacity, max_det, out_record);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}

@@ -6,10 +6,15 @@
 //
 // Key: ~asc(score) so that an ascending LSD sort yields descending scores.  Scores TF would
 // never push (NaN, or <= lowest float: "score > score_threshold" is false) get key 0xFFFFFFFF
-// and sort to the end; *n_valid_dev counts the rest.
+// and sort to the end; *n_valid_dev = n - (number of such scores).
 //
-// 4 passes x 8-bit digits.  Per pass: block histogram -> one-workgroup scan -> stable scatter
-// (wave64 ballot multi-split: 8 ballots give each lane the set of lanes sharing its digit).
+// 4 passes x 8-bit digits, 2 launches per pass:
+//   k_rs_hist    : per-block digit histogram, stored block-major (one coalesced 1 KiB row per block)
+//   k_rs_scatter : every block derives its own global offsets from the histogram table (256 threads =
+//                  256 digits, column sums over the L2-resident table + one block scan -- no separate
+//                  scan launch), ranks its 2048 keys with a wave64 ballot multi-split (8 ballots give
+//                  each lane the set of lanes sharing its digit) and scatters keys + payload.
+// Pass 0's histogram is produced by the key-building kernel.
 #include "odet_internal.h"
 
 #define RS_BLOCK 256
@@ -23,28 +28,40 @@ size_t odet_sort_hist_entries(int n) {
   return nblocks * RS_RADIX;
 }
 
-__global__ void __launch_bounds__(256) k_make_keys(const float* __restrict__ scores, int n, uint32_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals, int32_t* __restrict__ n_valid) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  bool valid = false;
-  if (i < n) {
-    float s = scores[i];
-    valid = s > -3.402823466e+38f;   // NonMaxSuppressionV3: score > score_threshold (= lowest); NaN fails
-    keys[i] = valid ? ~d_float_asc_key(s) : 0xFFFFFFFFu;
-    vals[i] = (uint32_t)i;
-  }
-  unsigned long long b = __ballot(valid);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
-}
-
 // element order inside a block: wave-contiguous: e = blockStart + (wave*ITEMS + item)*64 + lane
 __device__ __forceinline__ int rs_elem(int item) {
   int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   return blockIdx.x * RS_TILE + (w * RS_ITEMS + item) * 64 + lane;
 }
 
+// keys + payload + pass-0 histogram + count of scores that are not NMS candidates
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_make_keys(const float* __restrict__ scores, int n,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                           uint32_t* __restrict__ hist, int32_t* __restrict__ n_invalid) {
+  __shared__ uint32_t h[RS_RADIX];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  int invalid = 0;
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int e = rs_elem(it);
+    if (e < n) {
+      float s = scores[e];
+      bool valid = s > -3.402823466e+38f;   // NonMaxSuppressionV3: score > score_threshold (= lowest); NaN fails
+      uint32_t k = valid ? ~d_float_asc_key(s) : 0xFFFFFFFFu;
+      keys[e] = k;
+      vals[e] = (uint32_t)e;
+      invalid += valid ? 0 : 1;
+      atomicAdd(&h[k & 0xFF], 1u);
+    }
+  }
+  __syncthreads();
+  hist[(size_t)blockIdx.x * RS_RADIX + threadIdx.x] = h[threadIdx.x];   // block-major
+  if (invalid) atomicAdd(n_invalid, invalid);                           // rare
+}
+
 __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift,
-                                                      uint32_t* __restrict__ hist, int nblocks) {
+                                                      uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[RS_RADIX];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -54,7 +71,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const uint32_t* __restrict
     if (e < n) atomicAdd(&h[(keys[e] >> shift) & 0xFF], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];   // digit-major
+  hist[(size_t)blockIdx.x * RS_RADIX + threadIdx.x] = h[threadIdx.x];
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
@@ -67,46 +84,62 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   return v;
 }
 
-// exclusive scan of `count` entries in place, one workgroup of 1024 threads
-__global__ void __launch_bounds__(1024) k_rs_scan(uint32_t* __restrict__ hist, int count) {
-  __shared__ uint32_t wsum[17];
-  int per = (count + 1023) / 1024;
-  int lo = threadIdx.x * per;
-  uint32_t s = 0;
-  for (int k = 0; k < per; ++k)
-    if (lo + k < count) s += hist[lo + k];
-  uint32_t inc = wave_incl_scan_u32(s);
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int k = 0; k < 16; ++k) { uint32_t t = wsum[k]; wsum[k] = run; run += t; }
-  }
-  __syncthreads();
-  uint32_t ex = wsum[w] + inc - s;
-  for (int k = 0; k < per; ++k)
-    if (lo + k < count) { uint32_t t = hist[lo + k]; hist[lo + k] = ex; ex += t; }
-}
-
 __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restrict__ keys_in,
                                                          const uint32_t* __restrict__ vals_in, int n, int shift,
                                                          const uint32_t* __restrict__ hist, int nblocks,
                                                          uint32_t* __restrict__ keys_out,
                                                          uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t cnt[RS_WAVES][RS_RADIX];
-  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ uint32_t gbase[RS_RADIX];
+  __shared__ uint32_t wsum[RS_WAVES];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = threadIdx.x; k < RS_WAVES * RS_RADIX; k += RS_BLOCK) (&cnt[0][0])[k] = 0;
-  __syncthreads();
 
+  // issue this block's key loads first so they overlap the offset computation
   uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it) {
     int e = rs_elem(it);
     bool in = e < n;
     key[it] = in ? keys_in[e] : 0xFFFFFFFFu;
     val[it] = in ? vals_in[e] : 0u;
+  }
+
+  // global offset of digit d (= threadIdx.x) for this block:
+  //   sum over all blocks of digits < d   +   sum over earlier blocks of digit d
+  {
+    const int d = threadIdx.x;
+    uint32_t below = 0, total = 0;
+    const int b = blockIdx.x;
+    int bb = 0;
+    for (; bb + 4 <= nblocks; bb += 4) {
+      uint32_t t0 = hist[(size_t)(bb + 0) * RS_RADIX + d];
+      uint32_t t1 = hist[(size_t)(bb + 1) * RS_RADIX + d];
+      uint32_t t2 = hist[(size_t)(bb + 2) * RS_RADIX + d];
+      uint32_t t3 = hist[(size_t)(bb + 3) * RS_RADIX + d];
+      total += t0 + t1 + t2 + t3;
+      below += (bb + 0 < b ? t0 : 0) + (bb + 1 < b ? t1 : 0) + (bb + 2 < b ? t2 : 0) + (bb + 3 < b ? t3 : 0);
+    }
+    for (; bb < nblocks; ++bb) {
+      uint32_t t0 = hist[(size_t)bb * RS_RADIX + d];
+      total += t0;
+      below += (bb < b) ? t0 : 0;
+    }
+    uint32_t inc = wave_incl_scan_u32(total);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; ++k) woff += (k < w) ? wsum[k] : 0;
+    gbase[d] = woff + inc - total + below;
+  }
+  __syncthreads();
+
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int e = rs_elem(it);
+    bool in = e < n;
     uint32_t d = (key[it] >> shift) & 0xFF;
     // lanes of this wave holding the same digit (out-of-range lanes excluded)
     unsigned long long same = __ballot(in);
@@ -124,7 +157,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restr
   __syncthreads();
   // digit `threadIdx.x`: turn per-wave counts into per-wave bases (+ global block offset)
   {
-    uint32_t g = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    uint32_t g = gbase[threadIdx.x];
 #pragma unroll
     for (int k = 0; k < RS_WAVES; ++k) {
       uint32_t t = cnt[k][threadIdx.x];
@@ -146,22 +179,23 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restr
 }
 
 // Sorts indices 0..n-1 by (score desc, index asc).  keys_a/vals_a/keys_b/vals_b: n uint32
-// each; hist: odet_sort_hist_entries(n) uint32.  *sorted_vals points at the buffer holding
-// the result (vals_a after an even number of passes).
+// each; hist: odet_sort_hist_entries(n) uint32.  *n_invalid_dev must be zero on entry (the caller
+// clears it with its state memset) and receives the number of scores that are not candidates.
+// *sorted_vals points at the buffer holding the result (vals_a after an even number of passes).
 int odet_sort_pairs_desc(const float* scores, int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
-                         uint32_t* vals_b, uint32_t* hist, int32_t* n_valid_dev, uint32_t** sorted_vals,
+                         uint32_t* vals_b, uint32_t* hist, int32_t* n_invalid_dev, uint32_t** sorted_vals,
                          hipStream_t st) {
-  ODET_HIP(hipMemsetAsync(n_valid_dev, 0, sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_make_keys, dim3((n + 255) / 256), dim3(256), 0, st, scores, n, keys_a, vals_a, n_valid_dev);
-  ODET_LAUNCH_CHECK();
   int nblocks = (n + RS_TILE - 1) / RS_TILE;
+  hipLaunchKernelGGL(k_rs_make_keys, dim3(nblocks), dim3(RS_BLOCK), 0, st, scores, n, keys_a, vals_a, hist,
+                     n_invalid_dev);
+  ODET_LAUNCH_CHECK();
   uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
   for (int pass = 0; pass < 4; ++pass) {
     int shift = pass * 8;
-    hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, n, shift, hist, nblocks);
-    ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, hist, nblocks * RS_RADIX);
-    ODET_LAUNCH_CHECK();
+    if (pass > 0) {
+      hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, n, shift, hist);
+      ODET_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, vin, n, shift, hist, nblocks, kout,
                        vout);
     ODET_LAUNCH_CHECK();

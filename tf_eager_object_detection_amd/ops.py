@@ -222,15 +222,19 @@ def region_proposal(deltas, anchors, scores, image_shape, num_post_nms, iou_thre
     return rois, idx, cnt
 
 
-def assign_levels(rois, min_level, max_level, count_dev=None):
-    """-> (sorted rois [n,4], level int32 [n] (0-based), perm int64 [n], counts int32 [L])"""
+def assign_levels(rois, min_level, max_level, count_dev=None, out=None):
+    """-> (sorted rois [n,4], level int32 [n] (0-based), perm int64 [n], counts int32 [L]).
+    ``out`` = preallocated (sorted rois, level, perm, counts) to reuse."""
     rois = _boxes(rois, 'all_rois')
     n = rois.shape[0]
     nl = int(max_level) - int(min_level) + 1
-    out = torch.empty_like(rois)
-    lvl = torch.empty(max(n, 1), dtype=torch.int32, device=rois.device)
-    perm = torch.empty(max(n, 1), dtype=torch.int64, device=rois.device)
-    counts = torch.zeros(nl, dtype=torch.int32, device=rois.device)
+    if out is not None:
+        out, lvl, perm, counts = out
+    else:
+        out = torch.empty_like(rois)
+        lvl = torch.empty(max(n, 1), dtype=torch.int32, device=rois.device)
+        perm = torch.empty(max(n, 1), dtype=torch.int64, device=rois.device)
+        counts = torch.empty(nl, dtype=torch.int32, device=rois.device)
     L.check(L.lib().odet_assign_levels(L.dptr(rois), n, L.dptr(count_dev), int(min_level), int(max_level),
                                        L.dptr(out), L.dptr(lvl), L.dptr(perm), L.dptr(counts), L.stream()))
     return out, lvl[:n], perm[:n], counts
@@ -272,8 +276,9 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
 
 
 def post_ops(scores, deltas, rois, image_shape, means, stds, max_per_class, max_per_image, nms_iou_threshold,
-             score_threshold, min_edge, num_classes, count_dev=None):
-    """-> (boxes [M,4], labels int32 [M], scores [M]) padded to max_per_image, count int32[1]"""
+             score_threshold, min_edge, num_classes, count_dev=None, out=None, workspace=None):
+    """-> (boxes [M,4], labels int32 [M], scores [M]) padded to max_per_image, count int32[1].
+    ``out`` = preallocated (boxes, labels, scores, count); ``workspace`` = reusable uint8 buffer."""
     scores = L.f32c(scores, 'roi_scores_softmax')
     if scores.dim() != 2:
         raise ValueError('roi_scores_softmax must be [num_rois, num_classes]')
@@ -285,12 +290,15 @@ def post_ops(scores, deltas, rois, image_shape, means, stds, max_per_class, max_
     if rois.shape[0] != R:
         raise ValueError('rois has %d rows for %d score rows' % (rois.shape[0], R))
     M = max(int(max_per_image), 1)
-    ob = torch.empty((M, 4), dtype=torch.float32, device=scores.device)
-    ol = torch.empty(M, dtype=torch.int32, device=scores.device)
-    os_ = torch.empty(M, dtype=torch.float32, device=scores.device)
-    cnt = _count_tensor(scores.device)
+    if out is not None:
+        ob, ol, os_, cnt = out
+    else:
+        ob = torch.empty((M, 4), dtype=torch.float32, device=scores.device)
+        ol = torch.empty(M, dtype=torch.int32, device=scores.device)
+        os_ = torch.empty(M, dtype=torch.float32, device=scores.device)
+        cnt = _count_tensor(scores.device)
     nb = L.lib().odet_post_ops_workspace_bytes(int(num_classes), int(max_per_class))
-    ws = L.workspace(nb, scores.device)
+    ws = workspace if workspace is not None and workspace.numel() >= nb else L.workspace(nb, scores.device)
     L.check(L.lib().odet_post_ops(L.dptr(scores), L.dptr(deltas), L.dptr(rois), R, L.dptr(count_dev), Ccls,
                                   int(num_classes), int(image_shape[0]), int(image_shape[1]),
                                   L.host4(means, 'target_means'), L.host4(stds, 'target_stds'),

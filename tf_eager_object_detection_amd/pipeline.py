@@ -50,6 +50,19 @@ class FpnHotPath:
         self.roi_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nms_done = torch.zeros(1, dtype=torch.int32, device=dev)
         self.roi_features = torch.zeros((K, pool_size, pool_size, channels), dtype=torch.float32, device=dev)
+        nl = max_level - min_level + 1
+        self.sorted_rois = torch.zeros((K, 4), dtype=torch.float32, device=dev)
+        self.roi_level = torch.zeros(K, dtype=torch.int32, device=dev)
+        self.roi_perm = torch.zeros(K, dtype=torch.int64, device=dev)
+        self.level_counts = torch.zeros(nl, dtype=torch.int32, device=dev)
+        M = max(max_per_image, 1)
+        self.det_boxes = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+        self.det_labels = torch.zeros(M, dtype=torch.int32, device=dev)
+        self.det_scores = torch.zeros(M, dtype=torch.float32, device=dev)
+        self.det_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ws_post = torch.empty(ops.L.lib().odet_post_ops_workspace_bytes(num_classes, max_per_class),
+                                   dtype=torch.uint8, device=dev)
+        self.record = torch.zeros(M * 6 + 1, dtype=torch.float32, device=dev)
 
     # ---- stage 1: RPN outputs -> level-sorted proposals -------------------------------------
     def stage_proposals(self, rpn_logits, rpn_deltas):
@@ -60,8 +73,8 @@ class FpnHotPath:
                             self.cfg['rpn_means'], self.cfg['rpn_stds'], workspace=self.ws_rpn,
                             blind_chunks=self.blind_chunks, done=self.nms_done,
                             out=(self.rois, self.roi_idx, self.roi_count))              # :224
-        self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts = ops.assign_levels(
-            self.rois, self.min_level, self.max_level, count_dev=self.roi_count)        # :256 / :303-324
+        ops.assign_levels(self.rois, self.min_level, self.max_level, count_dev=self.roi_count,
+                          out=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts))   # :256 / :303-324
         return self.sorted_rois, self.roi_level, self.roi_count
 
     # ---- stage 2: RoI features ---------------------------------------------------------------
@@ -78,7 +91,15 @@ class FpnHotPath:
         c = self.cfg
         return ops.post_ops(cls_softmax, cls_deltas, self.sorted_rois, self.image_shape, c['roi_means'],
                             c['roi_stds'], c['max_per_class'], c['max_per_image'], c['nms_iou'],
-                            c['score_threshold'], 16, self.num_classes, count_dev=self.roi_count)   # :267-275
+                            c['score_threshold'], 16, self.num_classes, count_dev=self.roi_count,
+                            out=(self.det_boxes, self.det_labels, self.det_scores, self.det_count),
+                            workspace=self.ws_post)                                     # :267-275
+
+    def stage_record(self):
+        """Fixed-size detection record of this image for the image-parallel all-gather."""
+        from . import parallel
+        return parallel.pack_detections(self.det_boxes, self.det_labels, self.det_scores, self.det_count,
+                                        self.cfg['max_per_image'], out=self.record)
 
     def step(self, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
         """One image through the whole hot path (the RoI head that sits between stage 2 and 3 in the
