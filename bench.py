@@ -197,10 +197,11 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'ResNet-101-FPN @ 800x1333 detection hot path: anchors(267069) -> fg softmax '
-                                   '-> RegionProposal (decode+clip+NMS over all anchors, 1000 proposals) -> '
-                                   'assign_levels -> RoI crop14x14+maxpool over P2..P5x256 -> post_ops (21 classes); '
-                                   'conv backbone/heads out of scope (their outputs are synthetic inputs in HBM)',
+            'config': {'workload': 'ResNet-101-FPN @ 800x1333 detection hot path: anchors(267069, generated in '
+                                   'registers) -> fg softmax -> RegionProposal (decode+clip+exact NMS over all '
+                                   'anchors, 1000 proposals) -> assign_levels -> RoI crop14x14+maxpool over '
+                                   'P2..P5x256 -> post_ops (21 classes); conv backbone/heads out of scope (their '
+                                   'outputs are synthetic inputs in HBM)',
                        'images_per_step_per_gpu': 1, 'global_batch': world, 'rpn_scores': args.scores,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max)',

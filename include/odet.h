@@ -127,13 +127,16 @@ size_t odet_nms_workspace_bytes(int n, int max_output);
  * boxes, IoU without +1, strict '>', stop at max_output.  out_idx int32 [max_output]
  * (original indices in keep order), out_boxes (nullable) [max_output,4] gathered rows,
  * out_count device int32[1].
- * Candidates are consumed in score order in chunks of 4096.  `blind_chunks` (>= 1) chunks are
- * enqueued unconditionally (a chunk after completion is a no-op on the device).
+ * Candidates are consumed in (score desc, index asc) order in chunks: chunk 0 = the best
+ * ~1.5*max_output candidates (radix select, no full sort); if it does not reach max_output the
+ * remaining candidates are fully sorted and consumed in chunks of 4096.  `blind_chunks` (>= 1)
+ * chunks are enqueued unconditionally (the work of a chunk after completion is skipped on the
+ * device).
  *  - out_done == NULL  (exact mode): if more chunks may be needed the call host-syncs on
  *    `stream` once per further chunk until the device reports completion.  Always exact.
  *  - out_done != NULL  (sync-free mode, graph-capturable): exactly blind_chunks chunks run;
  *    *out_done (device int32) = 1 when the result is complete, 0 when max_output was not
- *    reached within blind_chunks*4096 candidates (caller re-runs in exact mode). */
+ *    reached within them (caller re-runs in exact mode). */
 int odet_nms(const float* boxes, const float* scores, int n, int max_output, float iou_threshold,
              int32_t* out_idx, float* out_boxes, int32_t* out_count, int blind_chunks,
              int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream);
@@ -148,6 +151,23 @@ int odet_region_proposal(const float* deltas, const float* anchors, const float*
                          int max_output, float iou_threshold, float* out_rois, int32_t* out_idx,
                          int32_t* out_count, int blind_chunks, int32_t* out_done, void* workspace,
                          size_t workspace_bytes, odet_stream_t stream);
+
+size_t odet_fpn_proposals_workspace_bytes(int n, int max_output);
+/* The whole proposal stage of model/fpn/base_fpn_model.py BaseFPN.call in one entry point:
+ * :220 _get_anchors (utils/anchor_generator.py:137-178, anchors are produced in registers and
+ * never stored), :223 softmax(rpn_score)[:,1], :224 RegionProposal (model/region_proposal.py:
+ * 55-81) and, when out_sorted_rois != NULL, :256 _assign_levels (:303-324) fused into the last
+ * NMS launch.  rpn_logits [n,2] (bg,fg) as RpnHead emits them (:429), rpn_deltas [n,4], levels
+ * concatenated in list order; fh/fw/stride/wh host arrays as in odet_anchors_fpn
+ * (n = sum fh*fw*A).  Outputs as odet_region_proposal + odet_assign_levels. */
+int odet_fpn_proposals(const float* rpn_logits, const float* rpn_deltas, int num_levels, int A,
+                       const int* fh, const int* fw, const int* stride, const float* wh,
+                       int image_h, int image_w, const float* means, const float* stds,
+                       int max_output, float iou_threshold, int min_level, int max_level,
+                       float* out_rois, int32_t* out_idx, int32_t* out_count,
+                       float* out_sorted_rois, int32_t* out_level, int64_t* out_perm,
+                       int32_t* out_level_counts, int blind_chunks, int32_t* out_done,
+                       void* workspace, size_t workspace_bytes, odet_stream_t stream);
 
 /* ---- FPN level assignment ------------------------------------------------------------ */
 

@@ -47,31 +47,10 @@ extern "C" int odet_anchors_shift(const float* anchor_base, int A, int feat_stri
   return ODET_OK;
 }
 
-struct FpnAnchorParams {
-  int num_levels;
-  int A;
-  int fw[ODET_MAX_LEVELS];
-  int stride[ODET_MAX_LEVELS];
-  int start[ODET_MAX_LEVELS + 1];  // first anchor of each level
-  float wh[ODET_MAX_LEVELS * ODET_MAX_ANCHORS_PER_CELL * 2];
-};
-
 __global__ void __launch_bounds__(256) k_anchors_fpn(FpnAnchorParams p, float4* __restrict__ out) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.start[p.num_levels]) return;
-  int l = 0;
-#pragma unroll
-  for (int k = 1; k < ODET_MAX_LEVELS; ++k)
-    if (k < p.num_levels && i >= p.start[k]) l = k;
-  int j = i - p.start[l];
-  int a = j % p.A;
-  int cell = j / p.A;
-  int x = cell % p.fw[l], y = cell / p.fw[l];
-  float fs = (float)p.stride[l];
-  float cx = (float)x * fs, cy = (float)y * fs;            // anchor_generator.py:146-147
-  float hw = 0.5f * p.wh[(l * p.A + a) * 2 + 0];           // :160-161
-  float hh = 0.5f * p.wh[(l * p.A + a) * 2 + 1];
-  out[i] = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+  out[i] = d_fpn_anchor(p, i);
 }
 
 extern "C" int odet_anchors_fpn(int num_levels, int A, const int* fh, const int* fw, const int* stride,
@@ -102,7 +81,6 @@ extern "C" int odet_anchors_fpn(int num_levels, int A, const int* fh, const int*
 }
 
 // ---------------------------------------------------------------------- decode / encode --
-struct Vec4 { float v[4]; };
 
 __global__ void __launch_bounds__(256) k_decode(const float4* __restrict__ anchors, const float* __restrict__ deltas,
                                                 int64_t delta_stride, int n, Vec4 means, Vec4 stds, int clip,
@@ -205,34 +183,6 @@ struct CompactArgs {
   int n;
   float minv, wmax, hmax, min_edge, thr;
 };
-
-__device__ __forceinline__ int wave_incl_scan(int v) {
-  int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
-
-// exclusive scan across a block of up to 1024 threads; returns exclusive prefix, sets total.
-__device__ __forceinline__ int block_excl_scan(int v, int* lds /*[17]*/, int* total) {
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int nw = (blockDim.x + 63) >> 6;
-  int inc = wave_incl_scan(v);
-  __syncthreads();
-  if (lane == 63) lds[w] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 0; k < nw; ++k) { int t = lds[k]; lds[k] = run; run += t; }
-    lds[16] = run;
-  }
-  __syncthreads();
-  *total = lds[16];
-  return lds[w] + inc - v;
-}
 
 template <int MODE>
 __device__ __forceinline__ bool cp_pred(const CompactArgs& a, int i) {
@@ -433,14 +383,6 @@ extern "C" int odet_gather_rows(const float* src, const void* idx, int idx_is_64
 }
 
 // ----------------------------------------------------------------------- RPN fg softmax --
-// tf.nn.softmax arithmetic on a (bg, fg) pair: e = exp(x - max); p = e_fg * (1 / (e_bg + e_fg)).
-__device__ __forceinline__ float d_fg_prob(float bg, float fg) {
-  float m = fmaxf(bg, fg);
-  float e0 = d_exp32(bg - m), e1 = d_exp32(fg - m);
-  float inv = 1.0f / (e0 + e1);
-  return e1 * inv;
-}
-
 __global__ void __launch_bounds__(256) k_rpn_fg_fpn(const float2* __restrict__ logits, int n, float* __restrict__ out) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -481,7 +423,6 @@ extern "C" int odet_rpn_fg_softmax(const float* logits, int nloc, int A, int lay
 // inside a level) -- the order tf.where + tf.gather + tf.concat produce in
 // base_fpn_model.py:316-324.
 #define AL_THREADS 1024
-#define AL_ITEMS (ODET_ASSIGN_MAX_ROIS / AL_THREADS)
 
 __global__ void __launch_bounds__(AL_THREADS) k_assign_levels(const float4* __restrict__ rois, int n,
                                                               const int32_t* __restrict__ count_dev, int min_level,
@@ -489,47 +430,9 @@ __global__ void __launch_bounds__(AL_THREADS) k_assign_levels(const float4* __re
                                                               int32_t* __restrict__ out_level,
                                                               int64_t* __restrict__ out_perm,
                                                               int32_t* __restrict__ out_counts) {
-  __shared__ int lds[17];
+  __shared__ int lds[ODET_MAX_LEVELS * 17];
   int cnt = count_dev ? min(*count_dev, n) : n;
-  int per = (cnt + AL_THREADS - 1) / AL_THREADS;
-  int lo = threadIdx.x * per;
-  int lv[AL_ITEMS];
-  const float log2v = d_log32(2.0f);
-#pragma unroll
-  for (int k = 0; k < AL_ITEMS; ++k) {
-    int i = lo + k;
-    lv[k] = -1;
-    if (k < per && i < cnt) {
-      float4 b = rois[i];
-      float h = fmaxf(0.0f, b.w - b.y);                       // base_fpn_model.py:307
-      float w = fmaxf(0.0f, b.z - b.x);                       // :308
-      float l = floorf(4.0f + d_log32(sqrtf(w * h + 1e-8f) / 224.0f) / log2v);   // :309
-      l = fmaxf(l, (float)min_level);                         // :312
-      l = fminf(l, (float)max_level);                         // :313
-      lv[k] = (int)l - min_level;
-    }
-  }
-  int base = 0;
-  for (int L = 0; L <= max_level - min_level; ++L) {
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < AL_ITEMS; ++k) c += (lv[k] == L) ? 1 : 0;
-    int total;
-    int pos = base + block_excl_scan(c, lds, &total);
-#pragma unroll
-    for (int k = 0; k < AL_ITEMS; ++k) {
-      if (lv[k] == L) {
-        int i = lo + k;
-        out_rois[pos] = rois[i];
-        out_level[pos] = L;
-        out_perm[pos] = i;
-        ++pos;
-      }
-    }
-    if (threadIdx.x == 0) out_counts[L] = total;
-    base += total;
-    __syncthreads();
-  }
+  d_assign_levels_block<AL_THREADS>(rois, cnt, min_level, max_level, out_rois, out_level, out_perm, out_counts, lds);
 }
 
 extern "C" int odet_assign_levels(const float* rois, int n, const int32_t* count_dev, int min_level, int max_level,

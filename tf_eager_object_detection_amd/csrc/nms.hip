@@ -1,54 +1,352 @@
-// Exact greedy NMS (tf.image.non_max_suppression / NonMaxSuppressionV3 semantics) and the
-// fused RegionProposal path (model/region_proposal.py:55-81).
+// Exact greedy NMS (tf.image.non_max_suppression / NonMaxSuppressionV3 semantics), the fused
+// RegionProposal path (model/region_proposal.py:55-81) and the fused FPN proposal stage
+// (model/fpn/base_fpn_model.py:220-224 + :303-324).
 //
-// TF's kernel is a serial loop: pop the best remaining candidate, test it against every box
-// kept so far, keep it if no IoU > threshold, stop at max_output.  The result only depends on
-// the candidates in descending-score order until max_output are kept, so the GPU version is:
+// TF's kernel is a serial loop: pop the best remaining candidate, test it against every box kept
+// so far, keep it if no IoU > threshold, stop at max_output.  The result only depends on the
+// candidates in (score desc, index asc) order until max_output are kept, so the GPU form is:
 //
-//   1. stable radix sort of all n (score, index) pairs                       (sort.hip)
-//   2. per chunk of sorted candidates (first chunk ~1.5*K, later ones 4096), until K kept or
-//      the candidates are exhausted:
-//      a. k_nms_gather : boxes of the chunk in sorted order, corners normalised
-//      b. k_nms_cross  : (chunks > 0) candidates vs. boxes kept by earlier chunks -> bitmask
-//      c. k_nms_mask   : upper-triangular suppression bit matrix of the chunk, one wave per
-//                        64x64 tile (whole chip busy), 64-bit word per (row, column block)
-//      d. k_nms_scan   : ONE workgroup walks the chunk in 64-candidate blocks: wave 0 resolves a
-//                        block serially on the scalar unit (ctz over the alive mask, diagonal
-//                        rows via v_readlane), then four waves OR the kept rows (prefetched
-//                        one block ahead into registers) into the removed-bit vector in LDS.
-//                        Outputs are written by all threads after the walk.
+//   1. k_rp_prepare   : one pass over all n candidates: (anchors in registers ->) fg softmax ->
+//                       decode -> clip -> box, 32-bit order key, 12-bit key histogram.
+//   2. radix SELECT of the best ~1.5 K candidates instead of sorting all n:
+//      k_sel_hist2    : every block finds the threshold bin of the 12-bit histogram (prefix scan in
+//                       the prologue), then histograms the next 12 key bits of that bin's members;
+//      k_sel_compact  : finds the 24-bit threshold prefix and appends every candidate at or below
+//                       it (wave64 ballot + one atomic per wave) -- a set closed under the order,
+//                       count <= 4096 (the boundary bin is dropped whole if it would not fit);
+//      k_sel_rank     : orders those (key, index) pairs by counting (rank = number of smaller
+//                       pairs; 64 candidates x 16 range slices per workgroup, list broadcast from
+//                       LDS) and gathers their corner-normalised boxes.
+//   3. k_nms_mask     : pairwise-suppression bit matrix of the chunk on the whole chip: one
+//                       workgroup per 64x64 tile of the LOWER triangle, four waves x 16 columns,
+//                       stored word-major  Lt[word b][candidate j]  (bit i: candidate 64b+i, earlier
+//                       in score order, suppresses j if it is kept) so that the scan reads it
+//                       coalesced; the diagonal tile is stored row-wise (who do I suppress).
+//   4. k_nms_scan     : ONE workgroup, thread = candidate.  64-candidate blocks are resolved in
+//                       order by the wave that owns them (ctz over the alive ballot + v_readlane of
+//                       the diagonal rows, only candidates that actually suppress a live later one
+//                       cost a serial step); after each block every later candidate folds
+//                       Lt[b][j] & kept[b] into its "suppressed" flag (loads prefetched two blocks
+//                       ahead).  One barrier per block, early exit at max_output.  The tail writes
+//                       the kept boxes in score order and, for the FPN stage, assigns pyramid levels
+//                       (stable partition) in the same launch.
+//   5. Only if the chunk did not reach max_output: full radix sort (sort.hip) and further chunks
+//      of 4096 candidates (k_nms_gather -> k_nms_cross vs. the boxes kept so far -> mask -> scan).
 //
-// The decision for every candidate is the same predicate TF evaluates (d_iou_gt), so kept
-// indices are identical to the serial algorithm, including the early stop at max_output.
+// Every decision is the predicate TF evaluates (d_iou_gt), so kept indices are identical to the
+// serial algorithm, including the early stop at max_output.
+#include <string.h>
+
+#include <algorithm>
+
 #include "odet_internal.h"
 
 #define NMS_CHUNK 4096
-#define NMS_WORDS (NMS_CHUNK / 64)   // 64 u64 words per mask row
+#define NMS_WORDS (NMS_CHUNK / 64)
+#define SEL_BINS 4096
+#define SEL_REPL 8   // copies of the first-level histogram (hot bins: same-address atomics serialise)
+#define SEL_BLOCK 256
+#define SEL_ITEMS 8
+#define SEL_TILE (SEL_BLOCK * SEL_ITEMS)
+#define PREP_ITEMS 2
+#define PREP_TILE (256 * PREP_ITEMS)
 
-struct NmsState {      // zeroed by one memset per call
-  int32_t n_invalid;   // scores TF would not push into its heap (NaN, <= lowest float)
-  int32_t kept;        // boxes kept so far
-  int32_t pos;         // sorted candidates consumed so far
-  int32_t done;        // kept == K or pos == n_valid
-  int32_t chunk_m;     // size of the current chunk
-  int32_t pad[3];
+typedef unsigned long long u64;
+
+// Up to this many 64-candidate blocks the whole strictly-lower suppression matrix of a chunk is staged
+// in LDS by the scan (276 tiles x 512 B = 138 KiB of the 160 KiB): its walk never waits for memory.
+#define SCAN_LDS_BLOCKS 24
+#define SCAN_LDS_CAND (SCAN_LDS_BLOCKS * 64)
+#define SCAN_LDS_WORDS (SCAN_LDS_BLOCKS * (SCAN_LDS_BLOCKS - 1) / 2 * 64)
+#define SCAN_LDS_SLACK_WORDS (8 * 64)   // unpredicated reads of the last wave may run past the image
+#define SCAN_DYN_LDS ((SCAN_LDS_WORDS + SCAN_LDS_SLACK_WORDS) * 8)
+// first word of column block cb inside the packed image (rows (cb+1)*64 .. nblk*64-1 follow each other)
+#define SCAN_MAT_OFF(cb, nblk) (64 * ((cb) * ((nblk)-1) - (cb) * ((cb)-1) / 2))
+
+struct NmsState {
+  int32_t n_invalid;     // scores TF would not push into its heap (NaN, <= lowest float)
+  int32_t kept;          // boxes kept so far
+  int32_t pos;           // candidates (in score order) consumed so far
+  int32_t done;          // kept == K or pos == n_valid
+  int32_t chunk_m;       // size of the current chunk
+  int32_t sel_count;     // candidates appended by k_sel_compact
+  int32_t reserved0;
+  int32_t sel_b1;        // threshold bin of the first 12 key bits
+  uint32_t sel_below1;   // candidates in bins < sel_b1
+  int32_t pad[7];
 };
 
-// a. gather the chunk's boxes in sorted order (corner-normalised) --------------------------
+struct NmsHeader {   // zeroed by ONE memset per call; starts the workspace
+  NmsState st;
+  u64 stamps[64];                      // diagnostic builds only (-DODET_STAMPS)
+  uint32_t hist1[SEL_REPL][SEL_BINS];  // replica r is fed by blocks with blockIdx % SEL_REPL == r
+  uint32_t hist2[SEL_BINS];
+};
+
+#ifdef ODET_STAMPS
+#define STAMP(hdr_, k_)                                                            \
+  do {                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x == 0) (hdr_)->stamps[k_] = wall_clock64();  \
+  } while (0)
+#define WSTAMP(hdr_, k_)                                                           \
+  do {                                                                             \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) (hdr_)->stamps[k_] = wall_clock64();  \
+  } while (0)
+#else
+#define STAMP(hdr_, k_) do { } while (0)
+#define WSTAMP(hdr_, k_) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------- 1. prepare -------
+enum { PREP_NMS = 0, PREP_RP = 1, PREP_FPN = 2 };
+
+struct PrepParams {
+  int n;
+  const float4* boxes_in;   // PREP_NMS: boxes (not rewritten); PREP_RP: anchors
+  const float* deltas;      // PREP_RP / PREP_FPN: [n,4]
+  const float* scores;      // PREP_NMS / PREP_RP
+  const float2* logits;     // PREP_FPN: (bg, fg) pairs
+  Vec4 means, stds;
+  float wmax, hmax;
+  float4* boxes_out;        // PREP_RP / PREP_FPN: decoded + clipped boxes
+  uint32_t* keys;
+  NmsHeader* hdr;
+  FpnAnchorParams fpn;      // PREP_FPN
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
+  __shared__ uint32_t h[SEL_BINS];
+  for (int k = threadIdx.x; k < SEL_BINS; k += 256) h[k] = 0;
+  // all loads of the tile first (independent, in flight together), then the arithmetic
+  float sc[PREP_ITEMS];
+  float2 lg[PREP_ITEMS];
+  float4 an[PREP_ITEMS], dl[PREP_ITEMS];
+#pragma unroll
+  for (int it = 0; it < PREP_ITEMS; ++it) {
+    const int e = blockIdx.x * PREP_TILE + it * 256 + threadIdx.x;
+    const bool in = e < p.n;
+    const int ee = in ? e : 0;
+    if (MODE == PREP_FPN) lg[it] = p.logits[ee]; else sc[it] = p.scores[ee];
+    if (MODE == PREP_RP) an[it] = p.boxes_in[ee];
+    if (MODE != PREP_NMS) dl[it] = reinterpret_cast<const float4*>(p.deltas)[ee];
+  }
+  __syncthreads();
+  int invalid = 0;
+#pragma unroll
+  for (int it = 0; it < PREP_ITEMS; ++it) {
+    const int e = blockIdx.x * PREP_TILE + it * 256 + threadIdx.x;
+    if (e < p.n) {
+      float s;
+      if (MODE == PREP_FPN) s = d_fg_prob(lg[it].x, lg[it].y);     // base_fpn_model.py:223
+      else s = sc[it];
+      if (MODE != PREP_NMS) {
+        const float4 a = (MODE == PREP_FPN) ? d_fpn_anchor(p.fpn, e) : an[it];   // :220 / :163-186
+        const float4 d = dl[it];
+        const float d0 = d.x * p.stds.v[0] + p.means.v[0];         // bbox_transform.py:37
+        const float d1 = d.y * p.stds.v[1] + p.means.v[1];
+        const float d2 = d.z * p.stds.v[2] + p.means.v[2];
+        const float d3 = d.w * p.stds.v[3] + p.means.v[3];
+        float4 b = d_decode_box(a, d0, d1, d2, d3);                // region_proposal.py:59
+        b = d_clip_box(b, 0.0f, p.wmax, p.hmax);                   // :63
+        p.boxes_out[e] = b;
+      }
+      const bool valid = s > -3.402823466e+38f;   // NonMaxSuppressionV3: score > score_threshold (= lowest)
+      const uint32_t k = valid ? ~d_float_asc_key(s) : 0xFFFFFFFFu;
+      p.keys[e] = k;
+      invalid += valid ? 0 : 1;
+      atomicAdd(&h[k >> 20], 1u);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SEL_BINS; k += 256) {
+    const uint32_t c = h[k];
+    if (c) atomicAdd(&p.hdr->hist1[blockIdx.x % SEL_REPL][k], c);
+  }
+  if (invalid) atomicAdd(&p.hdr->st.n_invalid, invalid);           // rare
+}
+
+// ------------------------------------------------------------------------- 2. select --------
+// Smallest bin whose inclusive prefix count reaches `target` (1 <= target), and the count below
+// it.  256 threads x 16 bins.  result[0] = bin, result[1] = below, result[2] = count of the bin.
+// target > total -> treated as total.
+template <int REPL>
+__device__ __forceinline__ void sel_find(const uint32_t* __restrict__ hist, uint32_t target, uint32_t* result,
+                                         int* lds17) {
+  uint32_t v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = 0;
+#pragma unroll
+  for (int r = 0; r < REPL; ++r) {
+    const uint4* h4 = reinterpret_cast<const uint4*>(hist + (size_t)r * SEL_BINS) + threadIdx.x * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 t = h4[q];
+      v[q * 4 + 0] += t.x; v[q * 4 + 1] += t.y; v[q * 4 + 2] += t.z; v[q * 4 + 3] += t.w;
+    }
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) s += v[q];
+  int total;
+  const uint32_t excl = (uint32_t)block_excl_scan((int)s, lds17, &total);
+  if ((uint32_t)total < target) target = (uint32_t)total;
+  if (threadIdx.x == 0 && total == 0) { result[0] = SEL_BINS - 1; result[1] = 0; result[2] = 0; }
+  if (s > 0 && excl < target && target <= excl + s) {
+    uint32_t run = excl;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (run < target && target <= run + v[q]) {
+        result[0] = threadIdx.x * 16 + q; result[1] = run; result[2] = v[q];
+      }
+      run += v[q];
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(NmsHeader* hdr, const uint32_t* __restrict__ keys, int n,
+                                                         uint32_t target) {
+  __shared__ uint32_t h[SEL_BINS];
+  __shared__ uint32_t res[3];
+  __shared__ int lds17[17];
+  sel_find<SEL_REPL>(&hdr->hist1[0][0], target, res, lds17);
+  const uint32_t b1 = res[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->st.sel_b1 = (int32_t)b1; hdr->st.sel_below1 = res[1]; }
+  uint32_t key[SEL_ITEMS];
+  bool match = false;
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
+    key[it] = (e < n) ? keys[e] : 0u;
+    match = match || (e < n && (key[it] >> 20) == b1);
+  }
+  if (!__syncthreads_or(match ? 1 : 0)) return;
+  for (int k = threadIdx.x; k < SEL_BINS; k += SEL_BLOCK) h[k] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
+    if (e < n && (key[it] >> 20) == b1) atomicAdd(&h[(key[it] >> 8) & 0xFFFu], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < SEL_BINS; k += SEL_BLOCK) {
+    const uint32_t c = h[k];
+    if (c) atomicAdd(&hdr->hist2[k], c);
+  }
+}
+
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(NmsHeader* hdr, const uint32_t* __restrict__ keys, int n,
+                                                           uint32_t target, uint32_t limit, u64* __restrict__ cand) {
+  __shared__ uint32_t res[3];
+  __shared__ int lds17[17];
+  const uint32_t b1 = (uint32_t)hdr->st.sel_b1;
+  const uint32_t below1 = hdr->st.sel_below1;
+  uint32_t total_n = (uint32_t)n;
+  uint32_t t2 = (target > total_n ? total_n : target) - below1;   // >= 1 by construction of b1
+  sel_find<1>(hdr->hist2, t2, res, lds17);
+  const uint32_t b2 = res[0];
+  // The selected set must be closed under the order, so the boundary bin (24-bit prefix b1:b2) is
+  // taken whole or not at all: whole if the set still fits `limit` candidates (the capacity of the
+  // chunk-0 scan), otherwise the chunk is the (smaller, still valid) set strictly below it and the
+  // fallback path picks up from there.
+  const bool incl = (below1 + res[1] + res[2]) <= limit;
+  // block-local append (LDS counter, one LDS atomic per wave and item), then ONE global atomic per block
+  __shared__ u64 stage[SEL_TILE];
+  __shared__ int s_cnt, s_base;
+  if (threadIdx.x == 0) s_cnt = 0;
+  uint32_t key[SEL_ITEMS];
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
+    key[it] = (e < n) ? keys[e] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
+    const uint32_t k = key[it];
+    const uint32_t p1 = k >> 20, p2 = (k >> 8) & 0xFFFu;
+    const bool sel = (e < n) && (p1 < b1 || (p1 == b1 && (p2 < b2 || (incl && p2 == b2))));
+    const u64 bal = __ballot(sel);
+    if (bal) {
+      int base = 0;
+      if (lane == __builtin_ctzll(bal)) base = atomicAdd(&s_cnt, (int)__popcll(bal));
+      base = __shfl(base, __builtin_ctzll(bal));
+      if (sel) stage[base + (int)__popcll(bal & lt_mask)] = ((u64)k << 32) | (uint32_t)e;
+    }
+  }
+  __syncthreads();
+  const int c = s_cnt;
+  if (c == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&hdr->st.sel_count, c);
+  __syncthreads();
+  const int gb = s_base;
+  for (int i = threadIdx.x; i < c; i += SEL_BLOCK)
+    if (gb + i < NMS_CHUNK) cand[gb + i] = stage[i];
+}
+
+// chunk 0: order the selected candidates by counting (all (key, index) pairs are distinct, so the
+// rank of a pair = number of smaller pairs is a permutation) and gather their boxes.  Workgroup =
+// 64 candidates (lane) x 16 slices of the comparison range (wave); the pair list is staged in LDS and
+// every wave reads it as a broadcast.
+#define RANK_THREADS 1024
+__global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(NmsHeader* hdr, int n, const u64* __restrict__ cand,
+                                                          const float4* __restrict__ boxes,
+                                                          uint32_t* __restrict__ sel_idx,
+                                                          float4* __restrict__ sboxes,
+                                                          float4* __restrict__ sorig) {
+  __shared__ u64 all[NMS_CHUNK];
+  __shared__ int part[16][64];
+  NmsState* st = &hdr->st;
+  const int cnt = min(st->sel_count, NMS_CHUNK);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->chunk_m = min(cnt, n - st->n_invalid);
+  if (blockIdx.x * 64 >= cnt) return;
+  for (int i = threadIdx.x; i < cnt; i += RANK_THREADS) all[i] = cand[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const u64 mine = (i < cnt) ? all[i] : ~0ull;
+  const int per = (cnt + 15) >> 4;
+  const int lo = w * per, hi = min(cnt, lo + per);
+  int c = 0;
+  for (int j = lo; j < hi; ++j) c += (all[j] < mine) ? 1 : 0;
+  part[w][lane] = c;
+  __syncthreads();
+  if (w == 0 && i < cnt) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r += part[k][lane];
+    const uint32_t idx = (uint32_t)mine;
+    sel_idx[r] = idx;
+    // invalid scores (key 0xFFFFFFFF) sort last; rows >= chunk_m are never read
+    const float4 bx = boxes[idx];
+    sboxes[r] = d_norm_box(bx);
+    sorig[r] = bx;
+  }
+}
+
+// later chunks: gather the chunk's boxes in sorted order (corner-normalised) -----------------
 __global__ void __launch_bounds__(256) k_nms_gather(NmsState* st, int n, int cap, const float4* __restrict__ boxes,
                                                     const uint32_t* __restrict__ sorted_idx,
-                                                    float4* __restrict__ sboxes) {
+                                                    float4* __restrict__ sboxes, float4* __restrict__ sorig) {
   const int pos = st->pos, nv = n - st->n_invalid;
   const int m = st->done ? 0 : min(cap, nv - pos);
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) st->chunk_m = m;
-  if (i < m) sboxes[i] = d_norm_box(boxes[sorted_idx[pos + i]]);
+  if (i < m) {
+    const float4 bx = boxes[sorted_idx[pos + i]];
+    sboxes[i] = d_norm_box(bx);
+    sorig[i] = bx;
+  }
 }
 
-// b. chunk candidates vs boxes kept by earlier chunks ---------------------------------------
+// chunk candidates vs boxes kept by earlier chunks ---------------------------------------------
 __global__ void __launch_bounds__(256) k_nms_cross(const NmsState* st, const float4* __restrict__ sboxes,
                                                    const float4* __restrict__ kept_boxes, float thr,
-                                                   unsigned long long* __restrict__ removed_init) {
+                                                   u64* __restrict__ removed_init) {
   __shared__ float4 kb[256];
   __shared__ float ka[256];
   const int m = st->chunk_m, nk = st->kept;
@@ -68,199 +366,404 @@ __global__ void __launch_bounds__(256) k_nms_cross(const NmsState* st, const flo
     const int lim = min(256, nk - k0);
     for (int k = 0; k < lim; ++k) sup = sup || d_iou_gt(b, area, kb[k], ka[k], thr);
   }
-  unsigned long long bal = __ballot(sup && j < m);
+  u64 bal = __ballot(sup && j < m);
   if ((threadIdx.x & 63) == 0) removed_init[j >> 6] = bal;
 }
 
-// c. suppression bit matrix -------------------------------------------------------------------
-// grid (col block, row block), one wave per 64x64 tile, only col block >= row block.
-// mask[row][cb] bit j: candidate cb*64+j (later in score order) is suppressed by `row`.
-__global__ void __launch_bounds__(64) k_nms_mask(const NmsState* st, const float4* __restrict__ sboxes, float thr,
-                                                 unsigned long long* __restrict__ mask,
-                                                 unsigned long long* __restrict__ diag) {
-  const int cb = blockIdx.x, rb = blockIdx.y;
-  if (cb < rb) return;
+// ------------------------------------------------------------------------- 3. mask ----------
+// 1-D grid over the lower-triangular tiles (rb, cb <= rb), row block major.  Workgroup = 4 waves,
+// lane = row of the tile, wave w tests the row against columns [16w, 16w+16) of the column block.
+__global__ void __launch_bounds__(256) k_nms_mask(const NmsState* st, const float4* __restrict__ sboxes, float thr,
+                                                  u64* __restrict__ Lt, u64* __restrict__ diag_up, int packed) {
+  const int t = blockIdx.x;
+  int rb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((rb + 1) * (rb + 2) / 2 <= t) ++rb;
+  while (rb * (rb + 1) / 2 > t) --rb;
+  const int cb = t - rb * (rb + 1) / 2;
   const int m = st->chunk_m;
   if (rb * 64 >= m) return;
   __shared__ float4 cbox[64];
   __shared__ float carea[64];
-  const int lane = threadIdx.x;
-  const int col = cb * 64 + lane;
-  const float4 c = (col < m) ? sboxes[col] : make_float4(0, 0, 0, 0);   // zero area never suppresses
-  cbox[lane] = c;
-  carea[lane] = d_box_area(c);
+  __shared__ uint32_t part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < 64) {
+    const int col = cb * 64 + lane;
+    const float4 c = (col < m) ? sboxes[col] : make_float4(0, 0, 0, 0);   // zero area never suppresses
+    cbox[lane] = c;
+    carea[lane] = d_box_area(c);
+  }
   __syncthreads();
   const int row = rb * 64 + lane;
   const float4 r = (row < m) ? sboxes[row] : make_float4(0, 0, 0, 0);
   const float ra = d_box_area(r);
-  unsigned long long bits = 0;
-#pragma unroll 8
-  for (int j = 0; j < 64; ++j) {
-    bool s = d_iou_gt(r, ra, cbox[j], carea[j], thr);
-    bits |= s ? (1ull << j) : 0ull;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int jj = w * 16 + j;
+    const bool s = d_iou_gt(r, ra, cbox[jj], carea[jj], thr);
+    bits |= s ? (1u << j) : 0u;
   }
-  if (cb == rb) {
-    // only later candidates (j > lane) can be suppressed by this row
-    const unsigned long long later = (lane == 63) ? 0ull : (~0ull << (lane + 1));
-    bits &= later;
-    if (row < m) diag[row] = bits;
+  part[w][lane] = bits;
+  __syncthreads();
+  if (w == 0 && row < m) {
+    const u64 word = (u64)part[0][lane] | ((u64)part[1][lane] << 16) | ((u64)part[2][lane] << 32) |
+                     ((u64)part[3][lane] << 48);
+    if (cb == rb) {
+      // diagonal tile, row-wise: later candidates (bit j > lane) this row suppresses when kept
+      const u64 later = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+      diag_up[row] = word & later;
+    } else {
+      // earlier candidates of block cb that suppress `row`; packed = the LDS image of k_nms_scan<true>
+      if (packed) Lt[SCAN_MAT_OFF(cb, (m + 63) >> 6) + row - (cb + 1) * 64] = word;
+      else Lt[(size_t)cb * NMS_CHUNK + row] = word;
+    }
   }
-  if (row < m) mask[(size_t)row * NMS_WORDS + cb] = bits;
 }
 
-// d. serial scan ------------------------------------------------------------------------------
-// LDS: two staging buffers of one 64-candidate block each (64 rows x 64 words + 64 diagonal words).
-// Iteration b: (1) issue the global loads of block b+1 (they fly during the resolve), (2) wave 0
-// resolves block b from LDS only, (3) all waves OR the kept rows of block b (LDS) into `removed`,
-// (4) the loaded rows of block b+1 are written to the other staging buffer.
-#define SCAN_THREADS 256
-#define SCAN_WAVES 4
-#define SCAN_ROWS 16   // rows of a 64-candidate block owned by each wave
-#define SCAN_STAGE_WORDS (64 * NMS_WORDS + 64)
-#define SCAN_DYN_LDS (2 * SCAN_STAGE_WORDS * 8)
+// ------------------------------------------------------------------------- 4. scan ----------
+struct AssignOut {      // optional fused _assign_levels (base_fpn_model.py:303-324) of the final RoIs
+  float4* rois;         // null = disabled
+  int32_t* level;
+  int64_t* perm;
+  int32_t* counts;
+  int min_level, max_level;
+};
 
-__device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
+#define SCAN_THREADS 512
+#define SCAN_WAVES (SCAN_THREADS / 64)
+#define SCAN_Q 8      // candidates per thread: wave w owns candidates [512w, 512w+512) = blocks 8w..8w+7
+#define SCAN_RING 4   // <false> path: column words of this many blocks are in flight per wave (registers)
+#define SCAN_STAGE_ITEMS ((SCAN_LDS_WORDS / 2 + SCAN_THREADS - 1) / SCAN_THREADS)   // 16-B units per thread
+
+__device__ __forceinline__ u64 rfl64(u64 v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
+  return ((u64)hi << 32) | lo;
 }
 
+// Resolve one 64-candidate block inside a wave.  alive: candidates not suppressed by earlier blocks
+// (wave-uniform mask); d: diagonal row of the lane's candidate (later candidates of the block it
+// suppresses when kept).  Only candidates that suppress a still-alive later one need a serial step; the
+// rest of the alive ones are kept.  Returns the kept bits truncated to `room` survivors.
+__device__ __forceinline__ u64 scan_resolve_block(u64 alive, u64 d, int room, int lane, u64 lt_lane, int* npop_out) {
+  const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
+  for (;;) {
+    const bool is_s = ((alive >> lane) & 1ull) && ((d & alive) != 0ull);
+    const u64 supp = __ballot(is_s);
+    if (supp == 0) break;
+    const int i = __builtin_ctzll(supp);
+    const uint32_t rlo = __builtin_amdgcn_readlane(dlo, i);
+    const uint32_t rhi = __builtin_amdgcn_readlane(dhi, i);
+    alive &= ~(((u64)rhi << 32) | rlo);
+  }
+  const int npop = (int)__popcll(alive);
+  u64 kept = alive;
+  if (npop > room) kept = __ballot(((alive >> lane) & 1ull) && (int)__popcll(alive & lt_lane) < room);
+  *npop_out = min(npop, room);
+  return kept;
+}
+
+// wait until block b is published; returns its kept bits, *nk = kept count after it
+__device__ __forceinline__ u64 scan_wait_block(const int* nkeptw, const u64* keepw, int b, int* nk) {
+  int v;
+  u64 kbv;
+  for (;;) {
+    // count first, bits second: LDS serves a wave's requests in order
+    v = __hip_atomic_load(&nkeptw[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    kbv = __hip_atomic_load(&keepw[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (v >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  *nk = __builtin_amdgcn_readfirstlane(v);
+  return rfl64(kbv);
+}
+
+__device__ __forceinline__ void scan_publish(int* nkeptw, u64* keepw, int b, u64 kept, int nk, int lane) {
+  if (lane == 0) __hip_atomic_store(&keepw[b], kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // kept bits are in LDS before the count
+  if (lane == 0) __hip_atomic_store(&nkeptw[b], nk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LDSMAT = true : chunk of at most SCAN_LDS_CAND candidates, Lt holds the packed image (k_nms_mask
+//                 packed = 1), staged in LDS up front; output rows prefetched before the walk.
+// LDSMAT = false: any chunk size, Lt word-major in global memory, column words streamed SCAN_RING
+//                 blocks ahead.
+template <bool LDSMAT>
 __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(
-    NmsState* st, int n, const unsigned long long* __restrict__ mask, const unsigned long long* __restrict__ diag,
-    const unsigned long long* __restrict__ removed_init, int use_init, const float4* __restrict__ sboxes,
-    const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ boxes, int K,
-    int32_t* __restrict__ out_idx, float4* __restrict__ out_boxes, float4* __restrict__ kept_boxes,
-    int32_t* __restrict__ out_count, int32_t* __restrict__ out_done) {
-  extern __shared__ __align__(16) unsigned long long stage[];   // [2][SCAN_STAGE_WORDS]
-  __shared__ unsigned long long removed[NMS_WORDS];
-  __shared__ unsigned long long keptbits[NMS_WORDS];
+    NmsState* st, int n, const u64* __restrict__ Lt, const u64* __restrict__ diag_up,
+    const u64* __restrict__ removed_init, int use_init, const float4* __restrict__ sboxes,
+    const float4* __restrict__ sorig, const uint32_t* __restrict__ sorted_idx, int K,
+    int32_t* __restrict__ out_idx, float4* out_boxes, float4* __restrict__ kept_boxes,
+    int32_t* __restrict__ out_count, int32_t* __restrict__ out_done, AssignOut ao) {
+  // The hand-off words are accessed with relaxed workgroup-scope atomics (plain ds_read / ds_write that
+  // the compiler may not cache or hoist).  NOT volatile: volatile __shared__ accesses are lowered to
+  // flat sc0 sc1 instructions + vmcnt(0), an order of magnitude slower and they drain the prefetch.
+  __shared__ u64 keepw[NMS_WORDS];
+  __shared__ int nkeptw[NMS_WORDS];           // < 0: block not published yet
   __shared__ int keptpre[NMS_WORDS + 1];
-  __shared__ unsigned long long s_kept64;
-  __shared__ int s_nkept;
+  __shared__ int lvl_cnt[ODET_MAX_LEVELS][NMS_WORDS];
+  __shared__ int lvl_tot[ODET_MAX_LEVELS];
+  extern __shared__ __align__(16) u64 mat[];  // packed strictly-lower matrix (LDSMAT)
+  if (st->done) return;                       // uniform: an earlier chunk finished the job
+  NmsHeader* hdr = reinterpret_cast<NmsHeader*>(st);   // the state is the header's first member
+  (void)hdr;
+  STAMP(hdr, 0);
+#ifdef ODET_STAMPS
+  if (threadIdx.x == 0) hdr->stamps[60] = clock64();
+#endif
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int m = st->chunk_m;
+  const int m = LDSMAT ? min(st->chunk_m, SCAN_LDS_CAND) : st->chunk_m;   // (<= by construction)
   const int pos0 = st->pos;
   const int nk0 = st->kept;
   const int nblk = (m + 63) >> 6;
-  if (threadIdx.x < NMS_WORDS) {
-    unsigned long long r = use_init ? removed_init[threadIdx.x] : 0ull;
-    // candidates beyond m do not exist
-    const int lo = threadIdx.x * 64;
-    if (lo + 64 > m) r |= (lo >= m) ? ~0ull : (~0ull << (m - lo));
-    removed[threadIdx.x] = r;
-    keptbits[threadIdx.x] = 0ull;
-  }
-  if (threadIdx.x == 0) { s_nkept = nk0; s_kept64 = 0; }
+  const int b_own = SCAN_Q * w;               // first block of this wave
+  const int jbase = w * (64 * SCAN_Q) + lane; // candidate of (q, lane) = jbase + 64 q
+  const u64 lt_lane = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-  unsigned long long nrows[SCAN_ROWS];
-  unsigned long long nd = 0;
-  // block 0 -> staging buffer 0
-  if (nblk > 0) {
+  u64 supm[SCAN_Q];                           // wave-uniform: candidates of own block q suppressed / absent
+  u64 dg[SCAN_Q];
+  float4 obox[SCAN_Q];
+  uint32_t oidx[SCAN_Q];
 #pragma unroll
-    for (int q = 0; q < SCAN_ROWS; ++q) {
-      const int r = w * SCAN_ROWS + q;
-      stage[(size_t)r * NMS_WORDS + lane] = (r < m) ? mask[(size_t)r * NMS_WORDS + lane] : 0ull;
+  for (int q = 0; q < SCAN_Q; ++q) {
+    const int j = jbase + 64 * q;
+    u64 sm = __ballot(j >= m);
+    if (use_init && b_own + q < nblk) sm |= removed_init[b_own + q];
+    supm[q] = sm;
+    dg[q] = (j < m) ? diag_up[j] : 0ull;
+  }
+  if (threadIdx.x < NMS_WORDS) { keepw[threadIdx.x] = 0ull; nkeptw[threadIdx.x] = -1; }
+  int nk = nk0;
+  bool stop = false;
+
+  // Block walk as a dataflow between the waves (no workgroup barrier inside): wave w first consumes the
+  // blocks of the earlier waves in order as they are published through LDS (kept bits + running kept
+  // count), folding Lt[b][j] & kept[b] into the "suppressed" masks of its own blocks, then resolves its
+  // own eight blocks back to back -- a hand-off to the next wave only every 512 candidates.  A wave that
+  // sees the kept count reach K stops; later waves see the same published count and stop before they
+  // would wait for a block that is never published.
+  if (LDSMAT) {
+    // output rows, fetched now (independent of every decision) and written after the walk
+#pragma unroll
+    for (int q = 0; q < SCAN_Q; ++q) {
+      const int j = jbase + 64 * q;
+      oidx[q] = (j < m) ? sorted_idx[pos0 + j] : 0u;
+      obox[q] = (j < m) ? sorig[j] : make_float4(0, 0, 0, 0);
     }
-    if (w == 0) stage[64 * NMS_WORDS + lane] = (lane < m) ? diag[lane] : 0ull;
+    // stage the packed image: one flat copy, all loads of a thread in flight together
+    {
+      const int units = SCAN_MAT_OFF(nblk - 1, nblk) / 2;    // 16-byte units (0 when nblk <= 1)
+      const uint4* src = reinterpret_cast<const uint4*>(Lt);
+      uint4* dst = reinterpret_cast<uint4*>(mat);
+      uint4 tmp[SCAN_STAGE_ITEMS];
+#pragma unroll
+      for (int i = 0; i < SCAN_STAGE_ITEMS; ++i) {
+        const int u = i * SCAN_THREADS + threadIdx.x;
+        tmp[i] = (u < units) ? src[u] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < SCAN_STAGE_ITEMS; ++i) {
+        const int u = i * SCAN_THREADS + threadIdx.x;
+        if (u < units) dst[u] = tmp[i];
+      }
+    }
+    __syncthreads();
+    STAMP(hdr, 1);
+    if (b_own < nblk) {
+      for (int b = 0; b < b_own; ++b) {
+        if (stop) break;
+        // words of (source block b -> own blocks); reads past nblk hit the slack, their masks are unused
+        const u64* col = mat + SCAN_MAT_OFF(b, nblk) + (b_own - (b + 1)) * 64 + lane;
+        u64 wd[SCAN_Q];
+#pragma unroll
+        for (int q = 0; q < SCAN_Q; ++q) wd[q] = col[q * 64];
+        const u64 kb = scan_wait_block(nkeptw, keepw, b, &nk);
+#pragma unroll
+        for (int q = 0; q < SCAN_Q; ++q) supm[q] |= __ballot((wd[q] & kb) != 0ull);
+        if (nk >= K) stop = true;
+      }
+      WSTAMP(hdr, 16 + w);
+#pragma unroll
+      for (int a = 0; a < SCAN_Q; ++a) {
+        const int b = b_own + a;
+        if (!stop && b < nblk) {                            // uniform
+          const u64* col = mat + SCAN_MAT_OFF(b, nblk) + lane;   // rows of block b+1 first
+          u64 wd[SCAN_Q];
+#pragma unroll
+          for (int q = a + 1; q < SCAN_Q; ++q) wd[q] = col[(q - a - 1) * 64];
+          int add;
+          const u64 kept = scan_resolve_block(~supm[a], dg[a], K - nk, lane, lt_lane, &add);
+          nk += add;
+          scan_publish(nkeptw, keepw, b, kept, nk, lane);
+#pragma unroll
+          for (int q = a + 1; q < SCAN_Q; ++q) supm[q] |= __ballot((wd[q] & kept) != 0ull);
+          if (nk >= K) stop = true;
+        }
+      }
+      WSTAMP(hdr, 32 + w);
+    }
+  } else {
+    u64 ring[SCAN_RING][SCAN_Q];
+    u64 own[SCAN_Q][SCAN_Q];                  // own[a][q] (a < q): Lt[own block a][own candidate of block q]
+#pragma unroll
+    for (int q = 0; q < SCAN_Q; ++q) {
+      const int j = jbase + 64 * q;
+#pragma unroll
+      for (int k = 0; k < SCAN_RING; ++k)
+        ring[k][q] = (j < m && k < b_own) ? Lt[(size_t)k * NMS_CHUNK + j] : 0ull;
+    }
+#pragma unroll
+    for (int a = 0; a < SCAN_Q; ++a) {
+#pragma unroll
+      for (int q = 0; q < SCAN_Q; ++q) {
+        const int j = jbase + 64 * q;
+        own[a][q] = (q > a && j < m) ? Lt[(size_t)(b_own + a) * NMS_CHUNK + j] : 0ull;
+      }
+    }
+    __syncthreads();
+    STAMP(hdr, 1);
+    if (b_own < nblk) {
+      for (int b0 = 0; b0 < b_own; b0 += SCAN_RING) {      // b_own is a multiple of SCAN_RING
+#pragma unroll
+        for (int k = 0; k < SCAN_RING; ++k) {
+          if (!stop) {
+            const int b = b0 + k;
+            const u64 kb = scan_wait_block(nkeptw, keepw, b, &nk);
+#pragma unroll
+            for (int q = 0; q < SCAN_Q; ++q) {
+              supm[q] |= __ballot((ring[k][q] & kb) != 0ull);
+              const int j = jbase + 64 * q;
+              ring[k][q] = (j < m && b + SCAN_RING < b_own) ? Lt[(size_t)(b + SCAN_RING) * NMS_CHUNK + j] : 0ull;
+            }
+            if (nk >= K) stop = true;
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < SCAN_Q; ++a) {
+        const int b = b_own + a;
+        if (!stop && b < nblk) {                            // uniform
+          int add;
+          const u64 kept = scan_resolve_block(~supm[a], dg[a], K - nk, lane, lt_lane, &add);
+          nk += add;
+          scan_publish(nkeptw, keepw, b, kept, nk, lane);
+#pragma unroll
+          for (int q = a + 1; q < SCAN_Q; ++q) supm[q] |= __ballot((own[a][q] & kept) != 0ull);
+          if (nk >= K) stop = true;
+        }
+      }
+    }
   }
   __syncthreads();
-
-  const unsigned long long lt_lane = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (int b = 0; b < nblk; ++b) {
-    unsigned long long* cur = stage + (size_t)(b & 1) * SCAN_STAGE_WORDS;
-    unsigned long long* nxt = stage + (size_t)((b + 1) & 1) * SCAN_STAGE_WORDS;
-    const bool more = (b + 1 < nblk);
-    // (1) loads of the next block (independent of any decision)
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < SCAN_ROWS; ++q) {
-        const int r = (b + 1) * 64 + w * SCAN_ROWS + q;
-        nrows[q] = (r < m) ? mask[(size_t)r * NMS_WORDS + lane] : 0ull;
-      }
-      if (w == 0) { const int r = (b + 1) * 64 + lane; nd = (r < m) ? diag[r] : 0ull; }
-    }
-    // (2) resolve this block: only candidates that actually suppress a still-alive later candidate
-    //     need a serial step; everything else that is alive is kept.
-    if (w == 0) {
-      unsigned long long alive = ~rfl64(removed[b]);
-      const int cnt0 = __builtin_amdgcn_readfirstlane(s_nkept);
-      const unsigned long long d = cur[64 * NMS_WORDS + lane];
-      const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
-      for (;;) {
-        const bool is_s = ((alive >> lane) & 1ull) && ((d & alive) != 0ull);
-        const unsigned long long supp = __ballot(is_s);
-        if (supp == 0) break;
-        const int i = __builtin_ctzll(supp);
-        const uint32_t rlo = __builtin_amdgcn_readlane(dlo, i);
-        const uint32_t rhi = __builtin_amdgcn_readlane(dhi, i);
-        alive &= ~(((unsigned long long)rhi << 32) | rlo);
-      }
-      // stop at max_output: keep only the first (K - cnt0) survivors
-      const int room = K - cnt0;
-      const int npop = (int)__popcll(alive);
-      unsigned long long kept = alive;
-      if (npop > room)
-        kept = __ballot(((alive >> lane) & 1ull) && (int)__popcll(alive & lt_lane) < room);
-      if (lane == 0) { s_kept64 = kept; s_nkept = cnt0 + min(npop, room); keptbits[b] = kept; }
-    }
-    __syncthreads();
-    // (3) OR the kept rows into the removed vector
-    const unsigned long long kept = rfl64(s_kept64);
-    const int nk = __builtin_amdgcn_readfirstlane(s_nkept);
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int q = 0; q < SCAN_ROWS; ++q) {
-      const int r = w * SCAN_ROWS + q;
-      if ((kept >> r) & 1ull) acc |= cur[(size_t)r * NMS_WORDS + lane];
-    }
-    if (lane > b && acc) atomicOr(&removed[lane], acc);
-    // (4) stage the next block
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < SCAN_ROWS; ++q) nxt[(size_t)(w * SCAN_ROWS + q) * NMS_WORDS + lane] = nrows[q];
-      if (w == 0) nxt[64 * NMS_WORDS + lane] = nd;
-    }
-    __syncthreads();
-    if (nk >= K) break;
-  }
+  STAMP(hdr, 2);
 
   // outputs: kept candidates in score order
-  if (threadIdx.x == 0) {
-    int run = nk0;
-    for (int k = 0; k < NMS_WORDS; ++k) { keptpre[k] = run; run += (int)__popcll(keptbits[k]); }
-    keptpre[NMS_WORDS] = run;
+  if (w == 0) {
+    const int pc = (int)__popcll(keepw[lane]);
+    const int inc = wave_incl_scan(pc);
+    keptpre[lane] = nk0 + inc - pc;
+    if (lane == 63) keptpre[NMS_WORDS] = nk0 + inc;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < m; c += SCAN_THREADS) {
-    const unsigned long long kb = keptbits[c >> 6];
-    const int bit = c & 63;
-    if ((kb >> bit) & 1ull) {
-      const unsigned long long lt = (bit == 0) ? 0ull : (~0ull >> (64 - bit));
-      const int p = keptpre[c >> 6] + (int)__popcll(kb & lt);
-      const uint32_t oi = sorted_idx[pos0 + c];
-      out_idx[p] = (int32_t)oi;
-      if (out_boxes) out_boxes[p] = boxes[oi];
-      kept_boxes[p] = sboxes[c];
+  STAMP(hdr, 6);
+  const int nkf = keptpre[NMS_WORDS];
+  const int np = pos0 + m;
+  const int done = (nkf >= K || np >= n - st->n_invalid) ? 1 : 0;
+  const bool want_assign = ao.rois && done && out_boxes;
+  const bool fused_lv = want_assign && nk0 == 0;
+  const int nl = ao.max_level - ao.min_level + 1;
+  // every block of the chunk is covered: wave w handles blocks 8w..8w+7 (rows past m are not kept)
+  int myp[SCAN_Q], mylv[SCAN_Q], myrank[SCAN_Q];
+  bool iskept[SCAN_Q];
+#pragma unroll
+  for (int q = 0; q < SCAN_Q; ++q) {
+    const int c = jbase + 64 * q;
+    const u64 kbits = keepw[b_own + q];
+    iskept[q] = (c < m) && ((kbits >> lane) & 1ull);
+    myp[q] = iskept[q] ? keptpre[b_own + q] + (int)__popcll(kbits & lt_lane) : -1;
+    if (!LDSMAT) {
+      oidx[q] = iskept[q] ? sorted_idx[pos0 + c] : 0u;
+      obox[q] = iskept[q] ? sorig[c] : make_float4(0, 0, 0, 0);
     }
   }
+  STAMP(hdr, 7);
+#pragma unroll
+  for (int q = 0; q < SCAN_Q; ++q) {
+    const int c = jbase + 64 * q;
+    mylv[q] = -1;
+    myrank[q] = 0;
+    if (iskept[q]) {
+      const int p = myp[q];
+      out_idx[p] = (int32_t)oidx[q];
+      if (out_boxes) out_boxes[p] = obox[q];
+      kept_boxes[p] = d_norm_box(obox[q]);     // == sboxes[c], without a load between the stores
+      if (fused_lv) mylv[q] = d_roi_level(obox[q], ao.min_level, ao.max_level);
+    }
+    if (fused_lv) {
+#pragma unroll
+      for (int L = 0; L < ODET_MAX_LEVELS; ++L) {
+        if (L < nl) {
+          const u64 bal = __ballot(mylv[q] == L);
+          if (mylv[q] == L) myrank[q] = (int)__popcll(bal & lt_lane);
+          if (lane == 0) lvl_cnt[L][b_own + q] = (int)__popcll(bal);
+        }
+      }
+    }
+  }
+  STAMP(hdr, 3);
+  __syncthreads();                 // everyone has read the state before it changes
   if (threadIdx.x == 0) {
-    const int nk = keptpre[NMS_WORDS];
-    const int np = pos0 + m;
-    const int done = (nk >= K || np >= n - st->n_invalid) ? 1 : 0;
-    st->kept = nk;
+    st->kept = nkf;
     st->pos = np;
     st->done = done;
-    *out_count = nk;
+    *out_count = nkf;
     if (out_done) *out_done = done;
   }
+  STAMP(hdr, 4);
+  if (fused_lv) {
+    // _assign_levels (base_fpn_model.py:303-324) as a stable partition by level without re-reading
+    // anything: per (level, block) counts -> exclusive scan over the 64 blocks (wave L scans level L),
+    // then every kept candidate knows its slot.
+    if (w < nl) {
+      const int v = lvl_cnt[w][lane];
+      const int inc = wave_incl_scan(v);
+      lvl_cnt[w][lane] = inc - v;
+      if (lane == 63) { lvl_tot[w] = inc; ao.counts[w] = inc; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SCAN_Q; ++q) {
+      if (mylv[q] >= 0) {
+        int base = 0;
+        for (int L = 0; L < mylv[q]; ++L) base += lvl_tot[L];
+        const int pos = base + lvl_cnt[mylv[q]][b_own + q] + myrank[q];
+        ao.rois[pos] = obox[q];
+        ao.level[pos] = mylv[q];
+        ao.perm[pos] = myp[q];
+      }
+    }
+  } else if (want_assign) {
+    // several chunks contributed (fallback path): partition the complete RoI list from memory
+    __shared__ int lds_al[ODET_MAX_LEVELS * 17];
+    __threadfence_block();
+    __syncthreads();               // out_boxes rows written above are visible to the whole workgroup
+    d_assign_levels_block<SCAN_THREADS>(out_boxes, nkf, ao.min_level, ao.max_level, ao.rois, ao.level, ao.perm,
+                                        ao.counts, lds_al);
+  }
+  STAMP(hdr, 5);
+#ifdef ODET_STAMPS
+  if (threadIdx.x == 0) hdr->stamps[61] = clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------ host side --
 struct NmsWorkspace {
+  NmsHeader* hdr;
   uint32_t *keys_a, *vals_a, *keys_b, *vals_b, *hist;
-  NmsState* state;
-  float4 *sboxes, *kept_boxes;
-  unsigned long long *mask, *diag, *removed_init;
+  u64* cand;
+  float4 *sboxes, *sorig, *kept_boxes;
+  u64 *Lt, *diag, *removed_init;
 };
 
 static size_t nms_carve(int n, int max_out, void* ws, size_t ws_bytes, NmsWorkspace* o) {
@@ -272,17 +775,19 @@ static size_t nms_carve(int n, int max_out, void* ws, size_t ws_bytes, NmsWorksp
     T* p_ = ar.take<T>(count);                                \
     if (o) o->field = ws ? p_ : nullptr;                      \
   } while (0)
-  TAKE(state, NmsState, 1);
+  TAKE(hdr, NmsHeader, 1);
   TAKE(keys_a, uint32_t, nn);
   TAKE(vals_a, uint32_t, nn);
   TAKE(keys_b, uint32_t, nn);
-  TAKE(vals_b, uint32_t, nn);
+  TAKE(vals_b, uint32_t, std::max(nn, (size_t)NMS_CHUNK));
   TAKE(hist, uint32_t, odet_sort_hist_entries(n));
+  TAKE(cand, u64, NMS_CHUNK);
   TAKE(sboxes, float4, NMS_CHUNK);
+  TAKE(sorig, float4, NMS_CHUNK);
   TAKE(kept_boxes, float4, kk);
-  TAKE(mask, unsigned long long, (size_t)NMS_CHUNK * NMS_WORDS);
-  TAKE(diag, unsigned long long, NMS_CHUNK);
-  TAKE(removed_init, unsigned long long, NMS_WORDS);
+  TAKE(Lt, u64, (size_t)NMS_WORDS * NMS_CHUNK);
+  TAKE(diag, u64, NMS_CHUNK);
+  TAKE(removed_init, u64, NMS_WORDS);
 #undef TAKE
   return ar.off + 256;
 }
@@ -291,67 +796,137 @@ extern "C" size_t odet_nms_workspace_bytes(int n, int max_output) {
   return nms_carve(n, max_output, nullptr, 0, nullptr);
 }
 
-// Size of the first chunk: with few overlaps K kept boxes need barely more than K candidates, so
-// the first bit matrix is sized ~1.5 K instead of 4096 (7x fewer IoU tiles for K = 1000).
-static int first_chunk_cap(int n, int K) {
+// Candidates selected for the first chunk: with few overlaps K kept boxes need barely more than K
+// candidates, so the first bit matrix is sized ~1.5 K instead of 4096 (7x fewer IoU tiles at K = 1000).
+static int first_chunk_target(int n, int K) {
   long long c = ((long long)K * 3 / 2 + 63) / 64 * 64;
+  if (c > 64) c -= 32;   // half a block of slack for boundary ties: K = 1000 -> 1504 -> at most 24 blocks
   if (c < 256) c = 256;
   if (c > NMS_CHUNK) c = NMS_CHUNK;
-  if (c > ((long long)n + 63) / 64 * 64) c = ((long long)n + 63) / 64 * 64;
+  if (c > n) c = n;
   return (int)c;
 }
 
-// blind_chunks >= 1 chunks are enqueued without looking at the device state (a chunk whose
-// predecessor already finished exits at once).  out_done == nullptr: exact mode -- afterwards the
-// host reads the state (one sync per further chunk) until the device reports done.
-// out_done != nullptr: sync-free mode -- exactly blind_chunks chunks, *out_done tells the caller
-// whether the result is complete.
-static int nms_run(const float* boxes, const float* scores, int n, int K, float thr, int32_t* out_idx,
-                   float* out_boxes, int32_t* out_count, int blind_chunks, int32_t* out_done, void* ws,
-                   size_t ws_bytes, hipStream_t st) {
+static inline int tri_tiles(int cap) {
+  int nb = (cap + 63) / 64;
+  return nb * (nb + 1) / 2;
+}
+
+struct NmsJob {
+  int mode;                 // PREP_*
+  PrepParams prep;          // n, inputs, boxes_out, ... (keys / hdr filled in by nms_run)
+  const float4* boxes;      // boxes the NMS runs on (= prep.boxes_out for RP / FPN)
+  int n, K;
+  float thr;
+  int32_t* out_idx;
+  float* out_boxes;
+  int32_t* out_count;
+  int blind_chunks;
+  int32_t* out_done;
+  AssignOut assign;
+};
+
+// Chunk 0 (select path) is always enqueued.  blind_chunks > 1: the fallback (full sort + further
+// chunks) is enqueued without looking at the device state; its kernels exit at once when chunk 0
+// finished the job.  out_done == nullptr: exact mode -- afterwards the host reads the state (one
+// sync per further chunk) until the device reports done.  out_done != nullptr: sync-free mode --
+// exactly blind_chunks chunks, *out_done tells the caller whether the result is complete.
+static int nms_run(NmsJob& J, void* ws, size_t ws_bytes, hipStream_t st) {
   NmsWorkspace w;
+  const int n = J.n, K = J.K;
   size_t need = nms_carve(n, K, nullptr, 0, nullptr);
   if (!ws || ws_bytes < need)
     return odet_set_error(ODET_E_WORKSPACE, "odet_nms: workspace too small (%zu < %zu)", ws_bytes, need);
   nms_carve(n, K, ws, ws_bytes, &w);
+  NmsState* state = &w.hdr->st;
   static bool attr_set = false;
   if (!attr_set) {
-    ODET_HIP(hipFuncSetAttribute((const void*)k_nms_scan, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_DYN_LDS));
+    ODET_HIP(hipFuncSetAttribute((const void*)k_nms_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 SCAN_DYN_LDS));
     attr_set = true;
   }
-  ODET_HIP(hipMemsetAsync(w.state, 0, sizeof(NmsState), st));
+  ODET_HIP(hipMemsetAsync(w.hdr, 0, sizeof(NmsHeader), st));
+  // 1. prepare
+  J.prep.n = n;
+  J.prep.keys = w.keys_a;
+  J.prep.hdr = w.hdr;
+  {
+    dim3 grid((n + PREP_TILE - 1) / PREP_TILE), block(256);
+    if (J.mode == PREP_NMS)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_NMS>), grid, block, 0, st, J.prep);
+    else if (J.mode == PREP_RP)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_RP>), grid, block, 0, st, J.prep);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_FPN>), grid, block, 0, st, J.prep);
+    ODET_LAUNCH_CHECK();
+  }
+  // 2. select + order the first chunk
+  const uint32_t target = (uint32_t)first_chunk_target(n, K);
+  // chunk 0 runs on the LDS-resident scan when its candidates are guaranteed to fit 24 blocks
+  const bool lds0 = target <= (uint32_t)SCAN_LDS_CAND;
+  const uint32_t limit = lds0 ? (uint32_t)SCAN_LDS_CAND : (uint32_t)NMS_CHUNK;
+  {
+    dim3 grid((n + SEL_TILE - 1) / SEL_TILE), block(SEL_BLOCK);
+    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, w.hdr, w.keys_a, n, target);
+    ODET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, w.hdr, w.keys_a, n, target, limit, w.cand);
+    ODET_LAUNCH_CHECK();
+    const int rank_wgs = (std::min(n, NMS_CHUNK) + 63) / 64;
+    hipLaunchKernelGGL(k_sel_rank, dim3(rank_wgs), dim3(RANK_THREADS), 0, st, w.hdr, n, w.cand, J.boxes, w.vals_b,
+                       w.sboxes, w.sorig);
+    ODET_LAUNCH_CHECK();
+  }
+  // 3./4. chunk 0
+  {
+    const int cap0 = std::min((int)limit, (n + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap0)), dim3(256), 0, st, state, w.sboxes, J.thr, w.Lt, w.diag,
+                       lds0 ? 1 : 0);
+    ODET_LAUNCH_CHECK();
+    if (lds0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<true>), dim3(1), dim3(SCAN_THREADS), SCAN_DYN_LDS, st, state, n,
+                         w.Lt, w.diag, w.removed_init, 0, w.sboxes, w.sorig, w.vals_b, K, J.out_idx,
+                         (float4*)J.out_boxes, w.kept_boxes, J.out_count, J.out_done, J.assign);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1), dim3(SCAN_THREADS), 0, st, state, n, w.Lt,
+                         w.diag, w.removed_init, 0, w.sboxes, w.sorig, w.vals_b, K, J.out_idx, (float4*)J.out_boxes,
+                         w.kept_boxes, J.out_count, J.out_done, J.assign);
+    ODET_LAUNCH_CHECK();
+  }
+  int blind = J.blind_chunks < 1 ? 1 : J.blind_chunks;
+  if (blind == 1) {
+    if (J.out_done) return ODET_OK;            // sync-free: the caller checks *out_done
+    NmsState h;
+    ODET_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+    ODET_HIP(hipStreamSynchronize(st));
+    if (h.done) return ODET_OK;
+  }
+  // 5. fallback: full order, then chunks of 4096 from wherever chunk 0 stopped
   uint32_t* sorted = nullptr;
-  int rc = odet_sort_pairs_desc(scores, n, w.keys_a, w.vals_a, w.keys_b, w.vals_b, w.hist, &w.state->n_invalid,
-                                &sorted, st);
+  int rc = odet_sort_keys_desc(n, w.keys_a, w.vals_a, w.keys_b, w.vals_b, w.hist, &state->done, &sorted, st);
   if (rc != ODET_OK) return rc;
-  if (blind_chunks < 1) blind_chunks = 1;
-  int consumed = 0;   // upper bound of candidates handed to chunks so far
-  for (int c = 0; consumed < n; ++c) {
-    if (c >= blind_chunks) {
-      if (out_done) break;
-      // exact mode: need the device's verdict to know whether another chunk is required
+  const int max_chunks = (n + NMS_CHUNK - 1) / NMS_CHUNK + 1;
+  for (int c = 1; c <= max_chunks; ++c) {
+    if (c >= blind && !(c == 1 && blind == 1)) {   // (c == 1 && blind == 1: the host has just seen "not done")
+      if (J.out_done) break;
       NmsState h;
-      ODET_HIP(hipMemcpyAsync(&h, w.state, sizeof(h), hipMemcpyDeviceToHost, st));
+      ODET_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
       ODET_HIP(hipStreamSynchronize(st));
       if (h.done) break;
     }
-    const int cap = (c == 0) ? first_chunk_cap(n, K) : std::min(NMS_CHUNK, (n - consumed + 63) / 64 * 64);
-    const int nb = (cap + 63) / 64;
-    hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, w.state, n, cap,
-                       (const float4*)boxes, sorted, w.sboxes);
+    const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
+    hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, state, n, cap, J.boxes, sorted,
+                       w.sboxes, w.sorig);
     ODET_LAUNCH_CHECK();
-    if (c > 0) {
-      hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, w.state, w.sboxes, w.kept_boxes,
-                         thr, w.removed_init);
-      ODET_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, st, w.state, w.sboxes, thr, w.mask, w.diag);
+    hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, state, w.sboxes, w.kept_boxes, J.thr,
+                       w.removed_init);
     ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(SCAN_THREADS), SCAN_DYN_LDS, st, w.state, n, w.mask, w.diag,
-                       w.removed_init, c > 0 ? 1 : 0, w.sboxes, sorted, (const float4*)boxes, K, out_idx,
-                       (float4*)out_boxes, w.kept_boxes, out_count, out_done);
+    hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap)), dim3(256), 0, st, state, w.sboxes, J.thr, w.Lt, w.diag, 0);
     ODET_LAUNCH_CHECK();
-    consumed += cap;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1), dim3(SCAN_THREADS), 0, st, state, n, w.Lt, w.diag,
+                       w.removed_init, 1,
+                       w.sboxes, w.sorig, sorted, K, J.out_idx, (float4*)J.out_boxes, w.kept_boxes, J.out_count,
+                       J.out_done, J.assign);
+    ODET_LAUNCH_CHECK();
   }
   return ODET_OK;
 }
@@ -365,6 +940,11 @@ static int nms_trivial(int32_t* out_count, int32_t* out_done, hipStream_t st) {
   return ODET_OK;
 }
 
+static void no_assign(AssignOut* a) {
+  a->rois = nullptr; a->level = nullptr; a->perm = nullptr; a->counts = nullptr;
+  a->min_level = 0; a->max_level = 0;
+}
+
 extern "C" int odet_nms(const float* boxes, const float* scores, int n, int max_output, float iou_threshold,
                         int32_t* out_idx, float* out_boxes, int32_t* out_count, int blind_chunks,
                         int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
@@ -372,14 +952,41 @@ extern "C" int odet_nms(const float* boxes, const float* scores, int n, int max_
   ODET_REQUIRE(out_count, "odet_nms: null out_count");
   if (n == 0 || max_output == 0) return nms_trivial(out_count, out_done, (hipStream_t)stream);
   ODET_REQUIRE(boxes && scores && out_idx, "odet_nms: null pointer");
-  return nms_run(boxes, scores, n, max_output, iou_threshold, out_idx, out_boxes, out_count, blind_chunks, out_done,
-                 workspace, workspace_bytes, (hipStream_t)stream);
+  NmsJob J;
+  memset(&J.prep, 0, sizeof(J.prep));
+  J.mode = PREP_NMS;
+  J.prep.boxes_in = (const float4*)boxes;
+  J.prep.scores = scores;
+  J.boxes = (const float4*)boxes;
+  J.n = n; J.K = max_output; J.thr = iou_threshold;
+  J.out_idx = out_idx; J.out_boxes = out_boxes; J.out_count = out_count;
+  J.blind_chunks = blind_chunks; J.out_done = out_done;
+  no_assign(&J.assign);
+  return nms_run(J, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static size_t rp_workspace_bytes(int n, int max_output) {
+  return odet_nms_workspace_bytes(n, max_output) + odet_align_up((size_t)(n > 0 ? n : 1) * 16, 256) +
+         odet_align_up((size_t)(max_output > 0 ? max_output : 1) * sizeof(int32_t), 256) + 512;
 }
 
 extern "C" size_t odet_region_proposal_workspace_bytes(int n, int max_output) {
-  return odet_align_up((size_t)(n > 0 ? n : 1) * 16, 256) +
-         odet_align_up((size_t)(max_output > 0 ? max_output : 1) * sizeof(int32_t), 256) +
-         odet_nms_workspace_bytes(n, max_output) + 512;
+  return rp_workspace_bytes(n, max_output);
+}
+
+// carve: [NMS workspace (header first, so the memset starts at the allocation)] [boxes n] [idx K]
+static int rp_carve(int n, int K, void* workspace, size_t workspace_bytes, const char* who, float4** boxes,
+                    int32_t** idx, void** nms_ws, size_t* nms_bytes) {
+  size_t need = rp_workspace_bytes(n, K);
+  if (!workspace || workspace_bytes < need)
+    return odet_set_error(ODET_E_WORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, need);
+  size_t nb = odet_align_up(odet_nms_workspace_bytes(n, K), 256);
+  OdetArena ar{(char*)workspace + nb, workspace_bytes - nb, 0};
+  *boxes = ar.take<float4>((size_t)n);
+  *idx = ar.take<int32_t>((size_t)K);
+  *nms_ws = workspace;
+  *nms_bytes = nb;
+  return ODET_OK;
 }
 
 extern "C" int odet_region_proposal(const float* deltas, const float* anchors, const float* scores, int n,
@@ -392,19 +999,92 @@ extern "C" int odet_region_proposal(const float* deltas, const float* anchors, c
   ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_region_proposal: bad image shape");
   if (n == 0 || max_output == 0) return nms_trivial(out_count, out_done, (hipStream_t)stream);
   ODET_REQUIRE(deltas && anchors && scores && means && stds && out_rois, "odet_region_proposal: null pointer");
-  size_t need = odet_region_proposal_workspace_bytes(n, max_output);
-  if (!workspace || workspace_bytes < need)
-    return odet_set_error(ODET_E_WORKSPACE, "odet_region_proposal: workspace too small (%zu < %zu)",
-                          workspace_bytes, need);
-  OdetArena ar{(char*)workspace, workspace_bytes, 0};
-  float* boxes = ar.take<float>((size_t)n * 4);
-  int32_t* idx_buf = out_idx;
-  if (!idx_buf) idx_buf = ar.take<int32_t>((size_t)max_output);
-  size_t off = odet_align_up(ar.off, 256);
-  // region_proposal.py:59 decode + :63 clip (min_edge=None), fused
-  int rc = odet_decode(anchors, deltas, 4, n, means, stds, image_h, image_w, boxes, stream);
+  float4* boxes; int32_t* idx_buf; void* nws; size_t nbytes;
+  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_region_proposal", &boxes, &idx_buf, &nws, &nbytes);
   if (rc != ODET_OK) return rc;
-  // region_proposal.py:73-76 NMS over all n, :81 gather
-  return nms_run(boxes, scores, n, max_output, iou_threshold, idx_buf, out_rois, out_count, blind_chunks, out_done,
-                 (char*)workspace + off, workspace_bytes - off, (hipStream_t)stream);
+  NmsJob J;
+  memset(&J.prep, 0, sizeof(J.prep));
+  J.mode = PREP_RP;
+  J.prep.boxes_in = (const float4*)anchors;
+  J.prep.deltas = deltas;
+  J.prep.scores = scores;
+  for (int k = 0; k < 4; ++k) { J.prep.means.v[k] = means[k]; J.prep.stds.v[k] = stds[k]; }
+  J.prep.wmax = (float)(image_w - 1); J.prep.hmax = (float)(image_h - 1);
+  J.prep.boxes_out = boxes;
+  J.boxes = boxes;
+  J.n = n; J.K = max_output; J.thr = iou_threshold;
+  J.out_idx = out_idx ? out_idx : idx_buf; J.out_boxes = out_rois; J.out_count = out_count;
+  J.blind_chunks = blind_chunks; J.out_done = out_done;
+  no_assign(&J.assign);
+  return nms_run(J, nws, nbytes, (hipStream_t)stream);
+}
+
+extern "C" size_t odet_fpn_proposals_workspace_bytes(int n, int max_output) {
+  return rp_workspace_bytes(n, max_output);
+}
+
+extern "C" int odet_fpn_proposals(const float* rpn_logits, const float* rpn_deltas, int num_levels, int A,
+                                  const int* fh, const int* fw, const int* stride, const float* wh, int image_h,
+                                  int image_w, const float* means, const float* stds, int max_output,
+                                  float iou_threshold, int min_level, int max_level, float* out_rois,
+                                  int32_t* out_idx, int32_t* out_count, float* out_sorted_rois, int32_t* out_level,
+                                  int64_t* out_perm, int32_t* out_level_counts, int blind_chunks, int32_t* out_done,
+                                  void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(rpn_logits && rpn_deltas && fh && fw && stride && wh && means && stds,
+               "odet_fpn_proposals: null pointer");
+  ODET_REQUIRE(out_rois && out_count, "odet_fpn_proposals: null output");
+  ODET_REQUIRE(num_levels > 0 && num_levels <= ODET_MAX_LEVELS, "odet_fpn_proposals: num_levels %d out of range",
+               num_levels);
+  ODET_REQUIRE(A > 0 && A <= ODET_MAX_ANCHORS_PER_CELL, "odet_fpn_proposals: A %d out of range", A);
+  ODET_REQUIRE(image_h > 0 && image_w > 0 && max_output > 0, "odet_fpn_proposals: bad sizes");
+  const bool assign = out_sorted_rois != nullptr;
+  if (assign) {
+    ODET_REQUIRE(out_level && out_perm && out_level_counts, "odet_fpn_proposals: null level outputs");
+    ODET_REQUIRE(max_level >= min_level && max_level - min_level < ODET_MAX_LEVELS, "odet_fpn_proposals: bad levels");
+    if (max_output > ODET_ASSIGN_MAX_ROIS)
+      return odet_set_error(ODET_E_LIMIT, "odet_fpn_proposals: max_output %d exceeds %d", max_output,
+                            ODET_ASSIGN_MAX_ROIS);
+  }
+  NmsJob J;
+  memset(&J.prep, 0, sizeof(J.prep));
+  FpnAnchorParams& p = J.prep.fpn;
+  p.num_levels = num_levels;
+  p.A = A;
+  int64_t total = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    ODET_REQUIRE(fh[l] >= 0 && fw[l] > 0 && stride[l] > 0, "odet_fpn_proposals: bad level %d", l);
+    p.fw[l] = fw[l];
+    p.stride[l] = stride[l];
+    p.start[l] = (int)total;
+    total += (int64_t)fh[l] * fw[l] * A;
+    ODET_REQUIRE(total < (1ll << 31), "odet_fpn_proposals: too many anchors");
+  }
+  for (int l = num_levels; l <= ODET_MAX_LEVELS; ++l) p.start[l] = (int)total;
+  for (int i = 0; i < num_levels * A * 2; ++i) p.wh[i] = wh[i];
+  const int n = (int)total;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    if (assign) ODET_HIP(hipMemsetAsync(out_level_counts, 0, sizeof(int32_t) * (max_level - min_level + 1), st));
+    return nms_trivial(out_count, out_done, st);
+  }
+  float4* boxes; int32_t* idx_buf; void* nws; size_t nbytes;
+  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_fpn_proposals", &boxes, &idx_buf, &nws, &nbytes);
+  if (rc != ODET_OK) return rc;
+  J.mode = PREP_FPN;
+  J.prep.logits = (const float2*)rpn_logits;
+  J.prep.deltas = rpn_deltas;
+  for (int k = 0; k < 4; ++k) { J.prep.means.v[k] = means[k]; J.prep.stds.v[k] = stds[k]; }
+  J.prep.wmax = (float)(image_w - 1); J.prep.hmax = (float)(image_h - 1);
+  J.prep.boxes_out = boxes;
+  J.boxes = boxes;
+  J.n = n; J.K = max_output; J.thr = iou_threshold;
+  J.out_idx = out_idx ? out_idx : idx_buf; J.out_boxes = out_rois; J.out_count = out_count;
+  J.blind_chunks = blind_chunks; J.out_done = out_done;
+  if (assign) {
+    J.assign.rois = (float4*)out_sorted_rois; J.assign.level = out_level; J.assign.perm = out_perm;
+    J.assign.counts = out_level_counts; J.assign.min_level = min_level; J.assign.max_level = max_level;
+  } else {
+    no_assign(&J.assign);
+  }
+  return nms_run(J, nws, nbytes, st);
 }

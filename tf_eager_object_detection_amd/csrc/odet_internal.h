@@ -95,12 +95,172 @@ __device__ __forceinline__ uint32_t d_float_asc_key(float f) {
 }
 #endif  // __HIPCC__
 
+
+// ---- shared parameter blocks / device helpers ------------------------------------------------
+struct Vec4 { float v[4]; };
+
+// utils/anchor_generator.py:137-178 make_anchors over all pyramid levels (base_fpn_model.py:163-186).
+struct FpnAnchorParams {
+  int num_levels;
+  int A;
+  int fw[ODET_MAX_LEVELS];
+  int stride[ODET_MAX_LEVELS];
+  int start[ODET_MAX_LEVELS + 1];  // first anchor of each level
+  float wh[ODET_MAX_LEVELS * ODET_MAX_ANCHORS_PER_CELL * 2];
+};
+
+#ifdef __HIPCC__
+// anchor i of the concatenated level list: location-major / anchor-minor inside a level.
+__device__ __forceinline__ float4 d_fpn_anchor(const FpnAnchorParams& p, int i) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < ODET_MAX_LEVELS; ++k)
+    if (k < p.num_levels && i >= p.start[k]) l = k;
+  int j = i - p.start[l];
+  int a = j % p.A;
+  int cell = j / p.A;
+  int x = cell % p.fw[l], y = cell / p.fw[l];
+  float fs = (float)p.stride[l];
+  float cx = (float)x * fs, cy = (float)y * fs;            // anchor_generator.py:146-147
+  float hw = 0.5f * p.wh[(l * p.A + a) * 2 + 0];           // :160-161
+  float hh = 0.5f * p.wh[(l * p.A + a) * 2 + 1];
+  return make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+}
+
+// tf.nn.softmax arithmetic on a (bg, fg) pair: e = exp(x - max); p = e_fg * (1 / (e_bg + e_fg)).
+__device__ __forceinline__ float d_fg_prob(float bg, float fg) {
+  float m = fmaxf(bg, fg);
+  float e0 = d_exp32(bg - m), e1 = d_exp32(fg - m);
+  float inv = 1.0f / (e0 + e1);
+  return e1 * inv;
+}
+
+// model/fpn/base_fpn_model.py:307-313 level of one RoI (0-based: level - min_level).
+// The reference value is floor(4 + log(sqrt(w*h + 1e-8) / 224) / log(2)) in float32 with a correctly
+// rounded log.  That log goes through float64 (~300 instructions); the hardware log2 gives the same
+// quantity to ~1e-5, which decides the floor unless the value sits within 1e-4 of an integer -- only
+// then is the exact expression evaluated, so the result is always the reference's.
+__device__ __forceinline__ int d_roi_level(float4 b, int min_level, int max_level) {
+  const float log2v = 0x1.62e43p-1f;   // (float)log(2.0): tf.log(2.) as a float32 constant
+  float h = fmaxf(0.0f, b.w - b.y);                       // :307
+  float w = fmaxf(0.0f, b.z - b.x);                       // :308
+  const float x = sqrtf(w * h + 1e-8f) / 224.0f;
+  float l;
+  const float ya = 4.0f + __log2f(x);
+  const float fl = floorf(ya);
+  const float fr = ya - fl;
+  if (fr > 1e-4f && fr < 1.0f - 1e-4f) {
+    l = fl;
+  } else {
+    l = floorf(4.0f + d_log32(x) / log2v);                // :309
+  }
+  l = fmaxf(l, (float)min_level);                         // :312
+  l = fminf(l, (float)max_level);                         // :313
+  return (int)l - min_level;
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan across a block of up to 1024 threads; returns exclusive prefix, sets total.
+__device__ __forceinline__ int block_excl_scan(int v, int* lds /*[17]*/, int* total) {
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int nw = (blockDim.x + 63) >> 6;
+  int inc = wave_incl_scan(v);
+  __syncthreads();
+  if (lane == 63) lds[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 0; k < nw; ++k) { int t = lds[k]; lds[k] = run; run += t; }
+    lds[16] = run;
+  }
+  __syncthreads();
+  *total = lds[16];
+  return lds[w] + inc - v;
+}
+
+// model/fpn/base_fpn_model.py:303-324 _assign_levels by ONE workgroup of THREADS threads: level per RoI,
+// then a stable partition by level (ascending original index inside a level) -- the order
+// tf.where + tf.gather + tf.concat produce at :316-324.  rois may have been written by this
+// workgroup (caller syncs first).  Thread t owns the ceil(cnt/THREADS) consecutive RoIs starting at
+// t*per, so (wave, lane, item) order is index order; per level: wave-scan of the per-thread counts,
+// per-wave totals through LDS, one small scan over (level, wave) by wave 0.  Two barriers.
+template <int THREADS>
+__device__ __forceinline__ void d_assign_levels_block(const float4* rois, int cnt, int min_level, int max_level,
+                                                      float4* __restrict__ out_rois, int32_t* __restrict__ out_level,
+                                                      int64_t* __restrict__ out_perm, int32_t* __restrict__ out_counts,
+                                                      int* lds /*[ODET_MAX_LEVELS * 16 + ODET_MAX_LEVELS]*/) {
+  constexpr int ITEMS = ODET_ASSIGN_MAX_ROIS / THREADS;
+  constexpr int NW = THREADS / 64;
+  const int nl = max_level - min_level + 1;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = (cnt + THREADS - 1) / THREADS;
+  const int lo = threadIdx.x * per;
+  int lv[ITEMS];
+  float4 rb[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = lo + k;
+    lv[k] = -1;
+    if (k < per && i < cnt) { rb[k] = rois[i]; lv[k] = d_roi_level(rb[k], min_level, max_level); }
+  }
+  int off[ODET_MAX_LEVELS];   // exclusive offset of this thread inside its wave, per level
+#pragma unroll
+  for (int L = 0; L < ODET_MAX_LEVELS; ++L) {
+    off[L] = 0;
+    if (L < nl) {
+      int c = 0;
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) c += (lv[k] == L) ? 1 : 0;
+      const int inc = wave_incl_scan(c);
+      off[L] = inc - c;
+      if (lane == 63) lds[L * 16 + w] = inc;
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    int base = 0;
+    for (int L = 0; L < nl; ++L) {
+      const int v = (lane < NW) ? lds[L * 16 + lane] : 0;
+      const int inc = wave_incl_scan(v);
+      const int total = __shfl(inc, NW - 1);
+      if (lane < NW) lds[L * 16 + lane] = base + inc - v;
+      if (lane == 0) { lds[ODET_MAX_LEVELS * 16 + L] = total; out_counts[L] = total; }
+      base += total;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int L = 0; L < ODET_MAX_LEVELS; ++L) {
+    if (L < nl) {
+      int pos = lds[L * 16 + w] + off[L];
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        if (lv[k] == L) {
+          out_rois[pos] = rb[k];
+          out_level[pos] = L;
+          out_perm[pos] = lo + k;
+          ++pos;
+        }
+      }
+    }
+  }
+}
+#endif  // __HIPCC__
+
 struct Float4Host { float v[4]; };
 
 // shared between translation units
-int odet_sort_pairs_desc(const float* scores, int n, uint32_t* keys_a, uint32_t* vals_a,
-                         uint32_t* keys_b, uint32_t* vals_b, uint32_t* hist, int32_t* n_invalid_dev,
-                         uint32_t** sorted_vals, hipStream_t stream);
+int odet_sort_keys_desc(int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
+                        uint32_t* hist, const int32_t* skip, uint32_t** sorted_vals, hipStream_t stream);
 size_t odet_sort_hist_entries(int n);
 
 #endif  // ODET_INTERNAL_H_

@@ -4,9 +4,14 @@
 // over ALL anchors: 267 069 at 800x1333 FPN).  TF pops a max-heap; a stable descending sort
 // gives the same visiting order with the declared tie rule (score desc, index asc).
 //
-// Key: ~asc(score) so that an ascending LSD sort yields descending scores.  Scores TF would
-// never push (NaN, or <= lowest float: "score > score_threshold" is false) get key 0xFFFFFFFF
-// and sort to the end; *n_valid_dev = n - (number of such scores).
+// This is the FALLBACK ordering of the NMS path: the common case orders only the best ~1.5 K
+// candidates (radix select + one-workgroup sort, nms.hip); the full sort runs when that chunk does
+// not reach max_output.  Every kernel takes a `skip` flag (the NMS "done" word in device memory) and
+// exits at once when it is set, so the sync-free mode can enqueue the fallback unconditionally.
+//
+// Key: ~asc(score) so that an ascending LSD sort yields descending scores (keys are produced by
+// k_rp_prepare in nms.hip; scores TF would never push -- NaN or <= lowest float -- have key
+// 0xFFFFFFFF and sort to the end).
 //
 // 4 passes x 8-bit digits, 2 launches per pass:
 //   k_rs_hist    : per-block digit histogram, stored block-major (one coalesced 1 KiB row per block)
@@ -14,7 +19,7 @@
 //                  256 digits, column sums over the L2-resident table + one block scan -- no separate
 //                  scan launch), ranks its 2048 keys with a wave64 ballot multi-split (8 ballots give
 //                  each lane the set of lanes sharing its digit) and scatters keys + payload.
-// Pass 0's histogram is produced by the key-building kernel.
+// Pass 0's histogram is produced by k_rs_init (which also writes the iota payload).
 #include "odet_internal.h"
 
 #define RS_BLOCK 256
@@ -34,34 +39,29 @@ __device__ __forceinline__ int rs_elem(int item) {
   return blockIdx.x * RS_TILE + (w * RS_ITEMS + item) * 64 + lane;
 }
 
-// keys + payload + pass-0 histogram + count of scores that are not NMS candidates
-__global__ void __launch_bounds__(RS_BLOCK) k_rs_make_keys(const float* __restrict__ scores, int n,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                           uint32_t* __restrict__ hist, int32_t* __restrict__ n_invalid) {
+// payload (iota) + pass-0 histogram from precomputed keys
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_init(const uint32_t* __restrict__ keys, int n,
+                                                      uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
+                                                      const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;
   __shared__ uint32_t h[RS_RADIX];
   h[threadIdx.x] = 0;
   __syncthreads();
-  int invalid = 0;
 #pragma unroll
   for (int it = 0; it < RS_ITEMS; ++it) {
     int e = rs_elem(it);
     if (e < n) {
-      float s = scores[e];
-      bool valid = s > -3.402823466e+38f;   // NonMaxSuppressionV3: score > score_threshold (= lowest); NaN fails
-      uint32_t k = valid ? ~d_float_asc_key(s) : 0xFFFFFFFFu;
-      keys[e] = k;
       vals[e] = (uint32_t)e;
-      invalid += valid ? 0 : 1;
-      atomicAdd(&h[k & 0xFF], 1u);
+      atomicAdd(&h[keys[e] & 0xFF], 1u);
     }
   }
   __syncthreads();
   hist[(size_t)blockIdx.x * RS_RADIX + threadIdx.x] = h[threadIdx.x];   // block-major
-  if (invalid) atomicAdd(n_invalid, invalid);                           // rare
 }
 
 __global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift,
-                                                      uint32_t* __restrict__ hist) {
+                                                      uint32_t* __restrict__ hist, const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;
   __shared__ uint32_t h[RS_RADIX];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -88,7 +88,9 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restr
                                                          const uint32_t* __restrict__ vals_in, int n, int shift,
                                                          const uint32_t* __restrict__ hist, int nblocks,
                                                          uint32_t* __restrict__ keys_out,
-                                                         uint32_t* __restrict__ vals_out) {
+                                                         uint32_t* __restrict__ vals_out,
+                                                         const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;
   __shared__ uint32_t cnt[RS_WAVES][RS_RADIX];
   __shared__ uint32_t gbase[RS_RADIX];
   __shared__ uint32_t wsum[RS_WAVES];
@@ -178,31 +180,28 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restr
   }
 }
 
-// Sorts indices 0..n-1 by (score desc, index asc).  keys_a/vals_a/keys_b/vals_b: n uint32
-// each; hist: odet_sort_hist_entries(n) uint32.  *n_invalid_dev must be zero on entry (the caller
-// clears it with its state memset) and receives the number of scores that are not candidates.
+// Sorts indices 0..n-1 by (key asc, index asc) = (score desc, index asc).  keys_a holds the keys on
+// entry; keys_a/vals_a/keys_b/vals_b: n uint32 each; hist: odet_sort_hist_entries(n) uint32.
 // *sorted_vals points at the buffer holding the result (vals_a after an even number of passes).
-int odet_sort_pairs_desc(const float* scores, int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b,
-                         uint32_t* vals_b, uint32_t* hist, int32_t* n_invalid_dev, uint32_t** sorted_vals,
-                         hipStream_t st) {
+int odet_sort_keys_desc(int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
+                        uint32_t* hist, const int32_t* skip, uint32_t** sorted_vals, hipStream_t st) {
   int nblocks = (n + RS_TILE - 1) / RS_TILE;
-  hipLaunchKernelGGL(k_rs_make_keys, dim3(nblocks), dim3(RS_BLOCK), 0, st, scores, n, keys_a, vals_a, hist,
-                     n_invalid_dev);
+  hipLaunchKernelGGL(k_rs_init, dim3(nblocks), dim3(RS_BLOCK), 0, st, keys_a, n, vals_a, hist, skip);
   ODET_LAUNCH_CHECK();
   uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
   for (int pass = 0; pass < 4; ++pass) {
     int shift = pass * 8;
     if (pass > 0) {
-      hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, n, shift, hist);
+      hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, n, shift, hist, skip);
       ODET_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, vin, n, shift, hist, nblocks, kout,
-                       vout);
+                       vout, skip);
     ODET_LAUNCH_CHECK();
     uint32_t* t;
     t = kin; kin = kout; kout = t;
     t = vin; vin = vout; vout = t;
   }
-  *sorted_vals = vin;   // == vals_a after 4 passes
+  *sorted_vals = vin;   // == vals_a after 4 passes (keys_a is sorted too)
   return ODET_OK;
 }

@@ -222,6 +222,49 @@ def region_proposal(deltas, anchors, scores, image_shape, num_post_nms, iou_thre
     return rois, idx, cnt
 
 
+def fpn_proposals(rpn_logits, rpn_deltas, fh_list, fw_list, stride_list, wh_table, image_shape, num_post_nms,
+                  iou_threshold, means, stds, min_level=None, max_level=None, workspace=None, blind_chunks=1,
+                  done=None, out=None, out_levels=None):
+    """The whole FPN proposal stage (anchors in registers -> fg softmax -> decode+clip -> NMS over all
+    anchors [-> level assignment]) as ONE C-ABI call.  -> (rois [K,4] padded, idx int32 [K], count int32[1])
+    and, when min_level is given, (sorted rois [K,4], level int32 [K], perm int64 [K], counts int32 [L])."""
+    logits = L.f32c(rpn_logits, 'rpn_score')
+    deltas = L.f32c(rpn_deltas, 'rpn_bbox_txtytwth')
+    nl = len(fh_list)
+    wh = np.ascontiguousarray(wh_table, dtype=np.float32)
+    A = wh.shape[1]
+    n = sum(int(a) * int(b) for a, b in zip(fh_list, fw_list)) * A
+    if logits.numel() != n * 2 or deltas.numel() != n * 4:
+        raise ValueError('fpn_proposals: %d anchors but rpn scores %s / deltas %s'
+                         % (n, tuple(logits.shape), tuple(deltas.shape)))
+    fh = (C.c_int * nl)(*[int(v) for v in fh_list])
+    fw = (C.c_int * nl)(*[int(v) for v in fw_list])
+    st = (C.c_int * nl)(*[int(v) for v in stride_list])
+    K = max(min(int(num_post_nms), n), 1)
+    dev = logits.device
+    if out is not None:
+        rois, idx, cnt = out
+    else:
+        rois = torch.empty((K, 4), dtype=torch.float32, device=dev)
+        idx = torch.empty(K, dtype=torch.int32, device=dev)
+        cnt = _count_tensor(dev)
+    lv = None
+    if min_level is not None:
+        nlv = int(max_level) - int(min_level) + 1
+        lv = out_levels if out_levels is not None else (
+            torch.empty((K, 4), dtype=torch.float32, device=dev), torch.empty(K, dtype=torch.int32, device=dev),
+            torch.empty(K, dtype=torch.int64, device=dev), torch.empty(nlv, dtype=torch.int32, device=dev))
+    nb = L.lib().odet_fpn_proposals_workspace_bytes(n, K)
+    ws = workspace if workspace is not None and workspace.numel() >= nb else L.workspace(nb, dev)
+    L.check(L.lib().odet_fpn_proposals(
+        L.dptr(logits), L.dptr(deltas), nl, A, fh, fw, st, wh.ctypes.data_as(C.c_void_p), int(image_shape[0]),
+        int(image_shape[1]), L.host4(means, 'target_means'), L.host4(stds, 'target_stds'), K, float(iou_threshold),
+        int(min_level or 0), int(max_level or 0), L.dptr(rois), L.dptr(idx), L.dptr(cnt),
+        L.dptr(lv[0]) if lv else None, L.dptr(lv[1]) if lv else None, L.dptr(lv[2]) if lv else None,
+        L.dptr(lv[3]) if lv else None, int(blind_chunks), L.dptr(done), L.dptr(ws), ws.numel(), L.stream()))
+    return (rois, idx, cnt) + ((lv,) if lv else ())
+
+
 def assign_levels(rois, min_level, max_level, count_dev=None, out=None):
     """-> (sorted rois [n,4], level int32 [n] (0-based), perm int64 [n], counts int32 [L]).
     ``out`` = preallocated (sorted rois, level, perm, counts) to reuse."""

@@ -7,8 +7,9 @@ buffers are allocated once at their maximum size, data-dependent counts stay in 
 are consumed by the next kernel, and nothing between the RPN head's output and the final padded
 detections touches the host -- so the whole stage sequence can be replayed from a HIP graph.
 
-    stage_proposals : anchors (all levels, 1 launch) -> fg softmax -> decode+clip -> radix sort ->
-                      bit-matrix NMS -> level assignment (stable partition)
+    stage_proposals : ONE C-ABI call (odet_fpn_proposals): anchors in registers -> fg softmax ->
+                      decode+clip -> radix select of the best candidates -> bit-matrix NMS -> level
+                      assignment (stable partition) in the NMS tail
     stage_roi       : fused crop_and_resize(14x14)+maxpool over P2..P5, level-sorted RoIs
     stage_detect    : per-class filter/decode/clip/NMS (one workgroup per class) -> top-k merge
 """
@@ -17,7 +18,7 @@ import torch
 
 from . import ops
 from . import synthetic as syn
-from .utils.anchor_generator import make_fpn_anchors
+from .utils.anchor_generator import fpn_level_tables
 
 
 class FpnHotPath:
@@ -26,7 +27,7 @@ class FpnHotPath:
                  roi_means=(0, 0, 0, 0), roi_stds=(0.1, 0.1, 0.2, 0.2), max_per_class=50, max_per_image=50,
                  nms_iou=0.3, score_threshold=0.0, min_level=2, max_level=5, strides=syn.FPN_STRIDES,
                  base_sizes=syn.FPN_BASE_SIZES, ratios=syn.FPN_RATIOS, scales=syn.FPN_SCALES,
-                 blind_chunks=2, device=None):
+                 blind_chunks=1, device=None):
         self.image_shape = [int(image_shape[0]), int(image_shape[1])]
         self.num_classes = num_classes
         self.K = num_proposals
@@ -43,7 +44,8 @@ class FpnHotPath:
         dev = self.device
         K = self.K
         # persistent buffers (allocated once; 288 GB of HBM makes this a non-issue)
-        nb = ops.L.lib().odet_region_proposal_workspace_bytes(self.N, K)
+        self.fh, self.fw, self.wh = fpn_level_tables(self.image_shape, strides, base_sizes, scales, ratios)
+        nb = ops.L.lib().odet_fpn_proposals_workspace_bytes(self.N, K)
         self.ws_rpn = torch.empty(nb, dtype=torch.uint8, device=dev)
         self.rois = torch.zeros((K, 4), dtype=torch.float32, device=dev)
         self.roi_idx = torch.zeros(K, dtype=torch.int32, device=dev)
@@ -67,14 +69,13 @@ class FpnHotPath:
     # ---- stage 1: RPN outputs -> level-sorted proposals -------------------------------------
     def stage_proposals(self, rpn_logits, rpn_deltas):
         """rpn_logits [N,2] (bg,fg) as RpnHead emits them (base_fpn_model.py:429), rpn_deltas [N,4]."""
-        anchors = make_fpn_anchors(self.image_shape, self.strides, self.base_sizes, self.scales, self.ratios)
-        scores = ops.rpn_fg_softmax(rpn_logits, 1, ops.RPN_LAYOUT_FPN)                  # :223
-        ops.region_proposal(rpn_deltas, anchors, scores, self.image_shape, self.K, self.cfg['rpn_nms_iou'],
-                            self.cfg['rpn_means'], self.cfg['rpn_stds'], workspace=self.ws_rpn,
-                            blind_chunks=self.blind_chunks, done=self.nms_done,
-                            out=(self.rois, self.roi_idx, self.roi_count))              # :224
-        ops.assign_levels(self.rois, self.min_level, self.max_level, count_dev=self.roi_count,
-                          out=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts))   # :256 / :303-324
+        ops.fpn_proposals(rpn_logits, rpn_deltas, self.fh, self.fw, self.strides, self.wh, self.image_shape, self.K,
+                          self.cfg['rpn_nms_iou'], self.cfg['rpn_means'], self.cfg['rpn_stds'],
+                          min_level=self.min_level, max_level=self.max_level, workspace=self.ws_rpn,
+                          blind_chunks=self.blind_chunks, done=self.nms_done,
+                          out=(self.rois, self.roi_idx, self.roi_count),
+                          out_levels=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts))
+        # base_fpn_model.py:220 (_get_anchors), :223 (fg softmax), :224 (RegionProposal), :256 / :303-324
         return self.sorted_rois, self.roi_level, self.roi_count
 
     # ---- stage 2: RoI features ---------------------------------------------------------------

@@ -13,7 +13,7 @@ from .. import ops
 from ._device import current_device, to_gpu_f32
 
 __all__ = ['generate_anchor_base', 'generate_by_anchor_base_np', 'generate_by_anchor_base_tf', 'make_anchors',
-           'make_fpn_anchors']
+           'make_fpn_anchors', 'fpn_level_tables']
 
 
 def generate_anchor_base(base_size=16, ratios=(0.5, 1, 2), scales=2 ** np.arange(3, 6)):
@@ -74,6 +74,15 @@ def make_anchors(base_anchor_size, anchor_scales, anchor_ratios, featuremap_heig
     fw = int(math.ceil(float(featuremap_width)))
     wh = _wh_table(base_anchor_size, anchor_scales, anchor_ratios)[None]
     return ops.anchors_fpn([fh], [fw], [int(stride)], wh, current_device())
+
+
+def fpn_level_tables(image_shape, anchor_stride_list, base_anchor_size_list, anchor_scales, anchor_ratios):
+    """Host tables of reference model/fpn/base_fpn_model.py:163-186 (_get_anchors): per level
+    ceil(H/stride), ceil(W/stride) and the float32 (w, h) table of make_anchors."""
+    fh = [int(math.ceil(image_shape[0] / s)) for s in anchor_stride_list]
+    fw = [int(math.ceil(image_shape[1] / s)) for s in anchor_stride_list]
+    wh = np.stack([_wh_table(b, anchor_scales, anchor_ratios) for b in base_anchor_size_list], axis=0)
+    return fh, fw, wh
 
 
 def make_fpn_anchors(image_shape, anchor_stride_list, base_anchor_size_list, anchor_scales, anchor_ratios):
