@@ -223,6 +223,16 @@ int odet_post_ops(const float* scores, const float* deltas, const float* rois, i
                   float* out_boxes, int32_t* out_labels, float* out_scores, int32_t* out_count,
                   void* workspace, size_t workspace_bytes, odet_stream_t stream);
 
+/* odet_post_ops that also writes the fixed-size detection record of odet_pack_detections
+ * (out_record float32 [max_per_image*6 + 1]) from the same merge launch. */
+int odet_post_ops_record(const float* scores, const float* deltas, const float* rois, int R,
+                         const int32_t* count_dev, int Ccls, int num_classes, int image_h,
+                         int image_w, const float* means, const float* stds, int max_per_class,
+                         int max_per_image, float nms_iou_threshold, float score_threshold,
+                         float min_edge, float* out_boxes, int32_t* out_labels, float* out_scores,
+                         int32_t* out_count, float* out_record, void* workspace,
+                         size_t workspace_bytes, odet_stream_t stream);
+
 /* ---- multi-GPU detection records ------------------------------------------------------ */
 
 /* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of

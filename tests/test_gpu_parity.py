@@ -400,6 +400,40 @@ def test_post_ops_prediction(R, ncls, mpc, mpi, sthr):
     _check_post(got, want)
 
 
+def test_post_ops_large_r_dense_suppression_and_record():
+    """More than 1024 RoIs (LDS bitonic path), heavily overlapping RoIs with zero deltas (the per-class
+    NMS needs many 128-candidate rounds and the cross test against earlier rounds), and the fused
+    detection record of odet_post_ops_record == odet_pack_detections of the padded outputs."""
+    from tf_eager_object_detection_amd.model.prediction import post_ops_prediction
+    from tf_eager_object_detection_amd import parallel
+    rng = np.random.default_rng(21)
+    shape = (800, 1333)
+    R, ncls = 2500, 21
+    S = syn.class_scores(R, ncls, rng)
+    D = syn.class_deltas(R, ncls, rng)
+    rois = syn.random_boxes(R, shape, rng, 16, 600)
+    got = post_ops_prediction(g(S), g(D), g(rois), list(shape), M0, S2, 100, 300, 0.3, 0.0, 16, num_classes=ncls)
+    _check_post(got, co.post_ops(S, D, rois, shape, M0, S2, 100, 300, 0.3, 0.0, 16, ncls))
+    # dense: 1000 RoIs in 12 tight clusters, deltas ~0 -> almost everything suppressed inside a cluster
+    R = 1000
+    centers = rng.uniform(150, 600, (12, 2)).astype(np.float32)
+    cid = rng.integers(0, 12, R)
+    ctr = centers[cid] + rng.uniform(-6, 6, (R, 2)).astype(np.float32)
+    half = (60 + rng.uniform(-4, 4, (R, 2))).astype(np.float32)
+    rois = np.concatenate([ctr - half, ctr + half], axis=1).astype(np.float32)
+    S = syn.class_scores(R, ncls, rng)
+    D = (syn.class_deltas(R, ncls, rng) * np.float32(0.02)).astype(np.float32)
+    for mpc, mpi in ((50, 50), (300, 1000)):
+        got = post_ops_prediction(g(S), g(D), g(rois), list(shape), M0, S2, mpc, mpi, 0.3, 0.0, 16, num_classes=ncls)
+        _check_post(got, co.post_ops(S, D, rois, shape, M0, S2, mpc, mpi, 0.3, 0.0, 16, ncls))
+    # record variant
+    rec = torch.empty(50 * 6 + 1, dtype=torch.float32, device='cuda')
+    ob, ol, os_, cnt = ops.post_ops(g(S), g(D), g(rois), shape, M0, S2, 50, 50, 0.3, 0.0, 16, ncls, record=rec)
+    want = parallel.pack_detections(ob, ol, os_, cnt, 50)
+    np.testing.assert_array_equal(h(rec), h(want))
+    assert float(rec[-1]) == float(cnt.item())
+
+
 def test_post_ops_edge_cases():
     from tf_eager_object_detection_amd.model.prediction import post_ops_prediction
     rng = np.random.default_rng(8)

@@ -51,6 +51,8 @@ SIGNATURES = {
     'odet_post_ops_workspace_bytes': (_sz, [_i, _i]),
     'odet_post_ops': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f,
                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'odet_post_ops_record': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'odet_pack_detections': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
 }
 

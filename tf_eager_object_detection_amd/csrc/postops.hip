@@ -4,22 +4,28 @@
 // iteration dispatches ~12 TF ops, one single-threaded NMS and one device->host sync
 // (prediction.py:147).  Here every class is one workgroup of ONE launch:
 //
-//   k_postops_class (grid = num_classes-1):
-//     1. score filter (strict >, :136), decode (:138-140), clip + min-edge filter (:141-143):
-//        one RoI per thread, box kept in LDS, 64-bit sort key (score desc, RoI index asc)
-//     2. bitonic sort of the keys in LDS
-//     3. wave 0: exact greedy NMS over the sorted candidates in 64-wide tiles -- each lane owns
-//        a candidate; phase 1 tests the tile against the boxes already kept (LDS broadcast),
-//        phase 2 resolves the tile with ctz over the alive ballot + v_readlane broadcast of the
-//        winner's box; stops at max_per_class (:146).
+//   k_postops_class (grid = num_classes-1, 1024 threads):
+//     1. score filter (strict >, :136), decode (:138-140), clip + min-edge filter (:141-143): one
+//        RoI per thread, box kept in LDS, 64-bit sort key (score desc, RoI index asc)
+//     2. bitonic sort of the keys: one key per thread, compare-exchange distances < 64 by wave
+//        shuffles, only the 10 stages with distance >= 64 go through LDS (more than 1024 RoIs:
+//        plain LDS bitonic)
+//     3. exact greedy NMS (:146) in rounds of 128 sorted candidates: all 16 waves build the
+//        128 x 128 lower-triangular suppression bit matrix (and test the round against the boxes
+//        kept by earlier rounds), then wave 0 resolves the two 64-blocks with ctz over the alive
+//        ballot; stops at max_per_class or when the candidates are exhausted.
 //   k_postops_merge (1 workgroup): concatenation in class order (:156-158), top-k by
-//     (score desc, position asc) (:160), gather (:162).
+//     (score desc, position asc) (:160), gather (:162), and optionally the fixed-size detection
+//     record of the image-parallel all-gather.
 //
 // Output order is the sorted order, one valid instance of tf.nn.top_k(sorted=False)'s
 // unspecified order.
 #include "odet_internal.h"
 
-#define PO_THREADS 256
+#define PO_THREADS 1024
+#define PO_ROUND 128          // candidates per NMS round
+
+typedef unsigned long long u64;
 
 struct PostOpsParams {
   const float* scores;   // [R, Ccls]
@@ -35,7 +41,7 @@ struct PostOpsParams {
   float* cls_scores;     // [ncls-1, K]
 };
 
-__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int P2, int nthreads) {
+__device__ __forceinline__ void bitonic_sort_u64(u64* keys, int P2, int nthreads) {
   for (int k = 2; k <= P2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = threadIdx.x; t < (P2 >> 1); t += nthreads) {
@@ -43,7 +49,7 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int P
         int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         int l = i | j;
         bool up = ((i & k) == 0);
-        unsigned long long a = keys[i], b = keys[l];
+        u64 a = keys[i], b = keys[l];
         if ((a > b) == up) { keys[i] = b; keys[l] = a; }
       }
       __syncthreads();
@@ -51,22 +57,68 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int P
   }
 }
 
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
+  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask);
+  uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+  return ((u64)hi << 32) | lo;
+}
+
+// Ascending bitonic sort of 1024 keys, one per thread of a 1024-thread workgroup; xch: LDS [2][1024].
+__device__ __forceinline__ u64 bitonic_sort_1024_reg(u64 key, u64* xch) {
+  const int tid = threadIdx.x;
+  int buf = 0;
+  for (int k = 2; k <= 1024; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      u64 other;
+      if (j >= 64) {
+        u64* x = xch + buf * 1024;
+        x[tid] = key;
+        __syncthreads();
+        other = x[tid ^ j];
+        buf ^= 1;               // the next LDS stage writes the other buffer: one barrier per stage
+      } else {
+        other = shfl_xor_u64(key, j);
+      }
+      const bool up = ((tid & k) == 0);
+      const bool lower = ((tid & j) == 0);
+      const u64 mn = key < other ? key : other, mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  return key;
+}
+
+__device__ __forceinline__ float key_to_score(uint32_t k) {   // inverse of ~d_float_asc_key
+  const uint32_t asc = ~k;
+  const uint32_t u = (asc & 0x80000000u) ? (asc & 0x7FFFFFFFu) : ~asc;
+  return __uint_as_float(u);
+}
+
 __global__ void __launch_bounds__(PO_THREADS) k_postops_class(PostOpsParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);          // [P2]
-  float4* lbox = reinterpret_cast<float4*>(smem + (size_t)p.P2 * 8);                // [R]
-  float4* kbox = lbox + p.R;                                                        // [K]
-  float* karea = reinterpret_cast<float*>(kbox + p.K);                              // [K]
-  __shared__ int s_nvalid;
+  // layout: keys [max(P2, 2048)] u64 | lbox [R] float4 | sbox [PO_ROUND] float4 | sarea [PO_ROUND] |
+  //         kbox [K] float4 | karea [K] float | mask [PO_ROUND][2] u64 | crossf [PO_ROUND] u32
+  const int nkeys = p.P2 > 2048 ? p.P2 : 2048;
+  u64* keys = reinterpret_cast<u64*>(smem);
+  float4* lbox = reinterpret_cast<float4*>(keys + nkeys);
+  float4* sbox = lbox + p.R;
+  float4* kbox = sbox + PO_ROUND;
+  u64* mask = reinterpret_cast<u64*>(kbox + p.K);
+  float* sarea = reinterpret_cast<float*>(mask + PO_ROUND * 2);
+  float* karea = sarea + PO_ROUND;
+  uint32_t* crossf = reinterpret_cast<uint32_t*>(karea + p.K);
+  __shared__ int s_nvalid, s_nk;
 
   const int c = blockIdx.x + 1;   // class id, prediction.py:135
   const int R = p.count_dev ? min(*p.count_dev, p.R) : p.R;
-  if (threadIdx.x == 0) s_nvalid = 0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) { s_nvalid = 0; s_nk = 0; }
   __syncthreads();
 
   // 1. filter + decode + clip
-  for (int r = threadIdx.x; r < p.P2; r += PO_THREADS) {
-    unsigned long long key = ~0ull;
+  u64 mykey = ~0ull;
+  for (int r = tid; r < p.P2; r += PO_THREADS) {
+    u64 key = ~0ull;
     if (r < R) {
       float s = p.scores[(size_t)r * p.Ccls + c];
       if (s > p.score_thr) {                                                   // :136
@@ -80,57 +132,106 @@ __global__ void __launch_bounds__(PO_THREADS) k_postops_class(PostOpsParams p) {
         float e0 = b.z - b.x + 1.0f, e1 = b.w - b.y + 1.0f;                    // bbox_tf.py:81-83
         if (e1 >= p.min_edge && e0 >= p.min_edge) {
           lbox[r] = b;
-          key = ((unsigned long long)(~d_float_asc_key(s)) << 32) | (unsigned)r;
-          atomicAdd(&s_nvalid, 1);
+          key = ((u64)(~d_float_asc_key(s)) << 32) | (unsigned)r;
         }
       }
     }
-    keys[r] = key;
+    if (p.P2 > 1024) keys[r] = key; else mykey = key;
+  }
+  {
+    const u64 bal = __ballot(p.P2 <= 1024 && mykey != ~0ull);
+    if (lane == 0 && bal) atomicAdd(&s_nvalid, (int)__popcll(bal));
   }
   __syncthreads();
 
   // 2. sort: score desc, RoI index asc; rejected rows (key = ~0) go last
-  bitonic_sort_u64(keys, p.P2, PO_THREADS);
-  const int nvalid = s_nvalid;
-
-  // 3. greedy NMS by wave 0
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    const int K = p.K;
-    int nk = 0;
-    for (int t0 = 0; t0 < nvalid && nk < K; t0 += 64) {
-      const int ci = t0 + lane;
-      const bool have = ci < nvalid;
-      const int r = have ? (int)(keys[ci] & 0xFFFFFFFFull) : 0;
-      const float4 ob = have ? lbox[r] : make_float4(0, 0, 0, 0);
-      const float4 nb = d_norm_box(ob);
-      const float area = d_box_area(nb);
-      bool sup = false;
-      for (int k = 0; k < nk; ++k) sup = sup || d_iou_gt(nb, area, kbox[k], karea[k], p.nms_thr);
-      unsigned long long alive = __ballot(have && !sup);
-      while (alive != 0 && nk < K) {
-        const int i = __builtin_ctzll(alive);
-        float4 wb;
-        wb.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nb.x), i));
-        wb.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nb.y), i));
-        wb.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nb.z), i));
-        wb.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nb.w), i));
-        const float wa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, area), i));
-        const bool s2 = d_iou_gt(nb, area, wb, wa, p.nms_thr);
-        alive &= ~__ballot(s2);
-        alive &= ~(1ull << i);
-        if (lane == i) {
-          kbox[nk] = nb;
-          karea[nk] = area;
-          p.cls_boxes[(size_t)blockIdx.x * K + nk] = ob;
-          p.cls_scores[(size_t)blockIdx.x * K + nk] = p.scores[(size_t)r * p.Ccls + c];
-        }
-        ++nk;
-        // make the new kept box visible to the next tile's phase 1 (same wave, LDS in order)
-      }
+  if (p.P2 <= 1024) {
+    mykey = bitonic_sort_1024_reg(mykey, keys);
+    __syncthreads();
+    keys[tid] = mykey;
+    __syncthreads();
+  } else {
+    bitonic_sort_u64(keys, p.P2, PO_THREADS);
+    if (tid == 0) {
+      // count valid keys by bisection (sorted, ~0 last)
+      int lo = 0, hi = p.P2;
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (keys[mid] != ~0ull) lo = mid + 1; else hi = mid; }
+      s_nvalid = lo;
     }
-    if (lane == 0) p.cls_count[blockIdx.x] = nk;
+    __syncthreads();
   }
+  const int nvalid = s_nvalid;
+  const int K = p.K;
+
+  // 3. greedy NMS in rounds of PO_ROUND sorted candidates
+  const u64 lt_lane = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int t0 = 0; t0 < nvalid; t0 += PO_ROUND) {
+    const int nk0 = s_nk;                       // kept so far (uniform: read after a barrier)
+    if (nk0 >= K) break;
+    const int mround = min(PO_ROUND, nvalid - t0);
+    // boxes of the round, corner-normalised
+    if (tid < PO_ROUND) {
+      float4 nb = make_float4(0, 0, 0, 0);
+      if (tid < mround) nb = d_norm_box(lbox[(int)(keys[t0 + tid] & 0xFFFFFFFFull)]);
+      sbox[tid] = nb;
+      sarea[tid] = d_box_area(nb);
+      crossf[tid] = 0;
+    }
+    __syncthreads();
+    {
+      // thread = (row, slice): 16 columns of the round's lower triangle + 1/8 of the kept list
+      const int row = tid & (PO_ROUND - 1), cs = tid >> 7;
+      const float4 rb = sbox[row];
+      const float ra = sarea[row];
+      uint32_t bits = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int col = cs * 16 + j;
+        const bool s = (col < row) && d_iou_gt(rb, ra, sbox[col], sarea[col], p.nms_thr);
+        bits |= s ? (1u << j) : 0u;
+      }
+      // 16-bit pieces of the row's 128-bit mask: 4 pieces per u64 word
+      reinterpret_cast<unsigned short*>(mask)[row * 8 + cs] = (unsigned short)bits;
+      bool sup = false;
+      for (int k = cs; k < nk0; k += 8) sup = sup || d_iou_gt(rb, ra, kbox[k], karea[k], p.nms_thr);
+      if (sup) atomicOr(&crossf[row], 1u);
+    }
+    __syncthreads();
+    if (w == 0) {
+      int nk = nk0;
+      u64 kept0 = 0;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const int row = blk * 64 + lane;
+        const u64 m0 = mask[row * 2 + 0], m1 = mask[row * 2 + 1];
+        bool dead = (row >= mround) || (crossf[row] != 0);
+        if (blk == 1) dead = dead || ((m0 & kept0) != 0ull);
+        const u64 mm = (blk == 0) ? m0 : m1;      // same-block earlier candidates that suppress me
+        u64 alive = __ballot(!dead);
+        u64 kept = 0;
+        while (alive != 0 && nk < K) {
+          const int i = __builtin_ctzll(alive);
+          kept |= 1ull << i;
+          ++nk;
+          alive &= ~(1ull << i);
+          alive &= ~__ballot((mm >> i) & 1ull);
+        }
+        if (blk == 0) kept0 = kept;
+        if ((kept >> lane) & 1ull) {
+          const int slot = nk0 + (blk == 1 ? (int)__popcll(kept0) : 0) + (int)__popcll(kept & lt_lane);
+          const u64 kk = keys[t0 + row];
+          const float4 ob = lbox[(int)(kk & 0xFFFFFFFFull)];
+          kbox[slot] = sbox[row];
+          karea[slot] = sarea[row];
+          p.cls_boxes[(size_t)blockIdx.x * K + slot] = ob;
+          p.cls_scores[(size_t)blockIdx.x * K + slot] = key_to_score((uint32_t)(kk >> 32));
+        }
+      }
+      if (lane == 0) s_nk = nk;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) p.cls_count[blockIdx.x] = s_nk;
 }
 
 struct MergeParams {
@@ -142,41 +243,82 @@ struct MergeParams {
   int32_t* out_labels;
   float* out_scores;
   int32_t* out_count;
+  float* out_record;     // nullable: [max_per_image*6 + 1]
 };
 
 __global__ void __launch_bounds__(1024) k_postops_merge(MergeParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [P2]
-  uint32_t* src = reinterpret_cast<uint32_t*>(smem + (size_t)p.P2 * 8);      // [P2] slot of position p
-  int* prefix = reinterpret_cast<int*>(src + p.P2);                          // [ncls1 + 1]
-  if (threadIdx.x == 0) {
+  const int nkeys = p.P2 > 2048 ? p.P2 : 2048;
+  u64* keys = reinterpret_cast<u64*>(smem);                  // [max(P2, 2048)]
+  uint32_t* src = reinterpret_cast<uint32_t*>(keys + nkeys);  // [P2] slot of position p
+  int* prefix = reinterpret_cast<int*>(src + p.P2);           // [ncls1 + 1]
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    // exclusive prefix of min(count, K) over classes (wave scan, 64 classes per step)
     int run = 0;
-    for (int c = 0; c < p.ncls1; ++c) { prefix[c] = run; run += min(p.cls_count[c], p.K); }
-    prefix[p.ncls1] = run;
+    for (int c0 = 0; c0 < p.ncls1; c0 += 64) {
+      const int c = c0 + tid;
+      const int v = (c < p.ncls1) ? min(p.cls_count[c], p.K) : 0;
+      const int inc = wave_incl_scan(v);
+      if (c < p.ncls1) prefix[c] = run + inc - v;
+      run += __shfl(inc, 63);
+    }
+    if (tid == 0) prefix[p.ncls1] = run;
   }
-  for (int i = threadIdx.x; i < p.P2; i += 1024) keys[i] = ~0ull;
   __syncthreads();
   const int total = prefix[p.ncls1];
   // concatenation order: class ascending, NMS order inside a class (prediction.py:156-158)
-  for (int slot = threadIdx.x; slot < p.ncls1 * p.K; slot += 1024) {
-    int c = slot / p.K, k = slot - c * p.K;
-    if (k < min(p.cls_count[c], p.K)) {
-      int pos = prefix[c] + k;
-      keys[pos] = ((unsigned long long)(~d_float_asc_key(p.cls_scores[slot])) << 32) | (unsigned)pos;
-      src[pos] = (uint32_t)slot;
+  u64 mykey = ~0ull;
+  if (p.P2 <= 1024) {
+    for (int slot = tid; slot < p.ncls1 * p.K; slot += 1024) {
+      int c = slot / p.K, k = slot - c * p.K;
+      if (k < min(p.cls_count[c], p.K)) src[prefix[c] + k] = (uint32_t)slot;
     }
+    __syncthreads();
+    if (tid < total) mykey = ((u64)(~d_float_asc_key(p.cls_scores[src[tid]])) << 32) | (unsigned)tid;
+    mykey = bitonic_sort_1024_reg(mykey, keys);
+    __syncthreads();
+    keys[tid] = mykey;
+  } else {
+    for (int i = tid; i < p.P2; i += 1024) keys[i] = ~0ull;
+    __syncthreads();
+    for (int slot = tid; slot < p.ncls1 * p.K; slot += 1024) {
+      int c = slot / p.K, k = slot - c * p.K;
+      if (k < min(p.cls_count[c], p.K)) {
+        int pos = prefix[c] + k;
+        keys[pos] = ((u64)(~d_float_asc_key(p.cls_scores[slot])) << 32) | (unsigned)pos;
+        src[pos] = (uint32_t)slot;
+      }
+    }
+    __syncthreads();
+    bitonic_sort_u64(keys, p.P2, 1024);
   }
   __syncthreads();
-  bitonic_sort_u64(keys, p.P2, 1024);
   const int M = min(total, p.max_per_image);                                 // prediction.py:160
-  for (int i = threadIdx.x; i < M; i += 1024) {
-    int pos = (int)(keys[i] & 0xFFFFFFFFull);
-    uint32_t slot = src[pos];
-    p.out_boxes[i] = p.cls_boxes[slot];
-    p.out_scores[i] = p.cls_scores[slot];
-    p.out_labels[i] = (int32_t)(slot / p.K) + 1;
+  for (int i = tid; i < p.max_per_image; i += 1024) {
+    float4 b = make_float4(0, 0, 0, 0);
+    float sc = -1.0f;
+    int lab = 0;
+    if (i < M) {
+      int pos = (int)(keys[i] & 0xFFFFFFFFull);
+      uint32_t slot = src[pos];
+      b = p.cls_boxes[slot];
+      sc = p.cls_scores[slot];
+      lab = (int32_t)(slot / p.K) + 1;
+      p.out_boxes[i] = b;
+      p.out_scores[i] = sc;
+      p.out_labels[i] = lab;
+    }
+    if (p.out_record) {
+      // fixed-size record of the image-parallel all-gather: (x1,y1,x2,y2,score,label), pad score -1
+      float* r = p.out_record + (size_t)i * 6;
+      r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w; r[4] = sc; r[5] = (float)lab;
+    }
   }
-  if (threadIdx.x == 0) *p.out_count = M;
+  if (tid == 0) {
+    *p.out_count = M;
+    if (p.out_record) p.out_record[(size_t)p.max_per_image * 6] = (float)M;
+  }
 }
 
 static int next_pow2(int v) {
@@ -191,18 +333,22 @@ extern "C" size_t odet_post_ops_workspace_bytes(int num_classes, int max_per_cla
   return odet_align_up(n1 * 4, 256) + odet_align_up(n1 * k * 16, 256) + odet_align_up(n1 * k * 4, 256) + 1024;
 }
 
-extern "C" int odet_post_ops(const float* scores, const float* deltas, const float* rois, int R,
-                             const int32_t* count_dev, int Ccls, int num_classes, int image_h, int image_w,
-                             const float* means, const float* stds, int max_per_class, int max_per_image,
-                             float nms_iou_threshold, float score_threshold, float min_edge, float* out_boxes,
-                             int32_t* out_labels, float* out_scores, int32_t* out_count, void* workspace,
-                             size_t workspace_bytes, odet_stream_t stream) {
-  hipStream_t st = (hipStream_t)stream;
+static int post_ops_impl(const float* scores, const float* deltas, const float* rois, int R,
+                         const int32_t* count_dev, int Ccls, int num_classes, int image_h, int image_w,
+                         const float* means, const float* stds, int max_per_class, int max_per_image,
+                         float nms_iou_threshold, float score_threshold, float min_edge, float* out_boxes,
+                         int32_t* out_labels, float* out_scores, int32_t* out_count, float* out_record,
+                         void* workspace, size_t workspace_bytes, hipStream_t st) {
   ODET_REQUIRE(out_count, "odet_post_ops: null out_count");
   ODET_REQUIRE(R >= 0 && Ccls > 0 && num_classes >= 1 && num_classes <= Ccls, "odet_post_ops: bad sizes");
   ODET_REQUIRE(max_per_class >= 0 && max_per_image >= 0, "odet_post_ops: negative cap");
   if (R == 0 || num_classes == 1 || max_per_class == 0 || max_per_image == 0) {
     ODET_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), st));
+    if (out_record && max_per_image > 0) {
+      // empty record: pad rows (score -1) are produced by the pack kernel of an empty result
+      return odet_pack_detections(out_boxes, out_labels, out_scores, out_count, 0, max_per_image, out_record,
+                                  (odet_stream_t)st);
+    }
     return ODET_OK;
   }
   ODET_REQUIRE(scores && deltas && rois && means && stds && out_boxes && out_labels && out_scores,
@@ -226,7 +372,9 @@ extern "C" int odet_post_ops(const float* scores, const float* deltas, const flo
   p.cls_count = ar.take<int32_t>(ncls1);
   p.cls_boxes = ar.take<float4>((size_t)ncls1 * max_per_class);
   p.cls_scores = ar.take<float>((size_t)ncls1 * max_per_class);
-  size_t lds1 = (size_t)p.P2 * 8 + (size_t)R * 16 + (size_t)max_per_class * 20;
+  const size_t nkeys1 = (size_t)(p.P2 > 2048 ? p.P2 : 2048);
+  size_t lds1 = nkeys1 * 8 + (size_t)R * 16 + PO_ROUND * 16 + (size_t)max_per_class * 16 + PO_ROUND * 16 +
+                PO_ROUND * 4 + (size_t)max_per_class * 4 + PO_ROUND * 4;
   if (lds1 > 150 * 1024)
     return odet_set_error(ODET_E_LIMIT, "odet_post_ops: R/max_per_class need %zu B of LDS (> 150 KiB)", lds1);
   static bool attr_set = false;
@@ -242,10 +390,37 @@ extern "C" int odet_post_ops(const float* scores, const float* deltas, const flo
   m.ncls1 = ncls1; m.K = max_per_class; m.P2 = next_pow2(ncls1 * max_per_class < 2 ? 2 : ncls1 * max_per_class);
   m.max_per_image = max_per_image;
   m.out_boxes = (float4*)out_boxes; m.out_labels = out_labels; m.out_scores = out_scores; m.out_count = out_count;
-  size_t lds2 = (size_t)m.P2 * 12 + (size_t)(ncls1 + 1) * 4;
+  m.out_record = out_record;
+  const size_t nkeys2 = (size_t)(m.P2 > 2048 ? m.P2 : 2048);
+  size_t lds2 = nkeys2 * 8 + (size_t)m.P2 * 4 + (size_t)(ncls1 + 1) * 4;
   hipLaunchKernelGGL(k_postops_merge, dim3(1), dim3(1024), lds2, st, m);
   ODET_LAUNCH_CHECK();
   return ODET_OK;
+}
+
+extern "C" int odet_post_ops(const float* scores, const float* deltas, const float* rois, int R,
+                             const int32_t* count_dev, int Ccls, int num_classes, int image_h, int image_w,
+                             const float* means, const float* stds, int max_per_class, int max_per_image,
+                             float nms_iou_threshold, float score_threshold, float min_edge, float* out_boxes,
+                             int32_t* out_labels, float* out_scores, int32_t* out_count, void* workspace,
+                             size_t workspace_bytes, odet_stream_t stream) {
+  return post_ops_impl(scores, deltas, rois, R, count_dev, Ccls, num_classes, image_h, image_w, means, stds,
+                       max_per_class, max_per_image, nms_iou_threshold, score_threshold, min_edge, out_boxes,
+                       out_labels, out_scores, out_count, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int odet_post_ops_record(const float* scores, const float* deltas, const float* rois, int R,
+                                    const int32_t* count_dev, int Ccls, int num_classes, int image_h, int image_w,
+                                    const float* means, const float* stds, int max_per_class, int max_per_image,
+                                    float nms_iou_threshold, float score_threshold, float min_edge,
+                                    float* out_boxes, int32_t* out_labels, float* out_scores, int32_t* out_count,
+                                    float* out_record, void* workspace, size_t workspace_bytes,
+                                    odet_stream_t stream) {
+  ODET_REQUIRE(out_record, "odet_post_ops_record: null out_record");
+  return post_ops_impl(scores, deltas, rois, R, count_dev, Ccls, num_classes, image_h, image_w, means, stds,
+                       max_per_class, max_per_image, nms_iou_threshold, score_threshold, min_edge, out_boxes,
+                       out_labels, out_scores, out_count, out_record, workspace, workspace_bytes,
+                       (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------- detection records --

@@ -319,9 +319,10 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
 
 
 def post_ops(scores, deltas, rois, image_shape, means, stds, max_per_class, max_per_image, nms_iou_threshold,
-             score_threshold, min_edge, num_classes, count_dev=None, out=None, workspace=None):
+             score_threshold, min_edge, num_classes, count_dev=None, out=None, workspace=None, record=None):
     """-> (boxes [M,4], labels int32 [M], scores [M]) padded to max_per_image, count int32[1].
-    ``out`` = preallocated (boxes, labels, scores, count); ``workspace`` = reusable uint8 buffer."""
+    ``out`` = preallocated (boxes, labels, scores, count); ``workspace`` = reusable uint8 buffer;
+    ``record`` = float32 [max_per_image*6+1] GPU tensor that also receives the detection record."""
     scores = L.f32c(scores, 'roi_scores_softmax')
     if scores.dim() != 2:
         raise ValueError('roi_scores_softmax must be [num_rois, num_classes]')
@@ -342,10 +343,15 @@ def post_ops(scores, deltas, rois, image_shape, means, stds, max_per_class, max_
         cnt = _count_tensor(scores.device)
     nb = L.lib().odet_post_ops_workspace_bytes(int(num_classes), int(max_per_class))
     ws = workspace if workspace is not None and workspace.numel() >= nb else L.workspace(nb, scores.device)
-    L.check(L.lib().odet_post_ops(L.dptr(scores), L.dptr(deltas), L.dptr(rois), R, L.dptr(count_dev), Ccls,
-                                  int(num_classes), int(image_shape[0]), int(image_shape[1]),
-                                  L.host4(means, 'target_means'), L.host4(stds, 'target_stds'),
-                                  int(max_per_class), int(max_per_image), float(nms_iou_threshold),
-                                  float(score_threshold), float(min_edge), L.dptr(ob), L.dptr(ol), L.dptr(os_),
-                                  L.dptr(cnt), L.dptr(ws), nb, L.stream()))
+    head = (L.dptr(scores), L.dptr(deltas), L.dptr(rois), R, L.dptr(count_dev), Ccls, int(num_classes),
+            int(image_shape[0]), int(image_shape[1]), L.host4(means, 'target_means'), L.host4(stds, 'target_stds'),
+            int(max_per_class), int(max_per_image), float(nms_iou_threshold), float(score_threshold),
+            float(min_edge), L.dptr(ob), L.dptr(ol), L.dptr(os_), L.dptr(cnt))
+    if record is None:
+        L.check(L.lib().odet_post_ops(*head, L.dptr(ws), nb, L.stream()))
+    else:
+        if record.numel() < M * 6 + 1:
+            raise ValueError('record must hold max_per_image*6+1 floats')
+        L.check(L.lib().odet_post_ops_record(*head, L.dptr(record, torch.float32, 'record'), L.dptr(ws), nb,
+                                             L.stream()))
     return ob, ol, os_, cnt

@@ -94,13 +94,12 @@ class FpnHotPath:
                             c['roi_stds'], c['max_per_class'], c['max_per_image'], c['nms_iou'],
                             c['score_threshold'], 16, self.num_classes, count_dev=self.roi_count,
                             out=(self.det_boxes, self.det_labels, self.det_scores, self.det_count),
-                            workspace=self.ws_post)                                     # :267-275
+                            workspace=self.ws_post, record=self.record)                 # :267-275
 
     def stage_record(self):
-        """Fixed-size detection record of this image for the image-parallel all-gather."""
-        from . import parallel
-        return parallel.pack_detections(self.det_boxes, self.det_labels, self.det_scores, self.det_count,
-                                        self.cfg['max_per_image'], out=self.record)
+        """Fixed-size detection record of this image for the image-parallel all-gather (written by the
+        merge launch of stage_detect; layout of parallel.pack_detections)."""
+        return self.record
 
     def step(self, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
         """One image through the whole hot path (the RoI head that sits between stage 2 and 3 in the
