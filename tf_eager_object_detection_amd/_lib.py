@@ -83,6 +83,36 @@ def lib():
     return _lib
 
 
+_recording = None
+
+
+class recording:
+    """Context manager: collects the (function, ctypes args) of every C-ABI call made through call()
+    so that a caller with persistent buffers (pipeline.FpnHotPath) can replay them without
+    re-marshalling the arguments -- a host-side launch plan; the library itself is stateless."""
+
+    def __enter__(self):
+        global _recording
+        self.calls = []
+        self._prev = _recording
+        _recording = self.calls
+        return self.calls
+
+    def __exit__(self, *exc):
+        global _recording
+        _recording = self._prev
+        return False
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    if _recording is not None:
+        _recording.append((fn, args))
+    rc = fn(*args)
+    if rc != 0:
+        check(rc)
+
+
 def check(rc):
     if rc != 0:
         raise OdetError('odet error %d: %s' % (rc, lib().odet_last_error().decode('utf-8', 'replace')))

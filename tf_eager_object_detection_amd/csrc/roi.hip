@@ -7,15 +7,28 @@
 //                                                          (NORM_TP_ALIGN, POOL_AVG2)
 //
 // The reference materialises the [R,14,14,C] crops (200 MB at R=1000, C=256) and pools them in
-// a second op.  Here one wave produces one output bin: it loads the <=16 feature cells its 2x2
-// samples tap (NHWC: a cell's C channels are contiguous, 64 lanes x float4 = 1 KiB coalesced per
-// cell), lerps in the exact TF operation order (no FMA) and reduces in registers -- max is exact
-// and the avg uses the same row-major sum, so results are bit-identical to the un-fused form.
+// a second op.  Here one workgroup produces one output ROW (P bins x C channels) of one RoI:
 //
-// Work decomposition: task = (roi, py, px) -> one wave; 4 waves per workgroup; consecutive
-// tasks of consecutive (level-sorted) RoIs are mapped to the same XCD so that each XCD's L2
-// mostly holds one pyramid level.
+//   * the sampling arithmetic (box normalisation, per-sample coordinates) is evaluated once per
+//     workgroup instead of once per bin;
+//   * LDS-staged RoI tile: when the feature cells tapped by the row's S x (P*S) samples form a
+//     small bounding tile (<= ROI_LDS_BYTES, i.e. sample spacing below ~1 cell -- the RoIs whose
+//     bilinear taps overlap), the tile is loaded ONCE (NHWC: a cell's C channels are contiguous,
+//     64 lanes x float4 = 1 KiB coalesced per cell) into LDS and all taps of the row are served
+//     from there: 4-5x less L2 traffic than fetching every tap.  RoIs with wider spacing share no
+//     taps; they read their taps straight from L2 (coalesced 1 KiB per tap).
+//   * lerps in the exact TF operation order (no FMA), 2x2 max / avg reduced in registers -- max
+//     is exact and the avg uses the same row-major sum, so results are bit-identical to the
+//     un-fused form.
+//
+// Workgroup = 4 waves; wave w computes bins w, w+4, ... of the row, lane = 4 channels.
+// Consecutive rows / (level-sorted) RoIs are mapped to the same XCD so that each XCD's L2 mostly
+// holds one neighbourhood of one pyramid level.
+#include <stdlib.h>
+
 #include "odet_internal.h"
+
+#define ROI_LDS_BYTES (40 * 1024)   // staged tile budget: 4 workgroups per CU
 
 struct RoiParams {
   const float* data[ODET_MAX_LEVELS];
@@ -32,39 +45,243 @@ struct Axis {
   float start;   // in_(0)
   float scale;   // per-sample step
   float limit;   // dim - 1 (in sampled-map coordinates)
+  float single;  // crop == 1: the one sample coordinate
 };
 
 // TF crop_and_resize_op.cc: in = lo_n * (dim-1) + i * scale, scale = (hi_n - lo_n)*(dim-1)/(crop-1)
-__device__ __forceinline__ Axis make_axis(float lo_n, float hi_n, int dim, int crop, float* single) {
+__device__ __forceinline__ Axis make_axis(float lo_n, float hi_n, int dim, int crop) {
   Axis a;
   a.limit = (float)(dim - 1);
   a.scale = (crop > 1) ? (hi_n - lo_n) * a.limit / (float)(crop - 1) : 0.0f;
   a.start = lo_n * a.limit;
-  *single = 0.5f * (lo_n + hi_n) * a.limit;   // crop == 1 path
+  a.single = 0.5f * (lo_n + hi_n) * a.limit;   // crop == 1 path
   return a;
 }
 
+__device__ __forceinline__ float axis_coord(const Axis& a, int i, int crop) {
+  return (crop > 1) ? a.start + (float)i * a.scale : a.single;
+}
+
+struct Tap {      // one sample along one axis (wave-uniform)
+  bool ok;        // TF: not extrapolated (0 <= in <= dim-1; NaN fails)
+  int lo, hi;     // floor / ceil cell (after the SYMMETRIC-pad remap for the tensorpack modes)
+  float lerp;
+};
+
+template <bool PAD>
+__device__ __forceinline__ Tap make_tap(const Axis& a, int i, int crop, int dim) {
+  Tap t;
+  const float in = axis_coord(a, i, crop);
+  // TF: extrapolate when (in < 0 || in > dim-1).  Written as the positive test so that a NaN
+  // coordinate can never turn into a tap index.
+  t.ok = (in >= 0.0f && in <= a.limit);
+  const float f = floorf(in);
+  t.lerp = in - f;
+  int lo = (int)f, hi = (int)ceilf(in);
+  if (PAD) {   // SYMMETRIC 1-px pad == edge replicate: padded[i] = src[clamp(i-1)]
+    lo = min(max(lo - 1, 0), dim - 1);
+    hi = min(max(hi - 1, 0), dim - 1);
+  }
+  t.lo = lo; t.hi = hi;
+  return t;
+}
+
+__device__ __forceinline__ float4 lerp_tap(float4 tl, float4 tr, float4 bl, float4 br, float xw, float yw) {
+  float4 r;
+  float t, b;
+  t = tl.x + (tr.x - tl.x) * xw; b = bl.x + (br.x - bl.x) * xw; r.x = t + (b - t) * yw;
+  t = tl.y + (tr.y - tl.y) * xw; b = bl.y + (br.y - bl.y) * xw; r.y = t + (b - t) * yw;
+  t = tl.z + (tr.z - tl.z) * xw; b = bl.z + (br.z - bl.z) * xw; r.z = t + (b - t) * yw;
+  t = tl.w + (tr.w - tl.w) * xw; b = bl.w + (br.w - bl.w) * xw; r.w = t + (b - t) * yw;
+  return r;
+}
+
 template <int POOL>
+__device__ __forceinline__ float4 pool4(const float4 (&v)[2][2]) {
+  float4 o;
+  if (POOL == ODET_ROI_POOL_NONE) {
+    o = v[0][0];
+  } else if (POOL == ODET_ROI_POOL_MAX2) {
+    o.x = fmaxf(fmaxf(v[0][0].x, v[0][1].x), fmaxf(v[1][0].x, v[1][1].x));
+    o.y = fmaxf(fmaxf(v[0][0].y, v[0][1].y), fmaxf(v[1][0].y, v[1][1].y));
+    o.z = fmaxf(fmaxf(v[0][0].z, v[0][1].z), fmaxf(v[1][0].z, v[1][1].z));
+    o.w = fmaxf(fmaxf(v[0][0].w, v[0][1].w), fmaxf(v[1][0].w, v[1][1].w));
+  } else {
+    o.x = (((v[0][0].x + v[0][1].x) + v[1][0].x) + v[1][1].x) / 4.0f;
+    o.y = (((v[0][0].y + v[0][1].y) + v[1][0].y) + v[1][1].y) / 4.0f;
+    o.z = (((v[0][0].z + v[0][1].z) + v[1][0].z) + v[1][1].z) / 4.0f;
+    o.w = (((v[0][0].w + v[0][1].w) + v[1][0].w) + v[1][1].w) / 4.0f;
+  }
+  return o;
+}
+
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// One bin whose 2 x 2 samples are all inside the map, with its tapped cells DEDUPLICATED IN REGISTERS:
+// along an axis the two samples tap cells (lo0, lo0+1) and (lo1, lo1+1); D = lo1 - lo0 in {0, 1} means
+// they share cells, so only 2 + D distinct rows / columns are loaded (4, 6 or 9 cells instead of 16
+// taps -- the RoIs whose sample spacing is below one cell, i.e. most of them).  D = 2 is the general
+// form: (lo0, hi0, lo1, hi1) taken as they are, no sharing assumed.  Same values, same lerp
+// arithmetic as the 16-tap form -> bit-identical results.
+template <int POOL, int DY, int DX>
+__device__ __forceinline__ float4 roi_bin_shared(const float* base, uint32_t C, uint32_t c, const uint32_t (&rowoff)[4],
+                                                 const uint32_t (&col)[4], const float (&xw)[2],
+                                                 const float (&yw)[2]) {
+  constexpr int NR = (DY == 2) ? 4 : 2 + DY, NC = (DX == 2) ? 4 : 2 + DX;
+  float4 blk[NR][NC];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      blk[i][j] = *reinterpret_cast<const float4*>(base + (rowoff[i] + col[j]) * C + c);
+  }
+  float4 v[2][2];
+#pragma unroll
+  for (int sy = 0; sy < 2; ++sy) {
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int rt = (DY == 2) ? 2 * sy : sy * DY, rb = rt + 1;
+      const int cl = (DX == 2) ? 2 * sx : sx * DX, cr = cl + 1;
+      v[sy][sx] = lerp_tap(blk[rt][cl], blk[rt][cr], blk[rb][cl], blk[rb][cr], xw[sx], yw[sy]);
+    }
+  }
+  return pool4<POOL>(v);
+}
+
+// Bins w, w+4, ... of the row (w = wave).  The x taps of ALL sample columns were computed once, one
+// per lane (txl: lane i = sample column i); a bin fetches its S columns with v_readlane.  A tap
+// (row y, col x) lives at float offset ((y - r0) * rs + (x - c0)) * C + c from `base` -- the feature
+// map itself (r0 = c0 = 0, rs = W) or the LDS tile.
+template <int POOL, bool PAD, bool LANE_TAPS>
+__device__ __forceinline__ void roi_row_bins(const float* base, int rs, int r0, int c0, int C, int P, int crop,
+                                             int Wdim, const Axis& ax, const Tap& txl, const Tap (&ty)[2],
+                                             float* __restrict__ orow) {
+  constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int txok = txl.ok ? 1 : 0;
+  // row offsets (in cells) of the S sample rows, wave-uniform
+  int rowlo[2], rowhi[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) { rowlo[s] = (ty[s].lo - r0) * rs; rowhi[s] = (ty[s].hi - r0) * rs; }
+  // register-sharing class of the row pair (S == 2, un-padded): 0 / 1 = rows shared, 2 = general
+  int dy = 2;
+  if (S == 2 && !PAD && ty[0].ok && ty[1].ok) {
+    const int d = ty[1].lo - ty[0].lo;
+    if (ty[0].hi == ty[0].lo + 1 && ty[1].hi == ty[1].lo + 1 && (d == 0 || d == 1)) dy = d;
+  }
+  const bool rows_ok = (S == 2) && !PAD && ty[0].ok && ty[1].ok;
+  uint32_t rowoff[4];
+  if (dy == 2) {
+    rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = (uint32_t)rowhi[0];
+    rowoff[2] = (uint32_t)rowlo[1]; rowoff[3] = (uint32_t)rowhi[1];
+  } else {
+    rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = rowoff[0] + (uint32_t)rs;
+    rowoff[2] = rowoff[1] + (uint32_t)rs; rowoff[3] = rowoff[2];
+  }
+  const float yw[2] = {ty[0].lerp, ty[1].lerp};
+  for (int px = w; px < P; px += 4) {
+    Tap tx[2];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      if (LANE_TAPS) {
+        const int xx = px * S + s;
+        tx[s].ok = rl_i(txok, xx) != 0;
+        tx[s].lo = rl_i(txl.lo, xx);
+        tx[s].hi = rl_i(txl.hi, xx);
+        tx[s].lerp = rl_f(txl.lerp, xx);
+      } else {
+        tx[s] = make_tap<PAD>(ax, px * S + s, crop, Wdim);
+      }
+    }
+    float* __restrict__ obin = orow + (size_t)px * C;
+    if (S == 2 && rows_ok && tx[0].ok && tx[1].ok) {
+      // all four samples inside the map: deduplicated loads
+      int dx = 2;
+      {
+        const int d = tx[1].lo - tx[0].lo;
+        if (tx[0].hi == tx[0].lo + 1 && tx[1].hi == tx[1].lo + 1 && (d == 0 || d == 1)) dx = d;
+      }
+      uint32_t col[4];
+      if (dx == 2) {
+        col[0] = (uint32_t)(tx[0].lo - c0); col[1] = (uint32_t)(tx[0].hi - c0);
+        col[2] = (uint32_t)(tx[1].lo - c0); col[3] = (uint32_t)(tx[1].hi - c0);
+      } else {
+        col[0] = (uint32_t)(tx[0].lo - c0); col[1] = col[0] + 1; col[2] = col[0] + 2; col[3] = col[2];
+      }
+      const float xw[2] = {tx[0].lerp, tx[1].lerp};
+      const int cls = dy * 3 + dx;
+      for (int c = lane * 4; c < C; c += 256) {
+        float4 o;
+        switch (cls) {
+          case 0: o = roi_bin_shared<POOL, 0, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 1: o = roi_bin_shared<POOL, 0, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 2: o = roi_bin_shared<POOL, 0, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 3: o = roi_bin_shared<POOL, 1, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 4: o = roi_bin_shared<POOL, 1, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 5: o = roi_bin_shared<POOL, 1, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 6: o = roi_bin_shared<POOL, 2, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 7: o = roi_bin_shared<POOL, 2, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          default: o = roi_bin_shared<POOL, 2, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+        }
+        *reinterpret_cast<float4*>(obin + c) = o;
+      }
+      continue;
+    }
+    // general form: every sample guarded (extrapolated samples are 0), 4 taps each
+    for (int c = lane * 4; c < C; c += 256) {
+      float4 v[2][2];
+#pragma unroll
+      for (int sy = 0; sy < S; ++sy) {
+#pragma unroll
+        for (int sx = 0; sx < S; ++sx) {
+          float4 res = make_float4(0, 0, 0, 0);
+          if (ty[sy].ok && tx[sx].ok) {
+            const uint32_t xl = (uint32_t)(tx[sx].lo - c0), xr = (uint32_t)(tx[sx].hi - c0);
+            const uint32_t otl = ((uint32_t)rowlo[sy] + xl) * (uint32_t)C + (uint32_t)c;
+            const uint32_t otr = ((uint32_t)rowlo[sy] + xr) * (uint32_t)C + (uint32_t)c;
+            const uint32_t obl = ((uint32_t)rowhi[sy] + xl) * (uint32_t)C + (uint32_t)c;
+            const uint32_t obr = ((uint32_t)rowhi[sy] + xr) * (uint32_t)C + (uint32_t)c;
+            const float4 tl = *reinterpret_cast<const float4*>(base + otl);
+            const float4 tr = *reinterpret_cast<const float4*>(base + otr);
+            const float4 bl = *reinterpret_cast<const float4*>(base + obl);
+            const float4 br = *reinterpret_cast<const float4*>(base + obr);
+            res = lerp_tap(tl, tr, bl, br, tx[sx].lerp, ty[sy].lerp);
+          }
+          v[sy][sx] = res;
+        }
+      }
+      *reinterpret_cast<float4*>(obin + c) = pool4<POOL>(v);
+    }
+  }
+}
+
+// NORM: ODET_ROI_NORM_*; STAGE: allow the LDS-staged tile path.
+template <int POOL, int NORM, bool STAGE>
 __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p, const float4* __restrict__ rois,
                                                   const int32_t* __restrict__ roi_level,
                                                   const int32_t* __restrict__ count_dev, float* __restrict__ out) {
+  extern __shared__ __align__(16) float tile[];
+  constexpr bool PAD = (NORM == ODET_ROI_NORM_TP_ALIGN);
   // XCD-aware remap: hardware deals workgroups round-robin over the 8 XCDs
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int lb = xcd * p.blocks_per_xcd + slot;
   if (slot >= p.blocks_per_xcd || lb >= p.nblocks) return;
   const int lane = threadIdx.x & 63;
-  const int task = lb * 4 + (threadIdx.x >> 6);
-  const int PP = p.P * p.P;
-  if (task >= p.n * PP) return;
-  const int r = task / PP;
-  const int bin = task - r * PP;
-  const int py = bin / p.P, px = bin - py * p.P;
-  const int C = p.C;
-  float* obase = out + ((size_t)task) * C;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int P = p.P, C = p.C;
+  const int r = lb / P;
+  const int py = lb - r * P;
+  float* __restrict__ orow = out + ((size_t)r * P + py) * P * C;
 
   const int cnt = count_dev ? min(*count_dev, p.n) : p.n;
   if (r >= cnt) {
-    for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(obase + c) = make_float4(0, 0, 0, 0);
+    for (int i = threadIdx.x * 4; i < P * C; i += 1024) *reinterpret_cast<float4*>(orow + i) = make_float4(0, 0, 0, 0);
     return;
   }
 
@@ -72,28 +289,27 @@ __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p, const float4* __r
   const float* __restrict__ feat = p.data[lvl];
   const int H = p.H[lvl], W = p.W[lvl];
   const float4 roi = rois[r];
-  const int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
-  const int crop = p.P * S;
+  constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
+  const int crop = P * S;
 
   // normalised box (y1,x1,y2,x2) exactly as the reference builds it
   float y1n, x1n, y2n, x2n;
   int Hs = H, Ws = W;     // dims of the map crop_and_resize samples (padded for TP_ALIGN)
-  if (p.norm_mode == ODET_ROI_NORM_IMAGE) {
+  if (NORM == ODET_ROI_NORM_IMAGE) {
     y1n = roi.y / p.image_h; x1n = roi.x / p.image_w;            // roi_pooling.py:30-35
     y2n = roi.w / p.image_h; x2n = roi.z / p.image_w;
-  } else if (p.norm_mode == ODET_ROI_NORM_STRIDE) {
+  } else if (NORM == ODET_ROI_NORM_STRIDE) {
     const float st = p.stride[lvl];
     const float hm = (float)(H - 1), wm = (float)(W - 1);
     y1n = (roi.y / st) / hm; x1n = (roi.x / st) / wm;            // roi_pooling.py:64,69-74
     y2n = (roi.w / st) / hm; x2n = (roi.z / st) / wm;
   } else {
     const float st = p.stride[lvl];
-    const bool padded = (p.norm_mode == ODET_ROI_NORM_TP_ALIGN);
-    const float off = padded ? 1.0f : 0.0f;
-    if (padded) { Hs = H + 2; Ws = W + 2; }                      // roi_pooling.py:100
+    const float off = PAD ? 1.0f : 0.0f;
+    if (PAD) { Hs = H + 2; Ws = W + 2; }                         // roi_pooling.py:100
     float x0 = roi.x / st, y0 = roi.y / st;                      // :175
     float x1 = roi.z / st, y1 = roi.w / st;
-    if (padded) { x0 = x0 + off; y0 = y0 + off; x1 = x1 + off; y1 = y1 + off; }   // :101
+    if (PAD) { x0 = x0 + off; y0 = y0 + off; x1 = x1 + off; y1 = y1 + off; }   // :101
     const float cs = (float)crop;
     const float sw = (x1 - x0) / cs, sh = (y1 - y0) / cs;        // :120-121
     const float imh = (float)(Hs - 1), imw = (float)(Ws - 1);
@@ -103,74 +319,101 @@ __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p, const float4* __r
     const float nh = sh * (float)(crop - 1) / imh;               // :128
     y2n = y1n + nh; x2n = x1n + nw;                              // :130
   }
-  float ysingle, xsingle;
-  const Axis ay = make_axis(y1n, y2n, Hs, crop, &ysingle);
-  const Axis ax = make_axis(x1n, x2n, Ws, crop, &xsingle);
-  const bool pad = (p.norm_mode == ODET_ROI_NORM_TP_ALIGN);
+  const Axis ay = make_axis(y1n, y2n, Hs, crop);
+  const Axis ax = make_axis(x1n, x2n, Ws, crop);
+  const int Hdim = PAD ? H : Hs, Wdim = PAD ? W : Ws;
 
-  // sample coordinates of this bin's S x S samples (wave-uniform)
-  bool yok[2], xok[2];
-  int ytop[2], ybot[2], xl[2], xr[2];
-  float ylerp[2], xlerp[2];
+  // the S sample rows of this output row (wave-uniform) and ALL sample columns, one per lane
+  Tap ty[2];
 #pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const int yy = py * S + s, xx = px * S + s;
-    const float in_y = (crop > 1) ? ay.start + (float)yy * ay.scale : ysingle;
-    const float in_x = (crop > 1) ? ax.start + (float)xx * ax.scale : xsingle;
-    // TF: extrapolate when (in < 0 || in > dim-1).  Written as the positive test so that a NaN
-    // coordinate can never turn into a tap index.
-    yok[s] = (in_y >= 0.0f && in_y <= ay.limit);
-    xok[s] = (in_x >= 0.0f && in_x <= ax.limit);
-    const float fy = floorf(in_y), fx = floorf(in_x);
-    ylerp[s] = in_y - fy;
-    xlerp[s] = in_x - fx;
-    int t = (int)fy, bt = (int)ceilf(in_y), l = (int)fx, rr = (int)ceilf(in_x);
-    if (pad) {   // SYMMETRIC 1-px pad == edge replicate: padded[i] = src[clamp(i-1)]
-      t = min(max(t - 1, 0), H - 1); bt = min(max(bt - 1, 0), H - 1);
-      l = min(max(l - 1, 0), W - 1); rr = min(max(rr - 1, 0), W - 1);
-    }
-    ytop[s] = t; ybot[s] = bt; xl[s] = l; xr[s] = rr;
+  for (int s = 0; s < 2; ++s) {
+    ty[s] = make_tap<PAD>(ay, py * S + (s < S ? s : 0), crop, Hdim);
+    // every lane computed the same values: tell the compiler (row offsets then live in SGPRs)
+    ty[s].lo = __builtin_amdgcn_readfirstlane(ty[s].lo);
+    ty[s].hi = __builtin_amdgcn_readfirstlane(ty[s].hi);
+    ty[s].ok = __builtin_amdgcn_readfirstlane(ty[s].ok ? 1 : 0) != 0;
+    ty[s].lerp = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ty[s].lerp)));
   }
+  const bool lane_taps = crop <= 64;
+  Tap txl = make_tap<PAD>(ax, min(lane, crop - 1), crop, Wdim);
 
-  for (int c = lane * 4; c < C; c += 256) {
-    float4 v[2][2];
+  // bounding tile of the cells this row taps; staged when it is small (only for the un-padded modes:
+  // the tensorpack modes read through the clamped indices straight from the map)
+  bool staged = false;
+  int r0 = 0, c0 = 0, ncols = 0, nrows = 0;
+  if (STAGE && !PAD) {
+    int rmin = 0x7fffffff, rmax = -1;
 #pragma unroll
-    for (int sy = 0; sy < S; ++sy) {
-#pragma unroll
-      for (int sx = 0; sx < S; ++sx) {
-        float4 res = make_float4(0, 0, 0, 0);
-        if (yok[sy] && xok[sx]) {
-          const float* rt = feat + ((size_t)ytop[sy] * W) * C + c;
-          const float* rb = feat + ((size_t)ybot[sy] * W) * C + c;
-          const float4 tl = *reinterpret_cast<const float4*>(rt + (size_t)xl[sx] * C);
-          const float4 tr = *reinterpret_cast<const float4*>(rt + (size_t)xr[sx] * C);
-          const float4 bl = *reinterpret_cast<const float4*>(rb + (size_t)xl[sx] * C);
-          const float4 br = *reinterpret_cast<const float4*>(rb + (size_t)xr[sx] * C);
-          const float xw = xlerp[sx], yw = ylerp[sy];
-          float t, b;
-          t = tl.x + (tr.x - tl.x) * xw; b = bl.x + (br.x - bl.x) * xw; res.x = t + (b - t) * yw;
-          t = tl.y + (tr.y - tl.y) * xw; b = bl.y + (br.y - bl.y) * xw; res.y = t + (b - t) * yw;
-          t = tl.z + (tr.z - tl.z) * xw; b = bl.z + (br.z - bl.z) * xw; res.z = t + (b - t) * yw;
-          t = tl.w + (tr.w - tl.w) * xw; b = bl.w + (br.w - bl.w) * xw; res.w = t + (b - t) * yw;
-        }
-        v[sy][sx] = res;
-      }
+    for (int s = 0; s < S; ++s)
+      if (ty[s].ok) { rmin = min(rmin, ty[s].lo); rmax = max(rmax, ty[s].hi); }
+    // in-bounds sample columns: coordinates are monotone in the sample index
+    int cmin = 0x7fffffff, cmax = -1;
+    {
+      const float first = axis_coord(ax, 0, crop), last = axis_coord(ax, crop - 1, crop);
+      const float lo = fminf(first, last), hi = fmaxf(first, last);
+      // any sample inside [0, limit] lies in [max(lo,0), min(hi,limit)]; the bounding cells of that
+      // interval contain every tapped column (a superset is fine: it only stages a few more cells)
+      const float a = fmaxf(lo, 0.0f), b = fminf(hi, ax.limit);
+      if (a <= b) { cmin = (int)floorf(a); cmax = (int)ceilf(b); }
     }
-    float4 o;
-    if (POOL == ODET_ROI_POOL_NONE) {
-      o = v[0][0];
-    } else if (POOL == ODET_ROI_POOL_MAX2) {
-      o.x = fmaxf(fmaxf(v[0][0].x, v[0][1].x), fmaxf(v[1][0].x, v[1][1].x));
-      o.y = fmaxf(fmaxf(v[0][0].y, v[0][1].y), fmaxf(v[1][0].y, v[1][1].y));
-      o.z = fmaxf(fmaxf(v[0][0].z, v[0][1].z), fmaxf(v[1][0].z, v[1][1].z));
-      o.w = fmaxf(fmaxf(v[0][0].w, v[0][1].w), fmaxf(v[1][0].w, v[1][1].w));
-    } else {
-      o.x = (((v[0][0].x + v[0][1].x) + v[1][0].x) + v[1][1].x) / 4.0f;
-      o.y = (((v[0][0].y + v[0][1].y) + v[1][0].y) + v[1][1].y) / 4.0f;
-      o.z = (((v[0][0].z + v[0][1].z) + v[1][0].z) + v[1][1].z) / 4.0f;
-      o.w = (((v[0][0].w + v[0][1].w) + v[1][0].w) + v[1][1].w) / 4.0f;
+    if (rmax >= 0 && cmax >= 0) {
+      nrows = rmax - rmin + 1;
+      ncols = cmax - cmin + 1;
+      r0 = rmin; c0 = cmin;
+      staged = (size_t)nrows * ncols * C * 4 <= ROI_LDS_BYTES && nrows * ncols < 2 * crop * S;
     }
-    *reinterpret_cast<float4*>(obase + c) = o;
+  }
+  if (STAGE && staged) {
+    // one coalesced pass: cell = wave-strided, channels = lanes x float4
+    const int cells = nrows * ncols;
+    for (int cell = w; cell < cells; cell += 4) {
+      const int rr = cell / ncols, cc = cell - rr * ncols;
+      const float* src = feat + ((size_t)(r0 + rr) * W + (c0 + cc)) * C;
+      float* dst = tile + (size_t)cell * C;
+      for (int c = lane * 4; c < C; c += 256)
+        *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
+    }
+    __syncthreads();
+    if (lane_taps) roi_row_bins<POOL, PAD, true>(tile, ncols, r0, c0, C, P, crop, Wdim, ax, txl, ty, orow);
+    else roi_row_bins<POOL, PAD, false>(tile, ncols, r0, c0, C, P, crop, Wdim, ax, txl, ty, orow);
+  } else {
+    if (lane_taps) roi_row_bins<POOL, PAD, true>(feat, W, 0, 0, C, P, crop, Wdim, ax, txl, ty, orow);
+    else roi_row_bins<POOL, PAD, false>(feat, W, 0, 0, C, P, crop, Wdim, ax, txl, ty, orow);
+  }
+}
+
+static bool roi_stage_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    // The LDS-staged tile path is kept for A/B measurements (ODET_ROI_STAGE=1).  It is OFF by default:
+    // every bilinear tap still has to be read once from LDS (128 B/clk/CU, only 2x the vector L1's
+    // 64 B/clk/CU) behind a load -> ds_write -> barrier chain, and measured 25-30 % slower than
+    // deduplicating the shared cells in registers (RoI kernel).
+    const char* e = getenv("ODET_ROI_STAGE");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v != 0;
+}
+
+template <int POOL, int NORM>
+static void roi_launch(dim3 grid, hipStream_t st, const RoiParams& p, const float* rois, const int32_t* roi_level,
+                       const int32_t* count_dev, float* out) {
+  if (NORM != ODET_ROI_NORM_TP_ALIGN && roi_stage_enabled())
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true>), grid, dim3(256), ROI_LDS_BYTES, st, p,
+                       (const float4*)rois, roi_level, count_dev, out);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false>), grid, dim3(256), 0, st, p,
+                       (const float4*)rois, roi_level, count_dev, out);
+}
+
+template <int POOL>
+static void roi_launch_norm(int norm_mode, dim3 grid, hipStream_t st, const RoiParams& p, const float* rois,
+                            const int32_t* roi_level, const int32_t* count_dev, float* out) {
+  switch (norm_mode) {
+    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, st, p, rois, roi_level, count_dev, out); break;
+    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, st, p, rois, roi_level, count_dev, out); break;
+    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, st, p, rois, roi_level, count_dev, out); break;
+    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, st, p, rois, roi_level, count_dev, out); break;
   }
 }
 
@@ -198,21 +441,15 @@ extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, 
   p.num_levels = num_levels;
   p.C = C; p.n = n; p.norm_mode = norm_mode; p.P = pool_size; p.pool_mode = pool_mode;
   p.image_h = (float)image_h; p.image_w = (float)image_w;
-  int64_t tasks = (int64_t)n * pool_size * pool_size;
-  ODET_REQUIRE(tasks < (1ll << 30), "odet_roi_pool: too many output bins");
-  p.nblocks = (int)((tasks + 3) / 4);
+  int64_t rows = (int64_t)n * pool_size;
+  ODET_REQUIRE(rows < (1ll << 30), "odet_roi_pool: too many output rows");
+  p.nblocks = (int)rows;
   p.blocks_per_xcd = (p.nblocks + 7) / 8;
-  dim3 grid(p.blocks_per_xcd * 8), block(256);
+  dim3 grid(p.blocks_per_xcd * 8);
   hipStream_t st = (hipStream_t)stream;
-  if (pool_mode == ODET_ROI_POOL_NONE)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<ODET_ROI_POOL_NONE>), grid, block, 0, st, p, (const float4*)rois,
-                       roi_level, count_dev, out);
-  else if (pool_mode == ODET_ROI_POOL_MAX2)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<ODET_ROI_POOL_MAX2>), grid, block, 0, st, p, (const float4*)rois,
-                       roi_level, count_dev, out);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<ODET_ROI_POOL_AVG2>), grid, block, 0, st, p, (const float4*)rois,
-                       roi_level, count_dev, out);
+  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, st, p, rois, roi_level, count_dev, out);
+  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out);
+  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out);
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }

@@ -256,12 +256,12 @@ def fpn_proposals(rpn_logits, rpn_deltas, fh_list, fw_list, stride_list, wh_tabl
             torch.empty(K, dtype=torch.int64, device=dev), torch.empty(nlv, dtype=torch.int32, device=dev))
     nb = L.lib().odet_fpn_proposals_workspace_bytes(n, K)
     ws = workspace if workspace is not None and workspace.numel() >= nb else L.workspace(nb, dev)
-    L.check(L.lib().odet_fpn_proposals(
-        L.dptr(logits), L.dptr(deltas), nl, A, fh, fw, st, wh.ctypes.data_as(C.c_void_p), int(image_shape[0]),
+    L.call(
+        'odet_fpn_proposals', L.dptr(logits), L.dptr(deltas), nl, A, fh, fw, st, wh.ctypes.data_as(C.c_void_p), int(image_shape[0]),
         int(image_shape[1]), L.host4(means, 'target_means'), L.host4(stds, 'target_stds'), K, float(iou_threshold),
         int(min_level or 0), int(max_level or 0), L.dptr(rois), L.dptr(idx), L.dptr(cnt),
         L.dptr(lv[0]) if lv else None, L.dptr(lv[1]) if lv else None, L.dptr(lv[2]) if lv else None,
-        L.dptr(lv[3]) if lv else None, int(blind_chunks), L.dptr(done), L.dptr(ws), ws.numel(), L.stream()))
+        L.dptr(lv[3]) if lv else None, int(blind_chunks), L.dptr(done), L.dptr(ws), ws.numel(), L.stream())
     return (rois, idx, cnt) + ((lv,) if lv else ())
 
 
@@ -313,8 +313,8 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
     ih, iw = (0, 0) if image_shape is None else (int(image_shape[0]), int(image_shape[1]))
     if roi_level is not None and roi_level.dtype != torch.int32:
         roi_level = roi_level.to(torch.int32)
-    L.check(L.lib().odet_roi_pool(levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
-                                  int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream()))
+    L.call('odet_roi_pool', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
+           int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream())
     return out
 
 
@@ -348,10 +348,9 @@ def post_ops(scores, deltas, rois, image_shape, means, stds, max_per_class, max_
             int(max_per_class), int(max_per_image), float(nms_iou_threshold), float(score_threshold),
             float(min_edge), L.dptr(ob), L.dptr(ol), L.dptr(os_), L.dptr(cnt))
     if record is None:
-        L.check(L.lib().odet_post_ops(*head, L.dptr(ws), nb, L.stream()))
+        L.call('odet_post_ops', *head, L.dptr(ws), nb, L.stream())
     else:
         if record.numel() < M * 6 + 1:
             raise ValueError('record must hold max_per_image*6+1 floats')
-        L.check(L.lib().odet_post_ops_record(*head, L.dptr(record, torch.float32, 'record'), L.dptr(ws), nb,
-                                             L.stream()))
+        L.call('odet_post_ops_record', *head, L.dptr(record, torch.float32, 'record'), L.dptr(ws), nb, L.stream())
     return ob, ol, os_, cnt

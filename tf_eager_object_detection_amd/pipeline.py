@@ -65,16 +65,40 @@ class FpnHotPath:
         self.ws_post = torch.empty(ops.L.lib().odet_post_ops_workspace_bytes(num_classes, max_per_class),
                                    dtype=torch.uint8, device=dev)
         self.record = torch.zeros(M * 6 + 1, dtype=torch.float32, device=dev)
+        self._plans = {}
+
+    # Host-side launch plans: every buffer of this object is persistent, so the marshalled ctypes
+    # arguments of a stage only depend on the input tensors' addresses and the stream.  The first call
+    # with a given set of inputs goes through ops.* (validation, marshalling) and records the C-ABI
+    # calls; later calls replay them (a few microseconds of host time per stage instead of ~50).
+    def _run(self, stage, inputs, fn):
+        ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in inputs)
+        key = (stage, torch.cuda.current_stream().cuda_stream) + tuple(t.data_ptr() for t in inputs)
+        plan = self._plans.get(key) if ok else None
+        if plan is not None:
+            for f, a in plan[0]:
+                rc = f(*a)
+                if rc != 0:
+                    ops.L.check(rc)
+            return plan[1]
+        with ops.L.recording() as calls:
+            out = fn()
+        if ok:
+            if len(self._plans) > 64:
+                self._plans.clear()
+            self._plans[key] = (calls, out, inputs)      # inputs kept alive with the plan
+        return out
 
     # ---- stage 1: RPN outputs -> level-sorted proposals -------------------------------------
     def stage_proposals(self, rpn_logits, rpn_deltas):
         """rpn_logits [N,2] (bg,fg) as RpnHead emits them (base_fpn_model.py:429), rpn_deltas [N,4]."""
-        ops.fpn_proposals(rpn_logits, rpn_deltas, self.fh, self.fw, self.strides, self.wh, self.image_shape, self.K,
-                          self.cfg['rpn_nms_iou'], self.cfg['rpn_means'], self.cfg['rpn_stds'],
-                          min_level=self.min_level, max_level=self.max_level, workspace=self.ws_rpn,
-                          blind_chunks=self.blind_chunks, done=self.nms_done,
-                          out=(self.rois, self.roi_idx, self.roi_count),
-                          out_levels=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts))
+        self._run('proposals', (rpn_logits, rpn_deltas), lambda: ops.fpn_proposals(
+            rpn_logits, rpn_deltas, self.fh, self.fw, self.strides, self.wh, self.image_shape, self.K,
+            self.cfg['rpn_nms_iou'], self.cfg['rpn_means'], self.cfg['rpn_stds'],
+            min_level=self.min_level, max_level=self.max_level, workspace=self.ws_rpn,
+            blind_chunks=self.blind_chunks, done=self.nms_done,
+            out=(self.rois, self.roi_idx, self.roi_count),
+            out_levels=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts)))
         # base_fpn_model.py:220 (_get_anchors), :223 (fg softmax), :224 (RegionProposal), :256 / :303-324
         return self.sorted_rois, self.roi_level, self.roi_count
 
@@ -82,19 +106,20 @@ class FpnHotPath:
     def stage_roi(self, p_list):
         """p_list: P2..P5 NHWC feature maps.  -> [K,P,P,C] (rows >= count are zero)."""
         nl = self.max_level - self.min_level + 1
-        return ops.roi_pool(list(p_list[:nl]), self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P,
-                            ops.ROI_POOL_MAX2, image_shape=self.image_shape, count_dev=self.roi_count,
-                            out=self.roi_features)                                      # :257 / :152-161
+        maps = list(p_list[:nl])
+        return self._run('roi', tuple(maps), lambda: ops.roi_pool(
+            maps, self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P, ops.ROI_POOL_MAX2,
+            image_shape=self.image_shape, count_dev=self.roi_count, out=self.roi_features))   # :257 / :152-161
 
     # ---- stage 3: RoI-head outputs -> detections ---------------------------------------------
     def stage_detect(self, cls_softmax, cls_deltas):
         """cls_softmax [K,Ccls], cls_deltas [K,Ccls,4] for the level-sorted RoIs (rows >= count ignored)."""
         c = self.cfg
-        return ops.post_ops(cls_softmax, cls_deltas, self.sorted_rois, self.image_shape, c['roi_means'],
-                            c['roi_stds'], c['max_per_class'], c['max_per_image'], c['nms_iou'],
-                            c['score_threshold'], 16, self.num_classes, count_dev=self.roi_count,
-                            out=(self.det_boxes, self.det_labels, self.det_scores, self.det_count),
-                            workspace=self.ws_post, record=self.record)                 # :267-275
+        return self._run('detect', (cls_softmax, cls_deltas), lambda: ops.post_ops(
+            cls_softmax, cls_deltas, self.sorted_rois, self.image_shape, c['roi_means'], c['roi_stds'],
+            c['max_per_class'], c['max_per_image'], c['nms_iou'], c['score_threshold'], 16, self.num_classes,
+            count_dev=self.roi_count, out=(self.det_boxes, self.det_labels, self.det_scores, self.det_count),
+            workspace=self.ws_post, record=self.record))                                  # :267-275
 
     def stage_record(self):
         """Fixed-size detection record of this image for the image-parallel all-gather (written by the
