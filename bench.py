@@ -123,6 +123,8 @@ def main():
     ap.add_argument('--scores', choices=['distinct', 'clustered'], default='distinct',
                     help='RPN score distribution (SURVEY 8d: distinct; clustered = trained-like)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--streams', type=int, default=8, help='independent images in flight per GPU')
+    ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -141,56 +143,95 @@ def main():
 
     from tf_eager_object_detection_amd import _lib, parallel
     from tf_eager_object_detection_amd import synthetic as syn
-    from tf_eager_object_detection_amd.pipeline import FpnHotPath, synthetic_fpn_inputs
+    from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
     _lib.lib()     # fail loudly without the HIP library
 
     host, dev = synthetic_fpn_inputs(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, seed=1234 + rank,
                                      score_kind=args.scores)
-    hot = FpnHotPath(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS)
+    # `streams` independent images in flight: one FpnHotPath slot + HIP stream + native enqueue thread each
+    S = max(1, args.streams)
+    pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, blind_chunks=args.blind_chunks)
+    rec_len = pool.slots[0].record.numel()
+    records = torch.zeros((S, rec_len), dtype=torch.float32, device='cuda')
+    for k in range(S):
+        pool.slots[k].record = records[k]                     # one contiguous block: ONE all-gather per round
+        pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+    hot = pool.slots[0]
     max_det = hot.cfg['max_per_image']
+    comm = torch.cuda.Stream()
+    gathered = torch.zeros((world, S, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
 
-    # HIP events around the RoI kernel, on the launch stream, inside the timed region.  An event
-    # record stalls the queue for ~5 us, so every EV_EVERY-th step is bracketed (>= 20 samples at the
-    # default K) instead of all of them.
-    EV_EVERY = 8 if args.steps >= 160 else 1
-    ev_roi = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for i in range(0, args.steps, EV_EVERY)}
+    # HIP events around the RoI kernel, on its launch stream, inside the timed region.  The kernel is
+    # timed ALONE: the step's stream first waits (on the GPU, no host sync) for the other streams and
+    # they wait for it afterwards, so only a few steps are bracketed.
+    EV_EVERY = max(8, args.steps // 10)
+    from tf_eager_object_detection_amd import ops
+    ev_roi = {i: (ops.ProfEvent(), ops.ProfEvent()) for i in range(0, args.steps, EV_EVERY)}
 
-    def one_step(i=None):
-        hot.stage_proposals(dev['rpn_logits'], dev['rpn_deltas'])
-        ev = ev_roi.get(i)
-        if ev is not None:
-            ev[0].record()
-        hot.stage_roi(dev['feats'])
-        if ev is not None:
-            ev[1].record()
-        hot.stage_detect(dev['cls_scores'], dev['cls_deltas'])
-        rec = hot.stage_record()
-        return parallel.all_gather_detections(rec) if world > 1 else rec
+    def drain():
+        pool.wait()
+        torch.cuda.synchronize()
+
+    def gather_round():
+        """image-parallel exchange: every rank's S records of this round in one RCCL all-gather"""
+        pool.wait()
+        for st in pool.streams:
+            comm.wait_stream(st)
+        with torch.cuda.stream(comm):
+            dist.all_gather_into_tensor(gathered, records)
+        for st in pool.streams:
+            st.wait_stream(comm)                              # the next round may overwrite the records
+
+    def one_step(i, timed):
+        slot = i % S
+        ev = ev_roi.get(i) if timed else None
+        if ev is None:
+            pool.submit(slot)
+        else:
+            pool.wait()                                       # every earlier image is enqueued (host side only)
+            mine = pool.streams[slot]
+            for st in pool.streams:
+                if st is not mine:
+                    mine.wait_stream(st)
+            with torch.cuda.stream(mine):
+                h = pool.slots[slot]
+                h.stage_proposals(dev['rpn_logits'], dev['rpn_deltas'])
+                h.stage_roi(dev['feats'], events=ev)          # start / stop events of the dispatch itself
+                h.stage_detect(dev['cls_scores'], dev['cls_deltas'])
+            for st in pool.streams:
+                if st is not mine:
+                    st.wait_stream(mine)
+        if world > 1 and slot == S - 1:
+            gather_round()
 
     def fence():
-        torch.cuda.synchronize()
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    for i in range(args.warmup):
+        one_step(i, False)
+    if world > 1 and args.warmup % S:
+        gather_round()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = one_step(i)
+        one_step(i, True)
+    if world > 1 and args.steps % S:
+        gather_round()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if int(hot.nms_done.item()) != 1:
-        raise SystemExit('NMS did not complete inside the blind chunks -- result would be invalid')
+    if any(int(h.nms_done.item()) != 1 for h in pool.slots):
+        raise SystemExit('NMS did not complete inside the blind chunks -- result would be invalid '
+                         '(use --blind-chunks 2 for score distributions with heavy suppression)')
 
     if rank == 0:
-        roi_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_roi.values()]))
+        roi_ms = float(np.mean([a.elapsed_ms(b) for a, b in ev_roi.values()]))
         k = int(hot.roi_count.item())
         srois = hot.sorted_rois[:k].cpu().numpy()
         lv = hot.roi_level[:k].cpu().numpy()
@@ -208,6 +249,7 @@ def main():
                                    'P2..P5x256 -> post_ops (21 classes); conv backbone/heads out of scope (their '
                                    'outputs are synthetic inputs in HBM)',
                        'images_per_step_per_gpu': 1, 'global_batch': world, 'rpn_scores': args.scores,
+                       'streams_per_gpu': S, 'enqueue_threads_per_gpu': S,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -218,6 +260,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
         print(json.dumps(result))
+    pool.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

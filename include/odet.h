@@ -205,6 +205,17 @@ int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, const float
                   int image_h, int image_w, int pool_size, int pool_mode, float* out,
                   odet_stream_t stream);
 
+/* odet_roi_pool with HIP events attached to the dispatch itself (hipExtLaunchKernel start/stop
+ * events, created with odet_prof_event_create): the kernel's own begin / end timestamps, for
+ * bench.py's roofline figure.  odet_prof_event_elapsed_ms host-syncs on the stop event. */
+int odet_roi_pool_timed(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                        const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode,
+                        int image_h, int image_w, int pool_size, int pool_mode, float* out,
+                        odet_stream_t stream, void* start_event, void* stop_event);
+int odet_prof_event_create(void** ev);
+int odet_prof_event_destroy(void* ev);
+int odet_prof_event_elapsed_ms(void* start, void* stop, float* ms);
+
 /* ---- detection post-processing ------------------------------------------------------- */
 
 #define ODET_POSTOPS_MAX_ROIS 4096
@@ -242,6 +253,72 @@ int odet_post_ops_record(const float* scores, const float* deltas, const float* 
 int odet_pack_detections(const float* boxes, const int32_t* labels, const float* scores,
                          const int32_t* count_dev, int capacity, int max_det, float* out_record,
                          odet_stream_t stream);
+
+/* ---- whole-step descriptor + native executor (throughput serving) ---------------------- */
+
+/* One image through the FPN hot path as the reference's BaseFPN.call runs it
+ * (model/fpn/base_fpn_model.py:208-276 minus the dense conv parts): every buffer is caller-owned
+ * device memory, the struct is plain data.  odet_fpn_step_enqueue() issues the selected stages on
+ * `stream` from the calling thread:
+ *   ODET_STAGE_PROPOSALS = odet_fpn_proposals   (anchors, fg softmax, RegionProposal, _assign_levels)
+ *   ODET_STAGE_ROI       = odet_roi_pool        (RoiPoolingCropAndResize2 over maps[0..num_maps))
+ *   ODET_STAGE_DETECT    = odet_post_ops_record (post_ops_prediction + detection record) */
+#define ODET_STAGE_PROPOSALS 1
+#define ODET_STAGE_ROI 2
+#define ODET_STAGE_DETECT 4
+#define ODET_STAGE_ALL 7
+
+typedef struct {
+  /* proposals */
+  int32_t image_h, image_w;
+  int32_t num_levels, A;                         /* RPN pyramid levels / anchors per cell */
+  int32_t fh[ODET_MAX_LEVELS], fw[ODET_MAX_LEVELS], stride[ODET_MAX_LEVELS];
+  float wh[ODET_MAX_LEVELS * ODET_MAX_ANCHORS_PER_CELL * 2];
+  float rpn_means[4], rpn_stds[4];
+  int32_t num_proposals;
+  float rpn_nms_iou;
+  int32_t min_level, max_level, blind_chunks;
+  /* roi */
+  int32_t num_maps, channels, pool_size;
+  odet_level_t maps[ODET_MAX_LEVELS];
+  /* detect */
+  int32_t ccls, num_classes, max_per_class, max_per_image;
+  float roi_means[4], roi_stds[4];
+  float nms_iou, score_threshold, min_edge;
+  /* inputs (device) */
+  const float* rpn_logits;   /* [n,2] */
+  const float* rpn_deltas;   /* [n,4] */
+  const float* cls_scores;   /* [num_proposals, ccls] */
+  const float* cls_deltas;   /* [num_proposals, ccls, 4] */
+  /* outputs / scratch (device, caller-owned) */
+  float* rois; int32_t* roi_idx; int32_t* roi_count; int32_t* nms_done;
+  float* sorted_rois; int32_t* roi_level; int64_t* roi_perm; int32_t* level_counts;
+  float* roi_features;
+  float* det_boxes; int32_t* det_labels; float* det_scores; int32_t* det_count; float* record;
+  void* ws_rpn; size_t ws_rpn_bytes;
+  void* ws_post; size_t ws_post_bytes;
+  odet_stream_t stream;
+} odet_fpn_step_t;
+
+size_t odet_fpn_step_sizeof(void);
+int odet_fpn_step_enqueue(const odet_fpn_step_t* step, int stages);
+
+/* Native executor: `num_workers` host threads, each draining its own FIFO of (step, stages) jobs by
+ * calling odet_fpn_step_enqueue.  A HIP kernel launch costs ~3 us of host time and one image is ~11
+ * launches, so one host thread saturates near 20k images/s; with one worker per stream the images of
+ * different streams are enqueued in parallel (the reference has no counterpart: it is a
+ * single-threaded Python loop).  A job only enqueues GPU work; completion is the stream's business.
+ * The step structs must stay alive and unchanged until odet_exec_wait() has returned.  Work that
+ * must be ordered after a job on the same stream from another thread (e.g. a torch op) has to be
+ * issued after odet_exec_wait(). */
+typedef struct odet_exec odet_exec_t;
+odet_exec_t* odet_exec_create(int num_workers);
+void odet_exec_destroy(odet_exec_t* ex);
+int odet_exec_submit(odet_exec_t* ex, int worker, const odet_fpn_step_t* step, int stages);
+/* blocks until every submitted job has been enqueued; returns the first error any job hit (0 = none;
+ * text through odet_exec_last_error) and clears it */
+int odet_exec_wait(odet_exec_t* ex);
+const char* odet_exec_last_error(odet_exec_t* ex);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,36 @@ class OdetLevel(C.Structure):
     _fields_ = [('data', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32), ('stride', C.c_float)]
 
 
+MAX_LEVELS = 8
+MAX_ANCHORS_PER_CELL = 32
+
+
+class OdetFpnStep(C.Structure):
+    """odet_fpn_step_t (include/odet.h); size checked against odet_fpn_step_sizeof() at load time."""
+    _fields_ = [
+        ('image_h', C.c_int32), ('image_w', C.c_int32), ('num_levels', C.c_int32), ('A', C.c_int32),
+        ('fh', C.c_int32 * MAX_LEVELS), ('fw', C.c_int32 * MAX_LEVELS), ('stride', C.c_int32 * MAX_LEVELS),
+        ('wh', C.c_float * (MAX_LEVELS * MAX_ANCHORS_PER_CELL * 2)),
+        ('rpn_means', C.c_float * 4), ('rpn_stds', C.c_float * 4),
+        ('num_proposals', C.c_int32), ('rpn_nms_iou', C.c_float),
+        ('min_level', C.c_int32), ('max_level', C.c_int32), ('blind_chunks', C.c_int32),
+        ('num_maps', C.c_int32), ('channels', C.c_int32), ('pool_size', C.c_int32),
+        ('maps', OdetLevel * MAX_LEVELS),
+        ('ccls', C.c_int32), ('num_classes', C.c_int32), ('max_per_class', C.c_int32), ('max_per_image', C.c_int32),
+        ('roi_means', C.c_float * 4), ('roi_stds', C.c_float * 4),
+        ('nms_iou', C.c_float), ('score_threshold', C.c_float), ('min_edge', C.c_float),
+        ('rpn_logits', C.c_void_p), ('rpn_deltas', C.c_void_p), ('cls_scores', C.c_void_p), ('cls_deltas', C.c_void_p),
+        ('rois', C.c_void_p), ('roi_idx', C.c_void_p), ('roi_count', C.c_void_p), ('nms_done', C.c_void_p),
+        ('sorted_rois', C.c_void_p), ('roi_level', C.c_void_p), ('roi_perm', C.c_void_p),
+        ('level_counts', C.c_void_p), ('roi_features', C.c_void_p),
+        ('det_boxes', C.c_void_p), ('det_labels', C.c_void_p), ('det_scores', C.c_void_p),
+        ('det_count', C.c_void_p), ('record', C.c_void_p),
+        ('ws_rpn', C.c_void_p), ('ws_rpn_bytes', C.c_size_t),
+        ('ws_post', C.c_void_p), ('ws_post_bytes', C.c_size_t),
+        ('stream', C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/odet.h one to one
 SIGNATURES = {
     'odet_version': (_i, []),
@@ -48,12 +78,23 @@ SIGNATURES = {
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     'odet_assign_levels': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'odet_roi_pool': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'odet_roi_pool_timed': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'odet_prof_event_create': (_i, [_vp]),
+    'odet_prof_event_destroy': (_i, [_vp]),
+    'odet_prof_event_elapsed_ms': (_i, [_vp, _vp, _vp]),
     'odet_post_ops_workspace_bytes': (_sz, [_i, _i]),
     'odet_post_ops': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f,
                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'odet_post_ops_record': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'odet_pack_detections': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'odet_fpn_step_sizeof': (_sz, []),
+    'odet_fpn_step_enqueue': (_i, [_vp, _i]),
+    'odet_exec_create': (_vp, [_i]),
+    'odet_exec_destroy': (None, [_vp]),
+    'odet_exec_submit': (_i, [_vp, _i, _vp, _i]),
+    'odet_exec_wait': (_i, [_vp]),
+    'odet_exec_last_error': (C.c_char_p, [_vp]),
 }
 
 
@@ -79,6 +120,9 @@ def lib():
             fn.argtypes = args
         if handle.odet_version() != 100:
             raise OdetError('libodet_hip.so version mismatch: %d' % handle.odet_version())
+        if handle.odet_fpn_step_sizeof() != C.sizeof(OdetFpnStep):
+            raise OdetError('odet_fpn_step_t layout mismatch: library %d bytes, binding %d'
+                            % (handle.odet_fpn_step_sizeof(), C.sizeof(OdetFpnStep)))
         _lib = handle
     return _lib
 

@@ -26,6 +26,8 @@
 // holds one neighbourhood of one pyramid level.
 #include <stdlib.h>
 
+#include <hip/hip_ext.h>
+
 #include "odet_internal.h"
 
 #define ROI_LDS_BYTES (40 * 1024)   // staged tile budget: 4 workgroups per CU
@@ -395,32 +397,33 @@ static bool roi_stage_enabled() {
   return v != 0;
 }
 
+struct RoiEvents { hipEvent_t start, stop; };   // optional: timestamps of the dispatch itself
+
 template <int POOL, int NORM>
 static void roi_launch(dim3 grid, hipStream_t st, const RoiParams& p, const float* rois, const int32_t* roi_level,
-                       const int32_t* count_dev, float* out) {
+                       const int32_t* count_dev, float* out, RoiEvents ev) {
   if (NORM != ODET_ROI_NORM_TP_ALIGN && roi_stage_enabled())
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true>), grid, dim3(256), ROI_LDS_BYTES, st, p,
-                       (const float4*)rois, roi_level, count_dev, out);
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true>), grid, dim3(256), ROI_LDS_BYTES, st, ev.start,
+                          ev.stop, 0, p, (const float4*)rois, roi_level, count_dev, out);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false>), grid, dim3(256), 0, st, p,
-                       (const float4*)rois, roi_level, count_dev, out);
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false>), grid, dim3(256), 0, st, ev.start, ev.stop, 0,
+                          p, (const float4*)rois, roi_level, count_dev, out);
 }
 
 template <int POOL>
 static void roi_launch_norm(int norm_mode, dim3 grid, hipStream_t st, const RoiParams& p, const float* rois,
-                            const int32_t* roi_level, const int32_t* count_dev, float* out) {
+                            const int32_t* roi_level, const int32_t* count_dev, float* out, RoiEvents ev) {
   switch (norm_mode) {
-    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, st, p, rois, roi_level, count_dev, out); break;
-    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, st, p, rois, roi_level, count_dev, out); break;
-    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, st, p, rois, roi_level, count_dev, out); break;
-    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, st, p, rois, roi_level, count_dev, out); break;
+    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
+    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
+    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
+    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
   }
 }
 
-extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, const float* rois,
-                             const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode,
-                             int image_h, int image_w, int pool_size, int pool_mode, float* out,
-                             odet_stream_t stream) {
+static int roi_pool_impl(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                         const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode, int image_h,
+                         int image_w, int pool_size, int pool_mode, float* out, odet_stream_t stream, RoiEvents ev) {
   ODET_REQUIRE(n >= 0, "odet_roi_pool: negative n");
   if (n == 0) return ODET_OK;
   ODET_REQUIRE(levels && rois && out, "odet_roi_pool: null pointer");
@@ -447,9 +450,46 @@ extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, 
   p.blocks_per_xcd = (p.nblocks + 7) / 8;
   dim3 grid(p.blocks_per_xcd * 8);
   hipStream_t st = (hipStream_t)stream;
-  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, st, p, rois, roi_level, count_dev, out);
-  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out);
-  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out);
+  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, st, p, rois, roi_level, count_dev, out, ev);
+  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out, ev);
+  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out, ev);
   ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                             const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode,
+                             int image_h, int image_w, int pool_size, int pool_mode, float* out,
+                             odet_stream_t stream) {
+  return roi_pool_impl(levels, num_levels, C, rois, roi_level, n, count_dev, norm_mode, image_h, image_w, pool_size,
+                       pool_mode, out, stream, RoiEvents{nullptr, nullptr});
+}
+
+extern "C" int odet_roi_pool_timed(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                                   const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode,
+                                   int image_h, int image_w, int pool_size, int pool_mode, float* out,
+                                   odet_stream_t stream, void* start_event, void* stop_event) {
+  ODET_REQUIRE(start_event && stop_event, "odet_roi_pool_timed: null event");
+  return roi_pool_impl(levels, num_levels, C, rois, roi_level, n, count_dev, norm_mode, image_h, image_w, pool_size,
+                       pool_mode, out, stream, RoiEvents{(hipEvent_t)start_event, (hipEvent_t)stop_event});
+}
+
+extern "C" int odet_prof_event_create(void** ev) {
+  ODET_REQUIRE(ev, "odet_prof_event_create: null pointer");
+  hipEvent_t e;
+  ODET_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return ODET_OK;
+}
+
+extern "C" int odet_prof_event_destroy(void* ev) {
+  if (ev) ODET_HIP(hipEventDestroy((hipEvent_t)ev));
+  return ODET_OK;
+}
+
+extern "C" int odet_prof_event_elapsed_ms(void* start, void* stop, float* ms) {
+  ODET_REQUIRE(start && stop && ms, "odet_prof_event_elapsed_ms: null pointer");
+  ODET_HIP(hipEventSynchronize((hipEvent_t)stop));
+  ODET_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
   return ODET_OK;
 }

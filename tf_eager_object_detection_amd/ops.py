@@ -283,9 +283,30 @@ def assign_levels(rois, min_level, max_level, count_dev=None, out=None):
     return out, lvl[:n], perm[:n], counts
 
 
+class ProfEvent:
+    """HIP event for odet_roi_pool_timed (the dispatch's own begin / end timestamps)."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        L.check(L.lib().odet_prof_event_create(C.byref(self.handle)))
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        L.check(L.lib().odet_prof_event_elapsed_ms(self.handle, stop.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L.lib().odet_prof_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
 def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, strides=None, image_shape=None,
-             count_dev=None, out=None):
-    """feature_maps: list of NHWC float32 GPU tensors [1,H,W,C] (one per level)."""
+             count_dev=None, out=None, events=None):
+    """feature_maps: list of NHWC float32 GPU tensors [1,H,W,C] (one per level).  ``events`` = (start, stop)
+    ProfEvent pair attached to the dispatch (profiling)."""
     rois = _boxes(rois, 'rois')
     n = rois.shape[0]
     nl = len(feature_maps)
@@ -313,8 +334,12 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
     ih, iw = (0, 0) if image_shape is None else (int(image_shape[0]), int(image_shape[1]))
     if roi_level is not None and roi_level.dtype != torch.int32:
         roi_level = roi_level.to(torch.int32)
-    L.call('odet_roi_pool', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
-           int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream())
+    if events is None:
+        L.call('odet_roi_pool', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
+               int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream())
+    else:
+        L.call('odet_roi_pool_timed', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
+               int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream(), events[0].handle, events[1].handle)
     return out
 
 

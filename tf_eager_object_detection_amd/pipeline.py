@@ -103,10 +103,15 @@ class FpnHotPath:
         return self.sorted_rois, self.roi_level, self.roi_count
 
     # ---- stage 2: RoI features ---------------------------------------------------------------
-    def stage_roi(self, p_list):
-        """p_list: P2..P5 NHWC feature maps.  -> [K,P,P,C] (rows >= count are zero)."""
+    def stage_roi(self, p_list, events=None):
+        """p_list: P2..P5 NHWC feature maps.  -> [K,P,P,C] (rows >= count are zero).  ``events``: a
+        (start, stop) ops.ProfEvent pair attached to the kernel dispatch (bench.py's roofline timing)."""
         nl = self.max_level - self.min_level + 1
         maps = list(p_list[:nl])
+        if events is not None:
+            return ops.roi_pool(maps, self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P,
+                                ops.ROI_POOL_MAX2, image_shape=self.image_shape, count_dev=self.roi_count,
+                                out=self.roi_features, events=events)
         return self._run('roi', tuple(maps), lambda: ops.roi_pool(
             maps, self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P, ops.ROI_POOL_MAX2,
             image_shape=self.image_shape, count_dev=self.roi_count, out=self.roi_features))   # :257 / :152-161
@@ -133,6 +138,111 @@ class FpnHotPath:
         feats = self.stage_roi(p_list)
         boxes, labels, scores, count = self.stage_detect(cls_softmax, cls_deltas)
         return feats, boxes, labels, scores, count
+
+
+class FpnStreamPool:
+    """Throughput arrangement: `n_streams` independent FpnHotPath slots, each with its own HIP stream
+    and persistent buffers, fed by the library's native executor (one host thread per stream; a HIP
+    launch costs ~3 us of host time and an image is ~11 launches, so a single enqueuing thread would
+    cap the rate).  Images are independent (the path has no cross-image state), so consecutive images
+    simply go to consecutive slots and their kernels overlap on the GPU: single-workgroup stages of
+    one image (NMS scan, merge) run beside the chip-wide stages of another (RoI crops).
+
+        pool = FpnStreamPool(4, image_shape, ...)
+        pool.bind(slot, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas)   # once per buffer set
+        pool.submit(slot)            # enqueue one image (all three stages) -- returns immediately
+        pool.wait()                  # every submitted image has been enqueued; then sync the streams
+
+    The stages of a submitted image are enqueued by a worker thread, so work that must follow them on
+    the same stream from Python (a torch op) has to be issued after wait().  A model that runs a dense
+    RoI head between the stages uses FpnHotPath directly."""
+
+    def __init__(self, n_streams, image_shape, num_classes=21, num_proposals=1000, channels=256, **kw):
+        import ctypes as C
+        self.n = int(n_streams)
+        self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
+        self.streams = [torch.cuda.Stream() for _ in range(self.n)]
+        self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
+        self._keep = [None] * self.n
+        self._C = C
+        self._lib = ops.L.lib()
+        self._exec = self._lib.odet_exec_create(self.n)
+        if not self._exec:
+            raise ops.L.OdetError('odet_exec_create failed: %s' % self._lib.odet_last_error().decode())
+        self._rr = 0
+
+    def bind(self, slot, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
+        """Points slot `slot` at one image's inputs (float32 contiguous GPU tensors, kept alive here)."""
+        h, st = self.slots[slot], self.steps[slot]
+        nl = h.max_level - h.min_level + 1
+        maps = list(p_list[:nl])
+        tensors = [rpn_logits, rpn_deltas, cls_softmax, cls_deltas] + maps
+        for t in tensors:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError('FpnStreamPool.bind needs float32 contiguous GPU tensors')
+        if rpn_logits.numel() != h.N * 2 or rpn_deltas.numel() != h.N * 4:
+            raise ValueError('%d anchors expected, got rpn scores %s / deltas %s'
+                             % (h.N, tuple(rpn_logits.shape), tuple(rpn_deltas.shape)))
+        if cls_softmax.dim() != 2 or cls_softmax.shape[0] != h.K or cls_deltas.numel() != cls_softmax.numel() * 4:
+            raise ValueError('class scores must be [%d, Ccls] and deltas [%d, Ccls, 4]' % (h.K, h.K))
+        c = h.cfg
+        st.image_h, st.image_w = h.image_shape
+        st.num_levels, st.A = len(h.fh), h.wh.shape[1]
+        for l in range(len(h.fh)):
+            st.fh[l], st.fw[l], st.stride[l] = h.fh[l], h.fw[l], int(h.strides[l])
+        flat = h.wh.reshape(-1)
+        for i in range(flat.shape[0]):
+            st.wh[i] = float(flat[i])
+        for k in range(4):
+            st.rpn_means[k], st.rpn_stds[k] = float(c['rpn_means'][k]), float(c['rpn_stds'][k])
+            st.roi_means[k], st.roi_stds[k] = float(c['roi_means'][k]), float(c['roi_stds'][k])
+        st.num_proposals, st.rpn_nms_iou = h.K, float(c['rpn_nms_iou'])
+        st.min_level, st.max_level, st.blind_chunks = h.min_level, h.max_level, h.blind_chunks
+        st.num_maps, st.channels, st.pool_size = nl, h.C, h.P
+        for l, fm in enumerate(maps):
+            if fm.dim() != 4 or fm.shape[0] != 1 or fm.shape[3] != h.C:
+                raise ValueError('feature maps must be NHWC [1,H,W,%d]' % h.C)
+            st.maps[l].data, st.maps[l].H, st.maps[l].W, st.maps[l].stride = fm.data_ptr(), fm.shape[1], fm.shape[2], 0.0
+        st.ccls, st.num_classes = cls_softmax.shape[1], h.num_classes
+        st.max_per_class, st.max_per_image = c['max_per_class'], c['max_per_image']
+        st.nms_iou, st.score_threshold, st.min_edge = float(c['nms_iou']), float(c['score_threshold']), 16.0
+        st.rpn_logits, st.rpn_deltas = rpn_logits.data_ptr(), rpn_deltas.data_ptr()
+        st.cls_scores, st.cls_deltas = cls_softmax.data_ptr(), cls_deltas.data_ptr()
+        st.rois, st.roi_idx, st.roi_count = h.rois.data_ptr(), h.roi_idx.data_ptr(), h.roi_count.data_ptr()
+        st.nms_done, st.sorted_rois = h.nms_done.data_ptr(), h.sorted_rois.data_ptr()
+        st.roi_level, st.roi_perm = h.roi_level.data_ptr(), h.roi_perm.data_ptr()
+        st.level_counts, st.roi_features = h.level_counts.data_ptr(), h.roi_features.data_ptr()
+        st.det_boxes, st.det_labels = h.det_boxes.data_ptr(), h.det_labels.data_ptr()
+        st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
+        st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
+        st.ws_post, st.ws_post_bytes = h.ws_post.data_ptr(), h.ws_post.numel()
+        st.stream = self.streams[slot].cuda_stream
+        self._keep[slot] = tensors
+
+    def submit(self, slot=None, stages=7):
+        """Enqueue one image on `slot` (round-robin when None).  Returns the slot used."""
+        if slot is None:
+            slot = self._rr
+            self._rr = (self._rr + 1) % self.n
+        ops.L.check(self._lib.odet_exec_submit(self._exec, slot, self._C.byref(self.steps[slot]), int(stages)))
+        return slot
+
+    def wait(self):
+        rc = self._lib.odet_exec_wait(self._exec)
+        if rc != 0:
+            raise ops.L.OdetError('odet error %d: %s' % (rc, self._lib.odet_exec_last_error(self._exec).decode()))
+
+    def close(self):
+        if self._exec:
+            self._lib.odet_exec_wait(self._exec)
+            self._lib.odet_exec_destroy(self._exec)
+            self._exec = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def synthetic_fpn_inputs(image_shape, num_classes=21, num_proposals=1000, channels=256, seed=1234,
