@@ -494,3 +494,58 @@ def test_properties_at_full_size():
     # idempotence: NMS of the kept set keeps everything, same order
     idx2, cnt2 = ops.nms(g(kb), g(scores[k]), 1000, 0.7)
     assert h(idx2[:int(cnt2.item())]).tolist() == list(range(1000))
+
+
+# ------------------------------------------------------------------ throughput arrangement ----
+def test_stream_pool_matches_single_path_and_oracle():
+    """FpnStreamPool (native executor, several images in flight on their own streams) must produce,
+    for every slot, exactly what the single-stream FpnHotPath produces -- and that is the oracle's."""
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, FpnStreamPool, synthetic_fpn_inputs
+    shape, K, ncls, ch = (320, 480), 300, 21, 64
+    sets = [synthetic_fpn_inputs(shape, ncls, K, channels=ch, seed=100 + i) for i in range(3)]
+    ref = FpnHotPath(shape, ncls, K, channels=ch)
+    want = []
+    for host, dev in sets:
+        ref.step(dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        torch.cuda.synchronize()
+        assert int(ref.nms_done.item()) == 1
+        want.append((ref.record.clone(), ref.roi_features.clone(), ref.roi_idx.clone(), int(ref.roi_count.item())))
+    # oracle check of image 0's proposals (the rest is covered stage by stage elsewhere)
+    host = sets[0][0]
+    fg = co.rpn_fg_fpn(host['rpn_logits'])
+    _, idx = co.region_proposal(host['rpn_deltas'], co.fpn_anchors(shape), fg, shape, K, 0.7)
+    np.testing.assert_array_equal(h(want[0][2][:want[0][3]]), idx)
+    pool = FpnStreamPool(3, shape, ncls, K, ch)
+    try:
+        for k, (host, dev) in enumerate(sets):
+            pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        for rnd in range(5):                      # several rounds: slots are re-used back to back
+            for k in range(3):
+                pool.submit(k)
+        pool.wait()
+        torch.cuda.synchronize()
+        for k in range(3):
+            slot = pool.slots[k]
+            assert int(slot.nms_done.item()) == 1
+            assert torch.equal(slot.record, want[k][0])
+            assert torch.equal(slot.roi_features, want[k][1])
+            assert int(slot.roi_count.item()) == want[k][3]
+            assert torch.equal(slot.roi_idx[:want[k][3]], want[k][2][:want[k][3]])
+        with pytest.raises(ValueError):
+            pool.bind(0, sets[0][1]['rpn_logits'][:-1], sets[0][1]['rpn_deltas'], sets[0][1]['feats'],
+                      sets[0][1]['cls_scores'], sets[0][1]['cls_deltas'])
+    finally:
+        pool.close()
+
+
+def test_roi_pool_timed_events():
+    rng = np.random.default_rng(3)
+    feat = _feat((40, 60), 64, rng)
+    rois = syn.random_boxes(50, (640, 960), rng, 16, 300)
+    e0, e1 = ops.ProfEvent(), ops.ProfEvent()
+    a = ops.roi_pool([g(feat)], g(rois), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_MAX2, strides=[16.0])
+    b = ops.roi_pool([g(feat)], g(rois), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_MAX2, strides=[16.0],
+                     events=(e0, e1))
+    ms = e0.elapsed_ms(e1)
+    assert torch.equal(a, b)
+    assert 0.0 < ms < 50.0
