@@ -244,6 +244,24 @@ int odet_post_ops_record(const float* scores, const float* deltas, const float* 
                          int32_t* out_count, float* out_record, void* workspace,
                          size_t workspace_bytes, odet_stream_t stream);
 
+/* evaluation/pascal_eval_files_utils.py:76-106 (the mAP-producing per-image loop; same loop inlined
+ * at scripts/eval_coco.py:117-164) on the outputs of im_detect (model/fpn/base_fpn_model.py:364-390,
+ * model/faster_rcnn/base_faster_rcnn_model.py:279-306): rois (resized-image pixels) are divided by
+ * img_scale, then per class 1..num_classes-1: score > score_threshold -> decode -> clip to the RAW
+ * image (raw_h, raw_w) with the min_size edge filter -> NMS(max_per_class, nms_iou_threshold); then
+ * the per-image cap: when more than max_per_image detections survive, those with score >= the
+ * max_per_image-th best score stay (ties all stay; max_per_image <= 0 disables the cap).
+ * Outputs in the order of the reference's all_boxes lists (class ascending, NMS order inside a
+ * class), capacity (num_classes-1)*max_per_class rows; out_count device int32[1].
+ * Workspace: odet_post_ops_workspace_bytes. */
+int odet_eval_detect(const float* scores, const float* deltas, const float* rois, int R,
+                     const int32_t* count_dev, int Ccls, int num_classes, float img_scale,
+                     float raw_h, float raw_w, const float* means, const float* stds,
+                     int max_per_class, int max_per_image, float nms_iou_threshold,
+                     float score_threshold, float min_size, float* out_boxes, int32_t* out_labels,
+                     float* out_scores, int32_t* out_count, void* workspace,
+                     size_t workspace_bytes, odet_stream_t stream);
+
 /* ---- multi-GPU detection records ------------------------------------------------------ */
 
 /* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of

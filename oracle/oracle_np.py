@@ -615,3 +615,106 @@ def voc_ap(rec, prec, use_07_metric=False):
     p = np.maximum.accumulate(p[::-1])[::-1]
     step = np.nonzero(r[1:] != r[:-1])[0]
     return np.sum((r[step + 1] - r[step]) * p[step + 1])
+
+
+def voc_eval_arrays(dets, gt_boxes, gt_difficult, ovthresh=0.5, use_07_metric=True):
+    """evaluation/detectron_pascal_evaluation_utils.py:86-222 for ONE class, on arrays instead of
+    files: dets = list over images of [n,5] float arrays (x1,y1,x2,y2,score) in file order (image
+    order, then the order of the image's rows), gt_boxes = list over images of [g,4], gt_difficult =
+    list over images of bool [g].  Detections are visited by descending confidence
+    (np.argsort(-confidence), :164 -- made stable here so that equal confidences keep file order),
+    matched to the ground-truth box of highest overlap (+1 pixel convention, :181-196), a match above
+    ovthresh is a TP the first time, FP afterwards, ignored on 'difficult' boxes (:198-206).
+    -> (rec, prec, ap)."""
+    npos = int(sum(int(np.sum(~np.asarray(d, dtype=bool))) for d in gt_difficult))
+    image_ids, conf, bb = [], [], []
+    for i, d in enumerate(dets):
+        d = np.asarray(d, dtype=np.float64).reshape(-1, 5)
+        for row in d:
+            image_ids.append(i)
+            conf.append(row[4])
+            bb.append(row[:4])
+    conf = np.asarray(conf, dtype=np.float64)
+    bb = np.asarray(bb, dtype=np.float64).reshape(-1, 4)
+    order = np.argsort(-conf, kind='stable')
+    bb = bb[order]
+    image_ids = [image_ids[k] for k in order]
+    nd = len(image_ids)
+    tp = np.zeros(nd)
+    fp = np.zeros(nd)
+    seen = [np.zeros(len(np.asarray(g).reshape(-1, 4)), dtype=bool) for g in gt_boxes]
+    for d in range(nd):
+        i = image_ids[d]
+        g = np.asarray(gt_boxes[i], dtype=np.float64).reshape(-1, 4)
+        diff = np.asarray(gt_difficult[i], dtype=bool).reshape(-1)
+        ovmax, jmax = -np.inf, -1
+        if g.size > 0:
+            ixmin = np.maximum(g[:, 0], bb[d, 0])
+            iymin = np.maximum(g[:, 1], bb[d, 1])
+            ixmax = np.minimum(g[:, 2], bb[d, 2])
+            iymax = np.minimum(g[:, 3], bb[d, 3])
+            iw = np.maximum(ixmax - ixmin + 1., 0.)
+            ih = np.maximum(iymax - iymin + 1., 0.)
+            inters = iw * ih
+            uni = ((bb[d, 2] - bb[d, 0] + 1.) * (bb[d, 3] - bb[d, 1] + 1.) +
+                   (g[:, 2] - g[:, 0] + 1.) * (g[:, 3] - g[:, 1] + 1.) - inters)
+            overlaps = inters / uni
+            ovmax = np.max(overlaps)
+            jmax = int(np.argmax(overlaps))
+        if ovmax > ovthresh:
+            if not diff[jmax]:
+                if not seen[i][jmax]:
+                    tp[d] = 1.
+                    seen[i][jmax] = True
+                else:
+                    fp[d] = 1.
+        else:
+            fp[d] = 1.
+    fp = np.cumsum(fp)
+    tp = np.cumsum(tp)
+    rec = tp / float(npos) if npos > 0 else tp * 0.0
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    return rec, prec, voc_ap(rec, prec, use_07_metric)
+
+
+# --------------------------------------------------------------------------------------
+# evaluation/pascal_eval_files_utils.py  (the mAP-producing per-image loop)
+# --------------------------------------------------------------------------------------
+def eval_detect_image(scores, roi_txtytwth, rois, img_scale, raw_h, raw_w, num_classes=21,
+                      score_threshold=0.0, iou_threshold=0.5, max_objects_per_class=50,
+                      max_objects_per_image=50, target_means=None, target_stds=None, min_size=10):
+    """evaluation/pascal_eval_files_utils.py:76-106 for one image, starting from the model's
+    im_detect outputs (model/fpn/base_fpn_model.py:364-390): softmax scores [R,Ccls], raw deltas
+    [R,4*Ccls] and rois in RESIZED-image pixels, divided by img_scale here as im_detect does (:390).
+    Per class j = 1..num_classes-1: where(score > thr) -> decode -> clip to the RAW image with
+    min_size filter -> NMS(max_objects_per_class) (:81-97); then the per-image cap: if more than
+    max_objects_per_image detections survive, keep those with score >= the max_objects_per_image-th
+    best score (:99-106; ties at the threshold are all kept).
+    -> list (index = class id, entry 0 unused) of float32 [n,5] arrays (x1,y1,x2,y2,score)."""
+    if target_stds is None:
+        target_stds = [0.1, 0.1, 0.2, 0.2]
+    if target_means is None:
+        target_means = [0, 0, 0, 0]
+    scores = f32(scores)
+    R = scores.shape[0]
+    D = f32(roi_txtytwth).reshape(R, -1, 4)
+    rois = (f32(rois).reshape(-1, 4) / F32(img_scale)).astype(np.float32)
+    raw_h = F32(raw_h)
+    raw_w = F32(raw_w)
+    out = [np.zeros((0, 5), np.float32) for _ in range(num_classes)]
+    for j in range(1, num_classes):
+        inds = np.nonzero(scores[:, j] > F32(score_threshold))[0]
+        cls_scores = scores[inds, j]
+        cls_boxes = decode_bbox_with_mean_and_std(rois[inds], D[inds, j, :], target_means, target_stds)
+        cls_boxes, keep_idx = bboxes_clip_filter(cls_boxes, 0, raw_h, raw_w, min_size)
+        cls_scores = cls_scores[keep_idx]
+        keep = tf_non_max_suppression(cls_boxes, cls_scores, max_objects_per_class, iou_threshold)
+        dets = np.hstack((cls_boxes, cls_scores[:, None])).astype(np.float32, copy=False)
+        out[j] = dets[keep, :]
+    if max_objects_per_image > 0:
+        image_scores = np.hstack([out[j][:, -1] for j in range(1, num_classes)])
+        if len(image_scores) > max_objects_per_image:
+            image_thresh = np.sort(image_scores)[-max_objects_per_image]
+            for j in range(1, num_classes):
+                out[j] = out[j][out[j][:, -1] >= image_thresh, :]
+    return out

@@ -1,0 +1,135 @@
+"""Evaluation harness: the mAP-producing per-image loop of
+evaluation/pascal_eval_files_utils.py and VOC AP of evaluation/detectron_pascal_evaluation_utils.py.
+CPU part: oracle vs the reference's golden voc_ap, closed-form AP cases, product host code vs oracle.
+GPU part (-m gpu): odet_eval_detect vs the oracle loop, and the mAP delta on a synthetic image set."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as on
+from tf_eager_object_detection_amd import synthetic as syn
+from tf_eager_object_detection_amd.evaluation import pascal_eval as pe
+
+
+def test_voc_ap_product_matches_reference_golden(golden):
+    for i in range(4):
+        rec, prec = golden['ap%d_rec' % i], golden['ap%d_prec' % i]
+        for key, flag in (('07', True), ('area', False)):
+            want = float(golden['ap%d_%s' % (i, key)])
+            assert abs(pe.voc_ap(rec, prec, flag) - want) < 1e-12
+            assert abs(on.voc_ap(rec, prec, flag) - want) < 1e-12
+
+
+def test_voc_eval_known_answers():
+    gt = [np.float64([[10, 10, 50, 50], [100, 100, 150, 160]]), np.zeros((0, 4))]
+    hard = [np.array([False, False]), np.zeros(0, bool)]
+    dets = [np.float32([[10, 10, 50, 50, 0.9],        # TP (IoU 1)
+                        [12, 12, 50, 50, 0.8],        # duplicate of the same object -> FP
+                        [300, 300, 320, 320, 0.7]]),  # background -> FP
+            np.float32([[100, 100, 150, 160, 0.85]])]  # image 1 has no object -> FP
+    for fn in (on.voc_eval_arrays, pe.voc_eval_arrays):
+        rec, prec, ap = fn(dets, gt, hard, 0.5, False)
+        np.testing.assert_allclose(rec, [0.5, 0.5, 0.5, 0.5])
+        np.testing.assert_allclose(prec, [1.0, 0.5, 1 / 3, 0.25])
+        assert abs(ap - 0.5) < 1e-12                       # area metric: 0.5 recall at precision 1
+        rec, prec, ap07 = fn(dets, gt, hard, 0.5, True)
+        assert abs(ap07 - 6 / 11) < 1e-12                  # recall points 0..0.5 at precision 1
+    # 'difficult' objects neither count as positives nor as false positives
+    hard2 = [np.array([False, True]), np.zeros(0, bool)]
+    dets2 = [np.float32([[100, 100, 150, 160, 0.95], [10, 10, 50, 50, 0.9]]), np.zeros((0, 5), np.float32)]
+    for fn in (on.voc_eval_arrays, pe.voc_eval_arrays):
+        rec, prec, ap = fn(dets2, gt, hard2, 0.5, False)
+        np.testing.assert_allclose(rec, [0.0, 1.0])
+        np.testing.assert_allclose(prec, [0.0, 1.0])
+
+
+def test_product_voc_eval_matches_oracle_on_random_sets():
+    rng = np.random.default_rng(5)
+    for trial in range(5):
+        n = 12
+        gt = [rng.uniform(0, 300, (int(rng.integers(0, 4)), 2)) for _ in range(n)]
+        gt = [np.hstack([g, g + rng.uniform(20, 120, g.shape)]) for g in gt]
+        hard = [rng.random(len(g)) < 0.2 for g in gt]
+        dets = []
+        for g in gt:
+            k = int(rng.integers(0, 6))
+            base = g[rng.integers(0, len(g), k)] if len(g) and k else np.zeros((0, 4))
+            noise = rng.normal(0, 12, base.shape)
+            sc = np.round(rng.random((len(base), 1)), 2)          # coarse scores -> ties
+            dets.append(np.hstack([base + noise, sc]).astype(np.float32))
+        for flag in (False, True):
+            a = on.voc_eval_arrays(dets, gt, hard, 0.5, flag)
+            b = pe.voc_eval_arrays(dets, gt, hard, 0.5, flag)
+            np.testing.assert_allclose(a[0], b[0])
+            np.testing.assert_allclose(a[1], b[1])
+            assert abs(a[2] - b[2]) < 1e-12
+
+
+def test_oracle_eval_loop_per_image_cap_keeps_ties():
+    # two classes, 3 boxes each, far apart; scores tie at the cap threshold
+    rois = np.float32([[i * 60, 10, i * 60 + 40, 60] for i in range(6)])
+    scores = np.zeros((6, 3), np.float32)
+    scores[:3, 1] = [0.9, 0.5, 0.5]
+    scores[3:, 2] = [0.8, 0.5, 0.3]
+    scores[:, 0] = 1 - scores.sum(axis=1)
+    deltas = np.zeros((6, 12), np.float32)
+    out = on.eval_detect_image(scores, deltas, rois, 1.0, 400, 600, num_classes=3, score_threshold=0.05,
+                               max_objects_per_class=50, max_objects_per_image=3, min_size=10)
+    # 3rd best score is 0.5 and three detections carry it: all of them stay (>= threshold)
+    assert [len(o) for o in out] == [0, 3, 2]
+    assert out[2][:, 4].tolist() == pytest.approx([0.8, 0.5])
+
+
+def test_write_voc_results_file(tmp_path):
+    p = tmp_path / 'car.txt'
+    pe.write_voc_results_file(str(p), ['000001', '000002'],
+                              [np.float32([[0, 1.24, 10.26, 20, 0.98765]]), np.zeros((0, 5), np.float32)])
+    assert p.read_text() == '000001 0.988 1.0 2.2 11.3 21.0\n'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('raw_shape,R,mpc,mpi', [((375, 500), 300, 50, 50), ((500, 333), 1000, 50, 100),
+                                                 ((480, 640), 300, 100, 0), ((375, 500), 300, 5, 7)])
+def test_detect_image_matches_oracle_loop(raw_shape, R, mpc, mpi):
+    import torch
+    rng = np.random.default_rng(R + mpc)
+    im = syn.eval_image(rng, raw_shape=raw_shape, num_rois=R)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = pe.detect_image(g(im['scores']), g(im['deltas']), g(im['rois']), im['img_scale'], im['raw_h'], im['raw_w'],
+                          score_threshold=0.05, iou_threshold=0.5, max_objects_per_class=mpc,
+                          max_objects_per_image=mpi, min_size=10)
+    want = on.eval_detect_image(im['scores'], im['deltas'], im['rois'], im['img_scale'], im['raw_h'], im['raw_w'],
+                                score_threshold=0.05, iou_threshold=0.5, max_objects_per_class=mpc,
+                                max_objects_per_image=mpi, min_size=10)
+    assert sum(len(w) for w in want) > 0
+    for j in range(1, 21):
+        assert got[j].shape == want[j].shape, (j, got[j].shape, want[j].shape)
+        if len(want[j]):
+            np.testing.assert_array_equal(got[j][:, 4], want[j][:, 4])            # scores: same rows, same order
+            assert np.max(np.abs(got[j][:, :4] - want[j][:, :4])) <= 1e-4 * max(1.0, float(np.abs(want[j]).max()))
+
+
+@pytest.mark.gpu
+def test_map_delta_on_synthetic_set_is_zero():
+    """BASELINE metric 'mAP delta vs ref': identical weights-free inputs through the GPU loop and through
+    the restated reference loop, scored by VOC AP (07 and area) -- the delta must be within 0.002
+    (it is exactly 0 when no detection crosses the 0.1-pixel rounding of the result files)."""
+    import torch
+    rng = np.random.default_rng(2024)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    shapes = [(375, 500), (500, 375), (333, 500), (480, 640)]
+    dets_gpu, dets_ref, gtb, gtl = [], [], [], []
+    for i in range(24):
+        im = syn.eval_image(rng, raw_shape=shapes[i % 4], num_rois=300)
+        kw = dict(score_threshold=0.05, iou_threshold=0.5, max_objects_per_class=50, max_objects_per_image=50,
+                  min_size=10)
+        dets_gpu.append(pe.detect_image(g(im['scores']), g(im['deltas']), g(im['rois']), im['img_scale'],
+                                        im['raw_h'], im['raw_w'], **kw))
+        dets_ref.append(on.eval_detect_image(im['scores'], im['deltas'], im['rois'], im['img_scale'], im['raw_h'],
+                                             im['raw_w'], **kw))
+        gtb.append(im['gt_boxes'])
+        gtl.append(im['gt_labels'])
+    for flag in (True, False):
+        m_gpu, _ = pe.evaluate_detections(dets_gpu, gtb, gtl, use_07_metric=flag)
+        m_ref, _ = pe.evaluate_detections(dets_ref, gtb, gtl, use_07_metric=flag)
+        assert m_ref > 0.3                                  # the synthetic detector is a sensible one
+        assert abs(m_gpu - m_ref) <= 0.002

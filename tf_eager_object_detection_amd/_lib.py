@@ -87,6 +87,8 @@ SIGNATURES = {
                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'odet_post_ops_record': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _f,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'odet_eval_detect': (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _f, _f, _f, _vp, _vp, _i, _i, _f, _f, _f,
+                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'odet_pack_detections': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'odet_fpn_step_sizeof': (_sz, []),
     'odet_fpn_step_enqueue': (_i, [_vp, _i]),

@@ -35,6 +35,7 @@ struct PostOpsParams {
   int R, Ccls, P2, K;
   float means[4], stds[4];
   float wmax, hmax, min_edge, score_thr, nms_thr;
+  float roi_div;         // rois are divided by this first (im_detect's rois / img_scale); 1 = as they are
   // per-class results
   int32_t* cls_count;    // [ncls-1]
   float4* cls_boxes;     // [ncls-1, K]
@@ -127,7 +128,11 @@ __global__ void __launch_bounds__(PO_THREADS) k_postops_class(PostOpsParams p) {
         float d1 = t[1] * p.stds[1] + p.means[1];
         float d2 = t[2] * p.stds[2] + p.means[2];
         float d3 = t[3] * p.stds[3] + p.means[3];
-        float4 b = d_decode_box(p.rois[r], d0, d1, d2, d3);                   // :138-140
+        float4 roi = p.rois[r];
+        if (p.roi_div != 1.0f) {                    // base_fpn_model.py:390 / base_faster_rcnn_model.py:306
+          roi.x = roi.x / p.roi_div; roi.y = roi.y / p.roi_div; roi.z = roi.z / p.roi_div; roi.w = roi.w / p.roi_div;
+        }
+        float4 b = d_decode_box(roi, d0, d1, d2, d3);                          // :138-140
         b = d_clip_box(b, 0.0f, p.wmax, p.hmax);                               // :141-143
         float e0 = b.z - b.x + 1.0f, e1 = b.w - b.y + 1.0f;                    // bbox_tf.py:81-83
         if (e1 >= p.min_edge && e0 >= p.min_edge) {
@@ -239,6 +244,7 @@ struct MergeParams {
   const float4* cls_boxes;
   const float* cls_scores;
   int ncls1, K, P2, max_per_image;
+  int mode;              // 0: prediction.py top-k (score order); 1: eval loop score-threshold cap (class order)
   float4* out_boxes;
   int32_t* out_labels;
   float* out_scores;
@@ -294,6 +300,38 @@ __global__ void __launch_bounds__(1024) k_postops_merge(MergeParams p) {
     bitonic_sort_u64(keys, p.P2, 1024);
   }
   __syncthreads();
+  if (p.mode == 1) {
+    // evaluation/pascal_eval_files_utils.py:99-106: when more than max_per_image detections survive,
+    // keep those with score >= the max_per_image-th best score (ties at the threshold all stay);
+    // order = class ascending, NMS order inside a class (the all_boxes[j][i] lists, concatenated).
+    __shared__ int lds17[17];
+    uint32_t tkey = 0xFFFFFFFFu;                     // keep everything
+    if (p.max_per_image > 0 && total > p.max_per_image) tkey = (uint32_t)(keys[p.max_per_image - 1] >> 32);
+    const int per = (total + 1023) / 1024;
+    const int lo = tid * per;
+    int c = 0;
+    for (int k = 0; k < per; ++k) {
+      const int pos = lo + k;
+      if (pos < total && ~d_float_asc_key(p.cls_scores[src[pos]]) <= tkey) ++c;
+    }
+    int kept_total;
+    int o = block_excl_scan(c, lds17, &kept_total);
+    for (int k = 0; k < per; ++k) {
+      const int pos = lo + k;
+      if (pos < total) {
+        const uint32_t slot = src[pos];
+        const float sc = p.cls_scores[slot];
+        if (~d_float_asc_key(sc) <= tkey) {
+          p.out_boxes[o] = p.cls_boxes[slot];
+          p.out_scores[o] = sc;
+          p.out_labels[o] = (int32_t)(slot / p.K) + 1;
+          ++o;
+        }
+      }
+    }
+    if (tid == 0) *p.out_count = kept_total;
+    return;
+  }
   const int M = min(total, p.max_per_image);                                 // prediction.py:160
   for (int i = tid; i < p.max_per_image; i += 1024) {
     float4 b = make_float4(0, 0, 0, 0);
@@ -333,8 +371,10 @@ extern "C" size_t odet_post_ops_workspace_bytes(int num_classes, int max_per_cla
   return odet_align_up(n1 * 4, 256) + odet_align_up(n1 * k * 16, 256) + odet_align_up(n1 * k * 4, 256) + 1024;
 }
 
+struct PostOpsExtra { float wmax, hmax, roi_div; int mode; };
+
 static int post_ops_impl(const float* scores, const float* deltas, const float* rois, int R,
-                         const int32_t* count_dev, int Ccls, int num_classes, int image_h, int image_w,
+                         const int32_t* count_dev, int Ccls, int num_classes, PostOpsExtra ex,
                          const float* means, const float* stds, int max_per_class, int max_per_image,
                          float nms_iou_threshold, float score_threshold, float min_edge, float* out_boxes,
                          int32_t* out_labels, float* out_scores, int32_t* out_count, float* out_record,
@@ -342,7 +382,7 @@ static int post_ops_impl(const float* scores, const float* deltas, const float* 
   ODET_REQUIRE(out_count, "odet_post_ops: null out_count");
   ODET_REQUIRE(R >= 0 && Ccls > 0 && num_classes >= 1 && num_classes <= Ccls, "odet_post_ops: bad sizes");
   ODET_REQUIRE(max_per_class >= 0 && max_per_image >= 0, "odet_post_ops: negative cap");
-  if (R == 0 || num_classes == 1 || max_per_class == 0 || max_per_image == 0) {
+  if (R == 0 || num_classes == 1 || max_per_class == 0 || (max_per_image == 0 && ex.mode == 0)) {
     ODET_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), st));
     if (out_record && max_per_image > 0) {
       // empty record: pad rows (score -1) are produced by the pack kernel of an empty result
@@ -367,7 +407,7 @@ static int post_ops_impl(const float* scores, const float* deltas, const float* 
   p.scores = scores; p.deltas = deltas; p.rois = (const float4*)rois; p.count_dev = count_dev;
   p.R = R; p.Ccls = Ccls; p.P2 = next_pow2(R < 2 ? 2 : R); p.K = max_per_class;
   for (int k = 0; k < 4; ++k) { p.means[k] = means[k]; p.stds[k] = stds[k]; }
-  p.wmax = (float)(image_w - 1); p.hmax = (float)(image_h - 1);
+  p.wmax = ex.wmax; p.hmax = ex.hmax; p.roi_div = ex.roi_div;
   p.min_edge = min_edge; p.score_thr = score_threshold; p.nms_thr = nms_iou_threshold;
   p.cls_count = ar.take<int32_t>(ncls1);
   p.cls_boxes = ar.take<float4>((size_t)ncls1 * max_per_class);
@@ -389,6 +429,7 @@ static int post_ops_impl(const float* scores, const float* deltas, const float* 
   m.cls_count = p.cls_count; m.cls_boxes = p.cls_boxes; m.cls_scores = p.cls_scores;
   m.ncls1 = ncls1; m.K = max_per_class; m.P2 = next_pow2(ncls1 * max_per_class < 2 ? 2 : ncls1 * max_per_class);
   m.max_per_image = max_per_image;
+  m.mode = ex.mode;
   m.out_boxes = (float4*)out_boxes; m.out_labels = out_labels; m.out_scores = out_scores; m.out_count = out_count;
   m.out_record = out_record;
   const size_t nkeys2 = (size_t)(m.P2 > 2048 ? m.P2 : 2048);
@@ -404,9 +445,24 @@ extern "C" int odet_post_ops(const float* scores, const float* deltas, const flo
                              float nms_iou_threshold, float score_threshold, float min_edge, float* out_boxes,
                              int32_t* out_labels, float* out_scores, int32_t* out_count, void* workspace,
                              size_t workspace_bytes, odet_stream_t stream) {
-  return post_ops_impl(scores, deltas, rois, R, count_dev, Ccls, num_classes, image_h, image_w, means, stds,
+  ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_post_ops: bad image shape");
+  return post_ops_impl(scores, deltas, rois, R, count_dev, Ccls, num_classes,
+                       PostOpsExtra{(float)(image_w - 1), (float)(image_h - 1), 1.0f, 0}, means, stds,
                        max_per_class, max_per_image, nms_iou_threshold, score_threshold, min_edge, out_boxes,
                        out_labels, out_scores, out_count, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int odet_eval_detect(const float* scores, const float* deltas, const float* rois, int R,
+                                const int32_t* count_dev, int Ccls, int num_classes, float img_scale, float raw_h,
+                                float raw_w, const float* means, const float* stds, int max_per_class,
+                                int max_per_image, float nms_iou_threshold, float score_threshold, float min_size,
+                                float* out_boxes, int32_t* out_labels, float* out_scores, int32_t* out_count,
+                                void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(img_scale > 0.0f && raw_h > 0.0f && raw_w > 0.0f, "odet_eval_detect: bad scale / image size");
+  return post_ops_impl(scores, deltas, rois, R, count_dev, Ccls, num_classes,
+                       PostOpsExtra{raw_w - 1.0f, raw_h - 1.0f, img_scale, 1}, means, stds, max_per_class,
+                       max_per_image, nms_iou_threshold, score_threshold, min_size, out_boxes, out_labels,
+                       out_scores, out_count, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int odet_post_ops_record(const float* scores, const float* deltas, const float* rois, int R,
@@ -417,7 +473,9 @@ extern "C" int odet_post_ops_record(const float* scores, const float* deltas, co
                                     float* out_record, void* workspace, size_t workspace_bytes,
                                     odet_stream_t stream) {
   ODET_REQUIRE(out_record, "odet_post_ops_record: null out_record");
-  return post_ops_impl(scores, deltas, rois, R, count_dev, Ccls, num_classes, image_h, image_w, means, stds,
+  ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_post_ops_record: bad image shape");
+  return post_ops_impl(scores, deltas, rois, R, count_dev, Ccls, num_classes,
+                       PostOpsExtra{(float)(image_w - 1), (float)(image_h - 1), 1.0f, 0}, means, stds,
                        max_per_class, max_per_image, nms_iou_threshold, score_threshold, min_edge, out_boxes,
                        out_labels, out_scores, out_count, out_record, workspace, workspace_bytes,
                        (hipStream_t)stream);

@@ -96,3 +96,54 @@ def class_scores(r, num_classes, rng, sigma=2.0):
 
 def class_deltas(r, num_classes, rng):
     return rng.normal(0.0, 1.0, size=(r, num_classes, 4)).astype(np.float32)
+
+
+def eval_image(rng, raw_shape=(375, 500), min_edge=600, max_edge=1000, num_rois=300, num_classes=21,
+               roi_stds=(0.1, 0.1, 0.2, 0.2)):
+    """One synthetic evaluation image: ground truth in RAW-image pixels plus what a (noisy but
+    sensible) detector's im_detect would return for it in RESIZED-image pixels -- RoIs that are
+    jittered ground-truth boxes or clutter, class scores peaked on the right label for the good ones,
+    deltas that point (noisily) from the RoI to its object.  Resize rule of the reference's input
+    pipeline: shorter side -> min_edge, capped by max_edge on the longer side
+    (dataset/utils/tf_dataset_utils.py:129-154).
+    -> dict(raw_h, raw_w, img_scale, gt_boxes [g,4], gt_labels [g], scores [R,C], deltas [R,C*4], rois [R,4])"""
+    raw_h, raw_w = raw_shape
+    img_scale = np.float32(min(min_edge / min(raw_h, raw_w), max_edge / max(raw_h, raw_w)))
+    g = int(rng.integers(1, 7))
+    cx = rng.uniform(0.15, 0.85, g) * raw_w
+    cy = rng.uniform(0.15, 0.85, g) * raw_h
+    w = rng.uniform(0.1, 0.5, g) * raw_w
+    h = rng.uniform(0.1, 0.5, g) * raw_h
+    gt = np.stack([np.clip(cx - w / 2, 0, raw_w - 1), np.clip(cy - h / 2, 0, raw_h - 1),
+                   np.clip(cx + w / 2, 0, raw_w - 1), np.clip(cy + h / 2, 0, raw_h - 1)], axis=1).astype(np.float32)
+    labels = rng.integers(1, num_classes, g).astype(np.int32)
+    owner = rng.integers(-1, g, num_rois)                      # -1 = clutter
+    rois = np.empty((num_rois, 4), np.float32)
+    logits = rng.normal(0, 1, (num_rois, num_classes)).astype(np.float32)
+    deltas = (rng.normal(0, 0.3, (num_rois, num_classes, 4))).astype(np.float32)
+    stds = np.asarray(roi_stds, np.float32)
+    for r in range(num_rois):
+        if owner[r] < 0:
+            bw, bh = rng.uniform(20, 0.6 * raw_w), rng.uniform(20, 0.6 * raw_h)
+            x1, y1 = rng.uniform(0, raw_w - bw), rng.uniform(0, raw_h - bh)
+            box = np.float32([x1, y1, x1 + bw, y1 + bh])
+            logits[r, 0] += 3.0
+        else:
+            b = gt[owner[r]]
+            bw, bh = b[2] - b[0] + 1, b[3] - b[1] + 1
+            jit = rng.normal(0, 0.12, 4) * np.float32([bw, bh, bw, bh])
+            box = (b + jit).astype(np.float32)
+            box = np.float32([min(box[0], box[2] - 4), min(box[1], box[3] - 4), box[2], box[3]])
+            lab = labels[owner[r]]
+            logits[r, lab] += rng.uniform(2.0, 6.0)
+            # deltas that lead from the RoI to the object (bbox_transform.py:4-29), plus noise
+            rw, rh = box[2] - box[0] + 1, box[3] - box[1] + 1
+            rcx, rcy = box[0] + 0.5 * rw, box[1] + 0.5 * rh
+            gcx, gcy = b[0] + 0.5 * bw, b[1] + 0.5 * bh
+            t = np.float32([(gcx - rcx) / rw, (gcy - rcy) / rh, np.log(bw / rw), np.log(bh / rh)]) / stds
+            deltas[r, lab] = t + rng.normal(0, 0.15, 4).astype(np.float32)
+        rois[r] = box * img_scale                               # im_detect sees resized-image pixels
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    scores = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+    return dict(raw_h=float(raw_h), raw_w=float(raw_w), img_scale=float(img_scale), gt_boxes=gt, gt_labels=labels,
+                scores=scores, deltas=deltas.reshape(num_rois, num_classes * 4).astype(np.float32), rois=rois)
