@@ -169,6 +169,19 @@ int odet_fpn_proposals(const float* rpn_logits, const float* rpn_deltas, int num
                        int32_t* out_level_counts, int blind_chunks, int32_t* out_done,
                        void* workspace, size_t workspace_bytes, odet_stream_t stream);
 
+size_t odet_frcnn_proposals_workspace_bytes(int n, int max_output);
+/* The proposal stage of model/faster_rcnn/base_faster_rcnn_model.py BaseFasterRcnn.call in one entry
+ * point: :139-142 generate_by_anchor_base_tf (utils/anchor_generator.py:46-60, anchors produced in
+ * registers), :149-152 fg probability from the [A bg | A fg] channel layout, :153 RegionProposal
+ * (model/region_proposal.py:55-81).  rpn_logits [fh*fw, 2A], rpn_deltas [fh*fw*A, 4],
+ * anchor_base host [A,4] float32 (generate_anchor_base cast to float32, :84).  n = fh*fw*A. */
+int odet_frcnn_proposals(const float* rpn_logits, const float* rpn_deltas, const float* anchor_base,
+                         int A, int feat_stride, int fh, int fw, int image_h, int image_w,
+                         const float* means, const float* stds, int max_output,
+                         float iou_threshold, float* out_rois, int32_t* out_idx,
+                         int32_t* out_count, int blind_chunks, int32_t* out_done, void* workspace,
+                         size_t workspace_bytes, odet_stream_t stream);
+
 /* ---- FPN level assignment ------------------------------------------------------------ */
 
 #define ODET_ASSIGN_MAX_ROIS 8192

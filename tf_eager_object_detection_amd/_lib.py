@@ -76,6 +76,9 @@ SIGNATURES = {
     'odet_fpn_proposals_workspace_bytes': (_sz, [_i, _i]),
     'odet_fpn_proposals': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    'odet_frcnn_proposals_workspace_bytes': (_sz, [_i, _i]),
+    'odet_frcnn_proposals': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp,
+                                   _vp, _sz, _vp]),
     'odet_assign_levels': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'odet_roi_pool': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'odet_roi_pool_timed': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -98,20 +98,20 @@ struct NmsHeader {   // zeroed by ONE memset per call; starts the workspace
 #endif
 
 // ------------------------------------------------------------------------- 1. prepare -------
-enum { PREP_NMS = 0, PREP_RP = 1, PREP_FPN = 2 };
+enum { PREP_NMS = 0, PREP_RP = 1, PREP_FPN = 2, PREP_FRCNN = 3 };
 
 struct PrepParams {
   int n;
   const float4* boxes_in;   // PREP_NMS: boxes (not rewritten); PREP_RP: anchors
   const float* deltas;      // PREP_RP / PREP_FPN: [n,4]
   const float* scores;      // PREP_NMS / PREP_RP
-  const float2* logits;     // PREP_FPN: (bg, fg) pairs
+  const float2* logits;     // PREP_FPN: (bg, fg) pairs; PREP_FRCNN: rows [A bg | A fg] (read as floats)
   Vec4 means, stds;
   float wmax, hmax;
   float4* boxes_out;        // PREP_RP / PREP_FPN: decoded + clipped boxes
   uint32_t* keys;
   NmsHeader* hdr;
-  FpnAnchorParams fpn;      // PREP_FPN
+  FpnAnchorParams fpn;      // PREP_FPN; PREP_FRCNN: A, fw[0], stride[0], wh[0..4A) = base anchors
 };
 
 template <int MODE>
@@ -127,7 +127,16 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
     const int e = blockIdx.x * PREP_TILE + it * 256 + threadIdx.x;
     const bool in = e < p.n;
     const int ee = in ? e : 0;
-    if (MODE == PREP_FPN) lg[it] = p.logits[ee]; else sc[it] = p.scores[ee];
+    if (MODE == PREP_FPN) {
+      lg[it] = p.logits[ee];
+    } else if (MODE == PREP_FRCNN) {
+      // base_faster_rcnn_model.py:149-152: per location [A bg | A fg]
+      const int loc = ee / p.fpn.A, a = ee - loc * p.fpn.A;
+      const float* row = reinterpret_cast<const float*>(p.logits) + (size_t)loc * 2 * p.fpn.A;
+      lg[it] = make_float2(row[a], row[p.fpn.A + a]);
+    } else {
+      sc[it] = p.scores[ee];
+    }
     if (MODE == PREP_RP) an[it] = p.boxes_in[ee];
     if (MODE != PREP_NMS) dl[it] = reinterpret_cast<const float4*>(p.deltas)[ee];
   }
@@ -138,10 +147,22 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
     const int e = blockIdx.x * PREP_TILE + it * 256 + threadIdx.x;
     if (e < p.n) {
       float s;
-      if (MODE == PREP_FPN) s = d_fg_prob(lg[it].x, lg[it].y);     // base_fpn_model.py:223
+      if (MODE == PREP_FPN || MODE == PREP_FRCNN) s = d_fg_prob(lg[it].x, lg[it].y);   // base_fpn_model.py:223
       else s = sc[it];
       if (MODE != PREP_NMS) {
-        const float4 a = (MODE == PREP_FPN) ? d_fpn_anchor(p.fpn, e) : an[it];   // :220 / :163-186
+        float4 a;
+        if (MODE == PREP_FPN) {
+          a = d_fpn_anchor(p.fpn, e);                              // :220 / :163-186
+        } else if (MODE == PREP_FRCNN) {
+          // anchor_generator.py:46-60 generate_by_anchor_base_tf, in registers
+          const int ai = e % p.fpn.A, cell = e / p.fpn.A;
+          const int x = cell % p.fpn.fw[0], y = cell / p.fpn.fw[0];
+          const float sx = (float)(x * p.fpn.stride[0]), sy = (float)(y * p.fpn.stride[0]);
+          a = make_float4(p.fpn.wh[ai * 4 + 0] + sx, p.fpn.wh[ai * 4 + 1] + sy, p.fpn.wh[ai * 4 + 2] + sx,
+                          p.fpn.wh[ai * 4 + 3] + sy);
+        } else {
+          a = an[it];
+        }
         const float4 d = dl[it];
         const float d0 = d.x * p.stds.v[0] + p.means.v[0];         // bbox_transform.py:37
         const float d1 = d.y * p.stds.v[1] + p.means.v[1];
@@ -856,6 +877,8 @@ static int nms_run(NmsJob& J, void* ws, size_t ws_bytes, hipStream_t st) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_NMS>), grid, block, 0, st, J.prep);
     else if (J.mode == PREP_RP)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_RP>), grid, block, 0, st, J.prep);
+    else if (J.mode == PREP_FRCNN)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_FRCNN>), grid, block, 0, st, J.prep);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_FPN>), grid, block, 0, st, J.prep);
     ODET_LAUNCH_CHECK();
@@ -1086,5 +1109,47 @@ extern "C" int odet_fpn_proposals(const float* rpn_logits, const float* rpn_delt
   } else {
     no_assign(&J.assign);
   }
+  return nms_run(J, nws, nbytes, st);
+}
+
+extern "C" size_t odet_frcnn_proposals_workspace_bytes(int n, int max_output) {
+  return rp_workspace_bytes(n, max_output);
+}
+
+extern "C" int odet_frcnn_proposals(const float* rpn_logits, const float* rpn_deltas, const float* anchor_base, int A,
+                                    int feat_stride, int fh, int fw, int image_h, int image_w, const float* means,
+                                    const float* stds, int max_output, float iou_threshold, float* out_rois,
+                                    int32_t* out_idx, int32_t* out_count, int blind_chunks, int32_t* out_done,
+                                    void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(rpn_logits && rpn_deltas && anchor_base && means && stds, "odet_frcnn_proposals: null pointer");
+  ODET_REQUIRE(out_rois && out_count, "odet_frcnn_proposals: null output");
+  ODET_REQUIRE(A > 0 && A <= ODET_MAX_ANCHORS_PER_CELL, "odet_frcnn_proposals: A %d out of range", A);
+  ODET_REQUIRE(feat_stride > 0 && fh >= 0 && fw >= 0 && image_h > 0 && image_w > 0 && max_output > 0,
+               "odet_frcnn_proposals: bad sizes");
+  const int64_t total = (int64_t)fh * fw * A;
+  ODET_REQUIRE(total < (1ll << 31), "odet_frcnn_proposals: too many anchors");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = (int)total;
+  if (n == 0) return nms_trivial(out_count, out_done, st);
+  NmsJob J;
+  memset(&J.prep, 0, sizeof(J.prep));
+  J.prep.fpn.A = A;
+  J.prep.fpn.fw[0] = fw;
+  J.prep.fpn.stride[0] = feat_stride;
+  for (int i = 0; i < A * 4; ++i) J.prep.fpn.wh[i] = anchor_base[i];
+  float4* boxes; int32_t* idx_buf; void* nws; size_t nbytes;
+  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_frcnn_proposals", &boxes, &idx_buf, &nws, &nbytes);
+  if (rc != ODET_OK) return rc;
+  J.mode = PREP_FRCNN;
+  J.prep.logits = (const float2*)rpn_logits;
+  J.prep.deltas = rpn_deltas;
+  for (int k = 0; k < 4; ++k) { J.prep.means.v[k] = means[k]; J.prep.stds.v[k] = stds[k]; }
+  J.prep.wmax = (float)(image_w - 1); J.prep.hmax = (float)(image_h - 1);
+  J.prep.boxes_out = boxes;
+  J.boxes = boxes;
+  J.n = n; J.K = max_output; J.thr = iou_threshold;
+  J.out_idx = out_idx ? out_idx : idx_buf; J.out_boxes = out_rois; J.out_count = out_count;
+  J.blind_chunks = blind_chunks; J.out_done = out_done;
+  no_assign(&J.assign);
   return nms_run(J, nws, nbytes, st);
 }

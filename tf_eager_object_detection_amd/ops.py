@@ -265,6 +265,37 @@ def fpn_proposals(rpn_logits, rpn_deltas, fh_list, fw_list, stride_list, wh_tabl
     return (rois, idx, cnt) + ((lv,) if lv else ())
 
 
+def frcnn_proposals(rpn_logits, rpn_deltas, anchor_base, feat_stride, fh, fw, image_shape, num_post_nms,
+                    iou_threshold, means, stds, workspace=None, blind_chunks=1, done=None, out=None):
+    """The proposal stage of BaseFasterRcnn.call (anchors in registers -> fg softmax of the [A bg | A fg]
+    layout -> decode+clip -> NMS over all anchors) as ONE C-ABI call.
+    -> (rois [K,4] padded, idx int32 [K], count int32[1])."""
+    logits = L.f32c(rpn_logits, 'rpn_score')
+    deltas = L.f32c(rpn_deltas, 'rpn_bbox_txtytwth')
+    base = np.ascontiguousarray(np.asarray(anchor_base, dtype=np.float32).reshape(-1, 4))
+    A = base.shape[0]
+    fh, fw = int(fh), int(fw)
+    n = fh * fw * A
+    if logits.numel() != n * 2 or deltas.numel() != n * 4:
+        raise ValueError('frcnn_proposals: %d anchors but rpn scores %s / deltas %s'
+                         % (n, tuple(logits.shape), tuple(deltas.shape)))
+    K = max(min(int(num_post_nms), n), 1)
+    dev = logits.device
+    if out is not None:
+        rois, idx, cnt = out
+    else:
+        rois = torch.empty((K, 4), dtype=torch.float32, device=dev)
+        idx = torch.empty(K, dtype=torch.int32, device=dev)
+        cnt = _count_tensor(dev)
+    nb = L.lib().odet_frcnn_proposals_workspace_bytes(n, K)
+    ws = workspace if workspace is not None and workspace.numel() >= nb else L.workspace(nb, dev)
+    L.call('odet_frcnn_proposals', L.dptr(logits), L.dptr(deltas), base.ctypes.data_as(C.c_void_p), A,
+           int(feat_stride), fh, fw, int(image_shape[0]), int(image_shape[1]), L.host4(means, 'target_means'),
+           L.host4(stds, 'target_stds'), K, float(iou_threshold), L.dptr(rois), L.dptr(idx), L.dptr(cnt),
+           int(blind_chunks), L.dptr(done), L.dptr(ws), ws.numel(), L.stream())
+    return rois, idx, cnt
+
+
 def assign_levels(rois, min_level, max_level, count_dev=None, out=None):
     """-> (sorted rois [n,4], level int32 [n] (0-based), perm int64 [n], counts int32 [L]).
     ``out`` = preallocated (sorted rois, level, perm, counts) to reuse."""

@@ -140,6 +140,83 @@ class FpnHotPath:
         return feats, boxes, labels, scores, count
 
 
+class FrcnnHotPath:
+    """Static-shape, sync-free single-level Faster R-CNN detection hot path: the inference branch of the
+    reference's BaseFasterRcnn.call (model/faster_rcnn/base_faster_rcnn_model.py:126-198) minus the
+    dense conv parts -- VGG16 (pool 14x14 + 2x2 max, 512 ch) and ResNet C4 (7x7 crop, 1024 ch).
+
+        stage_proposals : odet_frcnn_proposals (anchors in registers -> fg softmax of [A bg | A fg] ->
+                          decode+clip -> radix select -> bit-matrix NMS over ALL anchors)     :139-153
+        stage_roi       : RoiPoolingCropAndResize((feat, rois, 16)) fused crop (+ max-pool)       :182
+        stage_detect    : post_ops_prediction                                                 :189-197"""
+
+    def __init__(self, image_shape, num_classes=21, num_proposals=300, channels=1024, pool_size=7,
+                 max_pooling_flag=False, extractor_stride=16, anchor_base_size=16, ratios=(0.5, 1, 2),
+                 scales=(8, 16, 32), rpn_nms_iou=0.7, rpn_means=(0, 0, 0, 0), rpn_stds=(1, 1, 1, 1),
+                 roi_means=(0, 0, 0, 0), roi_stds=(0.1, 0.1, 0.2, 0.2), max_per_class=50, max_per_image=50,
+                 nms_iou=0.3, score_threshold=0.0, blind_chunks=1, device=None):
+        from .utils.anchor_generator import generate_anchor_base
+        import math
+        self.image_shape = [int(image_shape[0]), int(image_shape[1])]
+        self.num_classes, self.K, self.C, self.P = num_classes, num_proposals, channels, pool_size
+        self.max_pooling_flag = bool(max_pooling_flag)
+        self.stride = int(extractor_stride)
+        self.anchor_base = generate_anchor_base(anchor_base_size, ratios, scales).astype(np.float32)   # :83-84
+        self.A = self.anchor_base.shape[0]
+        self.fh = int(math.ceil(self.image_shape[0] / self.stride))                                    # :140-141
+        self.fw = int(math.ceil(self.image_shape[1] / self.stride))
+        self.N = self.fh * self.fw * self.A
+        self.cfg = dict(rpn_nms_iou=rpn_nms_iou, rpn_means=list(rpn_means), rpn_stds=list(rpn_stds),
+                        roi_means=list(roi_means), roi_stds=list(roi_stds), max_per_class=max_per_class,
+                        max_per_image=max_per_image, nms_iou=nms_iou, score_threshold=score_threshold)
+        self.blind_chunks = blind_chunks
+        dev = self.device = device or torch.device('cuda', torch.cuda.current_device())
+        K = self.K
+        self.ws_rpn = torch.empty(ops.L.lib().odet_frcnn_proposals_workspace_bytes(self.N, K), dtype=torch.uint8,
+                                  device=dev)
+        self.rois = torch.zeros((K, 4), dtype=torch.float32, device=dev)
+        self.roi_idx = torch.zeros(K, dtype=torch.int32, device=dev)
+        self.roi_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nms_done = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.roi_features = torch.zeros((K, pool_size, pool_size, channels), dtype=torch.float32, device=dev)
+        M = max(max_per_image, 1)
+        self.det_boxes = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+        self.det_labels = torch.zeros(M, dtype=torch.int32, device=dev)
+        self.det_scores = torch.zeros(M, dtype=torch.float32, device=dev)
+        self.det_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.ws_post = torch.empty(ops.L.lib().odet_post_ops_workspace_bytes(num_classes, max_per_class),
+                                   dtype=torch.uint8, device=dev)
+        self.record = torch.zeros(M * 6 + 1, dtype=torch.float32, device=dev)
+
+    def stage_proposals(self, rpn_logits, rpn_deltas):
+        """rpn_logits [fh*fw, 2A] as RpnHead emits them (:342-350), rpn_deltas [fh*fw*A, 4]."""
+        c = self.cfg
+        ops.frcnn_proposals(rpn_logits, rpn_deltas, self.anchor_base, self.stride, self.fh, self.fw,
+                            self.image_shape, self.K, c['rpn_nms_iou'], c['rpn_means'], c['rpn_stds'],
+                            workspace=self.ws_rpn, blind_chunks=self.blind_chunks, done=self.nms_done,
+                            out=(self.rois, self.roi_idx, self.roi_count))
+        return self.rois, self.roi_count
+
+    def stage_roi(self, feat):
+        mode = ops.ROI_POOL_MAX2 if self.max_pooling_flag else ops.ROI_POOL_NONE
+        return ops.roi_pool([feat], self.rois, None, ops.ROI_NORM_STRIDE, self.P, mode, strides=[float(self.stride)],
+                            count_dev=self.roi_count, out=self.roi_features)
+
+    def stage_detect(self, cls_softmax, cls_deltas):
+        c = self.cfg
+        return ops.post_ops(cls_softmax, cls_deltas, self.rois, self.image_shape, c['roi_means'], c['roi_stds'],
+                            c['max_per_class'], c['max_per_image'], c['nms_iou'], c['score_threshold'], self.stride,
+                            self.num_classes, count_dev=self.roi_count,
+                            out=(self.det_boxes, self.det_labels, self.det_scores, self.det_count),
+                            workspace=self.ws_post, record=self.record)
+
+    def step(self, rpn_logits, rpn_deltas, feat, cls_softmax, cls_deltas):
+        self.stage_proposals(rpn_logits, rpn_deltas)
+        feats = self.stage_roi(feat)
+        boxes, labels, scores, count = self.stage_detect(cls_softmax, cls_deltas)
+        return feats, boxes, labels, scores, count
+
+
 class FpnStreamPool:
     """Throughput arrangement: `n_streams` independent FpnHotPath slots, each with its own HIP stream
     and persistent buffers, fed by the library's native executor (one host thread per stream; a HIP
