@@ -1,0 +1,81 @@
+"""ResNet-FPN detector counterpart: shape bookkeeping and the TF1 legacy bilinear
+resize on CPU; on the GPU the assembled model's hot-path state against the oracle, given the tensors the
+dense parts produced."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from tf_eager_object_detection_amd import synthetic as syn
+
+
+def _np_legacy_resize(x, oh, ow):
+    """tf.image.resize_bilinear (TF 1.x, align_corners=False) restated with numpy loops; x [H,W]."""
+    H, W = x.shape
+    out = np.zeros((oh, ow), np.float32)
+    for y in range(oh):
+        iy = np.float32(y) * np.float32(H / oh)
+        t = int(np.floor(iy)); b = min(t + 1, H - 1); wy = np.float32(iy - t)
+        for xx in range(ow):
+            ix = np.float32(xx) * np.float32(W / ow)
+            l = int(np.floor(ix)); r = min(l + 1, W - 1); wx = np.float32(ix - l)
+            top = x[t, l] + (x[t, r] - x[t, l]) * wx
+            bot = x[b, l] + (x[b, r] - x[b, l]) * wx
+            out[y, xx] = top + (bot - top) * wy
+    return out
+
+
+def test_tf_legacy_resize_bilinear_cpu():
+    from tf_eager_object_detection_amd.model.fpn_detector import tf_legacy_resize_bilinear
+    rng = np.random.default_rng(0)
+    for (h, w), (oh, ow) in (((13, 21), (25, 42)), ((25, 42), (50, 84)), ((5, 7), (9, 13))):
+        x = rng.standard_normal((h, w)).astype(np.float32)
+        got = tf_legacy_resize_bilinear(torch.from_numpy(x)[None, None], (oh, ow))[0, 0].numpy()
+        np.testing.assert_allclose(got, _np_legacy_resize(x, oh, ow), rtol=0, atol=1e-6)
+
+
+def test_feature_map_sizes_match_anchor_grids_cpu():
+    """conv arithmetic of the extractor/neck must give ceil(H/stride) x ceil(W/stride)."""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    m = ResNetFpnDetector(50, 21, (160, 224), 100, dtype=torch.float32).eval()
+    img = torch.zeros((1, 160, 224, 3))
+    with torch.no_grad():
+        ps = m.features(img)
+    want = syn.fpn_level_shapes((160, 224))
+    assert [tuple(p.shape[2:]) for p in ps] == [tuple(s) for s in want]
+    sc, dl = m.rpn(ps)
+    assert sc.shape == (1, syn.num_fpn_anchors((160, 224)), 2) and dl.shape[-1] == 4
+
+
+@pytest.mark.gpu
+def test_detector_hot_path_state_matches_oracle():
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(1)
+    shape = (256, 352)
+    m = ResNetFpnDetector(50, 21, shape, 300, dtype=torch.float32, blind_chunks=3).prepare()
+    rng = np.random.default_rng(1)
+    img = torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    out = m(img)
+    torch.cuda.synchronize()
+    hot = m._hot[0]
+    assert int(hot.nms_done.item()) == 1
+    with torch.no_grad():
+        ps = m.features(img)
+        sc, dl = m.rpn(ps)
+    logits = sc[0].float().cpu().numpy()
+    deltas = dl[0].float().cpu().numpy()
+    fg = co.rpn_fg_fpn(logits)
+    rois, idx = co.region_proposal(deltas, co.fpn_anchors(shape), fg, shape, 300, 0.7)
+    k = int(hot.roi_count.item())
+    assert k == len(idx)
+    np.testing.assert_array_equal(hot.roi_idx[:k].cpu().numpy(), idx)
+    lv, perm, cnt = co.assign_levels(rois)
+    np.testing.assert_array_equal(hot.roi_perm[:k].cpu().numpy(), perm)
+    srois = rois[perm]
+    maps = [p.permute(0, 2, 3, 1).float().cpu().numpy()[0] for p in ps[:4]]
+    want = np.concatenate([co.roi_pool(maps[l], srois[lv[perm] == l + 2], image_shape=shape, pool=7)
+                           for l in range(4) if np.any(lv == l + 2)], axis=0)
+    got = hot.roi_features[:k].cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 1e-4 * max(1.0, float(np.abs(want).max()))
+    boxes, labels, scores, count = out[0]
+    assert int(count.item()) > 0
