@@ -100,22 +100,37 @@ struct NmsHeader {   // zeroed by ONE memset per call; starts the workspace
 // ------------------------------------------------------------------------- 1. prepare -------
 enum { PREP_NMS = 0, PREP_RP = 1, PREP_FPN = 2, PREP_FRCNN = 3 };
 
-struct PrepParams {
+struct PrepParams {          // pointer tables: one entry per image of the batch (blockIdx.y)
   int n;
-  const float4* boxes_in;   // PREP_NMS: boxes (not rewritten); PREP_RP: anchors
-  const float* deltas;      // PREP_RP / PREP_FPN: [n,4]
-  const float* scores;      // PREP_NMS / PREP_RP
-  const float2* logits;     // PREP_FPN: (bg, fg) pairs; PREP_FRCNN: rows [A bg | A fg] (read as floats)
+  PerImg<const float4*> boxes_in;   // PREP_NMS: boxes (not rewritten); PREP_RP: anchors
+  PerImg<const float*> deltas;      // PREP_RP / PREP_FPN: [n,4]
+  PerImg<const float*> scores;      // PREP_NMS / PREP_RP
+  PerImg<const float2*> logits;     // PREP_FPN: (bg, fg) pairs; PREP_FRCNN: rows [A bg | A fg] (read as floats)
   Vec4 means, stds;
   float wmax, hmax;
-  float4* boxes_out;        // PREP_RP / PREP_FPN: decoded + clipped boxes
-  uint32_t* keys;
-  NmsHeader* hdr;
+  PerImg<float4*> boxes_out;        // PREP_RP / PREP_FPN: decoded + clipped boxes
+  PerImg<uint32_t*> keys;
+  PerImg<NmsHeader*> hdr;
   FpnAnchorParams fpn;      // PREP_FPN; PREP_FRCNN: A, fw[0], stride[0], wh[0..4A) = base anchors
 };
 
+// zero the per-call header of every image of the batch (state + histograms)
+__global__ void __launch_bounds__(256) k_zero_headers(PerImg<NmsHeader*> hdr_) {
+  uint4* d = reinterpret_cast<uint4*>(hdr_.v[blockIdx.y]);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < (int)(sizeof(NmsHeader) / 16)) d[i] = make_uint4(0, 0, 0, 0);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
+  const int img = blockIdx.y;
+  const float4* __restrict__ in_boxes = p.boxes_in.v[img];
+  const float* __restrict__ in_deltas = p.deltas.v[img];
+  const float* __restrict__ in_scores = p.scores.v[img];
+  const float2* __restrict__ in_logits = p.logits.v[img];
+  float4* __restrict__ out_boxes_ = p.boxes_out.v[img];
+  uint32_t* __restrict__ out_keys = p.keys.v[img];
+  NmsHeader* hdr = p.hdr.v[img];
   __shared__ uint32_t h[SEL_BINS];
   for (int k = threadIdx.x; k < SEL_BINS; k += 256) h[k] = 0;
   // all loads of the tile first (independent, in flight together), then the arithmetic
@@ -128,17 +143,17 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
     const bool in = e < p.n;
     const int ee = in ? e : 0;
     if (MODE == PREP_FPN) {
-      lg[it] = p.logits[ee];
+      lg[it] = in_logits[ee];
     } else if (MODE == PREP_FRCNN) {
       // base_faster_rcnn_model.py:149-152: per location [A bg | A fg]
       const int loc = ee / p.fpn.A, a = ee - loc * p.fpn.A;
-      const float* row = reinterpret_cast<const float*>(p.logits) + (size_t)loc * 2 * p.fpn.A;
+      const float* row = reinterpret_cast<const float*>(in_logits) + (size_t)loc * 2 * p.fpn.A;
       lg[it] = make_float2(row[a], row[p.fpn.A + a]);
     } else {
-      sc[it] = p.scores[ee];
+      sc[it] = in_scores[ee];
     }
-    if (MODE == PREP_RP) an[it] = p.boxes_in[ee];
-    if (MODE != PREP_NMS) dl[it] = reinterpret_cast<const float4*>(p.deltas)[ee];
+    if (MODE == PREP_RP) an[it] = in_boxes[ee];
+    if (MODE != PREP_NMS) dl[it] = reinterpret_cast<const float4*>(in_deltas)[ee];
   }
   __syncthreads();
   int invalid = 0;
@@ -170,11 +185,11 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
         const float d3 = d.w * p.stds.v[3] + p.means.v[3];
         float4 b = d_decode_box(a, d0, d1, d2, d3);                // region_proposal.py:59
         b = d_clip_box(b, 0.0f, p.wmax, p.hmax);                   // :63
-        p.boxes_out[e] = b;
+        out_boxes_[e] = b;
       }
       const bool valid = s > -3.402823466e+38f;   // NonMaxSuppressionV3: score > score_threshold (= lowest)
       const uint32_t k = valid ? ~d_float_asc_key(s) : 0xFFFFFFFFu;
-      p.keys[e] = k;
+      out_keys[e] = k;
       invalid += valid ? 0 : 1;
       atomicAdd(&h[k >> 20], 1u);
     }
@@ -182,9 +197,9 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
   __syncthreads();
   for (int k = threadIdx.x; k < SEL_BINS; k += 256) {
     const uint32_t c = h[k];
-    if (c) atomicAdd(&p.hdr->hist1[blockIdx.x % SEL_REPL][k], c);
+    if (c) atomicAdd(&hdr->hist1[blockIdx.x % SEL_REPL][k], c);
   }
-  if (invalid) atomicAdd(&p.hdr->st.n_invalid, invalid);           // rare
+  if (invalid) atomicAdd(&hdr->st.n_invalid, invalid);             // rare
 }
 
 // ------------------------------------------------------------------------- 2. select --------
@@ -226,8 +241,10 @@ __device__ __forceinline__ void sel_find(const uint32_t* __restrict__ hist, uint
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(NmsHeader* hdr, const uint32_t* __restrict__ keys, int n,
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n,
                                                          uint32_t target) {
+  NmsHeader* hdr = hdr_.v[blockIdx.y];
+  const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
   __shared__ uint32_t h[SEL_BINS];
   __shared__ uint32_t res[3];
   __shared__ int lds17[17];
@@ -257,8 +274,11 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(NmsHeader* hdr, const u
   }
 }
 
-__global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(NmsHeader* hdr, const uint32_t* __restrict__ keys, int n,
-                                                           uint32_t target, uint32_t limit, u64* __restrict__ cand) {
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n,
+                                                           uint32_t target, uint32_t limit, PerImg<u64*> cand_) {
+  NmsHeader* hdr = hdr_.v[blockIdx.y];
+  const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
+  u64* __restrict__ cand = cand_.v[blockIdx.y];
   __shared__ uint32_t res[3];
   __shared__ int lds17[17];
   const uint32_t b1 = (uint32_t)hdr->st.sel_b1;
@@ -314,11 +334,15 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(NmsHeader* hdr, const
 // 64 candidates (lane) x 16 slices of the comparison range (wave); the pair list is staged in LDS and
 // every wave reads it as a broadcast.
 #define RANK_THREADS 1024
-__global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(NmsHeader* hdr, int n, const u64* __restrict__ cand,
-                                                          const float4* __restrict__ boxes,
-                                                          uint32_t* __restrict__ sel_idx,
-                                                          float4* __restrict__ sboxes,
-                                                          float4* __restrict__ sorig) {
+__global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hdr_, int n, PerImg<const u64*> cand_,
+                                                          PerImg<const float4*> boxes_, PerImg<uint32_t*> sel_idx_,
+                                                          PerImg<float4*> sboxes_, PerImg<float4*> sorig_) {
+  NmsHeader* hdr = hdr_.v[blockIdx.y];
+  const u64* __restrict__ cand = cand_.v[blockIdx.y];
+  const float4* __restrict__ boxes = boxes_.v[blockIdx.y];
+  uint32_t* __restrict__ sel_idx = sel_idx_.v[blockIdx.y];
+  float4* __restrict__ sboxes = sboxes_.v[blockIdx.y];
+  float4* __restrict__ sorig = sorig_.v[blockIdx.y];
   __shared__ u64 all[NMS_CHUNK];
   __shared__ int part[16][64];
   NmsState* st = &hdr->st;
@@ -394,8 +418,12 @@ __global__ void __launch_bounds__(256) k_nms_cross(const NmsState* st, const flo
 // ------------------------------------------------------------------------- 3. mask ----------
 // 1-D grid over the lower-triangular tiles (rb, cb <= rb), row block major.  Workgroup = 4 waves,
 // lane = row of the tile, wave w tests the row against columns [16w, 16w+16) of the column block.
-__global__ void __launch_bounds__(256) k_nms_mask(const NmsState* st, const float4* __restrict__ sboxes, float thr,
-                                                  u64* __restrict__ Lt, u64* __restrict__ diag_up, int packed) {
+__global__ void __launch_bounds__(256) k_nms_mask(PerImg<const NmsState*> st_, PerImg<const float4*> sboxes_, float thr,
+                                                  PerImg<u64*> Lt_, PerImg<u64*> diag_, int packed) {
+  const NmsState* st = st_.v[blockIdx.y];
+  const float4* __restrict__ sboxes = sboxes_.v[blockIdx.y];
+  u64* __restrict__ Lt = Lt_.v[blockIdx.y];
+  u64* __restrict__ diag_up = diag_.v[blockIdx.y];
   const int t = blockIdx.x;
   int rb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
   while ((rb + 1) * (rb + 2) / 2 <= t) ++rb;
@@ -510,13 +538,41 @@ __device__ __forceinline__ void scan_publish(int* nkeptw, u64* keepw, int b, u64
 //                 packed = 1), staged in LDS up front; output rows prefetched before the walk.
 // LDSMAT = false: any chunk size, Lt word-major in global memory, column words streamed SCAN_RING
 //                 blocks ahead.
+struct ScanParams {          // pointer tables: one entry per image of the batch (blockIdx.y)
+  PerImg<NmsState*> st;
+  PerImg<const u64*> Lt, diag_up, removed_init;
+  PerImg<const float4*> sboxes, sorig;
+  PerImg<const uint32_t*> sorted_idx;
+  PerImg<int32_t*> out_idx;
+  PerImg<float4*> out_boxes, kept_boxes;
+  PerImg<int32_t*> out_count, out_done;
+  PerImg<float4*> as_rois;                   // optional fused _assign_levels outputs (null = disabled)
+  PerImg<int32_t*> as_level;
+  PerImg<int64_t*> as_perm;
+  PerImg<int32_t*> as_counts;
+  int n, use_init, K, min_level, max_level;
+};
+
 template <bool LDSMAT>
-__global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(
-    NmsState* st, int n, const u64* __restrict__ Lt, const u64* __restrict__ diag_up,
-    const u64* __restrict__ removed_init, int use_init, const float4* __restrict__ sboxes,
-    const float4* __restrict__ sorig, const uint32_t* __restrict__ sorted_idx, int K,
-    int32_t* __restrict__ out_idx, float4* out_boxes, float4* __restrict__ kept_boxes,
-    int32_t* __restrict__ out_count, int32_t* __restrict__ out_done, AssignOut ao) {
+__global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
+  const int img = blockIdx.y;
+  NmsState* st = sp.st.v[img];
+  const int n = sp.n, use_init = sp.use_init, K = sp.K;
+  const u64* __restrict__ Lt = sp.Lt.v[img];
+  const u64* __restrict__ diag_up = sp.diag_up.v[img];
+  const u64* __restrict__ removed_init = sp.removed_init.v[img];
+  const float4* __restrict__ sboxes = sp.sboxes.v[img];
+  const float4* __restrict__ sorig = sp.sorig.v[img];
+  const uint32_t* __restrict__ sorted_idx = sp.sorted_idx.v[img];
+  int32_t* __restrict__ out_idx = sp.out_idx.v[img];
+  float4* out_boxes = sp.out_boxes.v[img];
+  float4* __restrict__ kept_boxes = sp.kept_boxes.v[img];
+  int32_t* __restrict__ out_count = sp.out_count.v[img];
+  int32_t* __restrict__ out_done = sp.out_done.v[img];
+  AssignOut ao;
+  ao.rois = sp.as_rois.v[img]; ao.level = sp.as_level.v[img]; ao.perm = sp.as_perm.v[img];
+  ao.counts = sp.as_counts.v[img]; ao.min_level = sp.min_level; ao.max_level = sp.max_level;
+  (void)sboxes;
   // The hand-off words are accessed with relaxed workgroup-scope atomics (plain ds_read / ds_write that
   // the compiler may not cache or hoist).  NOT volatile: volatile __shared__ accesses are lowered to
   // flat sc0 sc1 instructions + vmcnt(0), an order of magnitude slower and they drain the prefetch.
@@ -833,46 +889,82 @@ static inline int tri_tiles(int cap) {
   return nb * (nb + 1) / 2;
 }
 
-struct NmsJob {
-  int mode;                 // PREP_*
-  PrepParams prep;          // n, inputs, boxes_out, ... (keys / hdr filled in by nms_run)
-  const float4* boxes;      // boxes the NMS runs on (= prep.boxes_out for RP / FPN)
-  int n, K;
-  float thr;
+struct NmsImage {           // per-image pointers of a job
+  const float4* boxes_in;   // PREP_NMS: boxes; PREP_RP: anchors
+  const float* deltas;
+  const float* scores;
+  const float2* logits;
+  float4* boxes_out;        // PREP_RP / PREP_FPN / PREP_FRCNN: decoded boxes (carved from the workspace)
+  const float4* boxes;      // boxes the NMS runs on
   int32_t* out_idx;
   float* out_boxes;
   int32_t* out_count;
-  int blind_chunks;
   int32_t* out_done;
   AssignOut assign;
+  void* ws;                 // NMS workspace of this image
+  size_t ws_bytes;
 };
+
+struct NmsJob {
+  int mode;                 // PREP_*
+  PrepParams prep;          // common parameters (means, stds, clip, anchor tables); pointer tables filled by nms_run
+  int n, K;
+  float thr;
+  int blind_chunks;
+  int B;                    // images in the batch (1..ODET_MAX_BATCH)
+  NmsImage img[ODET_MAX_BATCH];
+};
+
+template <typename T, typename F>
+static PerImg<T> per_img(const NmsJob& J, F get) {
+  PerImg<T> t;
+  for (int i = 0; i < ODET_MAX_BATCH; ++i) t.v[i] = get(i < J.B ? i : 0);
+  return t;
+}
 
 // Chunk 0 (select path) is always enqueued.  blind_chunks > 1: the fallback (full sort + further
 // chunks) is enqueued without looking at the device state; its kernels exit at once when chunk 0
 // finished the job.  out_done == nullptr: exact mode -- afterwards the host reads the state (one
 // sync per further chunk) until the device reports done.  out_done != nullptr: sync-free mode --
 // exactly blind_chunks chunks, *out_done tells the caller whether the result is complete.
-static int nms_run(NmsJob& J, void* ws, size_t ws_bytes, hipStream_t st) {
-  NmsWorkspace w;
-  const int n = J.n, K = J.K;
-  size_t need = nms_carve(n, K, nullptr, 0, nullptr);
-  if (!ws || ws_bytes < need)
-    return odet_set_error(ODET_E_WORKSPACE, "odet_nms: workspace too small (%zu < %zu)", ws_bytes, need);
-  nms_carve(n, K, ws, ws_bytes, &w);
-  NmsState* state = &w.hdr->st;
+// Batches (B > 1) run chunk 0 of every image in the same launches (blockIdx.y = image); the
+// fallback is per image, so batches require the sync-free mode with blind_chunks == 1.
+static int nms_run(NmsJob& J, hipStream_t st) {
+  const int n = J.n, K = J.K, B = J.B;
+  if (B < 1 || B > ODET_MAX_BATCH) return odet_set_error(ODET_E_INVALID, "odet_nms: batch %d out of range", B);
+  NmsWorkspace w[ODET_MAX_BATCH];
+  const size_t need = nms_carve(n, K, nullptr, 0, nullptr);
+  for (int i = 0; i < B; ++i) {
+    if (!J.img[i].ws || J.img[i].ws_bytes < need)
+      return odet_set_error(ODET_E_WORKSPACE, "odet_nms: workspace too small (%zu < %zu)", J.img[i].ws_bytes, need);
+    nms_carve(n, K, J.img[i].ws, J.img[i].ws_bytes, &w[i]);
+  }
+  if (B > 1) {
+    for (int i = 0; i < B; ++i)
+      if (!J.img[i].out_done || J.blind_chunks > 1)
+        return odet_set_error(ODET_E_INVALID, "odet_nms: batches need the sync-free mode with blind_chunks == 1");
+  }
   static bool attr_set = false;
   if (!attr_set) {
     ODET_HIP(hipFuncSetAttribute((const void*)k_nms_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  SCAN_DYN_LDS));
     attr_set = true;
   }
-  ODET_HIP(hipMemsetAsync(w.hdr, 0, sizeof(NmsHeader), st));
+  const PerImg<NmsHeader*> hdrs = per_img<NmsHeader*>(J, [&](int i) { return w[i].hdr; });
+  const PerImg<const uint32_t*> keys = per_img<const uint32_t*>(J, [&](int i) { return (const uint32_t*)w[i].keys_a; });
+  hipLaunchKernelGGL(k_zero_headers, dim3((unsigned)((sizeof(NmsHeader) / 16 + 255) / 256), B), dim3(256), 0, st, hdrs);
+  ODET_LAUNCH_CHECK();
   // 1. prepare
   J.prep.n = n;
-  J.prep.keys = w.keys_a;
-  J.prep.hdr = w.hdr;
+  J.prep.boxes_in = per_img<const float4*>(J, [&](int i) { return J.img[i].boxes_in; });
+  J.prep.deltas = per_img<const float*>(J, [&](int i) { return J.img[i].deltas; });
+  J.prep.scores = per_img<const float*>(J, [&](int i) { return J.img[i].scores; });
+  J.prep.logits = per_img<const float2*>(J, [&](int i) { return J.img[i].logits; });
+  J.prep.boxes_out = per_img<float4*>(J, [&](int i) { return J.img[i].boxes_out; });
+  J.prep.keys = per_img<uint32_t*>(J, [&](int i) { return w[i].keys_a; });
+  J.prep.hdr = hdrs;
   {
-    dim3 grid((n + PREP_TILE - 1) / PREP_TILE), block(256);
+    dim3 grid((n + PREP_TILE - 1) / PREP_TILE, B), block(256);
     if (J.mode == PREP_NMS)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rp_prepare<PREP_NMS>), grid, block, 0, st, J.prep);
     else if (J.mode == PREP_RP)
@@ -888,36 +980,64 @@ static int nms_run(NmsJob& J, void* ws, size_t ws_bytes, hipStream_t st) {
   // chunk 0 runs on the LDS-resident scan when its candidates are guaranteed to fit 24 blocks
   const bool lds0 = target <= (uint32_t)SCAN_LDS_CAND;
   const uint32_t limit = lds0 ? (uint32_t)SCAN_LDS_CAND : (uint32_t)NMS_CHUNK;
+  const PerImg<const float4*> nboxes = per_img<const float4*>(J, [&](int i) { return J.img[i].boxes; });
+  const PerImg<float4*> sboxes = per_img<float4*>(J, [&](int i) { return w[i].sboxes; });
+  const PerImg<float4*> sorig = per_img<float4*>(J, [&](int i) { return w[i].sorig; });
   {
-    dim3 grid((n + SEL_TILE - 1) / SEL_TILE), block(SEL_BLOCK);
-    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, w.hdr, w.keys_a, n, target);
+    dim3 grid((n + SEL_TILE - 1) / SEL_TILE, B), block(SEL_BLOCK);
+    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, hdrs, keys, n, target);
     ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, w.hdr, w.keys_a, n, target, limit, w.cand);
+    const PerImg<u64*> cand = per_img<u64*>(J, [&](int i) { return w[i].cand; });
+    hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, hdrs, keys, n, target, limit, cand);
     ODET_LAUNCH_CHECK();
-    const int rank_wgs = (std::min(n, NMS_CHUNK) + 63) / 64;
-    hipLaunchKernelGGL(k_sel_rank, dim3(rank_wgs), dim3(RANK_THREADS), 0, st, w.hdr, n, w.cand, J.boxes, w.vals_b,
-                       w.sboxes, w.sorig);
+    const int rank_wgs = (std::min(n, (int)limit) + 63) / 64;
+    hipLaunchKernelGGL(k_sel_rank, dim3(rank_wgs, B), dim3(RANK_THREADS), 0, st, hdrs, n,
+                       per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].cand; }), nboxes,
+                       per_img<uint32_t*>(J, [&](int i) { return w[i].vals_b; }), sboxes, sorig);
     ODET_LAUNCH_CHECK();
   }
   // 3./4. chunk 0
+  const PerImg<const NmsState*> cstates = per_img<const NmsState*>(J, [&](int i) { return (const NmsState*)&w[i].hdr->st; });
+  const PerImg<const float4*> csboxes = per_img<const float4*>(J, [&](int i) { return (const float4*)w[i].sboxes; });
+  const PerImg<u64*> Lts = per_img<u64*>(J, [&](int i) { return w[i].Lt; });
+  const PerImg<u64*> diags = per_img<u64*>(J, [&](int i) { return w[i].diag; });
+  ScanParams sp;
+  sp.st = per_img<NmsState*>(J, [&](int i) { return &w[i].hdr->st; });
+  sp.Lt = per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].Lt; });
+  sp.diag_up = per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].diag; });
+  sp.removed_init = per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].removed_init; });
+  sp.sboxes = csboxes;
+  sp.sorig = per_img<const float4*>(J, [&](int i) { return (const float4*)w[i].sorig; });
+  sp.sorted_idx = per_img<const uint32_t*>(J, [&](int i) { return (const uint32_t*)w[i].vals_b; });
+  sp.out_idx = per_img<int32_t*>(J, [&](int i) { return J.img[i].out_idx; });
+  sp.out_boxes = per_img<float4*>(J, [&](int i) { return (float4*)J.img[i].out_boxes; });
+  sp.kept_boxes = per_img<float4*>(J, [&](int i) { return w[i].kept_boxes; });
+  sp.out_count = per_img<int32_t*>(J, [&](int i) { return J.img[i].out_count; });
+  sp.out_done = per_img<int32_t*>(J, [&](int i) { return J.img[i].out_done; });
+  sp.as_rois = per_img<float4*>(J, [&](int i) { return J.img[i].assign.rois; });
+  sp.as_level = per_img<int32_t*>(J, [&](int i) { return J.img[i].assign.level; });
+  sp.as_perm = per_img<int64_t*>(J, [&](int i) { return J.img[i].assign.perm; });
+  sp.as_counts = per_img<int32_t*>(J, [&](int i) { return J.img[i].assign.counts; });
+  sp.n = n; sp.use_init = 0; sp.K = K;
+  sp.min_level = J.img[0].assign.min_level; sp.max_level = J.img[0].assign.max_level;
   {
     const int cap0 = std::min((int)limit, (n + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap0)), dim3(256), 0, st, state, w.sboxes, J.thr, w.Lt, w.diag,
+    hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap0), B), dim3(256), 0, st, cstates, csboxes, J.thr, Lts, diags,
                        lds0 ? 1 : 0);
     ODET_LAUNCH_CHECK();
     if (lds0)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<true>), dim3(1), dim3(SCAN_THREADS), SCAN_DYN_LDS, st, state, n,
-                         w.Lt, w.diag, w.removed_init, 0, w.sboxes, w.sorig, w.vals_b, K, J.out_idx,
-                         (float4*)J.out_boxes, w.kept_boxes, J.out_count, J.out_done, J.assign);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<true>), dim3(1, B), dim3(SCAN_THREADS), SCAN_DYN_LDS, st, sp);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1), dim3(SCAN_THREADS), 0, st, state, n, w.Lt,
-                         w.diag, w.removed_init, 0, w.sboxes, w.sorig, w.vals_b, K, J.out_idx, (float4*)J.out_boxes,
-                         w.kept_boxes, J.out_count, J.out_done, J.assign);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, B), dim3(SCAN_THREADS), 0, st, sp);
     ODET_LAUNCH_CHECK();
   }
+  if (B > 1) return ODET_OK;                   // sync-free, one chunk: the caller checks every out_done
+  // ---- single image from here on ----
+  NmsState* state = &w[0].hdr->st;
+  const NmsWorkspace& w0 = w[0];
   int blind = J.blind_chunks < 1 ? 1 : J.blind_chunks;
   if (blind == 1) {
-    if (J.out_done) return ODET_OK;            // sync-free: the caller checks *out_done
+    if (J.img[0].out_done) return ODET_OK;     // sync-free: the caller checks *out_done
     NmsState h;
     ODET_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
     ODET_HIP(hipStreamSynchronize(st));
@@ -925,30 +1045,29 @@ static int nms_run(NmsJob& J, void* ws, size_t ws_bytes, hipStream_t st) {
   }
   // 5. fallback: full order, then chunks of 4096 from wherever chunk 0 stopped
   uint32_t* sorted = nullptr;
-  int rc = odet_sort_keys_desc(n, w.keys_a, w.vals_a, w.keys_b, w.vals_b, w.hist, &state->done, &sorted, st);
+  int rc = odet_sort_keys_desc(n, w0.keys_a, w0.vals_a, w0.keys_b, w0.vals_b, w0.hist, &state->done, &sorted, st);
   if (rc != ODET_OK) return rc;
+  sp.use_init = 1;
+  sp.sorted_idx = per_img<const uint32_t*>(J, [&](int) { return (const uint32_t*)sorted; });
   const int max_chunks = (n + NMS_CHUNK - 1) / NMS_CHUNK + 1;
   for (int c = 1; c <= max_chunks; ++c) {
     if (c >= blind && !(c == 1 && blind == 1)) {   // (c == 1 && blind == 1: the host has just seen "not done")
-      if (J.out_done) break;
+      if (J.img[0].out_done) break;
       NmsState h;
       ODET_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
       ODET_HIP(hipStreamSynchronize(st));
       if (h.done) break;
     }
     const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, state, n, cap, J.boxes, sorted,
-                       w.sboxes, w.sorig);
+    hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, state, n, cap, J.img[0].boxes, sorted,
+                       w0.sboxes, w0.sorig);
     ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, state, w.sboxes, w.kept_boxes, J.thr,
-                       w.removed_init);
+    hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, state, w0.sboxes, w0.kept_boxes, J.thr,
+                       w0.removed_init);
     ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap)), dim3(256), 0, st, state, w.sboxes, J.thr, w.Lt, w.diag, 0);
+    hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap), 1), dim3(256), 0, st, cstates, csboxes, J.thr, Lts, diags, 0);
     ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1), dim3(SCAN_THREADS), 0, st, state, n, w.Lt, w.diag,
-                       w.removed_init, 1,
-                       w.sboxes, w.sorig, sorted, K, J.out_idx, (float4*)J.out_boxes, w.kept_boxes, J.out_count,
-                       J.out_done, J.assign);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, 1), dim3(SCAN_THREADS), 0, st, sp);
     ODET_LAUNCH_CHECK();
   }
   return ODET_OK;
@@ -968,6 +1087,12 @@ static void no_assign(AssignOut* a) {
   a->min_level = 0; a->max_level = 0;
 }
 
+static void job_init(NmsJob* J, int mode, int n, int K, float thr, int blind_chunks, int B) {
+  memset(J, 0, sizeof(*J));
+  J->mode = mode; J->n = n; J->K = K; J->thr = thr; J->blind_chunks = blind_chunks; J->B = B;
+  for (int i = 0; i < ODET_MAX_BATCH; ++i) no_assign(&J->img[i].assign);
+}
+
 extern "C" int odet_nms(const float* boxes, const float* scores, int n, int max_output, float iou_threshold,
                         int32_t* out_idx, float* out_boxes, int32_t* out_count, int blind_chunks,
                         int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
@@ -976,16 +1101,14 @@ extern "C" int odet_nms(const float* boxes, const float* scores, int n, int max_
   if (n == 0 || max_output == 0) return nms_trivial(out_count, out_done, (hipStream_t)stream);
   ODET_REQUIRE(boxes && scores && out_idx, "odet_nms: null pointer");
   NmsJob J;
-  memset(&J.prep, 0, sizeof(J.prep));
-  J.mode = PREP_NMS;
-  J.prep.boxes_in = (const float4*)boxes;
-  J.prep.scores = scores;
-  J.boxes = (const float4*)boxes;
-  J.n = n; J.K = max_output; J.thr = iou_threshold;
-  J.out_idx = out_idx; J.out_boxes = out_boxes; J.out_count = out_count;
-  J.blind_chunks = blind_chunks; J.out_done = out_done;
-  no_assign(&J.assign);
-  return nms_run(J, workspace, workspace_bytes, (hipStream_t)stream);
+  job_init(&J, PREP_NMS, n, max_output, iou_threshold, blind_chunks, 1);
+  NmsImage& im = J.img[0];
+  im.boxes_in = (const float4*)boxes;
+  im.scores = scores;
+  im.boxes = (const float4*)boxes;
+  im.out_idx = out_idx; im.out_boxes = out_boxes; im.out_count = out_count; im.out_done = out_done;
+  im.ws = workspace; im.ws_bytes = workspace_bytes;
+  return nms_run(J, (hipStream_t)stream);
 }
 
 static size_t rp_workspace_bytes(int n, int max_output) {
@@ -997,18 +1120,20 @@ extern "C" size_t odet_region_proposal_workspace_bytes(int n, int max_output) {
   return rp_workspace_bytes(n, max_output);
 }
 
-// carve: [NMS workspace (header first, so the memset starts at the allocation)] [boxes n] [idx K]
-static int rp_carve(int n, int K, void* workspace, size_t workspace_bytes, const char* who, float4** boxes,
-                    int32_t** idx, void** nms_ws, size_t* nms_bytes) {
+// carve: [NMS workspace (header first)] [boxes n] [idx K]; fills the image's workspace / box fields
+static int rp_carve(int n, int K, void* workspace, size_t workspace_bytes, const char* who, NmsImage* im,
+                    int32_t* out_idx) {
   size_t need = rp_workspace_bytes(n, K);
   if (!workspace || workspace_bytes < need)
     return odet_set_error(ODET_E_WORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes, need);
   size_t nb = odet_align_up(odet_nms_workspace_bytes(n, K), 256);
   OdetArena ar{(char*)workspace + nb, workspace_bytes - nb, 0};
-  *boxes = ar.take<float4>((size_t)n);
-  *idx = ar.take<int32_t>((size_t)K);
-  *nms_ws = workspace;
-  *nms_bytes = nb;
+  im->boxes_out = ar.take<float4>((size_t)n);
+  int32_t* idx_buf = ar.take<int32_t>((size_t)K);
+  im->boxes = im->boxes_out;
+  im->out_idx = out_idx ? out_idx : idx_buf;
+  im->ws = workspace;
+  im->ws_bytes = nb;
   return ODET_OK;
 }
 
@@ -1022,54 +1147,44 @@ extern "C" int odet_region_proposal(const float* deltas, const float* anchors, c
   ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_region_proposal: bad image shape");
   if (n == 0 || max_output == 0) return nms_trivial(out_count, out_done, (hipStream_t)stream);
   ODET_REQUIRE(deltas && anchors && scores && means && stds && out_rois, "odet_region_proposal: null pointer");
-  float4* boxes; int32_t* idx_buf; void* nws; size_t nbytes;
-  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_region_proposal", &boxes, &idx_buf, &nws, &nbytes);
-  if (rc != ODET_OK) return rc;
   NmsJob J;
-  memset(&J.prep, 0, sizeof(J.prep));
-  J.mode = PREP_RP;
-  J.prep.boxes_in = (const float4*)anchors;
-  J.prep.deltas = deltas;
-  J.prep.scores = scores;
+  job_init(&J, PREP_RP, n, max_output, iou_threshold, blind_chunks, 1);
+  NmsImage& im = J.img[0];
+  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_region_proposal", &im, out_idx);
+  if (rc != ODET_OK) return rc;
+  im.boxes_in = (const float4*)anchors;
+  im.deltas = deltas;
+  im.scores = scores;
   for (int k = 0; k < 4; ++k) { J.prep.means.v[k] = means[k]; J.prep.stds.v[k] = stds[k]; }
   J.prep.wmax = (float)(image_w - 1); J.prep.hmax = (float)(image_h - 1);
-  J.prep.boxes_out = boxes;
-  J.boxes = boxes;
-  J.n = n; J.K = max_output; J.thr = iou_threshold;
-  J.out_idx = out_idx ? out_idx : idx_buf; J.out_boxes = out_rois; J.out_count = out_count;
-  J.blind_chunks = blind_chunks; J.out_done = out_done;
-  no_assign(&J.assign);
-  return nms_run(J, nws, nbytes, (hipStream_t)stream);
+  im.out_boxes = out_rois; im.out_count = out_count; im.out_done = out_done;
+  return nms_run(J, (hipStream_t)stream);
 }
 
 extern "C" size_t odet_fpn_proposals_workspace_bytes(int n, int max_output) {
   return rp_workspace_bytes(n, max_output);
 }
 
-extern "C" int odet_fpn_proposals(const float* rpn_logits, const float* rpn_deltas, int num_levels, int A,
-                                  const int* fh, const int* fw, const int* stride, const float* wh, int image_h,
-                                  int image_w, const float* means, const float* stds, int max_output,
-                                  float iou_threshold, int min_level, int max_level, float* out_rois,
-                                  int32_t* out_idx, int32_t* out_count, float* out_sorted_rois, int32_t* out_level,
-                                  int64_t* out_perm, int32_t* out_level_counts, int blind_chunks, int32_t* out_done,
-                                  void* workspace, size_t workspace_bytes, odet_stream_t stream) {
-  ODET_REQUIRE(rpn_logits && rpn_deltas && fh && fw && stride && wh && means && stds,
-               "odet_fpn_proposals: null pointer");
-  ODET_REQUIRE(out_rois && out_count, "odet_fpn_proposals: null output");
+struct FpnProposalIO {      // per-image arguments of the FPN proposal stage
+  const float* rpn_logits; const float* rpn_deltas;
+  float* out_rois; int32_t* out_idx; int32_t* out_count;
+  float* out_sorted_rois; int32_t* out_level; int64_t* out_perm; int32_t* out_level_counts;
+  int32_t* out_done; void* workspace; size_t workspace_bytes;
+};
+
+// shared by odet_fpn_proposals (B = 1) and odet_fpn_step_enqueue_batch (B images in the same launches)
+int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int A, const int* fh, const int* fw,
+                             const int* stride, const float* wh, int image_h, int image_w, const float* means,
+                             const float* stds, int max_output, float iou_threshold, int min_level, int max_level,
+                             int blind_chunks, hipStream_t st) {
+  ODET_REQUIRE(io && fh && fw && stride && wh && means && stds, "odet_fpn_proposals: null pointer");
+  ODET_REQUIRE(B >= 1 && B <= ODET_MAX_BATCH, "odet_fpn_proposals: batch %d out of range", B);
   ODET_REQUIRE(num_levels > 0 && num_levels <= ODET_MAX_LEVELS, "odet_fpn_proposals: num_levels %d out of range",
                num_levels);
   ODET_REQUIRE(A > 0 && A <= ODET_MAX_ANCHORS_PER_CELL, "odet_fpn_proposals: A %d out of range", A);
   ODET_REQUIRE(image_h > 0 && image_w > 0 && max_output > 0, "odet_fpn_proposals: bad sizes");
-  const bool assign = out_sorted_rois != nullptr;
-  if (assign) {
-    ODET_REQUIRE(out_level && out_perm && out_level_counts, "odet_fpn_proposals: null level outputs");
-    ODET_REQUIRE(max_level >= min_level && max_level - min_level < ODET_MAX_LEVELS, "odet_fpn_proposals: bad levels");
-    if (max_output > ODET_ASSIGN_MAX_ROIS)
-      return odet_set_error(ODET_E_LIMIT, "odet_fpn_proposals: max_output %d exceeds %d", max_output,
-                            ODET_ASSIGN_MAX_ROIS);
-  }
   NmsJob J;
-  memset(&J.prep, 0, sizeof(J.prep));
+  job_init(&J, PREP_FPN, 0, max_output, iou_threshold, blind_chunks, B);
   FpnAnchorParams& p = J.prep.fpn;
   p.num_levels = num_levels;
   p.A = A;
@@ -1085,31 +1200,53 @@ extern "C" int odet_fpn_proposals(const float* rpn_logits, const float* rpn_delt
   for (int l = num_levels; l <= ODET_MAX_LEVELS; ++l) p.start[l] = (int)total;
   for (int i = 0; i < num_levels * A * 2; ++i) p.wh[i] = wh[i];
   const int n = (int)total;
-  hipStream_t st = (hipStream_t)stream;
-  if (n == 0) {
-    if (assign) ODET_HIP(hipMemsetAsync(out_level_counts, 0, sizeof(int32_t) * (max_level - min_level + 1), st));
-    return nms_trivial(out_count, out_done, st);
-  }
-  float4* boxes; int32_t* idx_buf; void* nws; size_t nbytes;
-  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_fpn_proposals", &boxes, &idx_buf, &nws, &nbytes);
-  if (rc != ODET_OK) return rc;
-  J.mode = PREP_FPN;
-  J.prep.logits = (const float2*)rpn_logits;
-  J.prep.deltas = rpn_deltas;
+  J.n = n;
   for (int k = 0; k < 4; ++k) { J.prep.means.v[k] = means[k]; J.prep.stds.v[k] = stds[k]; }
   J.prep.wmax = (float)(image_w - 1); J.prep.hmax = (float)(image_h - 1);
-  J.prep.boxes_out = boxes;
-  J.boxes = boxes;
-  J.n = n; J.K = max_output; J.thr = iou_threshold;
-  J.out_idx = out_idx ? out_idx : idx_buf; J.out_boxes = out_rois; J.out_count = out_count;
-  J.blind_chunks = blind_chunks; J.out_done = out_done;
-  if (assign) {
-    J.assign.rois = (float4*)out_sorted_rois; J.assign.level = out_level; J.assign.perm = out_perm;
-    J.assign.counts = out_level_counts; J.assign.min_level = min_level; J.assign.max_level = max_level;
-  } else {
-    no_assign(&J.assign);
+  for (int i = 0; i < B; ++i) {
+    const FpnProposalIO& a = io[i];
+    ODET_REQUIRE(a.rpn_logits && a.rpn_deltas && a.out_rois && a.out_count, "odet_fpn_proposals: null pointer");
+    const bool assign = a.out_sorted_rois != nullptr;
+    if (assign) {
+      ODET_REQUIRE(a.out_level && a.out_perm && a.out_level_counts, "odet_fpn_proposals: null level outputs");
+      ODET_REQUIRE(max_level >= min_level && max_level - min_level < ODET_MAX_LEVELS, "odet_fpn_proposals: bad levels");
+      if (max_output > ODET_ASSIGN_MAX_ROIS)
+        return odet_set_error(ODET_E_LIMIT, "odet_fpn_proposals: max_output %d exceeds %d", max_output,
+                              ODET_ASSIGN_MAX_ROIS);
+    }
+    if (n == 0) {
+      if (assign) ODET_HIP(hipMemsetAsync(a.out_level_counts, 0, sizeof(int32_t) * (max_level - min_level + 1), st));
+      int rc0 = nms_trivial(a.out_count, a.out_done, st);
+      if (rc0 != ODET_OK) return rc0;
+      continue;
+    }
+    NmsImage& im = J.img[i];
+    int rc = rp_carve(n, max_output, a.workspace, a.workspace_bytes, "odet_fpn_proposals", &im, a.out_idx);
+    if (rc != ODET_OK) return rc;
+    im.logits = (const float2*)a.rpn_logits;
+    im.deltas = a.rpn_deltas;
+    im.out_boxes = a.out_rois; im.out_count = a.out_count; im.out_done = a.out_done;
+    if (assign) {
+      im.assign.rois = (float4*)a.out_sorted_rois; im.assign.level = a.out_level; im.assign.perm = a.out_perm;
+      im.assign.counts = a.out_level_counts;
+    }
+    im.assign.min_level = min_level; im.assign.max_level = max_level;
   }
-  return nms_run(J, nws, nbytes, st);
+  if (n == 0) return ODET_OK;
+  return nms_run(J, st);
+}
+
+extern "C" int odet_fpn_proposals(const float* rpn_logits, const float* rpn_deltas, int num_levels, int A,
+                                  const int* fh, const int* fw, const int* stride, const float* wh, int image_h,
+                                  int image_w, const float* means, const float* stds, int max_output,
+                                  float iou_threshold, int min_level, int max_level, float* out_rois,
+                                  int32_t* out_idx, int32_t* out_count, float* out_sorted_rois, int32_t* out_level,
+                                  int64_t* out_perm, int32_t* out_level_counts, int blind_chunks, int32_t* out_done,
+                                  void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  FpnProposalIO io{rpn_logits, rpn_deltas, out_rois, out_idx, out_count, out_sorted_rois, out_level, out_perm,
+                   out_level_counts, out_done, workspace, workspace_bytes};
+  return odet_fpn_proposals_batch(&io, 1, num_levels, A, fh, fw, stride, wh, image_h, image_w, means, stds,
+                                  max_output, iou_threshold, min_level, max_level, blind_chunks, (hipStream_t)stream);
 }
 
 extern "C" size_t odet_frcnn_proposals_workspace_bytes(int n, int max_output) {
@@ -1132,24 +1269,18 @@ extern "C" int odet_frcnn_proposals(const float* rpn_logits, const float* rpn_de
   const int n = (int)total;
   if (n == 0) return nms_trivial(out_count, out_done, st);
   NmsJob J;
-  memset(&J.prep, 0, sizeof(J.prep));
+  job_init(&J, PREP_FRCNN, n, max_output, iou_threshold, blind_chunks, 1);
   J.prep.fpn.A = A;
   J.prep.fpn.fw[0] = fw;
   J.prep.fpn.stride[0] = feat_stride;
   for (int i = 0; i < A * 4; ++i) J.prep.fpn.wh[i] = anchor_base[i];
-  float4* boxes; int32_t* idx_buf; void* nws; size_t nbytes;
-  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_frcnn_proposals", &boxes, &idx_buf, &nws, &nbytes);
+  NmsImage& im = J.img[0];
+  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_frcnn_proposals", &im, out_idx);
   if (rc != ODET_OK) return rc;
-  J.mode = PREP_FRCNN;
-  J.prep.logits = (const float2*)rpn_logits;
-  J.prep.deltas = rpn_deltas;
+  im.logits = (const float2*)rpn_logits;
+  im.deltas = rpn_deltas;
   for (int k = 0; k < 4; ++k) { J.prep.means.v[k] = means[k]; J.prep.stds.v[k] = stds[k]; }
   J.prep.wmax = (float)(image_w - 1); J.prep.hmax = (float)(image_h - 1);
-  J.prep.boxes_out = boxes;
-  J.boxes = boxes;
-  J.n = n; J.K = max_output; J.thr = iou_threshold;
-  J.out_idx = out_idx ? out_idx : idx_buf; J.out_boxes = out_rois; J.out_count = out_count;
-  J.blind_chunks = blind_chunks; J.out_done = out_done;
-  no_assign(&J.assign);
-  return nms_run(J, nws, nbytes, st);
+  im.out_boxes = out_rois; im.out_count = out_count; im.out_done = out_done;
+  return nms_run(J, st);
 }

@@ -99,6 +99,15 @@ __device__ __forceinline__ uint32_t d_float_asc_key(float f) {
 // ---- shared parameter blocks / device helpers ------------------------------------------------
 struct Vec4 { float v[4]; };
 
+// Batched launches: up to ODET_MAX_BATCH independent images per kernel launch (blockIdx.y = image).
+// Every image keeps its own caller-owned buffers, so a kernel receives a small table of pointers per
+// buffer kind; all shapes / parameters are common to the batch.
+#define ODET_MAX_BATCH 8
+template <typename T>
+struct PerImg {
+  T v[ODET_MAX_BATCH];
+};
+
 // utils/anchor_generator.py:137-178 make_anchors over all pyramid levels (base_fpn_model.py:163-186).
 struct FpnAnchorParams {
   int num_levels;
