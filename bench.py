@@ -146,12 +146,13 @@ def load_traffic(workload_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--scores', choices=['distinct', 'clustered'], default='distinct',
                     help='RPN score distribution (SURVEY 8d: distinct; clustered = trained-like)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--streams', type=int, default=8, help='independent images in flight per GPU')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams (+ native enqueue threads) per GPU')
+    ap.add_argument('--batch', type=int, default=8, help='images that share the kernel launches of a stream (1..8)')
     ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
     args = ap.parse_args()
 
@@ -176,60 +177,82 @@ def main():
 
     host, dev = synthetic_fpn_inputs(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, seed=1234 + rank,
                                      score_kind=args.scores)
-    # `streams` independent images in flight: one FpnHotPath slot + HIP stream + native enqueue thread each
-    S = max(1, args.streams)
-    pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, blind_chunks=args.blind_chunks)
+    # images in flight per GPU: `streams` HIP streams (one native enqueue thread each) x `batch` images
+    # that share every kernel launch of their stream (blockIdx.y = image)
+    S, B = max(1, args.streams), max(1, min(8, args.batch))
+    if args.blind_chunks != 1:
+        B = 1                                                   # the NMS fallback is per image
+    pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B,
+                         blind_chunks=args.blind_chunks)
+    nslots = pool.n
     rec_len = pool.slots[0].record.numel()
-    records = torch.zeros((S, rec_len), dtype=torch.float32, device='cuda')
-    for k in range(S):
+    records = torch.zeros((nslots, rec_len), dtype=torch.float32, device='cuda')
+    for k in range(nslots):
         pool.slots[k].record = records[k]                     # one contiguous block: ONE all-gather per round
         pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
     hot = pool.slots[0]
     max_det = hot.cfg['max_per_image']
     comm = torch.cuda.Stream()
-    gathered = torch.zeros((world, S, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
+    gathered = torch.zeros((world, nslots, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
+    gstreams = pool._group_streams
 
-    # HIP events around the RoI kernel, on its launch stream, inside the timed region.  The kernel is
-    # timed ALONE: the step's stream first waits (on the GPU, no host sync) for the other streams and
-    # they wait for it afterwards, so only a few steps are bracketed.
-    EV_EVERY = max(8, args.steps // 10)
+    # HIP events attached to the RoI kernel's dispatch, inside the timed region.  The kernel is timed
+    # ALONE as a one-image launch: the step's stream first waits (on the GPU, no host sync) for the
+    # other streams and they wait for it afterwards, so only a few steps are bracketed.
     from tf_eager_object_detection_amd import ops
-    ev_roi = {i: (ops.ProfEvent(), ops.ProfEvent()) for i in range(0, args.steps, EV_EVERY)}
+    n_events = max(1, min(10, args.steps // 100))
+    ev_at = set(int(round(j * args.steps / n_events)) for j in range(n_events))
+    ev_roi = []
 
     def drain():
         pool.wait()
         torch.cuda.synchronize()
 
     def gather_round():
-        """image-parallel exchange: every rank's S records of this round in one RCCL all-gather"""
+        """image-parallel exchange: every rank's records of this round in one RCCL all-gather"""
         pool.wait()
-        for st in pool.streams:
+        for st in gstreams:
             comm.wait_stream(st)
         with torch.cuda.stream(comm):
             dist.all_gather_into_tensor(gathered, records)
-        for st in pool.streams:
+        for st in gstreams:
             st.wait_stream(comm)                              # the next round may overwrite the records
 
-    def one_step(i, timed):
-        slot = i % S
-        ev = ev_roi.get(i) if timed else None
-        if ev is None:
-            pool.submit(slot)
-        else:
-            pool.wait()                                       # every earlier image is enqueued (host side only)
-            mine = pool.streams[slot]
-            for st in pool.streams:
-                if st is not mine:
-                    mine.wait_stream(st)
-            with torch.cuda.stream(mine):
-                h = pool.slots[slot]
-                h.stage_proposals(dev['rpn_logits'], dev['rpn_deltas'])
-                h.stage_roi(dev['feats'], events=ev)          # start / stop events of the dispatch itself
-                h.stage_detect(dev['cls_scores'], dev['cls_deltas'])
-            for st in pool.streams:
-                if st is not mine:
-                    st.wait_stream(mine)
-        if world > 1 and slot == S - 1:
+    def timed_single_image(slot):
+        ev = (ops.ProfEvent(), ops.ProfEvent())
+        ev_roi.append(ev)
+        pool.wait()                                           # every earlier image is enqueued (host side only)
+        mine = pool.streams[slot]
+        for st in gstreams:
+            if st is not mine:
+                mine.wait_stream(st)
+        with torch.cuda.stream(mine):
+            h = pool.slots[slot]
+            h.stage_proposals(dev['rpn_logits'], dev['rpn_deltas'])
+            h.stage_roi(dev['feats'], events=ev)              # start / stop events of the dispatch itself
+            h.stage_detect(dev['cls_scores'], dev['cls_deltas'])
+        for st in gstreams:
+            if st is not mine:
+                st.wait_stream(mine)
+
+    def run(num_images, timed):
+        """num_images steps: groups of B images share their launches; event steps and the remainder run
+        as single images."""
+        i, group = 0, 0
+        while i < num_images:
+            if timed and i in ev_at:
+                timed_single_image(group * B)
+                i += 1
+            elif num_images - i >= B and not (timed and any(j in ev_at for j in range(i + 1, i + B))):
+                pool.submit_group(group)
+                i += B
+            else:
+                pool.submit(group * B)
+                i += 1
+            group = (group + 1) % S
+            if world > 1 and group == 0:
+                gather_round()
+        if world > 1 and group != 0:
             gather_round()
 
     def fence():
@@ -238,16 +261,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_step(i, False)
-    if world > 1 and args.warmup % S:
-        gather_round()
+    run(max(args.warmup, nslots), False)                      # (at least one pass over every slot)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i, True)
-    if world > 1 and args.steps % S:
-        gather_round()
+    run(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -259,7 +276,7 @@ def main():
                          '(use --blind-chunks 2 for score distributions with heavy suppression)')
 
     if rank == 0:
-        roi_ms = float(np.mean([a.elapsed_ms(b) for a, b in ev_roi.values()]))
+        roi_ms = float(np.mean([a.elapsed_ms(b) for a, b in ev_roi]))
         k = int(hot.roi_count.item())
         srois = hot.sorted_rois[:k].cpu().numpy()
         lv = hot.roi_level[:k].cpu().numpy()
@@ -277,7 +294,7 @@ def main():
                                    'P2..P5x256 -> post_ops (21 classes); conv backbone/heads out of scope (their '
                                    'outputs are synthetic inputs in HBM)',
                        'images_per_step_per_gpu': 1, 'global_batch': world, 'rpn_scores': args.scores,
-                       'streams_per_gpu': S, 'enqueue_threads_per_gpu': S,
+                       'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max)',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -333,6 +333,12 @@ typedef struct {
 
 size_t odet_fpn_step_sizeof(void);
 int odet_fpn_step_enqueue(const odet_fpn_step_t* step, int stages);
+/* `count` (<= ODET_MAX_STEP_BATCH) images whose steps agree in every shape, parameter and the stream,
+ * processed by the SAME kernel launches (one grid dimension = image): per-launch costs are paid once
+ * per batch and the single-workgroup stages of the images run side by side.  Needs the sync-free NMS
+ * mode (nms_done != NULL) with blind_chunks == 1. */
+#define ODET_MAX_STEP_BATCH 8
+int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, int count, int stages);
 
 /* Native executor: `num_workers` host threads, each draining its own FIFO of (step, stages) jobs by
  * calling odet_fpn_step_enqueue.  A HIP kernel launch costs ~3 us of host time and one image is ~11
@@ -346,6 +352,8 @@ typedef struct odet_exec odet_exec_t;
 odet_exec_t* odet_exec_create(int num_workers);
 void odet_exec_destroy(odet_exec_t* ex);
 int odet_exec_submit(odet_exec_t* ex, int worker, const odet_fpn_step_t* step, int stages);
+int odet_exec_submit_batch(odet_exec_t* ex, int worker, const odet_fpn_step_t* const* steps, int count,
+                           int stages);
 /* blocks until every submitted job has been enqueued; returns the first error any job hit (0 = none;
  * text through odet_exec_last_error) and clears it */
 int odet_exec_wait(odet_exec_t* ex);

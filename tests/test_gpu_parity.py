@@ -538,6 +538,51 @@ def test_stream_pool_matches_single_path_and_oracle():
         pool.close()
 
 
+def test_batched_launches_match_single_path():
+    """odet_fpn_step_enqueue_batch: several images in the SAME kernel launches (blockIdx.y = image) must
+    give every image exactly the single-image result, stage by stage and for the whole step."""
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, FpnStreamPool, synthetic_fpn_inputs
+    shape, K, ncls, ch = (320, 480), 300, 21, 64
+    sets = [synthetic_fpn_inputs(shape, ncls, K, channels=ch, seed=200 + i) for i in range(6)]
+    ref = FpnHotPath(shape, ncls, K, channels=ch)
+    want = []
+    for host, dev in sets:
+        ref.step(dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        torch.cuda.synchronize()
+        assert int(ref.nms_done.item()) == 1
+        want.append([t.clone() for t in (ref.record, ref.roi_features, ref.sorted_rois, ref.roi_perm, ref.roi_level,
+                                         ref.level_counts, ref.roi_count, ref.det_boxes, ref.det_labels)])
+    pool = FpnStreamPool(2, shape, ncls, K, ch, batch=3)
+    try:
+        for k, (host, dev) in enumerate(sets):
+            pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        for stages in ((1, 2, 4), (7,), (3, 4)):                  # stage by stage, whole step, mixed
+            for h_ in pool.slots:
+                h_.record.zero_(); h_.roi_features.zero_()
+            for st_ in stages:
+                pool.submit_group(0, stages=st_)
+                pool.submit_group(1, stages=st_)
+            pool.wait()
+            torch.cuda.synchronize()
+            for k in range(6):
+                slot = pool.slots[k]
+                got = (slot.record, slot.roi_features, slot.sorted_rois, slot.roi_perm, slot.roi_level,
+                       slot.level_counts, slot.roi_count, slot.det_boxes, slot.det_labels)
+                assert int(slot.nms_done.item()) == 1
+                cnt = int(want[k][6].item())
+                for name, a, b in zip(('record', 'features', 'rois', 'perm', 'level', 'level_counts', 'count',
+                                       'boxes', 'labels'), got, want[k]):
+                    if name in ('rois', 'perm', 'level'):
+                        a, b = a[:cnt], b[:cnt]
+                    assert torch.equal(a, b), (k, name, stages)
+        # a single image through the same pool (launch sequence of its own) still works
+        pool.submit(4)
+        pool.wait(); torch.cuda.synchronize()
+        assert torch.equal(pool.slots[4].record, want[4][0])
+    finally:
+        pool.close()
+
+
 def test_roi_pool_timed_events():
     rng = np.random.default_rng(3)
     feat = _feat((40, 60), 64, rng)

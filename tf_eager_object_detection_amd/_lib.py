@@ -95,9 +95,11 @@ SIGNATURES = {
     'odet_pack_detections': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'odet_fpn_step_sizeof': (_sz, []),
     'odet_fpn_step_enqueue': (_i, [_vp, _i]),
+    'odet_fpn_step_enqueue_batch': (_i, [_vp, _i, _i]),
     'odet_exec_create': (_vp, [_i]),
     'odet_exec_destroy': (None, [_vp]),
     'odet_exec_submit': (_i, [_vp, _i, _vp, _i]),
+    'odet_exec_submit_batch': (_i, [_vp, _i, _vp, _i, _i]),
     'odet_exec_wait': (_i, [_vp]),
     'odet_exec_last_error': (C.c_char_p, [_vp]),
 }

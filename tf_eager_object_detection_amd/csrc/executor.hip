@@ -46,7 +46,76 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
   return rc;
 }
 
-struct Job { const odet_fpn_step_t* step; int stages; };
+// Several images whose steps share every shape and parameter, in the SAME launches (blockIdx.y =
+// image): the per-launch costs (host ~3 us, command processor, kernel-boundary cache maintenance) are
+// paid once per batch and the single-workgroup stages of the images run side by side.
+static bool same_config(const odet_fpn_step_t* a, const odet_fpn_step_t* b) {
+  if (a->image_h != b->image_h || a->image_w != b->image_w || a->num_levels != b->num_levels || a->A != b->A) return false;
+  for (int l = 0; l < a->num_levels; ++l)
+    if (a->fh[l] != b->fh[l] || a->fw[l] != b->fw[l] || a->stride[l] != b->stride[l]) return false;
+  for (int i = 0; i < a->num_levels * a->A * 2; ++i) if (a->wh[i] != b->wh[i]) return false;
+  for (int k = 0; k < 4; ++k)
+    if (a->rpn_means[k] != b->rpn_means[k] || a->rpn_stds[k] != b->rpn_stds[k] || a->roi_means[k] != b->roi_means[k] ||
+        a->roi_stds[k] != b->roi_stds[k]) return false;
+  return a->num_proposals == b->num_proposals && a->rpn_nms_iou == b->rpn_nms_iou && a->min_level == b->min_level &&
+         a->max_level == b->max_level && a->blind_chunks == b->blind_chunks && a->num_maps == b->num_maps &&
+         a->channels == b->channels && a->pool_size == b->pool_size && a->ccls == b->ccls &&
+         a->num_classes == b->num_classes && a->max_per_class == b->max_per_class &&
+         a->max_per_image == b->max_per_image && a->nms_iou == b->nms_iou &&
+         a->score_threshold == b->score_threshold && a->min_edge == b->min_edge && a->stream == b->stream;
+}
+
+extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, int count, int stages) {
+  ODET_REQUIRE(steps && count >= 1 && count <= ODET_MAX_BATCH, "odet_fpn_step_enqueue_batch: bad batch");
+  const odet_fpn_step_t* s = steps[0];
+  ODET_REQUIRE(s, "odet_fpn_step_enqueue_batch: null step");
+  if (count == 1) return odet_fpn_step_enqueue(s, stages);
+  for (int i = 1; i < count; ++i) {
+    ODET_REQUIRE(steps[i], "odet_fpn_step_enqueue_batch: null step");
+    ODET_REQUIRE(same_config(s, steps[i]), "odet_fpn_step_enqueue_batch: step %d differs in shape / parameters / stream", i);
+  }
+  hipStream_t st = (hipStream_t)s->stream;
+  int rc = ODET_OK;
+  if (stages & ODET_STAGE_PROPOSALS) {
+    int fh[ODET_MAX_LEVELS], fw[ODET_MAX_LEVELS], sd[ODET_MAX_LEVELS];
+    for (int l = 0; l < ODET_MAX_LEVELS; ++l) { fh[l] = s->fh[l]; fw[l] = s->fw[l]; sd[l] = s->stride[l]; }
+    FpnProposalIO io[ODET_MAX_BATCH];
+    for (int i = 0; i < count; ++i) {
+      const odet_fpn_step_t* t = steps[i];
+      io[i] = FpnProposalIO{t->rpn_logits, t->rpn_deltas, t->rois, t->roi_idx, t->roi_count, t->sorted_rois,
+                            t->roi_level, t->roi_perm, t->level_counts, t->nms_done, t->ws_rpn, t->ws_rpn_bytes};
+    }
+    rc = odet_fpn_proposals_batch(io, count, s->num_levels, s->A, fh, fw, sd, s->wh, s->image_h, s->image_w,
+                                  s->rpn_means, s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level,
+                                  s->max_level, s->blind_chunks, st);
+    if (rc != ODET_OK) return rc;
+  }
+  if (stages & ODET_STAGE_ROI) {
+    RoiImageIO io[ODET_MAX_BATCH];
+    for (int i = 0; i < count; ++i) {
+      const odet_fpn_step_t* t = steps[i];
+      io[i] = RoiImageIO{t->maps, t->sorted_rois, t->roi_level, t->roi_count, t->roi_features};
+    }
+    rc = odet_roi_pool_batch(io, count, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
+                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, st, RoiEvents{nullptr, nullptr});
+    if (rc != ODET_OK) return rc;
+  }
+  if (stages & ODET_STAGE_DETECT) {
+    PostOpsImageIO io[ODET_MAX_BATCH];
+    for (int i = 0; i < count; ++i) {
+      const odet_fpn_step_t* t = steps[i];
+      io[i] = PostOpsImageIO{t->cls_scores, t->cls_deltas, t->sorted_rois, t->roi_count, t->det_boxes, t->det_labels,
+                             t->det_scores, t->det_count, t->record, t->ws_post, t->ws_post_bytes};
+    }
+    rc = odet_post_ops_batch(io, count, s->num_proposals, s->ccls, s->num_classes,
+                             PostOpsExtra{(float)(s->image_w - 1), (float)(s->image_h - 1), 1.0f, 0}, s->roi_means,
+                             s->roi_stds, s->max_per_class, s->max_per_image, s->nms_iou, s->score_threshold,
+                             s->min_edge, st);
+  }
+  return rc;
+}
+
+struct Job { const odet_fpn_step_t* steps[ODET_MAX_BATCH]; int count; int stages; };
 
 struct Worker {
   std::thread th;
@@ -77,7 +146,7 @@ static void worker_main(odet_exec* ex, Worker* w) {
       job = w->q.front();
       w->q.pop_front();
     }
-    const int rc = odet_fpn_step_enqueue(job.step, job.stages);
+    const int rc = odet_fpn_step_enqueue_batch(job.steps, job.count, job.stages);
     {
       std::lock_guard<std::mutex> lk(ex->done_mu);
       if (rc != ODET_OK && ex->first_error == 0) {
@@ -117,14 +186,25 @@ extern "C" void odet_exec_destroy(odet_exec_t* ex) {
   delete ex;
 }
 
-extern "C" int odet_exec_submit(odet_exec_t* ex, int worker, const odet_fpn_step_t* step, int stages) {
-  ODET_REQUIRE(ex && step, "odet_exec_submit: null pointer");
+extern "C" int odet_exec_submit_batch(odet_exec_t* ex, int worker, const odet_fpn_step_t* const* steps, int count,
+                                      int stages) {
+  ODET_REQUIRE(ex && steps, "odet_exec_submit: null pointer");
+  ODET_REQUIRE(count >= 1 && count <= ODET_MAX_BATCH, "odet_exec_submit: batch %d out of range", count);
   ODET_REQUIRE(worker >= 0 && worker < (int)ex->workers.size(), "odet_exec_submit: worker %d out of range", worker);
+  Job job;
+  for (int i = 0; i < ODET_MAX_BATCH; ++i) job.steps[i] = (i < count) ? steps[i] : nullptr;
+  for (int i = 0; i < count; ++i) ODET_REQUIRE(steps[i], "odet_exec_submit: null step");
+  job.count = count;
+  job.stages = stages;
   { std::lock_guard<std::mutex> lk(ex->done_mu); ++ex->pending; }
   Worker* w = ex->workers[worker];
-  { std::lock_guard<std::mutex> lk(w->mu); w->q.push_back(Job{step, stages}); }
+  { std::lock_guard<std::mutex> lk(w->mu); w->q.push_back(job); }
   w->cv.notify_one();
   return ODET_OK;
+}
+
+extern "C" int odet_exec_submit(odet_exec_t* ex, int worker, const odet_fpn_step_t* step, int stages) {
+  return odet_exec_submit_batch(ex, worker, &step, 1, stages);
 }
 
 extern "C" int odet_exec_wait(odet_exec_t* ex) {

@@ -1165,13 +1165,6 @@ extern "C" size_t odet_fpn_proposals_workspace_bytes(int n, int max_output) {
   return rp_workspace_bytes(n, max_output);
 }
 
-struct FpnProposalIO {      // per-image arguments of the FPN proposal stage
-  const float* rpn_logits; const float* rpn_deltas;
-  float* out_rois; int32_t* out_idx; int32_t* out_count;
-  float* out_sorted_rois; int32_t* out_level; int64_t* out_perm; int32_t* out_level_counts;
-  int32_t* out_done; void* workspace; size_t workspace_bytes;
-};
-
 // shared by odet_fpn_proposals (B = 1) and odet_fpn_step_enqueue_batch (B images in the same launches)
 int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int A, const int* fh, const int* fw,
                              const int* stride, const float* wh, int image_h, int image_w, const float* means,

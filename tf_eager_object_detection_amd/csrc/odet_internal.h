@@ -267,6 +267,35 @@ __device__ __forceinline__ void d_assign_levels_block(const float4* rois, int cn
 
 struct Float4Host { float v[4]; };
 
+// ---- batched internals shared between translation units (executor.hip drives them) -----------
+struct FpnProposalIO {      // per-image arguments of the FPN proposal stage
+  const float* rpn_logits; const float* rpn_deltas;
+  float* out_rois; int32_t* out_idx; int32_t* out_count;
+  float* out_sorted_rois; int32_t* out_level; int64_t* out_perm; int32_t* out_level_counts;
+  int32_t* out_done; void* workspace; size_t workspace_bytes;
+};
+int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int A, const int* fh, const int* fw,
+                             const int* stride, const float* wh, int image_h, int image_w, const float* means,
+                             const float* stds, int max_output, float iou_threshold, int min_level, int max_level,
+                             int blind_chunks, hipStream_t st);
+
+struct RoiEvents { hipEvent_t start, stop; };   // optional: timestamps of the dispatch itself
+struct RoiImageIO {         // per-image arguments
+  const odet_level_t* levels; const float* rois; const int32_t* roi_level; const int32_t* count_dev; float* out;
+};
+int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int n, int norm_mode, int image_h,
+                        int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev);
+
+struct PostOpsExtra { float wmax, hmax, roi_div; int mode; };
+struct PostOpsImageIO {     // per-image arguments
+  const float* scores; const float* deltas; const float* rois; const int32_t* count_dev;
+  float* out_boxes; int32_t* out_labels; float* out_scores; int32_t* out_count; float* out_record;
+  void* workspace; size_t workspace_bytes;
+};
+int odet_post_ops_batch(const PostOpsImageIO* io, int B, int R, int Ccls, int num_classes, PostOpsExtra ex,
+                        const float* means, const float* stds, int max_per_class, int max_per_image,
+                        float nms_iou_threshold, float score_threshold, float min_edge, hipStream_t st);
+
 // shared between translation units
 int odet_sort_keys_desc(int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
                         uint32_t* hist, const int32_t* skip, uint32_t** sorted_vals, hipStream_t stream);

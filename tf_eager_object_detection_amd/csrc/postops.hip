@@ -27,19 +27,19 @@
 
 typedef unsigned long long u64;
 
-struct PostOpsParams {
-  const float* scores;   // [R, Ccls]
-  const float* deltas;   // [R, Ccls, 4]
-  const float4* rois;    // [R]
-  const int32_t* count_dev;
+struct PostOpsParams {    // pointer tables: one entry per image of the batch (blockIdx.y)
+  PerImg<const float*> scores_t;     // [R, Ccls]
+  PerImg<const float*> deltas_t;     // [R, Ccls, 4]
+  PerImg<const float4*> rois_t;      // [R]
+  PerImg<const int32_t*> count_dev_t;
   int R, Ccls, P2, K;
   float means[4], stds[4];
   float wmax, hmax, min_edge, score_thr, nms_thr;
   float roi_div;         // rois are divided by this first (im_detect's rois / img_scale); 1 = as they are
   // per-class results
-  int32_t* cls_count;    // [ncls-1]
-  float4* cls_boxes;     // [ncls-1, K]
-  float* cls_scores;     // [ncls-1, K]
+  PerImg<int32_t*> cls_count_t;    // [ncls-1]
+  PerImg<float4*> cls_boxes_t;     // [ncls-1, K]
+  PerImg<float*> cls_scores_t;     // [ncls-1, K]
 };
 
 __device__ __forceinline__ void bitonic_sort_u64(u64* keys, int P2, int nthreads) {
@@ -97,6 +97,14 @@ __device__ __forceinline__ float key_to_score(uint32_t k) {   // inverse of ~d_f
 
 __global__ void __launch_bounds__(PO_THREADS) k_postops_class(PostOpsParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const int img = blockIdx.y;
+  const float* __restrict__ in_scores = p.scores_t.v[img];
+  const float* __restrict__ in_deltas = p.deltas_t.v[img];
+  const float4* __restrict__ in_rois = p.rois_t.v[img];
+  const int32_t* __restrict__ in_count = p.count_dev_t.v[img];
+  int32_t* __restrict__ cls_count = p.cls_count_t.v[img];
+  float4* __restrict__ cls_boxes = p.cls_boxes_t.v[img];
+  float* __restrict__ cls_scores = p.cls_scores_t.v[img];
   // layout: keys [max(P2, 2048)] u64 | lbox [R] float4 | sbox [PO_ROUND] float4 | sarea [PO_ROUND] |
   //         kbox [K] float4 | karea [K] float | mask [PO_ROUND][2] u64 | crossf [PO_ROUND] u32
   const int nkeys = p.P2 > 2048 ? p.P2 : 2048;
@@ -111,7 +119,7 @@ __global__ void __launch_bounds__(PO_THREADS) k_postops_class(PostOpsParams p) {
   __shared__ int s_nvalid, s_nk;
 
   const int c = blockIdx.x + 1;   // class id, prediction.py:135
-  const int R = p.count_dev ? min(*p.count_dev, p.R) : p.R;
+  const int R = in_count ? min(*in_count, p.R) : p.R;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) { s_nvalid = 0; s_nk = 0; }
   __syncthreads();
@@ -121,14 +129,14 @@ __global__ void __launch_bounds__(PO_THREADS) k_postops_class(PostOpsParams p) {
   for (int r = tid; r < p.P2; r += PO_THREADS) {
     u64 key = ~0ull;
     if (r < R) {
-      float s = p.scores[(size_t)r * p.Ccls + c];
+      float s = in_scores[(size_t)r * p.Ccls + c];
       if (s > p.score_thr) {                                                   // :136
-        const float* t = p.deltas + ((size_t)r * p.Ccls + c) * 4;
+        const float* t = in_deltas + ((size_t)r * p.Ccls + c) * 4;
         float d0 = t[0] * p.stds[0] + p.means[0];
         float d1 = t[1] * p.stds[1] + p.means[1];
         float d2 = t[2] * p.stds[2] + p.means[2];
         float d3 = t[3] * p.stds[3] + p.means[3];
-        float4 roi = p.rois[r];
+        float4 roi = in_rois[r];
         if (p.roi_div != 1.0f) {                    // base_fpn_model.py:390 / base_faster_rcnn_model.py:306
           roi.x = roi.x / p.roi_div; roi.y = roi.y / p.roi_div; roi.z = roi.z / p.roi_div; roi.w = roi.w / p.roi_div;
         }
@@ -228,32 +236,44 @@ __global__ void __launch_bounds__(PO_THREADS) k_postops_class(PostOpsParams p) {
           const float4 ob = lbox[(int)(kk & 0xFFFFFFFFull)];
           kbox[slot] = sbox[row];
           karea[slot] = sarea[row];
-          p.cls_boxes[(size_t)blockIdx.x * K + slot] = ob;
-          p.cls_scores[(size_t)blockIdx.x * K + slot] = key_to_score((uint32_t)(kk >> 32));
+          cls_boxes[(size_t)blockIdx.x * K + slot] = ob;
+          cls_scores[(size_t)blockIdx.x * K + slot] = key_to_score((uint32_t)(kk >> 32));
         }
       }
       if (lane == 0) s_nk = nk;
     }
     __syncthreads();
   }
-  if (tid == 0) p.cls_count[blockIdx.x] = s_nk;
+  if (tid == 0) cls_count[blockIdx.x] = s_nk;
 }
 
-struct MergeParams {
-  const int32_t* cls_count;
-  const float4* cls_boxes;
-  const float* cls_scores;
+struct MergeParams {      // pointer tables: one entry per image of the batch (blockIdx.y)
+  PerImg<const int32_t*> cls_count_t;
+  PerImg<const float4*> cls_boxes_t;
+  PerImg<const float*> cls_scores_t;
   int ncls1, K, P2, max_per_image;
   int mode;              // 0: prediction.py top-k (score order); 1: eval loop score-threshold cap (class order)
-  float4* out_boxes;
-  int32_t* out_labels;
-  float* out_scores;
-  int32_t* out_count;
-  float* out_record;     // nullable: [max_per_image*6 + 1]
+  PerImg<float4*> out_boxes_t;
+  PerImg<int32_t*> out_labels_t;
+  PerImg<float*> out_scores_t;
+  PerImg<int32_t*> out_count_t;
+  PerImg<float*> out_record_t;     // nullable: [max_per_image*6 + 1]
 };
 
-__global__ void __launch_bounds__(1024) k_postops_merge(MergeParams p) {
+struct MergeView {        // one image's pointers, same field names as before
+  const int32_t* cls_count; const float4* cls_boxes; const float* cls_scores;
+  int ncls1, K, P2, max_per_image, mode;
+  float4* out_boxes; int32_t* out_labels; float* out_scores; int32_t* out_count; float* out_record;
+};
+
+__global__ void __launch_bounds__(1024) k_postops_merge(MergeParams mp) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const int img = blockIdx.y;
+  MergeView p;
+  p.cls_count = mp.cls_count_t.v[img]; p.cls_boxes = mp.cls_boxes_t.v[img]; p.cls_scores = mp.cls_scores_t.v[img];
+  p.ncls1 = mp.ncls1; p.K = mp.K; p.P2 = mp.P2; p.max_per_image = mp.max_per_image; p.mode = mp.mode;
+  p.out_boxes = mp.out_boxes_t.v[img]; p.out_labels = mp.out_labels_t.v[img]; p.out_scores = mp.out_scores_t.v[img];
+  p.out_count = mp.out_count_t.v[img]; p.out_record = mp.out_record_t.v[img];
   const int nkeys = p.P2 > 2048 ? p.P2 : 2048;
   u64* keys = reinterpret_cast<u64*>(smem);                  // [max(P2, 2048)]
   uint32_t* src = reinterpret_cast<uint32_t*>(keys + nkeys);  // [P2] slot of position p
@@ -371,47 +391,57 @@ extern "C" size_t odet_post_ops_workspace_bytes(int num_classes, int max_per_cla
   return odet_align_up(n1 * 4, 256) + odet_align_up(n1 * k * 16, 256) + odet_align_up(n1 * k * 4, 256) + 1024;
 }
 
-struct PostOpsExtra { float wmax, hmax, roi_div; int mode; };
-
-static int post_ops_impl(const float* scores, const float* deltas, const float* rois, int R,
-                         const int32_t* count_dev, int Ccls, int num_classes, PostOpsExtra ex,
-                         const float* means, const float* stds, int max_per_class, int max_per_image,
-                         float nms_iou_threshold, float score_threshold, float min_edge, float* out_boxes,
-                         int32_t* out_labels, float* out_scores, int32_t* out_count, float* out_record,
-                         void* workspace, size_t workspace_bytes, hipStream_t st) {
-  ODET_REQUIRE(out_count, "odet_post_ops: null out_count");
+// B images in the same two launches (blockIdx.y = image); shapes and parameters are common
+int odet_post_ops_batch(const PostOpsImageIO* io, int B, int R, int Ccls, int num_classes, PostOpsExtra ex,
+                        const float* means, const float* stds, int max_per_class, int max_per_image,
+                        float nms_iou_threshold, float score_threshold, float min_edge, hipStream_t st) {
+  ODET_REQUIRE(io && B >= 1 && B <= ODET_MAX_BATCH, "odet_post_ops: bad batch");
   ODET_REQUIRE(R >= 0 && Ccls > 0 && num_classes >= 1 && num_classes <= Ccls, "odet_post_ops: bad sizes");
   ODET_REQUIRE(max_per_class >= 0 && max_per_image >= 0, "odet_post_ops: negative cap");
+  for (int i = 0; i < B; ++i) ODET_REQUIRE(io[i].out_count, "odet_post_ops: null out_count");
   if (R == 0 || num_classes == 1 || max_per_class == 0 || (max_per_image == 0 && ex.mode == 0)) {
-    ODET_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), st));
-    if (out_record && max_per_image > 0) {
-      // empty record: pad rows (score -1) are produced by the pack kernel of an empty result
-      return odet_pack_detections(out_boxes, out_labels, out_scores, out_count, 0, max_per_image, out_record,
-                                  (odet_stream_t)st);
+    for (int i = 0; i < B; ++i) {
+      ODET_HIP(hipMemsetAsync(io[i].out_count, 0, sizeof(int32_t), st));
+      if (io[i].out_record && max_per_image > 0) {
+        // empty record: pad rows (score -1) are produced by the pack kernel of an empty result
+        int rc = odet_pack_detections(io[i].out_boxes, io[i].out_labels, io[i].out_scores, io[i].out_count, 0,
+                                      max_per_image, io[i].out_record, (odet_stream_t)st);
+        if (rc != ODET_OK) return rc;
+      }
     }
     return ODET_OK;
   }
-  ODET_REQUIRE(scores && deltas && rois && means && stds && out_boxes && out_labels && out_scores,
-               "odet_post_ops: null pointer");
+  ODET_REQUIRE(means && stds, "odet_post_ops: null pointer");
   if (R > ODET_POSTOPS_MAX_ROIS)
     return odet_set_error(ODET_E_LIMIT, "odet_post_ops: R %d exceeds %d", R, ODET_POSTOPS_MAX_ROIS);
   const int ncls1 = num_classes - 1;
   if ((int64_t)ncls1 * max_per_class > ODET_POSTOPS_MAX_CANDIDATES)
     return odet_set_error(ODET_E_LIMIT, "odet_post_ops: (num_classes-1)*max_per_class %lld exceeds %d",
                           (long long)ncls1 * max_per_class, ODET_POSTOPS_MAX_CANDIDATES);
-  size_t need = odet_post_ops_workspace_bytes(num_classes, max_per_class);
-  if (!workspace || workspace_bytes < need)
-    return odet_set_error(ODET_E_WORKSPACE, "odet_post_ops: workspace too small (%zu < %zu)", workspace_bytes, need);
-  OdetArena ar{(char*)workspace, workspace_bytes, 0};
+  const size_t need = odet_post_ops_workspace_bytes(num_classes, max_per_class);
   PostOpsParams p;
-  p.scores = scores; p.deltas = deltas; p.rois = (const float4*)rois; p.count_dev = count_dev;
+  MergeParams m;
+  for (int i = 0; i < ODET_MAX_BATCH; ++i) {
+    const PostOpsImageIO& a = io[i < B ? i : 0];
+    ODET_REQUIRE(a.scores && a.deltas && a.rois && a.out_boxes && a.out_labels && a.out_scores,
+                 "odet_post_ops: null pointer");
+    if (!a.workspace || a.workspace_bytes < need)
+      return odet_set_error(ODET_E_WORKSPACE, "odet_post_ops: workspace too small (%zu < %zu)", a.workspace_bytes, need);
+    OdetArena ar{(char*)a.workspace, a.workspace_bytes, 0};
+    int32_t* cc = ar.take<int32_t>(ncls1);
+    float4* cb = ar.take<float4>((size_t)ncls1 * max_per_class);
+    float* cs = ar.take<float>((size_t)ncls1 * max_per_class);
+    p.scores_t.v[i] = a.scores; p.deltas_t.v[i] = a.deltas; p.rois_t.v[i] = (const float4*)a.rois;
+    p.count_dev_t.v[i] = a.count_dev;
+    p.cls_count_t.v[i] = cc; p.cls_boxes_t.v[i] = cb; p.cls_scores_t.v[i] = cs;
+    m.cls_count_t.v[i] = cc; m.cls_boxes_t.v[i] = cb; m.cls_scores_t.v[i] = cs;
+    m.out_boxes_t.v[i] = (float4*)a.out_boxes; m.out_labels_t.v[i] = a.out_labels; m.out_scores_t.v[i] = a.out_scores;
+    m.out_count_t.v[i] = a.out_count; m.out_record_t.v[i] = a.out_record;
+  }
   p.R = R; p.Ccls = Ccls; p.P2 = next_pow2(R < 2 ? 2 : R); p.K = max_per_class;
   for (int k = 0; k < 4; ++k) { p.means[k] = means[k]; p.stds[k] = stds[k]; }
   p.wmax = ex.wmax; p.hmax = ex.hmax; p.roi_div = ex.roi_div;
   p.min_edge = min_edge; p.score_thr = score_threshold; p.nms_thr = nms_iou_threshold;
-  p.cls_count = ar.take<int32_t>(ncls1);
-  p.cls_boxes = ar.take<float4>((size_t)ncls1 * max_per_class);
-  p.cls_scores = ar.take<float>((size_t)ncls1 * max_per_class);
   const size_t nkeys1 = (size_t)(p.P2 > 2048 ? p.P2 : 2048);
   size_t lds1 = nkeys1 * 8 + (size_t)R * 16 + PO_ROUND * 16 + (size_t)max_per_class * 16 + PO_ROUND * 16 +
                 PO_ROUND * 4 + (size_t)max_per_class * 4 + PO_ROUND * 4;
@@ -423,20 +453,29 @@ static int post_ops_impl(const float* scores, const float* deltas, const float* 
     ODET_HIP(hipFuncSetAttribute((const void*)k_postops_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_postops_class, dim3(ncls1), dim3(PO_THREADS), lds1, st, p);
+  hipLaunchKernelGGL(k_postops_class, dim3(ncls1, B), dim3(PO_THREADS), lds1, st, p);
   ODET_LAUNCH_CHECK();
-  MergeParams m;
-  m.cls_count = p.cls_count; m.cls_boxes = p.cls_boxes; m.cls_scores = p.cls_scores;
   m.ncls1 = ncls1; m.K = max_per_class; m.P2 = next_pow2(ncls1 * max_per_class < 2 ? 2 : ncls1 * max_per_class);
   m.max_per_image = max_per_image;
   m.mode = ex.mode;
-  m.out_boxes = (float4*)out_boxes; m.out_labels = out_labels; m.out_scores = out_scores; m.out_count = out_count;
-  m.out_record = out_record;
   const size_t nkeys2 = (size_t)(m.P2 > 2048 ? m.P2 : 2048);
   size_t lds2 = nkeys2 * 8 + (size_t)m.P2 * 4 + (size_t)(ncls1 + 1) * 4;
-  hipLaunchKernelGGL(k_postops_merge, dim3(1), dim3(1024), lds2, st, m);
+  hipLaunchKernelGGL(k_postops_merge, dim3(1, B), dim3(1024), lds2, st, m);
   ODET_LAUNCH_CHECK();
   return ODET_OK;
+}
+
+static int post_ops_impl(const float* scores, const float* deltas, const float* rois, int R,
+                         const int32_t* count_dev, int Ccls, int num_classes, PostOpsExtra ex,
+                         const float* means, const float* stds, int max_per_class, int max_per_image,
+                         float nms_iou_threshold, float score_threshold, float min_edge, float* out_boxes,
+                         int32_t* out_labels, float* out_scores, int32_t* out_count, float* out_record,
+                         void* workspace, size_t workspace_bytes, hipStream_t st) {
+  PostOpsImageIO io{scores, deltas, rois, count_dev, out_boxes, out_labels, out_scores, out_count, out_record,
+                    workspace, workspace_bytes};
+  ODET_REQUIRE(out_count, "odet_post_ops: null out_count");
+  return odet_post_ops_batch(&io, 1, R, Ccls, num_classes, ex, means, stds, max_per_class, max_per_image,
+                             nms_iou_threshold, score_threshold, min_edge, st);
 }
 
 extern "C" int odet_post_ops(const float* scores, const float* deltas, const float* rois, int R,

@@ -33,7 +33,11 @@
 #define ROI_LDS_BYTES (40 * 1024)   // staged tile budget: 4 workgroups per CU
 
 struct RoiParams {
-  const float* data[ODET_MAX_LEVELS];
+  const float* data[ODET_MAX_BATCH][ODET_MAX_LEVELS];   // [image of the batch][pyramid level]
+  PerImg<const float4*> rois;
+  PerImg<const int32_t*> roi_level;
+  PerImg<const int32_t*> count_dev;
+  PerImg<float*> out;
   int H[ODET_MAX_LEVELS];
   int W[ODET_MAX_LEVELS];
   float stride[ODET_MAX_LEVELS];
@@ -265,10 +269,13 @@ __device__ __forceinline__ void roi_row_bins(const float* base, int rs, int r0, 
 
 // NORM: ODET_ROI_NORM_*; STAGE: allow the LDS-staged tile path.
 template <int POOL, int NORM, bool STAGE>
-__global__ void __launch_bounds__(256) k_roi_pool(RoiParams p, const float4* __restrict__ rois,
-                                                  const int32_t* __restrict__ roi_level,
-                                                  const int32_t* __restrict__ count_dev, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_roi_pool(RoiParams p) {
   extern __shared__ __align__(16) float tile[];
+  const int img = blockIdx.y;
+  const float4* __restrict__ rois = p.rois.v[img];
+  const int32_t* __restrict__ roi_level = p.roi_level.v[img];
+  const int32_t* __restrict__ count_dev = p.count_dev.v[img];
+  float* __restrict__ out = p.out.v[img];
   constexpr bool PAD = (NORM == ODET_ROI_NORM_TP_ALIGN);
   // XCD-aware remap: hardware deals workgroups round-robin over the 8 XCDs
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -288,7 +295,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p, const float4* __r
   }
 
   const int lvl = roi_level ? min(max(roi_level[r], 0), p.num_levels - 1) : 0;
-  const float* __restrict__ feat = p.data[lvl];
+  const float* __restrict__ feat = p.data[img][lvl];
   const int H = p.H[lvl], W = p.W[lvl];
   const float4 roi = rois[r];
   constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
@@ -397,49 +404,56 @@ static bool roi_stage_enabled() {
   return v != 0;
 }
 
-struct RoiEvents { hipEvent_t start, stop; };   // optional: timestamps of the dispatch itself
 
 template <int POOL, int NORM>
-static void roi_launch(dim3 grid, hipStream_t st, const RoiParams& p, const float* rois, const int32_t* roi_level,
-                       const int32_t* count_dev, float* out, RoiEvents ev) {
+static void roi_launch(dim3 grid, hipStream_t st, const RoiParams& p, RoiEvents ev) {
   if (NORM != ODET_ROI_NORM_TP_ALIGN && roi_stage_enabled())
     hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true>), grid, dim3(256), ROI_LDS_BYTES, st, ev.start,
-                          ev.stop, 0, p, (const float4*)rois, roi_level, count_dev, out);
+                          ev.stop, 0, p);
   else
     hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false>), grid, dim3(256), 0, st, ev.start, ev.stop, 0,
-                          p, (const float4*)rois, roi_level, count_dev, out);
+                          p);
 }
 
 template <int POOL>
-static void roi_launch_norm(int norm_mode, dim3 grid, hipStream_t st, const RoiParams& p, const float* rois,
-                            const int32_t* roi_level, const int32_t* count_dev, float* out, RoiEvents ev) {
+static void roi_launch_norm(int norm_mode, dim3 grid, hipStream_t st, const RoiParams& p, RoiEvents ev) {
   switch (norm_mode) {
-    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
-    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
-    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
-    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, st, p, rois, roi_level, count_dev, out, ev); break;
+    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, st, p, ev); break;
+    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, st, p, ev); break;
+    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, st, p, ev); break;
+    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, st, p, ev); break;
   }
 }
 
-static int roi_pool_impl(const odet_level_t* levels, int num_levels, int C, const float* rois,
-                         const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode, int image_h,
-                         int image_w, int pool_size, int pool_mode, float* out, odet_stream_t stream, RoiEvents ev) {
+// B images in one launch (blockIdx.y = image); all images share shapes and parameters
+int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int n, int norm_mode, int image_h,
+                        int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev) {
   ODET_REQUIRE(n >= 0, "odet_roi_pool: negative n");
   if (n == 0) return ODET_OK;
-  ODET_REQUIRE(levels && rois && out, "odet_roi_pool: null pointer");
+  ODET_REQUIRE(io && B >= 1 && B <= ODET_MAX_BATCH, "odet_roi_pool: bad batch");
   ODET_REQUIRE(num_levels > 0 && num_levels <= ODET_MAX_LEVELS, "odet_roi_pool: num_levels %d out of range", num_levels);
   ODET_REQUIRE(C > 0 && (C & 3) == 0, "odet_roi_pool: C must be a positive multiple of 4 (got %d)", C);
   ODET_REQUIRE(pool_size > 0 && pool_size <= 64, "odet_roi_pool: pool_size out of range");
   ODET_REQUIRE(norm_mode >= 0 && norm_mode <= 3, "odet_roi_pool: unknown norm_mode %d", norm_mode);
   ODET_REQUIRE(pool_mode >= 0 && pool_mode <= 2, "odet_roi_pool: unknown pool_mode %d", pool_mode);
-  ODET_REQUIRE(num_levels == 1 || roi_level, "odet_roi_pool: roi_level required with several levels");
   if (norm_mode == ODET_ROI_NORM_IMAGE) ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_roi_pool: bad image shape");
   RoiParams p;
-  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
-    const odet_level_t* L = &levels[l < num_levels ? l : 0];
-    ODET_REQUIRE(L->data && L->H > 0 && L->W > 0, "odet_roi_pool: bad level %d", l);
-    if (norm_mode != ODET_ROI_NORM_IMAGE) ODET_REQUIRE(L->stride > 0.0f, "odet_roi_pool: bad stride on level %d", l);
-    p.data[l] = L->data; p.H[l] = L->H; p.W[l] = L->W; p.stride[l] = L->stride;
+  for (int i = 0; i < ODET_MAX_BATCH; ++i) {
+    const RoiImageIO& a = io[i < B ? i : 0];
+    ODET_REQUIRE(a.levels && a.rois && a.out, "odet_roi_pool: null pointer");
+    ODET_REQUIRE(num_levels == 1 || a.roi_level, "odet_roi_pool: roi_level required with several levels");
+    for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
+      const odet_level_t* L = &a.levels[l < num_levels ? l : 0];
+      ODET_REQUIRE(L->data && L->H > 0 && L->W > 0, "odet_roi_pool: bad level %d", l);
+      if (norm_mode != ODET_ROI_NORM_IMAGE) ODET_REQUIRE(L->stride > 0.0f, "odet_roi_pool: bad stride on level %d", l);
+      if (i > 0 && i < B)
+        ODET_REQUIRE(L->H == p.H[l] && L->W == p.W[l] && L->stride == p.stride[l],
+                     "odet_roi_pool: the images of a batch must share the level shapes");
+      p.data[i][l] = L->data;
+      if (i == 0) { p.H[l] = L->H; p.W[l] = L->W; p.stride[l] = L->stride; }
+    }
+    p.rois.v[i] = (const float4*)a.rois; p.roi_level.v[i] = a.roi_level; p.count_dev.v[i] = a.count_dev;
+    p.out.v[i] = a.out;
   }
   p.num_levels = num_levels;
   p.C = C; p.n = n; p.norm_mode = norm_mode; p.P = pool_size; p.pool_mode = pool_mode;
@@ -448,13 +462,21 @@ static int roi_pool_impl(const odet_level_t* levels, int num_levels, int C, cons
   ODET_REQUIRE(rows < (1ll << 30), "odet_roi_pool: too many output rows");
   p.nblocks = (int)rows;
   p.blocks_per_xcd = (p.nblocks + 7) / 8;
-  dim3 grid(p.blocks_per_xcd * 8);
-  hipStream_t st = (hipStream_t)stream;
-  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, st, p, rois, roi_level, count_dev, out, ev);
-  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out, ev);
-  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, st, p, rois, roi_level, count_dev, out, ev);
+  dim3 grid(p.blocks_per_xcd * 8, B);
+  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, st, p, ev);
+  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, st, p, ev);
+  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, st, p, ev);
   ODET_LAUNCH_CHECK();
   return ODET_OK;
+}
+
+static int roi_pool_impl(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                         const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode, int image_h,
+                         int image_w, int pool_size, int pool_mode, float* out, odet_stream_t stream, RoiEvents ev) {
+  RoiImageIO io{levels, rois, roi_level, count_dev, out};
+  if (n > 0) ODET_REQUIRE(levels && rois && out, "odet_roi_pool: null pointer");
+  return odet_roi_pool_batch(&io, 1, num_levels, C, n, norm_mode, image_h, image_w, pool_size, pool_mode,
+                             (hipStream_t)stream, ev);
 }
 
 extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, const float* rois,

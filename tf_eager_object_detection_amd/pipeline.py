@@ -234,16 +234,27 @@ class FpnStreamPool:
     the same stream from Python (a torch op) has to be issued after wait().  A model that runs a dense
     RoI head between the stages uses FpnHotPath directly."""
 
-    def __init__(self, n_streams, image_shape, num_classes=21, num_proposals=1000, channels=256, **kw):
+    def __init__(self, n_streams, image_shape, num_classes=21, num_proposals=1000, channels=256, batch=1, **kw):
         import ctypes as C
-        self.n = int(n_streams)
+        self.n_streams = int(n_streams)
+        self.batch = int(batch)
+        if not 1 <= self.batch <= 8:
+            raise ValueError('batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
+        if self.batch > 1 and kw.get('blind_chunks', 1) != 1:
+            raise ValueError('batched steps need blind_chunks == 1 (the NMS fallback is per image)')
+        self.n = self.n_streams * self.batch            # slots; slot k belongs to group k // batch
         self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
-        self.streams = [torch.cuda.Stream() for _ in range(self.n)]
+        self._group_streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
+        self.streams = [self._group_streams[k // self.batch] for k in range(self.n)]
         self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
+        self._groups = []
+        for g in range(self.n_streams):
+            arr = (C.c_void_p * self.batch)(*[C.addressof(self.steps[g * self.batch + j]) for j in range(self.batch)])
+            self._groups.append(arr)
         self._keep = [None] * self.n
         self._C = C
         self._lib = ops.L.lib()
-        self._exec = self._lib.odet_exec_create(self.n)
+        self._exec = self._lib.odet_exec_create(self.n_streams)
         if not self._exec:
             raise ops.L.OdetError('odet_exec_create failed: %s' % self._lib.odet_last_error().decode())
         self._rr = 0
@@ -297,12 +308,23 @@ class FpnStreamPool:
         self._keep[slot] = tensors
 
     def submit(self, slot=None, stages=7):
-        """Enqueue one image on `slot` (round-robin when None).  Returns the slot used."""
+        """Enqueue one image on `slot` (round-robin when None) as a launch sequence of its own.
+        Returns the slot used."""
         if slot is None:
             slot = self._rr
             self._rr = (self._rr + 1) % self.n
-        ops.L.check(self._lib.odet_exec_submit(self._exec, slot, self._C.byref(self.steps[slot]), int(stages)))
+        ops.L.check(self._lib.odet_exec_submit(self._exec, slot // self.batch, self._C.byref(self.steps[slot]),
+                                               int(stages)))
         return slot
+
+    def submit_group(self, group=None, stages=7):
+        """Enqueue the `batch` images of stream group `group` (round-robin when None) in the SAME kernel
+        launches (odet_fpn_step_enqueue_batch).  Returns the group used."""
+        if group is None:
+            group = self._rr % self.n_streams
+            self._rr = (self._rr + 1) % self.n_streams
+        ops.L.check(self._lib.odet_exec_submit_batch(self._exec, group, self._groups[group], self.batch, int(stages)))
+        return group
 
     def wait(self):
         rc = self._lib.odet_exec_wait(self._exec)

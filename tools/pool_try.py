@@ -7,21 +7,18 @@ ref.step(dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], 
 torch.cuda.synchronize()
 want = ref.record.clone()
 wantf = ref.roi_features.clone()
-for S in (2, 3, 4, 6, 8):
-    pool = FpnStreamPool(S, (800, 1333), 21, 1000, 256)
-    for k in range(S):
+for S, B in ((8, 1), (1, 8), (2, 8), (3, 8), (2, 4), (4, 4), (4, 2)):
+    pool = FpnStreamPool(S, (800, 1333), 21, 1000, 256, batch=B)
+    for k in range(pool.n):
         pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
-    for i in range(4 * S): pool.submit()
+    for i in range(4 * S): pool.submit_group()
     pool.wait(); torch.cuda.synchronize()
-    N = 800
+    N = 200
     t0 = time.perf_counter()
-    for i in range(N): pool.submit()
-    t1 = time.perf_counter()
+    for i in range(N): pool.submit_group()
     pool.wait()
-    t2 = time.perf_counter()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ok = all(torch.equal(h.record, want) and torch.equal(h.roi_features, wantf) and int(h.nms_done.item()) == 1 for h in pool.slots)
-    print('pool streams %d: %.1f us/image, %.0f img/s (submit %.1f us, enqueued after %.1f us/img) identical=%s'
-          % (S, dt / N * 1e6, N / dt, (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6, ok))
+    print('streams %d x batch %d: %.1f us/image, %.0f img/s identical=%s' % (S, B, dt / (N * B) * 1e6, N * B / dt, ok))
     pool.close()
