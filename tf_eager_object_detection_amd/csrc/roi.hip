@@ -26,6 +26,8 @@
 // holds one neighbourhood of one pyramid level.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <hip/hip_ext.h>
 
 #include "odet_internal.h"
@@ -45,6 +47,9 @@ struct RoiParams {
   float image_h, image_w;
   int nblocks;        // logical workgroups (before padding the grid to a multiple of 8)
   int blocks_per_xcd;
+  int rows_per_wg;    // output rows of one RoI per workgroup
+  int groups_per_roi; // ceil(P / rows_per_wg)
+  int use_desc;       // whole-RoI descriptor form (roi_bins_desc)
 };
 
 struct Axis {
@@ -141,9 +146,25 @@ __device__ __forceinline__ float4 roi_bin_shared(const float* base, uint32_t C, 
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
 #pragma unroll
-    for (int j = 0; j < NC; ++j)
+    for (int j = 0; j < NC; ++j) {
+#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 1   /* diagnostic: no loads */
+      blk[i][j] = make_float4((float)(rowoff[i] + col[j]), xw[0], yw[0], (float)c);
+#else
       blk[i][j] = *reinterpret_cast<const float4*>(base + (rowoff[i] + col[j]) * C + c);
+#endif
+    }
   }
+#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 2     /* diagnostic: loads, no lerp arithmetic */
+  {
+    float4 acc = blk[0][0];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+      for (int j = 0; j < NC; ++j) acc.x = fmaxf(acc.x, blk[i][j].y + blk[i][j].z + blk[i][j].w + blk[i][j].x);
+    }
+    return acc;
+  }
+#endif
   float4 v[2][2];
 #pragma unroll
   for (int sy = 0; sy < 2; ++sy) {
@@ -159,61 +180,67 @@ __device__ __forceinline__ float4 roi_bin_shared(const float* base, uint32_t C, 
   return pool4<POOL>(v);
 }
 
-// Bins w, w+4, ... of the row (w = wave).  The x taps of ALL sample columns were computed once, one
-// per lane (txl: lane i = sample column i); a bin fetches its S columns with v_readlane.  A tap
-// (row y, col x) lives at float offset ((y - r0) * rs + (x - c0)) * C + c from `base` -- the feature
-// map itself (r0 = c0 = 0, rs = W) or the LDS tile.
+// Bins w, w+4, ... of `nrows` consecutive output rows starting at row0 (w = wave).  The taps of ALL
+// sample rows / columns were computed once, one per lane (tyl / txl: lane i = sample i); a bin fetches
+// its S x S taps with v_readlane.  A tap (row y, col x) lives at float offset
+// ((y - r0) * rs + (x - c0)) * C + c from `base` -- the feature map itself (r0 = c0 = 0, rs = W) or
+// the LDS tile.
 template <int POOL, bool PAD, bool LANE_TAPS>
-__device__ __forceinline__ void roi_row_bins(const float* base, int rs, int r0, int c0, int C, int P, int crop,
-                                             int Wdim, const Axis& ax, const Tap& txl, const Tap (&ty)[2],
-                                             float* __restrict__ orow) {
+__device__ __forceinline__ void roi_bins(const float* base, int rs, int r0, int c0, int C, int P, int crop,
+                                         int Hdim, int Wdim, const Axis& ay, const Axis& ax, const Tap& tyl,
+                                         const Tap& txl, int row0, int nrows, float* __restrict__ orow0) {
   constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int txok = txl.ok ? 1 : 0;
-  // row offsets (in cells) of the S sample rows, wave-uniform
-  int rowlo[2], rowhi[2];
+  const int txok = txl.ok ? 1 : 0, tyok = tyl.ok ? 1 : 0;
+#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 4        /* diagnostic: prologue only */
+  const int nbins = (tyl.lerp == 1.2345e30f) ? nrows * P : 0;
+#else
+  const int nbins = nrows * P;
+#endif
+  for (int b = w; b < nbins; b += 4) {
+    const int pr = b / P;
+    const int px = b - pr * P;
+    const int py = row0 + pr;
+    Tap tx[2], ty[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) { rowlo[s] = (ty[s].lo - r0) * rs; rowhi[s] = (ty[s].hi - r0) * rs; }
-  // register-sharing class of the row pair (S == 2, un-padded): 0 / 1 = rows shared, 2 = general
-  int dy = 2;
-  if (S == 2 && !PAD && ty[0].ok && ty[1].ok) {
-    const int d = ty[1].lo - ty[0].lo;
-    if (ty[0].hi == ty[0].lo + 1 && ty[1].hi == ty[1].lo + 1 && (d == 0 || d == 1)) dy = d;
-  }
-  const bool rows_ok = (S == 2) && !PAD && ty[0].ok && ty[1].ok;
-  uint32_t rowoff[4];
-  if (dy == 2) {
-    rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = (uint32_t)rowhi[0];
-    rowoff[2] = (uint32_t)rowlo[1]; rowoff[3] = (uint32_t)rowhi[1];
-  } else {
-    rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = rowoff[0] + (uint32_t)rs;
-    rowoff[2] = rowoff[1] + (uint32_t)rs; rowoff[3] = rowoff[2];
-  }
-  const float yw[2] = {ty[0].lerp, ty[1].lerp};
-  for (int px = w; px < P; px += 4) {
-    Tap tx[2];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < 2; ++s) {
+      const int xx = px * S + (s < S ? s : 0), yy = py * S + (s < S ? s : 0);
       if (LANE_TAPS) {
-        const int xx = px * S + s;
-        tx[s].ok = rl_i(txok, xx) != 0;
-        tx[s].lo = rl_i(txl.lo, xx);
-        tx[s].hi = rl_i(txl.hi, xx);
+        tx[s].ok = rl_i(txok, xx) != 0; tx[s].lo = rl_i(txl.lo, xx); tx[s].hi = rl_i(txl.hi, xx);
         tx[s].lerp = rl_f(txl.lerp, xx);
+        ty[s].ok = rl_i(tyok, yy) != 0; ty[s].lo = rl_i(tyl.lo, yy); ty[s].hi = rl_i(tyl.hi, yy);
+        ty[s].lerp = rl_f(tyl.lerp, yy);
       } else {
-        tx[s] = make_tap<PAD>(ax, px * S + s, crop, Wdim);
+        tx[s] = make_tap<PAD>(ax, xx, crop, Wdim);
+        ty[s] = make_tap<PAD>(ay, yy, crop, Hdim);
+        ty[s].lo = __builtin_amdgcn_readfirstlane(ty[s].lo);
+        ty[s].hi = __builtin_amdgcn_readfirstlane(ty[s].hi);
       }
     }
-    float* __restrict__ obin = orow + (size_t)px * C;
-    if (S == 2 && rows_ok && tx[0].ok && tx[1].ok) {
-      // all four samples inside the map: deduplicated loads
-      int dx = 2;
+    // row offsets (in cells) of the S sample rows, wave-uniform
+    int rowlo[2], rowhi[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { rowlo[s] = (ty[s].lo - r0) * rs; rowhi[s] = (ty[s].hi - r0) * rs; }
+    float* __restrict__ obin = orow0 + ((size_t)pr * P + px) * C;
+    if (S == 2 && !PAD && ty[0].ok && ty[1].ok && tx[0].ok && tx[1].ok) {
+      // all four samples inside the map: deduplicated loads.  Register-sharing class per axis:
+      // 0 / 1 = the two samples share cells, 2 = general
+      int dy = 2, dx = 2;
       {
-        const int d = tx[1].lo - tx[0].lo;
-        if (tx[0].hi == tx[0].lo + 1 && tx[1].hi == tx[1].lo + 1 && (d == 0 || d == 1)) dx = d;
+        const int d = ty[1].lo - ty[0].lo;
+        if (ty[0].hi == ty[0].lo + 1 && ty[1].hi == ty[1].lo + 1 && (d == 0 || d == 1)) dy = d;
+        const int e = tx[1].lo - tx[0].lo;
+        if (tx[0].hi == tx[0].lo + 1 && tx[1].hi == tx[1].lo + 1 && (e == 0 || e == 1)) dx = e;
       }
-      uint32_t col[4];
+      uint32_t rowoff[4], col[4];
+      if (dy == 2) {
+        rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = (uint32_t)rowhi[0];
+        rowoff[2] = (uint32_t)rowlo[1]; rowoff[3] = (uint32_t)rowhi[1];
+      } else {
+        rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = rowoff[0] + (uint32_t)rs;
+        rowoff[2] = rowoff[1] + (uint32_t)rs; rowoff[3] = rowoff[2];
+      }
       if (dx == 2) {
         col[0] = (uint32_t)(tx[0].lo - c0); col[1] = (uint32_t)(tx[0].hi - c0);
         col[2] = (uint32_t)(tx[1].lo - c0); col[3] = (uint32_t)(tx[1].hi - c0);
@@ -221,6 +248,7 @@ __device__ __forceinline__ void roi_row_bins(const float* base, int rs, int r0, 
         col[0] = (uint32_t)(tx[0].lo - c0); col[1] = col[0] + 1; col[2] = col[0] + 2; col[3] = col[2];
       }
       const float xw[2] = {tx[0].lerp, tx[1].lerp};
+      const float yw[2] = {ty[0].lerp, ty[1].lerp};
       const int cls = dy * 3 + dx;
       for (int c = lane * 4; c < C; c += 256) {
         float4 o;
@@ -235,7 +263,11 @@ __device__ __forceinline__ void roi_row_bins(const float* base, int rs, int r0, 
           case 7: o = roi_bin_shared<POOL, 2, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
           default: o = roi_bin_shared<POOL, 2, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
         }
+#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 3      /* diagnostic: no stores */
+        if (o.x == 1.2345e30f) *reinterpret_cast<float4*>(obin + c) = o;
+#else
         *reinterpret_cast<float4*>(obin + c) = o;
+#endif
       }
       continue;
     }
@@ -267,9 +299,99 @@ __device__ __forceinline__ void roi_row_bins(const float* base, int rs, int r0, 
   }
 }
 
+// Whole-RoI form for the pooled modes with P*P <= 64 bins (un-padded): every lane first builds the
+// DESCRIPTOR of one bin -- its four taps, the register-sharing class, the cell offsets of the rows /
+// columns it loads and the lerp weights -- so the per-bin scalar bookkeeping is done once, 64 bins in
+// parallel on the vector unit; a wave then walks its bins (wave, wave + nwaves, ...) and only fetches a
+// descriptor with v_readlane before loading / lerping / storing.
+template <int POOL>
+__device__ __forceinline__ void roi_bins_desc(const float* base, int W, int C, int P, int crop, const Axis& ay,
+                                              const Axis& ax, float* __restrict__ oroi) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int nbins = P * P;
+  // ---- descriptor of bin `lane`
+  const int bpy = lane / P, bpx = lane - bpy * P;
+  const Tap ty0 = make_tap<false>(ay, min(2 * bpy, crop - 1), crop, 0);
+  const Tap ty1 = make_tap<false>(ay, min(2 * bpy + 1, crop - 1), crop, 0);
+  const Tap tx0 = make_tap<false>(ax, min(2 * bpx, crop - 1), crop, 0);
+  const Tap tx1 = make_tap<false>(ax, min(2 * bpx + 1, crop - 1), crop, 0);
+  const int okbits = (ty0.ok ? 1 : 0) | (ty1.ok ? 2 : 0) | (tx0.ok ? 4 : 0) | (tx1.ok ? 8 : 0);
+  int dy = 2, dx = 2;
+  {
+    const int d = ty1.lo - ty0.lo;
+    if (ty0.hi == ty0.lo + 1 && ty1.hi == ty1.lo + 1 && (d == 0 || d == 1)) dy = d;
+    const int e = tx1.lo - tx0.lo;
+    if (tx0.hi == tx0.lo + 1 && tx1.hi == tx1.lo + 1 && (e == 0 || e == 1)) dx = e;
+  }
+  const int cls_l = (okbits == 15) ? dy * 3 + dx : 9;          // 9 = general guarded form
+  int ro0 = ty0.lo * W, ro1 = ty0.hi * W, ro2 = ty1.lo * W, ro3 = ty1.hi * W;
+  int co0 = tx0.lo, co1 = tx0.hi, co2 = tx1.lo, co3 = tx1.hi;
+  if (cls_l != 9) {
+    if (dy != 2) { ro1 = ro0 + W; ro2 = ro1 + W; ro3 = ro2; }
+    if (dx != 2) { co1 = co0 + 1; co2 = co0 + 2; co3 = co2; }
+  }
+  const float xw0 = tx0.lerp, xw1 = tx1.lerp, yw0 = ty0.lerp, yw1 = ty1.lerp;
+
+  for (int b = w; b < nbins; b += nwaves) {
+    const int cls = rl_i(cls_l, b);
+    const uint32_t rowoff[4] = {(uint32_t)rl_i(ro0, b), (uint32_t)rl_i(ro1, b), (uint32_t)rl_i(ro2, b),
+                                (uint32_t)rl_i(ro3, b)};
+    const uint32_t col[4] = {(uint32_t)rl_i(co0, b), (uint32_t)rl_i(co1, b), (uint32_t)rl_i(co2, b),
+                             (uint32_t)rl_i(co3, b)};
+    const float xw[2] = {rl_f(xw0, b), rl_f(xw1, b)};
+    const float yw[2] = {rl_f(yw0, b), rl_f(yw1, b)};
+    float* __restrict__ obin = oroi + (size_t)b * C;
+    if (cls != 9) {
+      for (int c = lane * 4; c < C; c += 256) {
+        float4 o;
+        switch (cls) {
+          case 0: o = roi_bin_shared<POOL, 0, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 1: o = roi_bin_shared<POOL, 0, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 2: o = roi_bin_shared<POOL, 0, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 3: o = roi_bin_shared<POOL, 1, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 4: o = roi_bin_shared<POOL, 1, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 5: o = roi_bin_shared<POOL, 1, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 6: o = roi_bin_shared<POOL, 2, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          case 7: o = roi_bin_shared<POOL, 2, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+          default: o = roi_bin_shared<POOL, 2, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
+        }
+        *reinterpret_cast<float4*>(obin + c) = o;
+      }
+    } else {
+      // general form: every sample guarded (extrapolated samples are 0), 4 taps each
+      const int ok = rl_i(okbits, b);
+      for (int c = lane * 4; c < C; c += 256) {
+        float4 v[2][2];
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy) {
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) {
+            float4 res = make_float4(0, 0, 0, 0);
+            if (((ok >> sy) & 1) && ((ok >> (2 + sx)) & 1)) {
+              const uint32_t otl = (rowoff[2 * sy] + col[2 * sx]) * (uint32_t)C + (uint32_t)c;
+              const uint32_t otr = (rowoff[2 * sy] + col[2 * sx + 1]) * (uint32_t)C + (uint32_t)c;
+              const uint32_t obl = (rowoff[2 * sy + 1] + col[2 * sx]) * (uint32_t)C + (uint32_t)c;
+              const uint32_t obr = (rowoff[2 * sy + 1] + col[2 * sx + 1]) * (uint32_t)C + (uint32_t)c;
+              const float4 tl = *reinterpret_cast<const float4*>(base + otl);
+              const float4 tr = *reinterpret_cast<const float4*>(base + otr);
+              const float4 bl = *reinterpret_cast<const float4*>(base + obl);
+              const float4 br = *reinterpret_cast<const float4*>(base + obr);
+              res = lerp_tap(tl, tr, bl, br, xw[sx], yw[sy]);
+            }
+            v[sy][sx] = res;
+          }
+        }
+        *reinterpret_cast<float4*>(obin + c) = pool4<POOL>(v);
+      }
+    }
+  }
+}
+
 // NORM: ODET_ROI_NORM_*; STAGE: allow the LDS-staged tile path.
 template <int POOL, int NORM, bool STAGE>
-__global__ void __launch_bounds__(256) k_roi_pool(RoiParams p) {
+__global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   extern __shared__ __align__(16) float tile[];
   const int img = blockIdx.y;
   const float4* __restrict__ rois = p.rois.v[img];
@@ -284,20 +406,27 @@ __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int P = p.P, C = p.C;
-  const int r = lb / P;
-  const int py = lb - r * P;
-  float* __restrict__ orow = out + ((size_t)r * P + py) * P * C;
+  const int gpr = p.groups_per_roi;                 // workgroups per RoI (row groups of p.rows_per_wg rows)
+  const int r = lb / gpr;
+  const int row0 = (lb - r * gpr) * p.rows_per_wg;
+  const int nrows = min(p.rows_per_wg, P - row0);
+  float* __restrict__ orow = out + ((size_t)r * P + row0) * P * C;
 
-  const int cnt = count_dev ? min(*count_dev, p.n) : p.n;
+  // the three loads of the prologue are independent (r < n always addresses valid rows): one memory
+  // latency instead of a chain of three
+  const int cnt_raw = count_dev ? *count_dev : p.n;
+  const int lvl_raw = roi_level ? roi_level[r] : 0;
+  const float4 roi = rois[r];
+  const int cnt = min(cnt_raw, p.n);
   if (r >= cnt) {
-    for (int i = threadIdx.x * 4; i < P * C; i += 1024) *reinterpret_cast<float4*>(orow + i) = make_float4(0, 0, 0, 0);
+    for (int i = threadIdx.x * 4; i < nrows * P * C; i += blockDim.x * 4)
+      *reinterpret_cast<float4*>(orow + i) = make_float4(0, 0, 0, 0);
     return;
   }
 
-  const int lvl = roi_level ? min(max(roi_level[r], 0), p.num_levels - 1) : 0;
+  const int lvl = min(max(lvl_raw, 0), p.num_levels - 1);
   const float* __restrict__ feat = p.data[img][lvl];
   const int H = p.H[lvl], W = p.W[lvl];
-  const float4 roi = rois[r];
   constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
   const int crop = P * S;
 
@@ -332,29 +461,28 @@ __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p) {
   const Axis ax = make_axis(x1n, x2n, Ws, crop);
   const int Hdim = PAD ? H : Hs, Wdim = PAD ? W : Ws;
 
-  // the S sample rows of this output row (wave-uniform) and ALL sample columns, one per lane
-  Tap ty[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    ty[s] = make_tap<PAD>(ay, py * S + (s < S ? s : 0), crop, Hdim);
-    // every lane computed the same values: tell the compiler (row offsets then live in SGPRs)
-    ty[s].lo = __builtin_amdgcn_readfirstlane(ty[s].lo);
-    ty[s].hi = __builtin_amdgcn_readfirstlane(ty[s].hi);
-    ty[s].ok = __builtin_amdgcn_readfirstlane(ty[s].ok ? 1 : 0) != 0;
-    ty[s].lerp = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ty[s].lerp)));
+  if (!STAGE && !PAD && S == 2 && p.use_desc) {
+    // whole RoI per workgroup, per-bin descriptors built lane-parallel (P*P <= 64 checked on the host)
+    roi_bins_desc<POOL>(feat, W, C, P, crop, ay, ax, orow);
+    return;
   }
+
+  // ALL sample rows and columns, one per lane
   const bool lane_taps = crop <= 64;
-  Tap txl = make_tap<PAD>(ax, min(lane, crop - 1), crop, Wdim);
+  const Tap txl = make_tap<PAD>(ax, min(lane, crop - 1), crop, Wdim);
+  const Tap tyl = make_tap<PAD>(ay, min(lane, crop - 1), crop, Hdim);
 
   // bounding tile of the cells this row taps; staged when it is small (only for the un-padded modes:
   // the tensorpack modes read through the clamped indices straight from the map)
   bool staged = false;
-  int r0 = 0, c0 = 0, ncols = 0, nrows = 0;
-  if (STAGE && !PAD) {
+  int r0 = 0, c0 = 0, ncols = 0, trows = 0;
+  if (STAGE && !PAD && nrows == 1 && lane_taps) {
     int rmin = 0x7fffffff, rmax = -1;
 #pragma unroll
-    for (int s = 0; s < S; ++s)
-      if (ty[s].ok) { rmin = min(rmin, ty[s].lo); rmax = max(rmax, ty[s].hi); }
+    for (int s = 0; s < S; ++s) {
+      const int yy = row0 * S + s;
+      if (rl_i(tyl.ok ? 1 : 0, yy)) { rmin = min(rmin, rl_i(tyl.lo, yy)); rmax = max(rmax, rl_i(tyl.hi, yy)); }
+    }
     // in-bounds sample columns: coordinates are monotone in the sample index
     int cmin = 0x7fffffff, cmax = -1;
     {
@@ -366,15 +494,15 @@ __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p) {
       if (a <= b) { cmin = (int)floorf(a); cmax = (int)ceilf(b); }
     }
     if (rmax >= 0 && cmax >= 0) {
-      nrows = rmax - rmin + 1;
+      trows = rmax - rmin + 1;
       ncols = cmax - cmin + 1;
       r0 = rmin; c0 = cmin;
-      staged = (size_t)nrows * ncols * C * 4 <= ROI_LDS_BYTES && nrows * ncols < 2 * crop * S;
+      staged = (size_t)trows * ncols * C * 4 <= ROI_LDS_BYTES && trows * ncols < 2 * crop * S;
     }
   }
   if (STAGE && staged) {
     // one coalesced pass: cell = wave-strided, channels = lanes x float4
-    const int cells = nrows * ncols;
+    const int cells = trows * ncols;
     for (int cell = w; cell < cells; cell += 4) {
       const int rr = cell / ncols, cc = cell - rr * ncols;
       const float* src = feat + ((size_t)(r0 + rr) * W + (c0 + cc)) * C;
@@ -383,11 +511,10 @@ __global__ void __launch_bounds__(256) k_roi_pool(RoiParams p) {
         *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
     }
     __syncthreads();
-    if (lane_taps) roi_row_bins<POOL, PAD, true>(tile, ncols, r0, c0, C, P, crop, Wdim, ax, txl, ty, orow);
-    else roi_row_bins<POOL, PAD, false>(tile, ncols, r0, c0, C, P, crop, Wdim, ax, txl, ty, orow);
+    roi_bins<POOL, PAD, true>(tile, ncols, r0, c0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
   } else {
-    if (lane_taps) roi_row_bins<POOL, PAD, true>(feat, W, 0, 0, C, P, crop, Wdim, ax, txl, ty, orow);
-    else roi_row_bins<POOL, PAD, false>(feat, W, 0, 0, C, P, crop, Wdim, ax, txl, ty, orow);
+    if (lane_taps) roi_bins<POOL, PAD, true>(feat, W, 0, 0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
+    else roi_bins<POOL, PAD, false>(feat, W, 0, 0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
   }
 }
 
@@ -406,22 +533,22 @@ static bool roi_stage_enabled() {
 
 
 template <int POOL, int NORM>
-static void roi_launch(dim3 grid, hipStream_t st, const RoiParams& p, RoiEvents ev) {
+static void roi_launch(dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev) {
   if (NORM != ODET_ROI_NORM_TP_ALIGN && roi_stage_enabled())
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true>), grid, dim3(256), ROI_LDS_BYTES, st, ev.start,
-                          ev.stop, 0, p);
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true>), grid, dim3(threads), ROI_LDS_BYTES, st,
+                          ev.start, ev.stop, 0, p);
   else
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false>), grid, dim3(256), 0, st, ev.start, ev.stop, 0,
-                          p);
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false>), grid, dim3(threads), 0, st, ev.start,
+                          ev.stop, 0, p);
 }
 
 template <int POOL>
-static void roi_launch_norm(int norm_mode, dim3 grid, hipStream_t st, const RoiParams& p, RoiEvents ev) {
+static void roi_launch_norm(int norm_mode, dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev) {
   switch (norm_mode) {
-    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, st, p, ev); break;
-    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, st, p, ev); break;
-    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, st, p, ev); break;
-    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, st, p, ev); break;
+    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, threads, st, p, ev); break;
+    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, threads, st, p, ev); break;
+    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, threads, st, p, ev); break;
+    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, threads, st, p, ev); break;
   }
 }
 
@@ -458,14 +585,29 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   p.num_levels = num_levels;
   p.C = C; p.n = n; p.norm_mode = norm_mode; p.P = pool_size; p.pool_mode = pool_mode;
   p.image_h = (float)image_h; p.image_w = (float)image_w;
-  int64_t rows = (int64_t)n * pool_size;
-  ODET_REQUIRE(rows < (1ll << 30), "odet_roi_pool: too many output rows");
+  static int rows_env = -1;
+  if (rows_env < 0) { const char* e = getenv("ODET_ROI_ROWS"); rows_env = e ? atoi(e) : 0; }
+  // one workgroup per RoI by default (the per-workgroup prologue -- three memory latencies of RoI /
+  // level / count loads and the box normalisation -- is paid once per 49 bins); the LDS-staged path
+  // works on single rows
+  p.rows_per_wg = (roi_stage_enabled() && norm_mode != ODET_ROI_NORM_TP_ALIGN) ? 1
+                  : (rows_env > 0 ? std::min(rows_env, pool_size) : pool_size);
+  static int desc_env = -1, threads_env = -1;
+  if (desc_env < 0) { const char* e = getenv("ODET_ROI_DESC"); desc_env = e ? atoi(e) : 1; }
+  if (threads_env < 0) { const char* e = getenv("ODET_ROI_THREADS"); threads_env = e ? atoi(e) : 512; }
+  p.use_desc = (desc_env && !roi_stage_enabled() && pool_mode != ODET_ROI_POOL_NONE &&
+                norm_mode != ODET_ROI_NORM_TP_ALIGN && pool_size * pool_size <= 64) ? 1 : 0;
+  if (p.use_desc) p.rows_per_wg = pool_size;
+  p.groups_per_roi = (pool_size + p.rows_per_wg - 1) / p.rows_per_wg;
+  const int threads = p.use_desc ? ((threads_env == 256 || threads_env == 512) ? threads_env : 512) : 256;
+  int64_t rows = (int64_t)n * p.groups_per_roi;
+  ODET_REQUIRE(rows < (1ll << 30), "odet_roi_pool: too many workgroups");
   p.nblocks = (int)rows;
   p.blocks_per_xcd = (p.nblocks + 7) / 8;
   dim3 grid(p.blocks_per_xcd * 8, B);
-  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, st, p, ev);
-  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, st, p, ev);
-  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, st, p, ev);
+  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, threads, st, p, ev);
+  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, threads, st, p, ev);
+  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, threads, st, p, ev);
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
