@@ -5,17 +5,22 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric "images/sec ResNet-101-FPN @ 800x1333", configs[2]): one image per
-step through region_proposal -> roi_pooling -> prediction (+ anchor generation, fg softmax, level
-assignment) at the ResNet-101-FPN shapes: 267 069 anchors, 1000 proposals, P2..P5 x 256 channels,
-21 classes.  The dense conv parts of the model (backbone, neck, RPN head, RoI head) are NOT part of
-this path: their outputs are the synthetic inputs, resident in HBM before the
-timed region.  One process per GPU; images shard by rank (weak scaling: one image per GPU per step);
-with N > 1 every step ends with one RCCL all-gather of the fixed-size detection records.
+Workload (BASELINE.json metric "images/sec ResNet-101-FPN @ 800x1333", configs[2]): a step = one image
+through region_proposal -> roi_pooling -> prediction (+ anchor generation, fg softmax, level assignment)
+at the ResNet-101-FPN shapes: 267 069 anchors, 1000 proposals, P2..P5 x 256 channels, 21 classes.  The
+dense conv parts of the model (backbone, neck, RPN head, RoI head) are NOT part of this path (SURVEY.md
+section 8): their outputs are the synthetic inputs, resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the
-fused RoI crop+pool kernel, HBM bound) and `cpu_baseline` (the C restatement of the reference path
-timed on this box's host cores; kind "port").
+Serving arrangement: images are independent, so `--streams` HIP streams (each fed by a native enqueue
+thread of the library) carry `--batch` images each whose kernels share their launches (one grid dimension
+= image).  One process per GPU; images shard by rank (weak scaling: the same number of images per GPU per
+step); with N > 1 every round of streams x batch images ends with ONE RCCL all-gather of the fixed-size
+detection records.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the fused
+RoI crop+pool kernel, HBM bound; timed alone, as a one-image launch, with HIP events attached to its
+dispatch on a few steps of the timed region) and `cpu_baseline` (the C restatement of the reference path
+timed on this box's host cores, kind "port"; it also carries the mAP delta of the evaluation loop).
 """
 import argparse
 import json
