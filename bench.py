@@ -192,9 +192,23 @@ def main():
     nslots = pool.n
     rec_len = pool.slots[0].record.numel()
     records = torch.zeros((nslots, rec_len), dtype=torch.float32, device='cuda')
+    # every in-flight image has its OWN inputs in HBM (slot 0 = the seeded numpy set the CPU baseline also
+    # uses; the others: fresh normal feature maps, the RPN / RoI-head outputs of slot 0 row-permuted), so
+    # that no image is served from lines another image pulled into L2 / Infinity Cache
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(4321 + rank)
+    slot_inputs = [dev]
+    for k in range(1, nslots):
+        pa = torch.randperm(dev['rpn_logits'].shape[0], device='cuda', generator=gen)
+        pr = torch.randperm(dev['cls_scores'].shape[0], device='cuda', generator=gen)
+        slot_inputs.append(dict(
+            rpn_logits=dev['rpn_logits'][pa].contiguous(), rpn_deltas=dev['rpn_deltas'][pa].contiguous(),
+            feats=[torch.randn(f.shape, device='cuda', dtype=torch.float32, generator=gen) for f in dev['feats']],
+            cls_scores=dev['cls_scores'][pr].contiguous(), cls_deltas=dev['cls_deltas'][pr].contiguous()))
     for k in range(nslots):
         pool.slots[k].record = records[k]                     # one contiguous block: ONE all-gather per round
-        pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        d = slot_inputs[k]
+        pool.bind(k, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
     hot = pool.slots[0]
     max_det = hot.cfg['max_per_image']
     comm = torch.cuda.Stream()
@@ -233,9 +247,10 @@ def main():
                 mine.wait_stream(st)
         with torch.cuda.stream(mine):
             h = pool.slots[slot]
-            h.stage_proposals(dev['rpn_logits'], dev['rpn_deltas'])
-            h.stage_roi(dev['feats'], events=ev)              # start / stop events of the dispatch itself
-            h.stage_detect(dev['cls_scores'], dev['cls_deltas'])
+            d = slot_inputs[slot]
+            h.stage_proposals(d['rpn_logits'], d['rpn_deltas'])
+            h.stage_roi(d['feats'], events=ev)                # start / stop events of the dispatch itself
+            h.stage_detect(d['cls_scores'], d['cls_deltas'])
         for st in gstreams:
             if st is not mine:
                 st.wait_stream(mine)
@@ -246,7 +261,7 @@ def main():
         i, group = 0, 0
         while i < num_images:
             if timed and i in ev_at:
-                timed_single_image(group * B)
+                timed_single_image(0)
                 i += 1
             elif num_images - i >= B and not (timed and any(j in ev_at for j in range(i + 1, i + B))):
                 pool.submit_group(group)

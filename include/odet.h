@@ -229,6 +229,21 @@ int odet_prof_event_create(void** ev);
 int odet_prof_event_destroy(void* ev);
 int odet_prof_event_elapsed_ms(void* start, void* stop, float* ms);
 
+/* Spatial processing order for odet_roi_pool_ordered: out_order int32 [n] = the RoI rows sorted by
+ * (level, y centre, x centre) (padded rows >= count last).  Native addition (no reference counterpart):
+ * output row r still holds RoI r, only the order in which workgroups pick RoIs changes, so that the
+ * chunk of RoIs one XCD processes taps one band of one pyramid level (fewer lines fetched into several
+ * L2s, sliding working set).  n <= 8192. */
+int odet_roi_order(const float* rois, const int32_t* roi_level, int n, const int32_t* count_dev,
+                   int image_h, int image_w, int32_t* out_order, odet_stream_t stream);
+/* odet_roi_pool processing the RoIs in `order` (nullable = index order); start/stop events nullable
+ * (see odet_roi_pool_timed). */
+int odet_roi_pool_ordered(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                          const int32_t* roi_level, int n, const int32_t* count_dev,
+                          const int32_t* order, int norm_mode, int image_h, int image_w,
+                          int pool_size, int pool_mode, float* out, odet_stream_t stream,
+                          void* start_event, void* stop_event);
+
 /* ---- detection post-processing ------------------------------------------------------- */
 
 #define ODET_POSTOPS_MAX_ROIS 4096
@@ -325,6 +340,7 @@ typedef struct {
   float* rois; int32_t* roi_idx; int32_t* roi_count; int32_t* nms_done;
   float* sorted_rois; int32_t* roi_level; int64_t* roi_perm; int32_t* level_counts;
   float* roi_features;
+  int32_t* roi_order;        /* nullable scratch int32 [num_proposals]: spatial processing order (odet_roi_order) */
   float* det_boxes; int32_t* det_labels; float* det_scores; int32_t* det_count; float* record;
   void* ws_rpn; size_t ws_rpn_bytes;
   void* ws_post; size_t ws_post_bytes;

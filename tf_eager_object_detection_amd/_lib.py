@@ -43,7 +43,7 @@ class OdetFpnStep(C.Structure):
         ('rpn_logits', C.c_void_p), ('rpn_deltas', C.c_void_p), ('cls_scores', C.c_void_p), ('cls_deltas', C.c_void_p),
         ('rois', C.c_void_p), ('roi_idx', C.c_void_p), ('roi_count', C.c_void_p), ('nms_done', C.c_void_p),
         ('sorted_rois', C.c_void_p), ('roi_level', C.c_void_p), ('roi_perm', C.c_void_p),
-        ('level_counts', C.c_void_p), ('roi_features', C.c_void_p),
+        ('level_counts', C.c_void_p), ('roi_features', C.c_void_p), ('roi_order', C.c_void_p),
         ('det_boxes', C.c_void_p), ('det_labels', C.c_void_p), ('det_scores', C.c_void_p),
         ('det_count', C.c_void_p), ('record', C.c_void_p),
         ('ws_rpn', C.c_void_p), ('ws_rpn_bytes', C.c_size_t),
@@ -82,6 +82,8 @@ SIGNATURES = {
     'odet_assign_levels': (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'odet_roi_pool': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'odet_roi_pool_timed': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'odet_roi_order': (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    'odet_roi_pool_ordered': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'odet_prof_event_create': (_i, [_vp]),
     'odet_prof_event_destroy': (_i, [_vp]),
     'odet_prof_event_elapsed_ms': (_i, [_vp, _vp, _vp]),

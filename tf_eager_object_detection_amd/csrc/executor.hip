@@ -31,9 +31,14 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_ROI) {
-    rc = odet_roi_pool(s->maps, s->num_maps, s->channels, s->sorted_rois, s->roi_level, s->num_proposals,
-                       s->roi_count, ODET_ROI_NORM_IMAGE, s->image_h, s->image_w, s->pool_size, ODET_ROI_POOL_MAX2,
-                       s->roi_features, s->stream);
+    if (s->roi_order) {
+      rc = odet_roi_order(s->sorted_rois, s->roi_level, s->num_proposals, s->roi_count, s->image_h, s->image_w,
+                          s->roi_order, s->stream);
+      if (rc != ODET_OK) return rc;
+    }
+    rc = odet_roi_pool_ordered(s->maps, s->num_maps, s->channels, s->sorted_rois, s->roi_level, s->num_proposals,
+                               s->roi_count, s->roi_order, ODET_ROI_NORM_IMAGE, s->image_h, s->image_w, s->pool_size,
+                               ODET_ROI_POOL_MAX2, s->roi_features, s->stream, nullptr, nullptr);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_DETECT) {
@@ -92,9 +97,18 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
   }
   if (stages & ODET_STAGE_ROI) {
     RoiImageIO io[ODET_MAX_BATCH];
+    RoiOrderIO oo[ODET_MAX_BATCH];
+    bool ordered = true;
+    for (int i = 0; i < count; ++i) ordered = ordered && steps[i]->roi_order != nullptr;
     for (int i = 0; i < count; ++i) {
       const odet_fpn_step_t* t = steps[i];
-      io[i] = RoiImageIO{t->maps, t->sorted_rois, t->roi_level, t->roi_count, t->roi_features};
+      io[i] = RoiImageIO{t->maps, t->sorted_rois, t->roi_level, t->roi_count, ordered ? t->roi_order : nullptr,
+                         t->roi_features};
+      oo[i] = RoiOrderIO{t->sorted_rois, t->roi_level, t->roi_count, t->roi_order};
+    }
+    if (ordered) {
+      rc = odet_roi_order_batch(oo, count, s->num_proposals, s->image_h, s->image_w, st);
+      if (rc != ODET_OK) return rc;
     }
     rc = odet_roi_pool_batch(io, count, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
                              s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, st, RoiEvents{nullptr, nullptr});

@@ -196,6 +196,54 @@ __device__ __forceinline__ int block_excl_scan(int v, int* lds /*[17]*/, int* to
   return lds[w] + inc - v;
 }
 
+// ---- in-workgroup sorts of 64-bit keys ---------------------------------------------------------
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int P2, int nthreads) {
+  for (int k = 2; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (P2 >> 1); t += nthreads) {
+        // index of the lower element of the t-th compare-exchange pair at distance j
+        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        int l = i | j;
+        bool up = ((i & k) == 0);
+        unsigned long long a = keys[i], b = keys[l];
+        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask);
+  uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Ascending bitonic sort of 1024 keys, one per thread of a 1024-thread workgroup; xch: LDS [2][1024].
+__device__ __forceinline__ unsigned long long bitonic_sort_1024_reg(unsigned long long key, unsigned long long* xch) {
+  const int tid = threadIdx.x;
+  int buf = 0;
+  for (int k = 2; k <= 1024; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long other;
+      if (j >= 64) {
+        unsigned long long* x = xch + buf * 1024;
+        x[tid] = key;
+        __syncthreads();
+        other = x[tid ^ j];
+        buf ^= 1;               // the next LDS stage writes the other buffer: one barrier per stage
+      } else {
+        other = shfl_xor_u64(key, j);
+      }
+      const bool up = ((tid & k) == 0);
+      const bool lower = ((tid & j) == 0);
+      const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+      key = (lower == up) ? mn : mx;
+    }
+  }
+  return key;
+}
+
 // model/fpn/base_fpn_model.py:303-324 _assign_levels by ONE workgroup of THREADS threads: level per RoI,
 // then a stable partition by level (ascending original index inside a level) -- the order
 // tf.where + tf.gather + tf.concat produce at :316-324.  rois may have been written by this
@@ -280,9 +328,12 @@ int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int
                              int blind_chunks, hipStream_t st);
 
 struct RoiEvents { hipEvent_t start, stop; };   // optional: timestamps of the dispatch itself
-struct RoiImageIO {         // per-image arguments
-  const odet_level_t* levels; const float* rois; const int32_t* roi_level; const int32_t* count_dev; float* out;
+struct RoiImageIO {         // per-image arguments (order: nullable processing order, odet_roi_order)
+  const odet_level_t* levels; const float* rois; const int32_t* roi_level; const int32_t* count_dev;
+  const int32_t* order; float* out;
 };
+struct RoiOrderIO { const float* rois; const int32_t* roi_level; const int32_t* count_dev; int32_t* order; };
+int odet_roi_order_batch(const RoiOrderIO* io, int B, int n, int image_h, int image_w, hipStream_t st);
 int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int n, int norm_mode, int image_h,
                         int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev);
 

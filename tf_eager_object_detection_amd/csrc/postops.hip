@@ -42,53 +42,6 @@ struct PostOpsParams {    // pointer tables: one entry per image of the batch (b
   PerImg<float*> cls_scores_t;     // [ncls-1, K]
 };
 
-__device__ __forceinline__ void bitonic_sort_u64(u64* keys, int P2, int nthreads) {
-  for (int k = 2; k <= P2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (P2 >> 1); t += nthreads) {
-        // index of the lower element of the t-th compare-exchange pair at distance j
-        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        int l = i | j;
-        bool up = ((i & k) == 0);
-        u64 a = keys[i], b = keys[l];
-        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
-  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask);
-  uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);
-  return ((u64)hi << 32) | lo;
-}
-
-// Ascending bitonic sort of 1024 keys, one per thread of a 1024-thread workgroup; xch: LDS [2][1024].
-__device__ __forceinline__ u64 bitonic_sort_1024_reg(u64 key, u64* xch) {
-  const int tid = threadIdx.x;
-  int buf = 0;
-  for (int k = 2; k <= 1024; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      u64 other;
-      if (j >= 64) {
-        u64* x = xch + buf * 1024;
-        x[tid] = key;
-        __syncthreads();
-        other = x[tid ^ j];
-        buf ^= 1;               // the next LDS stage writes the other buffer: one barrier per stage
-      } else {
-        other = shfl_xor_u64(key, j);
-      }
-      const bool up = ((tid & k) == 0);
-      const bool lower = ((tid & j) == 0);
-      const u64 mn = key < other ? key : other, mx = key < other ? other : key;
-      key = (lower == up) ? mn : mx;
-    }
-  }
-  return key;
-}
-
 __device__ __forceinline__ float key_to_score(uint32_t k) {   // inverse of ~d_float_asc_key
   const uint32_t asc = ~k;
   const uint32_t u = (asc & 0x80000000u) ? (asc & 0x7FFFFFFFu) : ~asc;

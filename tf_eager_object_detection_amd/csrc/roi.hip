@@ -39,6 +39,7 @@ struct RoiParams {
   PerImg<const float4*> rois;
   PerImg<const int32_t*> roi_level;
   PerImg<const int32_t*> count_dev;
+  PerImg<const int32_t*> order;      // nullable: processing order of the RoIs (spatially sorted, odet_roi_order)
   PerImg<float*> out;
   int H[ODET_MAX_LEVELS];
   int W[ODET_MAX_LEVELS];
@@ -50,6 +51,8 @@ struct RoiParams {
   int rows_per_wg;    // output rows of one RoI per workgroup
   int groups_per_roi; // ceil(P / rows_per_wg)
   int use_desc;       // whole-RoI descriptor form (roi_bins_desc)
+  int xcd_images;     // 1: the image is derived from the XCD slot (batch of 2 / 4 / 8), 0: blockIdx.y
+  int xcds_per_img;   // XCDs that serve one image (8 / batch)
 };
 
 struct Axis {
@@ -393,22 +396,27 @@ __device__ __forceinline__ void roi_bins_desc(const float* base, int W, int C, i
 template <int POOL, int NORM, bool STAGE>
 __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   extern __shared__ __align__(16) float tile[];
-  const int img = blockIdx.y;
+  constexpr bool PAD = (NORM == ODET_ROI_NORM_TP_ALIGN);
+  // XCD-aware remap: hardware deals workgroups round-robin over the 8 XCDs (each has its own L2).
+  // A batch of 1 / 2 / 4 / 8 images gives every image 8 / 4 / 2 / 1 XCDs of its own, so that an XCD's L2
+  // only ever holds lines of one image's maps; inside an image consecutive (level-sorted) RoIs share an XCD.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int img = p.xcd_images ? xcd / p.xcds_per_img : blockIdx.y;
+  const int sub = p.xcd_images ? xcd - img * p.xcds_per_img : xcd;
+  const int lb = sub * p.blocks_per_xcd + slot;
+  if (slot >= p.blocks_per_xcd || lb >= p.nblocks) return;
   const float4* __restrict__ rois = p.rois.v[img];
   const int32_t* __restrict__ roi_level = p.roi_level.v[img];
   const int32_t* __restrict__ count_dev = p.count_dev.v[img];
   float* __restrict__ out = p.out.v[img];
-  constexpr bool PAD = (NORM == ODET_ROI_NORM_TP_ALIGN);
-  // XCD-aware remap: hardware deals workgroups round-robin over the 8 XCDs
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int lb = xcd * p.blocks_per_xcd + slot;
-  if (slot >= p.blocks_per_xcd || lb >= p.nblocks) return;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int P = p.P, C = p.C;
   const int gpr = p.groups_per_roi;                 // workgroups per RoI (row groups of p.rows_per_wg rows)
-  const int r = lb / gpr;
-  const int row0 = (lb - r * gpr) * p.rows_per_wg;
+  const int32_t* __restrict__ order = p.order.v[img];
+  const int ri = lb / gpr;
+  const int r = order ? min(max(order[ri], 0), p.n - 1) : ri;
+  const int row0 = (lb - ri * gpr) * p.rows_per_wg;
   const int nrows = min(p.rows_per_wg, P - row0);
   float* __restrict__ orow = out + ((size_t)r * P + row0) * P * C;
 
@@ -580,6 +588,7 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
       if (i == 0) { p.H[l] = L->H; p.W[l] = L->W; p.stride[l] = L->stride; }
     }
     p.rois.v[i] = (const float4*)a.rois; p.roi_level.v[i] = a.roi_level; p.count_dev.v[i] = a.count_dev;
+    p.order.v[i] = a.order;
     p.out.v[i] = a.out;
   }
   p.num_levels = num_levels;
@@ -603,8 +612,10 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   int64_t rows = (int64_t)n * p.groups_per_roi;
   ODET_REQUIRE(rows < (1ll << 30), "odet_roi_pool: too many workgroups");
   p.nblocks = (int)rows;
-  p.blocks_per_xcd = (p.nblocks + 7) / 8;
-  dim3 grid(p.blocks_per_xcd * 8, B);
+  p.xcd_images = (B == 2 || B == 4 || B == 8) ? 1 : 0;
+  p.xcds_per_img = p.xcd_images ? 8 / B : 8;
+  p.blocks_per_xcd = (p.nblocks + p.xcds_per_img - 1) / p.xcds_per_img;   // per XCD of an image
+  dim3 grid(p.blocks_per_xcd * 8, p.xcd_images ? 1 : B);
   if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, threads, st, p, ev);
   else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, threads, st, p, ev);
   else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, threads, st, p, ev);
@@ -612,10 +623,87 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   return ODET_OK;
 }
 
+// ---- spatial processing order -------------------------------------------------------------------
+// Output row r always holds RoI r; only the ORDER in which workgroups pick RoIs changes: sorted by
+// (level, y centre, x centre) so that the RoIs an XCD processes (a contiguous chunk of the order) tap one
+// band of one pyramid level -- fewer lines fetched by several XCDs, and a sliding working set in each L2.
+struct RoiOrderParams {
+  PerImg<const float4*> rois;
+  PerImg<const int32_t*> roi_level;
+  PerImg<const int32_t*> count_dev;
+  PerImg<int32_t*> order;
+  int n, P2;
+  float inv_h, inv_w;
+};
+
+__global__ void __launch_bounds__(1024) k_roi_order(RoiOrderParams p) {
+  extern __shared__ __align__(16) unsigned long long okeys[];   // [max(P2, 2048)]
+  const int img = blockIdx.y;
+  const float4* __restrict__ rois = p.rois.v[img];
+  const int32_t* __restrict__ lvl = p.roi_level.v[img];
+  const int32_t* __restrict__ cd = p.count_dev.v[img];
+  int32_t* __restrict__ order = p.order.v[img];
+  const int cnt = cd ? min(*cd, p.n) : p.n;
+  const int tid = threadIdx.x;
+  auto make_key = [&](int r) -> unsigned long long {
+    if (r >= p.n) return ~0ull;
+    if (r >= cnt) return (0xFFFFFFFEull << 32) | (unsigned)r;          // padded rows last (they are zero-filled)
+    const float4 b = rois[r];
+    const int l = lvl ? min(max(lvl[r], 0), 7) : 0;
+    const int qy = min(max((int)((b.y + b.w) * 0.5f * p.inv_h * 4096.0f), 0), 4095);
+    const int qx = min(max((int)((b.x + b.z) * 0.5f * p.inv_w * 4096.0f), 0), 4095);
+    return ((unsigned long long)((l << 24) | (qy << 12) | qx) << 32) | (unsigned)r;
+  };
+  if (p.P2 <= 1024) {
+    unsigned long long k = make_key(tid);
+    k = bitonic_sort_1024_reg(k, okeys);
+    if (tid < p.n) order[tid] = (int32_t)(k & 0xFFFFFFFFull);
+  } else {
+    for (int i = tid; i < p.P2; i += 1024) okeys[i] = make_key(i);
+    __syncthreads();
+    bitonic_sort_u64(okeys, p.P2, 1024);
+    for (int i = tid; i < p.n; i += 1024) order[i] = (int32_t)(okeys[i] & 0xFFFFFFFFull);
+  }
+}
+
+int odet_roi_order_batch(const RoiOrderIO* io, int B, int n, int image_h, int image_w, hipStream_t st) {
+  ODET_REQUIRE(io && B >= 1 && B <= ODET_MAX_BATCH, "odet_roi_order: bad batch");
+  ODET_REQUIRE(n >= 0 && n <= 8192, "odet_roi_order: n %d out of range (<= 8192)", n);
+  ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_roi_order: bad image shape");
+  if (n == 0) return ODET_OK;
+  RoiOrderParams p;
+  for (int i = 0; i < ODET_MAX_BATCH; ++i) {
+    const RoiOrderIO& a = io[i < B ? i : 0];
+    ODET_REQUIRE(a.rois && a.order, "odet_roi_order: null pointer");
+    p.rois.v[i] = (const float4*)a.rois; p.roi_level.v[i] = a.roi_level; p.count_dev.v[i] = a.count_dev;
+    p.order.v[i] = a.order;
+  }
+  p.n = n;
+  p.P2 = 2;
+  while (p.P2 < n) p.P2 <<= 1;
+  p.inv_h = 1.0f / (float)image_h; p.inv_w = 1.0f / (float)image_w;
+  const size_t lds = (size_t)(p.P2 > 2048 ? p.P2 : 2048) * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ODET_HIP(hipFuncSetAttribute((const void*)k_roi_order, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_roi_order, dim3(1, B), dim3(1024), lds, st, p);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+extern "C" int odet_roi_order(const float* rois, const int32_t* roi_level, int n, const int32_t* count_dev, int image_h,
+                              int image_w, int32_t* out_order, odet_stream_t stream) {
+  RoiOrderIO io{rois, roi_level, count_dev, out_order};
+  return odet_roi_order_batch(&io, 1, n, image_h, image_w, (hipStream_t)stream);
+}
+
 static int roi_pool_impl(const odet_level_t* levels, int num_levels, int C, const float* rois,
-                         const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode, int image_h,
-                         int image_w, int pool_size, int pool_mode, float* out, odet_stream_t stream, RoiEvents ev) {
-  RoiImageIO io{levels, rois, roi_level, count_dev, out};
+                         const int32_t* roi_level, int n, const int32_t* count_dev, const int32_t* order,
+                         int norm_mode, int image_h, int image_w, int pool_size, int pool_mode, float* out,
+                         odet_stream_t stream, RoiEvents ev) {
+  RoiImageIO io{levels, rois, roi_level, count_dev, order, out};
   if (n > 0) ODET_REQUIRE(levels && rois && out, "odet_roi_pool: null pointer");
   return odet_roi_pool_batch(&io, 1, num_levels, C, n, norm_mode, image_h, image_w, pool_size, pool_mode,
                              (hipStream_t)stream, ev);
@@ -625,8 +713,17 @@ extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, 
                              const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode,
                              int image_h, int image_w, int pool_size, int pool_mode, float* out,
                              odet_stream_t stream) {
-  return roi_pool_impl(levels, num_levels, C, rois, roi_level, n, count_dev, norm_mode, image_h, image_w, pool_size,
-                       pool_mode, out, stream, RoiEvents{nullptr, nullptr});
+  return roi_pool_impl(levels, num_levels, C, rois, roi_level, n, count_dev, nullptr, norm_mode, image_h, image_w,
+                       pool_size, pool_mode, out, stream, RoiEvents{nullptr, nullptr});
+}
+
+extern "C" int odet_roi_pool_ordered(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                                     const int32_t* roi_level, int n, const int32_t* count_dev,
+                                     const int32_t* order, int norm_mode, int image_h, int image_w, int pool_size,
+                                     int pool_mode, float* out, odet_stream_t stream, void* start_event,
+                                     void* stop_event) {
+  return roi_pool_impl(levels, num_levels, C, rois, roi_level, n, count_dev, order, norm_mode, image_h, image_w,
+                       pool_size, pool_mode, out, stream, RoiEvents{(hipEvent_t)start_event, (hipEvent_t)stop_event});
 }
 
 extern "C" int odet_roi_pool_timed(const odet_level_t* levels, int num_levels, int C, const float* rois,
@@ -634,8 +731,8 @@ extern "C" int odet_roi_pool_timed(const odet_level_t* levels, int num_levels, i
                                    int image_h, int image_w, int pool_size, int pool_mode, float* out,
                                    odet_stream_t stream, void* start_event, void* stop_event) {
   ODET_REQUIRE(start_event && stop_event, "odet_roi_pool_timed: null event");
-  return roi_pool_impl(levels, num_levels, C, rois, roi_level, n, count_dev, norm_mode, image_h, image_w, pool_size,
-                       pool_mode, out, stream, RoiEvents{(hipEvent_t)start_event, (hipEvent_t)stop_event});
+  return roi_pool_impl(levels, num_levels, C, rois, roi_level, n, count_dev, nullptr, norm_mode, image_h, image_w,
+                       pool_size, pool_mode, out, stream, RoiEvents{(hipEvent_t)start_event, (hipEvent_t)stop_event});
 }
 
 extern "C" int odet_prof_event_create(void** ev) {

@@ -334,10 +334,23 @@ class ProfEvent:
             pass
 
 
+def roi_order(rois, roi_level, image_shape, count_dev=None, out=None):
+    """Spatial processing order (int32 [n]) of the RoIs for roi_pool(order=...): sorted by (level, y, x)."""
+    rois = _boxes(rois, 'rois')
+    n = rois.shape[0]
+    if out is None:
+        out = torch.empty(max(n, 1), dtype=torch.int32, device=rois.device)
+    if roi_level is not None and roi_level.dtype != torch.int32:
+        roi_level = roi_level.to(torch.int32)
+    L.call('odet_roi_order', L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev), int(image_shape[0]),
+           int(image_shape[1]), L.dptr(out), L.stream())
+    return out
+
+
 def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, strides=None, image_shape=None,
-             count_dev=None, out=None, events=None):
+             count_dev=None, out=None, events=None, order=None):
     """feature_maps: list of NHWC float32 GPU tensors [1,H,W,C] (one per level).  ``events`` = (start, stop)
-    ProfEvent pair attached to the dispatch (profiling)."""
+    ProfEvent pair attached to the dispatch (profiling); ``order`` = int32 processing order (roi_order)."""
     rois = _boxes(rois, 'rois')
     n = rois.shape[0]
     nl = len(feature_maps)
@@ -365,7 +378,11 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
     ih, iw = (0, 0) if image_shape is None else (int(image_shape[0]), int(image_shape[1]))
     if roi_level is not None and roi_level.dtype != torch.int32:
         roi_level = roi_level.to(torch.int32)
-    if events is None:
+    if order is not None:
+        L.call('odet_roi_pool_ordered', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
+               L.dptr(order, torch.int32, 'order'), int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream(),
+               events[0].handle if events else None, events[1].handle if events else None)
+    elif events is None:
         L.call('odet_roi_pool', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
                int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream())
     else:

@@ -27,7 +27,7 @@ class FpnHotPath:
                  roi_means=(0, 0, 0, 0), roi_stds=(0.1, 0.1, 0.2, 0.2), max_per_class=50, max_per_image=50,
                  nms_iou=0.3, score_threshold=0.0, min_level=2, max_level=5, strides=syn.FPN_STRIDES,
                  base_sizes=syn.FPN_BASE_SIZES, ratios=syn.FPN_RATIOS, scales=syn.FPN_SCALES,
-                 blind_chunks=1, device=None):
+                 blind_chunks=1, device=None, spatial_order=True):
         self.image_shape = [int(image_shape[0]), int(image_shape[1])]
         self.num_classes = num_classes
         self.K = num_proposals
@@ -57,6 +57,7 @@ class FpnHotPath:
         self.roi_level = torch.zeros(K, dtype=torch.int32, device=dev)
         self.roi_perm = torch.zeros(K, dtype=torch.int64, device=dev)
         self.level_counts = torch.zeros(nl, dtype=torch.int32, device=dev)
+        self.roi_order = torch.zeros(K, dtype=torch.int32, device=dev) if spatial_order and K <= 8192 else None
         M = max(max_per_image, 1)
         self.det_boxes = torch.zeros((M, 4), dtype=torch.float32, device=dev)
         self.det_labels = torch.zeros(M, dtype=torch.int32, device=dev)
@@ -108,13 +109,16 @@ class FpnHotPath:
         (start, stop) ops.ProfEvent pair attached to the kernel dispatch (bench.py's roofline timing)."""
         nl = self.max_level - self.min_level + 1
         maps = list(p_list[:nl])
-        if events is not None:
+        def go(ev=None):
+            if self.roi_order is not None:
+                ops.roi_order(self.sorted_rois, self.roi_level, self.image_shape, count_dev=self.roi_count,
+                              out=self.roi_order)
             return ops.roi_pool(maps, self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P,
                                 ops.ROI_POOL_MAX2, image_shape=self.image_shape, count_dev=self.roi_count,
-                                out=self.roi_features, events=events)
-        return self._run('roi', tuple(maps), lambda: ops.roi_pool(
-            maps, self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P, ops.ROI_POOL_MAX2,
-            image_shape=self.image_shape, count_dev=self.roi_count, out=self.roi_features))   # :257 / :152-161
+                                out=self.roi_features, events=ev, order=self.roi_order)    # :257 / :152-161
+        if events is not None:
+            return go(events)
+        return self._run('roi', tuple(maps), go)
 
     # ---- stage 3: RoI-head outputs -> detections ---------------------------------------------
     def stage_detect(self, cls_softmax, cls_deltas):
@@ -300,6 +304,7 @@ class FpnStreamPool:
         st.nms_done, st.sorted_rois = h.nms_done.data_ptr(), h.sorted_rois.data_ptr()
         st.roi_level, st.roi_perm = h.roi_level.data_ptr(), h.roi_perm.data_ptr()
         st.level_counts, st.roi_features = h.level_counts.data_ptr(), h.roi_features.data_ptr()
+        st.roi_order = h.roi_order.data_ptr() if h.roi_order is not None else None
         st.det_boxes, st.det_labels = h.det_boxes.data_ptr(), h.det_labels.data_ptr()
         st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
         st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
