@@ -244,6 +244,15 @@ int odet_roi_pool_ordered(const odet_level_t* levels, int num_levels, int C, con
                           int pool_size, int pool_mode, float* out, odet_stream_t stream,
                           void* start_event, void* stop_event);
 
+/* odet_roi_pool_ordered for float16 feature maps (BASELINE config 5): levels[i].data points at NHWC
+ * float16, out is float16 [n,P,P,C]; boxes stay float32, taps are widened to float32, lerped and pooled in
+ * the same operation order, and rounded to nearest-even on the store.  Pooled (max / avg) un-padded modes
+ * with pool_size <= 8. */
+int odet_roi_pool_f16(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                      const int32_t* roi_level, int n, const int32_t* count_dev, const int32_t* order,
+                      int norm_mode, int image_h, int image_w, int pool_size, int pool_mode, void* out,
+                      odet_stream_t stream);
+
 /* ---- detection post-processing ------------------------------------------------------- */
 
 #define ODET_POSTOPS_MAX_ROIS 4096

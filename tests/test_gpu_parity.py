@@ -583,6 +583,37 @@ def test_batched_launches_match_single_path():
         pool.close()
 
 
+def test_roi_pool_float16_feature_maps_bit_exact():
+    """BASELINE config 5: float16 feature maps into the RoI kernel (float32 boxes, float32 lerp, float16
+    store).  Oracle: the same crops on the float16 values widened to float32, rounded to float16."""
+    rng = np.random.default_rng(55)
+    shape = (336, 336)
+    shapes = syn.fpn_level_shapes(shape)[:4]
+    feats16 = [rng.standard_normal((1, h_, w_, 64)).astype(np.float16) for h_, w_ in shapes]
+    rois = syn.random_boxes(300, shape, rng, 8, 300)
+    lv, perm, cnt = co.assign_levels(rois)
+    srois, slv = rois[perm], (lv[perm] - 2).astype(np.int32)
+    for mode in (ops.ROI_POOL_MAX2, ops.ROI_POOL_AVG2):
+        for with_order in (False, True):
+            order = ops.roi_order(g(srois), g(slv), shape) if with_order else None
+            got = ops.roi_pool([g(f) for f in feats16], g(srois), g(slv), ops.ROI_NORM_IMAGE, 7, mode,
+                               image_shape=shape, order=order)
+            assert got.dtype == torch.float16
+            want = np.concatenate([
+                (co.roi_pool(feats16[l].astype(np.float32), srois[slv == l], image_shape=shape, pool=7)
+                 if mode == ops.ROI_POOL_MAX2 else
+                 on.tf_avg_pool_2x2(on.tf_crop_and_resize(
+                     feats16[l].astype(np.float32),
+                     np.stack([srois[slv == l][:, 1] / np.float32(shape[0]), srois[slv == l][:, 0] / np.float32(shape[1]),
+                               srois[slv == l][:, 3] / np.float32(shape[0]), srois[slv == l][:, 2] / np.float32(shape[1])],
+                              axis=1).astype(np.float32), np.zeros(int(np.sum(slv == l)), np.int32), (14, 14))))
+                for l in range(4) if np.any(slv == l)], axis=0).astype(np.float16)
+            np.testing.assert_array_equal(h(got).view(np.uint16), want.view(np.uint16))
+    # un-pooled / padded modes are float32 only
+    with pytest.raises(Exception):
+        ops.roi_pool([g(feats16[0])], g(srois[:4]), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_NONE, strides=[4.0])
+
+
 def test_roi_pool_timed_events():
     rng = np.random.default_rng(3)
     feat = _feat((40, 60), 64, rng)

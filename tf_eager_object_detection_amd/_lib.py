@@ -84,6 +84,7 @@ SIGNATURES = {
     'odet_roi_pool_timed': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'odet_roi_order': (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     'odet_roi_pool_ordered': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'odet_roi_pool_f16': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'odet_prof_event_create': (_i, [_vp]),
     'odet_prof_event_destroy': (_i, [_vp]),
     'odet_prof_event_elapsed_ms': (_i, [_vp, _vp, _vp]),

@@ -335,7 +335,7 @@ struct RoiImageIO {         // per-image arguments (order: nullable processing o
 struct RoiOrderIO { const float* rois; const int32_t* roi_level; const int32_t* count_dev; int32_t* order; };
 int odet_roi_order_batch(const RoiOrderIO* io, int B, int n, int image_h, int image_w, hipStream_t st);
 int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int n, int norm_mode, int image_h,
-                        int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev);
+                        int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev, int f16 = 0);
 
 struct PostOpsExtra { float wmax, hmax, roi_div; int mode; };
 struct PostOpsImageIO {     // per-image arguments

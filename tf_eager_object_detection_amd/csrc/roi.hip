@@ -29,18 +29,21 @@
 #include <algorithm>
 
 #include <hip/hip_ext.h>
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
 
 #include "odet_internal.h"
 
 #define ROI_LDS_BYTES (40 * 1024)   // staged tile budget: 4 workgroups per CU
 
 struct RoiParams {
-  const float* data[ODET_MAX_BATCH][ODET_MAX_LEVELS];   // [image of the batch][pyramid level]
+  const void* data[ODET_MAX_BATCH][ODET_MAX_LEVELS];    // [image of the batch][pyramid level]; float32 or float16
   PerImg<const float4*> rois;
   PerImg<const int32_t*> roi_level;
   PerImg<const int32_t*> count_dev;
   PerImg<const int32_t*> order;      // nullable: processing order of the RoIs (spatially sorted, odet_roi_order)
-  PerImg<float*> out;
+  PerImg<void*> out;
   int H[ODET_MAX_LEVELS];
   int W[ODET_MAX_LEVELS];
   float stride[ODET_MAX_LEVELS];
@@ -53,6 +56,7 @@ struct RoiParams {
   int use_desc;       // whole-RoI descriptor form (roi_bins_desc)
   int xcd_images;     // 1: the image is derived from the XCD slot (batch of 2 / 4 / 8), 0: blockIdx.y
   int xcds_per_img;   // XCDs that serve one image (8 / batch)
+  int f16;            // float16 feature maps / output
 };
 
 struct Axis {
@@ -129,6 +133,24 @@ __device__ __forceinline__ float4 pool4(const float4 (&v)[2][2]) {
   return o;
 }
 
+// 4 consecutive channels of a cell: float32 maps as they are, float16 maps (BASELINE config 5) widened
+// to float32 for the lerps and rounded to nearest-even on the way out
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __half* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+  const float2 fa = __half22float2(a), fb = __half22float2(b);
+  return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__half* p, float4 v) {
+  const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+  uint2 u;
+  u.x = *reinterpret_cast<const uint32_t*>(&a);
+  u.y = *reinterpret_cast<const uint32_t*>(&b);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
@@ -140,8 +162,8 @@ __device__ __forceinline__ float rl_f(float v, int l) {
 // taps -- the RoIs whose sample spacing is below one cell, i.e. most of them).  D = 2 is the general
 // form: (lo0, hi0, lo1, hi1) taken as they are, no sharing assumed.  Same values, same lerp
 // arithmetic as the 16-tap form -> bit-identical results.
-template <int POOL, int DY, int DX>
-__device__ __forceinline__ float4 roi_bin_shared(const float* base, uint32_t C, uint32_t c, const uint32_t (&rowoff)[4],
+template <int POOL, int DY, int DX, typename FT>
+__device__ __forceinline__ float4 roi_bin_shared(const FT* base, uint32_t C, uint32_t c, const uint32_t (&rowoff)[4],
                                                  const uint32_t (&col)[4], const float (&xw)[2],
                                                  const float (&yw)[2]) {
   constexpr int NR = (DY == 2) ? 4 : 2 + DY, NC = (DX == 2) ? 4 : 2 + DX;
@@ -153,7 +175,7 @@ __device__ __forceinline__ float4 roi_bin_shared(const float* base, uint32_t C, 
 #if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 1   /* diagnostic: no loads */
       blk[i][j] = make_float4((float)(rowoff[i] + col[j]), xw[0], yw[0], (float)c);
 #else
-      blk[i][j] = *reinterpret_cast<const float4*>(base + (rowoff[i] + col[j]) * C + c);
+      blk[i][j] = ld4(base + (rowoff[i] + col[j]) * C + c);
 #endif
     }
   }
@@ -307,9 +329,9 @@ __device__ __forceinline__ void roi_bins(const float* base, int rs, int r0, int 
 // columns it loads and the lerp weights -- so the per-bin scalar bookkeeping is done once, 64 bins in
 // parallel on the vector unit; a wave then walks its bins (wave, wave + nwaves, ...) and only fetches a
 // descriptor with v_readlane before loading / lerping / storing.
-template <int POOL>
-__device__ __forceinline__ void roi_bins_desc(const float* base, int W, int C, int P, int crop, const Axis& ay,
-                                              const Axis& ax, float* __restrict__ oroi) {
+template <int POOL, typename FT>
+__device__ __forceinline__ void roi_bins_desc(const FT* base, int W, int C, int P, int crop, const Axis& ay,
+                                              const Axis& ax, FT* __restrict__ oroi) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
@@ -345,7 +367,7 @@ __device__ __forceinline__ void roi_bins_desc(const float* base, int W, int C, i
                              (uint32_t)rl_i(co3, b)};
     const float xw[2] = {rl_f(xw0, b), rl_f(xw1, b)};
     const float yw[2] = {rl_f(yw0, b), rl_f(yw1, b)};
-    float* __restrict__ obin = oroi + (size_t)b * C;
+    FT* __restrict__ obin = oroi + (size_t)b * C;
     if (cls != 9) {
       for (int c = lane * 4; c < C; c += 256) {
         float4 o;
@@ -360,7 +382,7 @@ __device__ __forceinline__ void roi_bins_desc(const float* base, int W, int C, i
           case 7: o = roi_bin_shared<POOL, 2, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
           default: o = roi_bin_shared<POOL, 2, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
         }
-        *reinterpret_cast<float4*>(obin + c) = o;
+        st4(obin + c, o);
       }
     } else {
       // general form: every sample guarded (extrapolated samples are 0), 4 taps each
@@ -377,23 +399,23 @@ __device__ __forceinline__ void roi_bins_desc(const float* base, int W, int C, i
               const uint32_t otr = (rowoff[2 * sy] + col[2 * sx + 1]) * (uint32_t)C + (uint32_t)c;
               const uint32_t obl = (rowoff[2 * sy + 1] + col[2 * sx]) * (uint32_t)C + (uint32_t)c;
               const uint32_t obr = (rowoff[2 * sy + 1] + col[2 * sx + 1]) * (uint32_t)C + (uint32_t)c;
-              const float4 tl = *reinterpret_cast<const float4*>(base + otl);
-              const float4 tr = *reinterpret_cast<const float4*>(base + otr);
-              const float4 bl = *reinterpret_cast<const float4*>(base + obl);
-              const float4 br = *reinterpret_cast<const float4*>(base + obr);
+              const float4 tl = ld4(base + otl);
+              const float4 tr = ld4(base + otr);
+              const float4 bl = ld4(base + obl);
+              const float4 br = ld4(base + obr);
               res = lerp_tap(tl, tr, bl, br, xw[sx], yw[sy]);
             }
             v[sy][sx] = res;
           }
         }
-        *reinterpret_cast<float4*>(obin + c) = pool4<POOL>(v);
+        st4(obin + c, pool4<POOL>(v));
       }
     }
   }
 }
 
 // NORM: ODET_ROI_NORM_*; STAGE: allow the LDS-staged tile path.
-template <int POOL, int NORM, bool STAGE>
+template <int POOL, int NORM, bool STAGE, typename FT>
 __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   extern __shared__ __align__(16) float tile[];
   constexpr bool PAD = (NORM == ODET_ROI_NORM_TP_ALIGN);
@@ -408,7 +430,7 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   const float4* __restrict__ rois = p.rois.v[img];
   const int32_t* __restrict__ roi_level = p.roi_level.v[img];
   const int32_t* __restrict__ count_dev = p.count_dev.v[img];
-  float* __restrict__ out = p.out.v[img];
+  FT* __restrict__ out = reinterpret_cast<FT*>(p.out.v[img]);
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int P = p.P, C = p.C;
@@ -418,7 +440,7 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   const int r = order ? min(max(order[ri], 0), p.n - 1) : ri;
   const int row0 = (lb - ri * gpr) * p.rows_per_wg;
   const int nrows = min(p.rows_per_wg, P - row0);
-  float* __restrict__ orow = out + ((size_t)r * P + row0) * P * C;
+  FT* __restrict__ orow = out + ((size_t)r * P + row0) * P * C;
 
   // the three loads of the prologue are independent (r < n always addresses valid rows): one memory
   // latency instead of a chain of three
@@ -427,13 +449,12 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   const float4 roi = rois[r];
   const int cnt = min(cnt_raw, p.n);
   if (r >= cnt) {
-    for (int i = threadIdx.x * 4; i < nrows * P * C; i += blockDim.x * 4)
-      *reinterpret_cast<float4*>(orow + i) = make_float4(0, 0, 0, 0);
+    for (int i = threadIdx.x * 4; i < nrows * P * C; i += blockDim.x * 4) st4(orow + i, make_float4(0, 0, 0, 0));
     return;
   }
 
   const int lvl = min(max(lvl_raw, 0), p.num_levels - 1);
-  const float* __restrict__ feat = p.data[img][lvl];
+  const FT* __restrict__ feat = reinterpret_cast<const FT*>(p.data[img][lvl]);
   const int H = p.H[lvl], W = p.W[lvl];
   constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
   const int crop = P * S;
@@ -471,9 +492,12 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
 
   if (!STAGE && !PAD && S == 2 && p.use_desc) {
     // whole RoI per workgroup, per-bin descriptors built lane-parallel (P*P <= 64 checked on the host)
-    roi_bins_desc<POOL>(feat, W, C, P, crop, ay, ax, orow);
+    roi_bins_desc<POOL, FT>(feat, W, C, P, crop, ay, ax, orow);
     return;
   }
+  if constexpr (!std::is_same<FT, float>::value) {
+    return;     // float16 maps are only served by the descriptor form (checked on the host)
+  } else {
 
   // ALL sample rows and columns, one per lane
   const bool lane_taps = crop <= 64;
@@ -524,6 +548,7 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
     if (lane_taps) roi_bins<POOL, PAD, true>(feat, W, 0, 0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
     else roi_bins<POOL, PAD, false>(feat, W, 0, 0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
   }
+  }   // FT == float
 }
 
 static bool roi_stage_enabled() {
@@ -542,11 +567,14 @@ static bool roi_stage_enabled() {
 
 template <int POOL, int NORM>
 static void roi_launch(dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev) {
-  if (NORM != ODET_ROI_NORM_TP_ALIGN && roi_stage_enabled())
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true>), grid, dim3(threads), ROI_LDS_BYTES, st,
+  if (p.f16)
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false, __half>), grid, dim3(threads), 0, st, ev.start,
+                          ev.stop, 0, p);
+  else if (NORM != ODET_ROI_NORM_TP_ALIGN && roi_stage_enabled())
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true, float>), grid, dim3(threads), ROI_LDS_BYTES, st,
                           ev.start, ev.stop, 0, p);
   else
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false>), grid, dim3(threads), 0, st, ev.start,
+    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false, float>), grid, dim3(threads), 0, st, ev.start,
                           ev.stop, 0, p);
 }
 
@@ -562,7 +590,7 @@ static void roi_launch_norm(int norm_mode, dim3 grid, int threads, hipStream_t s
 
 // B images in one launch (blockIdx.y = image); all images share shapes and parameters
 int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int n, int norm_mode, int image_h,
-                        int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev) {
+                        int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev, int f16) {
   ODET_REQUIRE(n >= 0, "odet_roi_pool: negative n");
   if (n == 0) return ODET_OK;
   ODET_REQUIRE(io && B >= 1 && B <= ODET_MAX_BATCH, "odet_roi_pool: bad batch");
@@ -599,13 +627,18 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   // one workgroup per RoI by default (the per-workgroup prologue -- three memory latencies of RoI /
   // level / count loads and the box normalisation -- is paid once per 49 bins); the LDS-staged path
   // works on single rows
-  p.rows_per_wg = (roi_stage_enabled() && norm_mode != ODET_ROI_NORM_TP_ALIGN) ? 1
+  p.rows_per_wg = (!f16 && roi_stage_enabled() && norm_mode != ODET_ROI_NORM_TP_ALIGN) ? 1
                   : (rows_env > 0 ? std::min(rows_env, pool_size) : pool_size);
   static int desc_env = -1, threads_env = -1;
   if (desc_env < 0) { const char* e = getenv("ODET_ROI_DESC"); desc_env = e ? atoi(e) : 1; }
   if (threads_env < 0) { const char* e = getenv("ODET_ROI_THREADS"); threads_env = e ? atoi(e) : 512; }
-  p.use_desc = (desc_env && !roi_stage_enabled() && pool_mode != ODET_ROI_POOL_NONE &&
-                norm_mode != ODET_ROI_NORM_TP_ALIGN && pool_size * pool_size <= 64) ? 1 : 0;
+  const bool desc_ok = pool_mode != ODET_ROI_POOL_NONE && norm_mode != ODET_ROI_NORM_TP_ALIGN &&
+                       pool_size * pool_size <= 64;
+  p.f16 = f16 ? 1 : 0;
+  if (f16 && !desc_ok)
+    return odet_set_error(ODET_E_INVALID, "odet_roi_pool_f16: float16 maps need a pooled (max / avg), un-padded mode "
+                          "with pool_size <= 8");
+  p.use_desc = (desc_ok && (f16 || (desc_env && !roi_stage_enabled()))) ? 1 : 0;
   if (p.use_desc) p.rows_per_wg = pool_size;
   p.groups_per_roi = (pool_size + p.rows_per_wg - 1) / p.rows_per_wg;
   const int threads = p.use_desc ? ((threads_env == 256 || threads_env == 512) ? threads_env : 512) : 256;
@@ -706,7 +739,17 @@ static int roi_pool_impl(const odet_level_t* levels, int num_levels, int C, cons
   RoiImageIO io{levels, rois, roi_level, count_dev, order, out};
   if (n > 0) ODET_REQUIRE(levels && rois && out, "odet_roi_pool: null pointer");
   return odet_roi_pool_batch(&io, 1, num_levels, C, n, norm_mode, image_h, image_w, pool_size, pool_mode,
-                             (hipStream_t)stream, ev);
+                             (hipStream_t)stream, ev, 0);
+}
+
+extern "C" int odet_roi_pool_f16(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                                 const int32_t* roi_level, int n, const int32_t* count_dev, const int32_t* order,
+                                 int norm_mode, int image_h, int image_w, int pool_size, int pool_mode, void* out,
+                                 odet_stream_t stream) {
+  RoiImageIO io{levels, rois, roi_level, count_dev, order, (float*)out};
+  if (n > 0) ODET_REQUIRE(levels && rois && out, "odet_roi_pool_f16: null pointer");
+  return odet_roi_pool_batch(&io, 1, num_levels, C, n, norm_mode, image_h, image_w, pool_size, pool_mode,
+                             (hipStream_t)stream, RoiEvents{nullptr, nullptr}, 1);
 }
 
 extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, const float* rois,

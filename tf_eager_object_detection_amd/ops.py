@@ -359,8 +359,14 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
     levels = (L.OdetLevel * nl)()
     keep = []
     Cc = None
+    f16 = all(isinstance(fm, torch.Tensor) and fm.dtype == torch.float16 for fm in feature_maps)
     for i, fm in enumerate(feature_maps):
-        fm = L.f32c(fm, 'shared_layers')
+        if f16:
+            if not fm.is_cuda:
+                raise L.OdetError('shared_layers must live on the GPU: tf_eager_object_detection_amd has no CPU path')
+            fm = fm.contiguous()
+        else:
+            fm = L.f32c(fm, 'shared_layers')
         if fm.dim() != 4 or fm.shape[0] != 1:
             raise ValueError('feature map must be NHWC with batch 1, got %s' % (tuple(fm.shape),))
         if Cc is None:
@@ -374,11 +380,19 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
         levels[i].stride = float(strides[i]) if strides is not None else 0.0
     P = int(pool_size)
     if out is None:
-        out = torch.empty((n, P, P, Cc), dtype=torch.float32, device=rois.device)
+        out = torch.empty((n, P, P, Cc), dtype=torch.float16 if f16 else torch.float32, device=rois.device)
     ih, iw = (0, 0) if image_shape is None else (int(image_shape[0]), int(image_shape[1]))
     if roi_level is not None and roi_level.dtype != torch.int32:
         roi_level = roi_level.to(torch.int32)
-    if order is not None:
+    if f16:
+        if events is not None:
+            raise ValueError('timed launches are float32 only')
+        if out.dtype != torch.float16:
+            raise TypeError('out must be float16 for float16 feature maps')
+        L.call('odet_roi_pool_f16', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
+               L.dptr(order, torch.int32, 'order') if order is not None else None, int(norm_mode), ih, iw, P,
+               int(pool_mode), C.c_void_p(out.data_ptr()), L.stream())
+    elif order is not None:
         L.call('odet_roi_pool_ordered', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
                L.dptr(order, torch.int32, 'order'), int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream(),
                events[0].handle if events else None, events[1].handle if events else None)
