@@ -143,7 +143,8 @@ class ResNetFpnDetector(nn.Module):
 
     def prepare(self, device='cuda'):
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
-        self._hot = [FpnHotPath(*self._hot_args, **self._hot_kwargs) for _ in range(self._max_batch)]
+        fd = torch.float16 if self.dtype == torch.float16 else torch.float32
+        self._hot = [FpnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs) for _ in range(self._max_batch)]
         return self
 
     # ---- dense parts ---------------------------------------------------------------------------
@@ -189,7 +190,11 @@ class ResNetFpnDetector(nn.Module):
         p_list = self.features(images_nhwc)
         rpn_scores, rpn_deltas = self.rpn(p_list)
         rpn_scores, rpn_deltas = rpn_scores.float().contiguous(), rpn_deltas.float().contiguous()
-        maps = [p.permute(0, 2, 3, 1).float() for p in p_list[:4]]                # NHWC float32 views / copies
+        # NHWC views of P2..P5: float16 maps go to the RoI kernel as they are, anything else as float32
+        if self.dtype == torch.float16:
+            maps = [p.permute(0, 2, 3, 1) for p in p_list[:4]]
+        else:
+            maps = [p.permute(0, 2, 3, 1).float() for p in p_list[:4]]
         outs = []
         for b in range(B):
             hot = self._hot[b]

@@ -27,7 +27,7 @@ class FpnHotPath:
                  roi_means=(0, 0, 0, 0), roi_stds=(0.1, 0.1, 0.2, 0.2), max_per_class=50, max_per_image=50,
                  nms_iou=0.3, score_threshold=0.0, min_level=2, max_level=5, strides=syn.FPN_STRIDES,
                  base_sizes=syn.FPN_BASE_SIZES, ratios=syn.FPN_RATIOS, scales=syn.FPN_SCALES,
-                 blind_chunks=1, device=None, spatial_order=True):
+                 blind_chunks=1, device=None, spatial_order=True, feature_dtype=torch.float32):
         self.image_shape = [int(image_shape[0]), int(image_shape[1])]
         self.num_classes = num_classes
         self.K = num_proposals
@@ -51,7 +51,8 @@ class FpnHotPath:
         self.roi_idx = torch.zeros(K, dtype=torch.int32, device=dev)
         self.roi_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nms_done = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.roi_features = torch.zeros((K, pool_size, pool_size, channels), dtype=torch.float32, device=dev)
+        # float16 maps (BASELINE config 5) give float16 RoI features; everything else stays float32
+        self.roi_features = torch.zeros((K, pool_size, pool_size, channels), dtype=feature_dtype, device=dev)
         nl = max_level - min_level + 1
         self.sorted_rois = torch.zeros((K, 4), dtype=torch.float32, device=dev)
         self.roi_level = torch.zeros(K, dtype=torch.int32, device=dev)
@@ -118,6 +119,8 @@ class FpnHotPath:
                                 out=self.roi_features, events=ev, order=self.roi_order)    # :257 / :152-161
         if events is not None:
             return go(events)
+        if maps[0].dtype != torch.float32:
+            return go()                       # (launch plans are kept for the float32 path only)
         return self._run('roi', tuple(maps), go)
 
     # ---- stage 3: RoI-head outputs -> detections ---------------------------------------------
