@@ -38,6 +38,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "odet_internal.h"
 
@@ -944,12 +945,13 @@ static int nms_run(NmsJob& J, hipStream_t st) {
       if (!J.img[i].out_done || J.blind_chunks > 1)
         return odet_set_error(ODET_E_INVALID, "odet_nms: batches need the sync-free mode with blind_chunks == 1");
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    ODET_HIP(hipFuncSetAttribute((const void*)k_nms_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 SCAN_DYN_LDS));
-    attr_set = true;
-  }
+  static std::once_flag once;       // (executor threads may arrive here together)
+  static hipError_t once_rc = hipSuccess;
+  std::call_once(once, [] {
+    once_rc = hipFuncSetAttribute((const void*)k_nms_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SCAN_DYN_LDS);
+  });
+  ODET_HIP(once_rc);
   const PerImg<NmsHeader*> hdrs = per_img<NmsHeader*>(J, [&](int i) { return w[i].hdr; });
   const PerImg<const uint32_t*> keys = per_img<const uint32_t*>(J, [&](int i) { return (const uint32_t*)w[i].keys_a; });
   hipLaunchKernelGGL(k_zero_headers, dim3((unsigned)((sizeof(NmsHeader) / 16 + 255) / 256), B), dim3(256), 0, st, hdrs);

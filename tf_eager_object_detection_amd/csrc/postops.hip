@@ -20,6 +20,8 @@
 //
 // Output order is the sorted order, one valid instance of tf.nn.top_k(sorted=False)'s
 // unspecified order.
+#include <mutex>
+
 #include "odet_internal.h"
 
 #define PO_THREADS 1024
@@ -400,12 +402,14 @@ int odet_post_ops_batch(const PostOpsImageIO* io, int B, int R, int Ccls, int nu
                 PO_ROUND * 4 + (size_t)max_per_class * 4 + PO_ROUND * 4;
   if (lds1 > 150 * 1024)
     return odet_set_error(ODET_E_LIMIT, "odet_post_ops: R/max_per_class need %zu B of LDS (> 150 KiB)", lds1);
-  static bool attr_set = false;
-  if (!attr_set) {
-    ODET_HIP(hipFuncSetAttribute((const void*)k_postops_class, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    ODET_HIP(hipFuncSetAttribute((const void*)k_postops_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
-  }
+  static std::once_flag once;       // (executor threads may arrive here together)
+  static hipError_t once_rc = hipSuccess;
+  std::call_once(once, [] {
+    once_rc = hipFuncSetAttribute((const void*)k_postops_class, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (once_rc == hipSuccess)
+      once_rc = hipFuncSetAttribute((const void*)k_postops_merge, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  });
+  ODET_HIP(once_rc);
   hipLaunchKernelGGL(k_postops_class, dim3(ncls1, B), dim3(PO_THREADS), lds1, st, p);
   ODET_LAUNCH_CHECK();
   m.ncls1 = ncls1; m.K = max_per_class; m.P2 = next_pow2(ncls1 * max_per_class < 2 ? 2 : ncls1 * max_per_class);

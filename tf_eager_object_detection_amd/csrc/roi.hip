@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
@@ -551,19 +552,32 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   }   // FT == float
 }
 
-static bool roi_stage_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    // The LDS-staged tile path is kept for A/B measurements (ODET_ROI_STAGE=1).  It is OFF by default:
-    // every bilinear tap still has to be read once from LDS (128 B/clk/CU, only 2x the vector L1's
-    // 64 B/clk/CU) behind a load -> ds_write -> barrier chain, and measured 25-30 % slower than
-    // deduplicating the shared cells in registers (RoI kernel).
+// A/B switches for profiling, read once (function-local static: thread-safe initialisation).
+//   ODET_ROI_STAGE=1   the LDS-staged tile path.  OFF by default: every bilinear tap still has to be read
+//                      once from LDS (128 B/clk/CU, only 2x the vector L1's 64 B/clk/CU) behind a
+//                      load -> ds_write -> barrier chain, and it measured 25-30 % slower than deduplicating
+//                      the shared cells in registers (RoI kernel)
+//   ODET_ROI_DESC=0    per-row / per-bin tap computation instead of the lane-parallel bin descriptors
+//   ODET_ROI_ROWS=k    output rows per workgroup of the non-descriptor form
+//   ODET_ROI_THREADS   256 | 512 threads per workgroup of the descriptor form
+struct RoiEnv {
+  int stage, desc, rows, threads;
+  RoiEnv() {
     const char* e = getenv("ODET_ROI_STAGE");
-    v = (e && e[0] == '1') ? 1 : 0;
+    stage = (e && e[0] == '1') ? 1 : 0;
+    e = getenv("ODET_ROI_DESC");
+    desc = e ? atoi(e) : 1;
+    e = getenv("ODET_ROI_ROWS");
+    rows = e ? atoi(e) : 0;
+    e = getenv("ODET_ROI_THREADS");
+    threads = e ? atoi(e) : 512;
   }
-  return v != 0;
+};
+static const RoiEnv& roi_env() {
+  static const RoiEnv env;
+  return env;
 }
-
+static bool roi_stage_enabled() { return roi_env().stage != 0; }
 
 template <int POOL, int NORM>
 static void roi_launch(dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev) {
@@ -622,16 +636,13 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   p.num_levels = num_levels;
   p.C = C; p.n = n; p.norm_mode = norm_mode; p.P = pool_size; p.pool_mode = pool_mode;
   p.image_h = (float)image_h; p.image_w = (float)image_w;
-  static int rows_env = -1;
-  if (rows_env < 0) { const char* e = getenv("ODET_ROI_ROWS"); rows_env = e ? atoi(e) : 0; }
+  const int rows_env = roi_env().rows;
   // one workgroup per RoI by default (the per-workgroup prologue -- three memory latencies of RoI /
   // level / count loads and the box normalisation -- is paid once per 49 bins); the LDS-staged path
   // works on single rows
   p.rows_per_wg = (!f16 && roi_stage_enabled() && norm_mode != ODET_ROI_NORM_TP_ALIGN) ? 1
                   : (rows_env > 0 ? std::min(rows_env, pool_size) : pool_size);
-  static int desc_env = -1, threads_env = -1;
-  if (desc_env < 0) { const char* e = getenv("ODET_ROI_DESC"); desc_env = e ? atoi(e) : 1; }
-  if (threads_env < 0) { const char* e = getenv("ODET_ROI_THREADS"); threads_env = e ? atoi(e) : 512; }
+  const int desc_env = roi_env().desc, threads_env = roi_env().threads;
   const bool desc_ok = pool_mode != ODET_ROI_POOL_NONE && norm_mode != ODET_ROI_NORM_TP_ALIGN &&
                        pool_size * pool_size <= 64;
   p.f16 = f16 ? 1 : 0;
@@ -716,11 +727,12 @@ int odet_roi_order_batch(const RoiOrderIO* io, int B, int n, int image_h, int im
   while (p.P2 < n) p.P2 <<= 1;
   p.inv_h = 1.0f / (float)image_h; p.inv_w = 1.0f / (float)image_w;
   const size_t lds = (size_t)(p.P2 > 2048 ? p.P2 : 2048) * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    ODET_HIP(hipFuncSetAttribute((const void*)k_roi_order, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-    attr_set = true;
-  }
+  static std::once_flag once;       // (executor threads may arrive here together)
+  static hipError_t once_rc = hipSuccess;
+  std::call_once(once, [] {
+    once_rc = hipFuncSetAttribute((const void*)k_roi_order, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
+  });
+  ODET_HIP(once_rc);
   hipLaunchKernelGGL(k_roi_order, dim3(1, B), dim3(1024), lds, st, p);
   ODET_LAUNCH_CHECK();
   return ODET_OK;

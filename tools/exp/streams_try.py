@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, "/root/repo")
 from tf_eager_object_detection_amd.pipeline import FpnHotPath, synthetic_fpn_inputs
 host, dev = synthetic_fpn_inputs((800, 1333), 21, 1000, 256, seed=1234)
 for S in (1, 2, 3, 4, 6, 8):
