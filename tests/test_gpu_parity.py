@@ -614,6 +614,44 @@ def test_roi_pool_float16_feature_maps_bit_exact():
         ops.roi_pool([g(feats16[0])], g(srois[:4]), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_NONE, strides=[4.0])
 
 
+def test_executor_reports_job_errors_and_recovers():
+    """A job that fails inside a worker thread (workspace too small) must surface at wait() with the C
+    ABI's error text, and the executor must keep working afterwards."""
+    from tf_eager_object_detection_amd import _lib
+    from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
+    shape, K, ncls, ch = (200, 320), 200, 21, 32
+    host, dev = synthetic_fpn_inputs(shape, ncls, K, channels=ch, seed=3)
+    pool = FpnStreamPool(2, shape, ncls, K, ch)
+    try:
+        for k in range(2):
+            pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        good = pool.steps[1].ws_rpn_bytes
+        pool.steps[1].ws_rpn_bytes = 1024                      # sabotage slot 1
+        pool.submit(0)
+        pool.submit(1)
+        with pytest.raises(_lib.OdetError, match='workspace too small'):
+            pool.wait()
+        pool.steps[1].ws_rpn_bytes = good
+        pool.submit(0)
+        pool.submit(1)
+        pool.wait()                                            # no stale error
+        torch.cuda.synchronize()
+        assert int(pool.slots[1].nms_done.item()) == 1 and int(pool.slots[1].det_count.item()) > 0
+        # batches must agree in configuration
+        pool2 = FpnStreamPool(1, shape, ncls, K, ch, batch=2)
+        try:
+            for k in range(2):
+                pool2.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+            pool2.steps[1].max_per_class = 7
+            pool2.submit_group(0)
+            with pytest.raises(_lib.OdetError, match='differs'):
+                pool2.wait()
+        finally:
+            pool2.close()
+    finally:
+        pool.close()
+
+
 def test_roi_pool_timed_events():
     rng = np.random.default_rng(3)
     feat = _feat((40, 60), 64, rng)
