@@ -637,11 +637,10 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   p.C = C; p.n = n; p.norm_mode = norm_mode; p.P = pool_size; p.pool_mode = pool_mode;
   p.image_h = (float)image_h; p.image_w = (float)image_w;
   const int rows_env = roi_env().rows;
-  // one workgroup per RoI by default (the per-workgroup prologue -- three memory latencies of RoI /
-  // level / count loads and the box normalisation -- is paid once per 49 bins); the LDS-staged path
-  // works on single rows
-  p.rows_per_wg = (!f16 && roi_stage_enabled() && norm_mode != ODET_ROI_NORM_TP_ALIGN) ? 1
-                  : (rows_env > 0 ? std::min(rows_env, pool_size) : pool_size);
+  // the row form (un-pooled 7x7 crops, tensorpack modes, LDS staging) works best with one output row
+  // per workgroup (measured: 39 us vs 45 us for whole-RoI workgroups); the descriptor form below takes
+  // the whole RoI
+  p.rows_per_wg = rows_env > 0 ? std::min(rows_env, pool_size) : 1;
   const int desc_env = roi_env().desc, threads_env = roi_env().threads;
   const bool desc_ok = pool_mode != ODET_ROI_POOL_NONE && norm_mode != ODET_ROI_NORM_TP_ALIGN &&
                        pool_size * pool_size <= 64;
