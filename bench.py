@@ -159,6 +159,8 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='HIP streams (+ native enqueue threads) per GPU')
     ap.add_argument('--batch', type=int, default=8, help='images that share the kernel launches of a stream (1..8)')
     ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; "
+                    "'gloo' only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -168,12 +170,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' %
                              (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == 'nccl' and local_rank >= ndev:
+        raise SystemExit('rank %d: local rank %d but only %d GPU(s) visible' % (rank, local_rank, ndev))
+    local_dev = local_rank % max(ndev, 1)                     # (rehearsal with gloo: ranks may share a GPU)
+    torch.cuda.set_device(local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev))
+        else:
+            dist.init_process_group(args.backend)
 
     from tf_eager_object_detection_amd import _lib, parallel
     from tf_eager_object_detection_amd import synthetic as syn
@@ -212,7 +221,8 @@ def main():
     hot = pool.slots[0]
     max_det = hot.cfg['max_per_image']
     comm = torch.cuda.Stream()
-    gathered = torch.zeros((world, nslots, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
+    gathered = torch.zeros((S, world, B, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
+    staging = torch.zeros((S, B, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
     gstreams = pool._group_streams
 
     # HIP events attached to the RoI kernel's dispatch, inside the timed region.  The kernel is timed
@@ -227,15 +237,19 @@ def main():
         pool.wait()
         torch.cuda.synchronize()
 
-    def gather_round():
-        """image-parallel exchange: every rank's records of this round in one RCCL all-gather"""
-        pool.wait()
-        for st in gstreams:
-            comm.wait_stream(st)
+    def gather_group(g):
+        """image-parallel exchange: the records of stream group g (B images) of every rank in ONE RCCL
+        all-gather.  Only group g's stream is involved and it only waits for a 10 KB staging copy, so the
+        collective overlaps the other streams and the group's own next images."""
+        pool.wait()                                           # host: the group's launches are enqueued
+        st = gstreams[g]
+        comm.wait_stream(st)
         with torch.cuda.stream(comm):
-            dist.all_gather_into_tensor(gathered, records)
-        for st in gstreams:
-            st.wait_stream(comm)                              # the next round may overwrite the records
+            staging[g].copy_(records[g * B:(g + 1) * B])
+            copied = torch.cuda.Event()
+            copied.record(comm)
+            dist.all_gather_into_tensor(gathered[g].view(world * B, rec_len), staging[g])   # concatenation form
+        st.wait_event(copied)                                 # the next images of the group may overwrite the records
 
     def timed_single_image(slot):
         ev = (ops.ProfEvent(), ops.ProfEvent())
@@ -262,18 +276,19 @@ def main():
         while i < num_images:
             if timed and i in ev_at:
                 timed_single_image(0)
+                done_group = 0
                 i += 1
             elif num_images - i >= B and not (timed and any(j in ev_at for j in range(i + 1, i + B))):
                 pool.submit_group(group)
+                done_group = group
                 i += B
             else:
                 pool.submit(group * B)
+                done_group = group
                 i += 1
+            if world > 1:
+                gather_group(done_group)
             group = (group + 1) % S
-            if world > 1 and group == 0:
-                gather_round()
-        if world > 1 and group != 0:
-            gather_round()
 
     def fence():
         drain()

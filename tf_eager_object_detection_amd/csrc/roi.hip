@@ -173,7 +173,7 @@ __device__ __forceinline__ float4 roi_bin_shared(const FT* base, uint32_t C, uin
   for (int i = 0; i < NR; ++i) {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 1   /* diagnostic: no loads */
+#if defined(ODET_ROI_ABLATE) && (ODET_ROI_ABLATE == 1 || ODET_ROI_ABLATE == 5)   /* diagnostic: no loads (5: nor stores) */
       blk[i][j] = make_float4((float)(rowoff[i] + col[j]), xw[0], yw[0], (float)c);
 #else
       blk[i][j] = ld4(base + (rowoff[i] + col[j]) * C + c);
@@ -360,7 +360,12 @@ __device__ __forceinline__ void roi_bins_desc(const FT* base, int W, int C, int 
   }
   const float xw0 = tx0.lerp, xw1 = tx1.lerp, yw0 = ty0.lerp, yw1 = ty1.lerp;
 
-  for (int b = w; b < nbins; b += nwaves) {
+#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 4        /* diagnostic: prologue + descriptors only */
+  const int nb_run = (xw0 == 1.2345e30f) ? nbins : 0;
+#else
+  const int nb_run = nbins;
+#endif
+  for (int b = w; b < nb_run; b += nwaves) {
     const int cls = rl_i(cls_l, b);
     const uint32_t rowoff[4] = {(uint32_t)rl_i(ro0, b), (uint32_t)rl_i(ro1, b), (uint32_t)rl_i(ro2, b),
                                 (uint32_t)rl_i(ro3, b)};
@@ -383,7 +388,11 @@ __device__ __forceinline__ void roi_bins_desc(const FT* base, int W, int C, int 
           case 7: o = roi_bin_shared<POOL, 2, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
           default: o = roi_bin_shared<POOL, 2, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
         }
+#if defined(ODET_ROI_ABLATE) && (ODET_ROI_ABLATE == 3 || ODET_ROI_ABLATE == 5)     /* diagnostic: no stores */
+        if (o.x == 1.2345e30f) st4(obin + c, o);
+#else
         st4(obin + c, o);
+#endif
       }
     } else {
       // general form: every sample guarded (extrapolated samples are 0), 4 taps each
