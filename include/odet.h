@@ -299,6 +299,16 @@ int odet_eval_detect(const float* scores, const float* deltas, const float* rois
                      float* out_scores, int32_t* out_count, void* workspace,
                      size_t workspace_bytes, odet_stream_t stream);
 
+/* ---- FPN neck: top-down merge -------------------------------------- */
+
+/* model/fpn/resnet_fpn.py:385-398 (ResnetFpnNeck.call): P_k = Add([resize_bilinear(P_{k+1},
+ * size(C_k)) * 0.5, lateral(C_k) * 0.5]) with tf.image.resize_bilinear of TF 1.x
+ * (align_corners=False: src = dst * in/out, lo = floor, hi = min(lo + 1, in - 1)) in one
+ * launch.  NHWC: top [B,h,w,C], lateral and out [B,H,W,C]; f16 != 0: float16 maps (float32
+ * arithmetic, one rounding at the end), C % 8 == 0; otherwise float32, C % 4 == 0. */
+int odet_fpn_topdown_merge(const void* top, int h, int w, const void* lateral, int H, int W,
+                           int B, int C, void* out, int f16, odet_stream_t stream);
+
 /* ---- multi-GPU detection records ------------------------------------------------------ */
 
 /* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of

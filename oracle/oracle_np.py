@@ -596,6 +596,42 @@ def fpn_roi_features(rois_list, p_list, image_shape, pool_size=7):
 
 
 # --------------------------------------------------------------------------------------
+# model/fpn/resnet_fpn.py (neck, top-down merge) -- SURVEY 8(f) rank 3
+# --------------------------------------------------------------------------------------
+def tf_resize_bilinear_legacy(x, out_hw):
+    """tf.image.resize_bilinear(x, size) of TF 1.x, align_corners=False (resize_bilinear_op.cc, SURVEY
+    Appendix A): scale = in / out (float32); src = dst * scale; lo = floor(src); hi = min(lo + 1, in - 1);
+    top = tl + (tr - tl) * xl; bottom = bl + (br - bl) * xl; out = top + (bottom - top) * yl.  x: [B,H,W,C]."""
+    x = f32(x)
+    B, H, W, Cc = x.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    ys = F32(H) / F32(oh)
+    xs = F32(W) / F32(ow)
+    fy = (np.arange(oh, dtype=np.float32) * ys).astype(np.float32)
+    fx = (np.arange(ow, dtype=np.float32) * xs).astype(np.float32)
+    y0 = np.floor(fy).astype(np.int64)
+    x0 = np.floor(fx).astype(np.int64)
+    y1 = np.minimum(y0 + 1, H - 1)
+    x1 = np.minimum(x0 + 1, W - 1)
+    yl = (fy - y0.astype(np.float32)).astype(np.float32)[None, :, None, None]
+    xl = (fx - x0.astype(np.float32)).astype(np.float32)[None, None, :, None]
+    tl = x[:, y0][:, :, x0]
+    tr = x[:, y0][:, :, x1]
+    bl = x[:, y1][:, :, x0]
+    br = x[:, y1][:, :, x1]
+    top = (tl + ((tr - tl) * xl).astype(np.float32)).astype(np.float32)
+    bot = (bl + ((br - bl) * xl).astype(np.float32)).astype(np.float32)
+    return (top + ((bot - top) * yl).astype(np.float32)).astype(np.float32)
+
+
+def fpn_topdown_merge(top, lateral):
+    """model/fpn/resnet_fpn.py:385-398: Add([resize_bilinear(P_{k+1}, size(C_k)) * 0.5, lateral * 0.5])."""
+    lateral = f32(lateral)
+    up = tf_resize_bilinear_legacy(top, lateral.shape[1:3])
+    return ((up * F32(0.5)).astype(np.float32) + (lateral * F32(0.5)).astype(np.float32)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
 # evaluation/detectron_pascal_evaluation_utils.py
 # --------------------------------------------------------------------------------------
 def voc_ap(rec, prec, use_07_metric=False):

@@ -34,6 +34,57 @@ def test_tf_legacy_resize_bilinear_cpu():
         np.testing.assert_allclose(got, _np_legacy_resize(x, oh, ow), rtol=0, atol=1e-6)
 
 
+def test_oracle_topdown_merge_matches_loop_restatement_cpu():
+    """oracle_np.tf_resize_bilinear_legacy / fpn_topdown_merge against the scalar loop restatement above."""
+    from oracle import oracle_np as on
+    rng = np.random.default_rng(3)
+    for (h, w), (oh, ow) in (((13, 21), (25, 42)), ((25, 42), (50, 84)), ((5, 7), (9, 13)), ((6, 6), (6, 6))):
+        top = rng.standard_normal((2, h, w, 3)).astype(np.float32)
+        lat = rng.standard_normal((2, oh, ow, 3)).astype(np.float32)
+        up = on.tf_resize_bilinear_legacy(top, (oh, ow))
+        for b in range(2):
+            for c in range(3):
+                np.testing.assert_array_equal(up[b, :, :, c], _np_legacy_resize(top[b, :, :, c], oh, ow))
+        want = (up * np.float32(0.5) + lat * np.float32(0.5)).astype(np.float32)
+        np.testing.assert_array_equal(on.fpn_topdown_merge(top, lat), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('hw,HW,C', [((25, 42), (50, 84), 256), ((50, 84), (100, 167), 256), ((7, 5), (13, 10), 8),
+                                      ((9, 9), (9, 9), 16)])
+def test_fpn_topdown_merge_bit_exact(hw, HW, C):
+    """odet_fpn_topdown_merge (float32): identical bits to the TF1 restatement; float16 maps: float32 arithmetic
+    on the float16 inputs, one rounding at the end."""
+    from oracle import oracle_np as on
+    from tf_eager_object_detection_amd import ops
+    rng = np.random.default_rng(C + hw[0])
+    B = 3
+    top = rng.standard_normal((B,) + hw + (C,)).astype(np.float32)
+    lat = rng.standard_normal((B,) + HW + (C,)).astype(np.float32)
+    got = ops.fpn_topdown_merge(torch.from_numpy(top).cuda(), torch.from_numpy(lat).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, on.fpn_topdown_merge(top, lat))
+    t16, l16 = top.astype(np.float16), lat.astype(np.float16)
+    got16 = ops.fpn_topdown_merge(torch.from_numpy(t16).cuda(), torch.from_numpy(l16).cuda()).cpu().numpy()
+    assert got16.dtype == np.float16
+    want16 = on.fpn_topdown_merge(t16.astype(np.float32), l16.astype(np.float32)).astype(np.float16)
+    np.testing.assert_array_equal(got16, want16)
+    with pytest.raises(TypeError):
+        ops.fpn_topdown_merge(torch.from_numpy(top).cuda(), torch.from_numpy(l16).cuda())
+
+
+@pytest.mark.gpu
+def test_detector_neck_uses_fused_merge_and_matches_torch_formulation():
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector, tf_legacy_resize_bilinear
+    torch.manual_seed(2)
+    cl = torch.channels_last
+    top = torch.randn(2, 256, 13, 21, device='cuda').contiguous(memory_format=cl)
+    lat = torch.randn(2, 256, 25, 42, device='cuda').contiguous(memory_format=cl)
+    got = ResNetFpnDetector._merge(top, lat)
+    want = tf_legacy_resize_bilinear(top, (25, 42)) * 0.5 + lat * 0.5
+    assert got.shape == want.shape and got.is_contiguous(memory_format=cl)
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-6)
+
+
 def test_feature_map_sizes_match_anchor_grids_cpu():
     """conv arithmetic of the extractor/neck must give ceil(H/stride) x ceil(W/stride)."""
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector

@@ -97,6 +97,7 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'odet_pack_detections': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     'odet_fpn_step_sizeof': (_sz, []),
+    'odet_fpn_topdown_merge': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'odet_fpn_step_enqueue': (_i, [_vp, _i]),
     'odet_fpn_step_enqueue_batch': (_i, [_vp, _i, _i]),
     'odet_exec_create': (_vp, [_i]),

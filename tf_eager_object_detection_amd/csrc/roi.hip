@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
 //   ODET_ROI_ROWS=k    output rows per workgroup of the non-descriptor form
 //   ODET_ROI_THREADS   256 | 512 threads per workgroup of the descriptor form
 struct RoiEnv {
-  int stage, desc, rows, threads;
+  int stage, desc, rows, threads, xcd_images;
   RoiEnv() {
     const char* e = getenv("ODET_ROI_STAGE");
     stage = (e && e[0] == '1') ? 1 : 0;
@@ -588,6 +588,8 @@ struct RoiEnv {
     rows = e ? atoi(e) : 0;
     e = getenv("ODET_ROI_THREADS");
     threads = e ? atoi(e) : 512;
+    e = getenv("ODET_ROI_XCD_IMAGES");
+    xcd_images = e ? atoi(e) : 1;
   }
 };
 static const RoiEnv& roi_env() {
@@ -672,7 +674,7 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   int64_t rows = (int64_t)n * p.groups_per_roi;
   ODET_REQUIRE(rows < (1ll << 30), "odet_roi_pool: too many workgroups");
   p.nblocks = (int)rows;
-  p.xcd_images = (B == 2 || B == 4 || B == 8) ? 1 : 0;
+  p.xcd_images = ((B == 2 || B == 4 || B == 8) && roi_env().xcd_images) ? 1 : 0;
   p.xcds_per_img = p.xcd_images ? 8 / B : 8;
   p.blocks_per_xcd = (p.nblocks + p.xcds_per_img - 1) / p.xcds_per_img;   // per XCD of an image
   dim3 grid(p.blocks_per_xcd * 8, p.xcd_images ? 1 : B);

@@ -11,7 +11,8 @@ frozen batch-norm (epsilon 1.001e-5, inference statistics) is folded into the co
 Shapes follow the reference exactly so that feature maps and anchor grids agree:
 conv1 = pad 3 + 7x7/2 valid, pool1 = pad 1 + 3x3/2 valid, the stride of a stage sits on the first
 1x1 convolution of its first block, P6 = P5[::2, ::2], top-down merge = 0.5 * resize_bilinear(P_{k+1})
-+ 0.5 * lateral with TF1's legacy resize (src = dst * in/out, no half-pixel offset).
++ 0.5 * lateral with TF1's legacy resize (src = dst * in/out, no half-pixel offset) -- one fused HIP
+kernel per merge on the GPU (ops.fpn_topdown_merge).
 """
 import math
 
@@ -19,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..pipeline import FpnHotPath
 
 __all__ = ['ResNetFpnDetector', 'tf_legacy_resize_bilinear']
@@ -159,10 +161,20 @@ class ResNetFpnDetector(nn.Module):
         c5 = self.conv5(c4)
         p5 = self.p5(c5)
         p6 = p5[:, :, ::2, ::2]                                                  # MaxPooling2D(1x1, stride 2)
-        p4 = tf_legacy_resize_bilinear(p5, c4.shape[2:]) * 0.5 + self.l4(c4) * 0.5
-        p3 = tf_legacy_resize_bilinear(p4, c3.shape[2:]) * 0.5 + self.l3(c3) * 0.5
-        p2 = tf_legacy_resize_bilinear(p3, c2.shape[2:]) * 0.5 + self.l2(c2) * 0.5
+        p4 = self._merge(p5, self.l4(c4))
+        p3 = self._merge(p4, self.l3(c3))
+        p2 = self._merge(p3, self.l2(c2))
         return self.s2(p2), self.s3(p3), self.s4(p4), p5, p6
+
+    @staticmethod
+    def _merge(top, lateral):
+        """0.5 * resize_bilinear(top) + 0.5 * lateral (resnet_fpn.py:385-398).  On the GPU one launch of the
+        fused HIP kernel (odet_fpn_topdown_merge) on the NHWC memory of the channels_last tensors; the torch
+        formulation only serves the CPU shape-bookkeeping test and dtypes the kernel does not take."""
+        if top.is_cuda and top.dtype in (torch.float32, torch.float16):
+            out = ops.fpn_topdown_merge(top.permute(0, 2, 3, 1), lateral.permute(0, 2, 3, 1))
+            return out.permute(0, 3, 1, 2)
+        return tf_legacy_resize_bilinear(top, lateral.shape[2:]) * 0.5 + lateral * 0.5
 
     def rpn(self, p_list):
         """shared RpnHead on every level; outputs concatenated P2->P6 in (y, x, anchor) order

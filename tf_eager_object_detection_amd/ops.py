@@ -314,6 +314,29 @@ def assign_levels(rois, min_level, max_level, count_dev=None, out=None):
     return out, lvl[:n], perm[:n], counts
 
 
+def fpn_topdown_merge(top, lateral, out=None):
+    """P_k = 0.5 * tf.image.resize_bilinear(P_{k+1}, size(lateral)) + 0.5 * lateral (reference
+    model/fpn/resnet_fpn.py:385-398, TF 1.x legacy resize) in one launch.  ``top`` [B,h,w,C] and
+    ``lateral`` [B,H,W,C]: NHWC GPU tensors of the same dtype (float32 or float16); contiguous NHWC memory."""
+    if top.dim() != 4 or lateral.dim() != 4:
+        raise ValueError('top and lateral must be [B,h,w,C] tensors')
+    if top.dtype != lateral.dtype or top.dtype not in (torch.float32, torch.float16):
+        raise TypeError('top and lateral must both be float32 or both float16')
+    if top.shape[0] != lateral.shape[0] or top.shape[3] != lateral.shape[3]:
+        raise ValueError('top %s and lateral %s must agree in batch and channels' % (tuple(top.shape), tuple(lateral.shape)))
+    if not top.is_contiguous():
+        top = top.contiguous()
+    if not lateral.is_contiguous():
+        lateral = lateral.contiguous()
+    B, h, w, Cc = (int(v) for v in top.shape)
+    H, W = int(lateral.shape[1]), int(lateral.shape[2])
+    if out is None:
+        out = torch.empty_like(lateral)
+    L.call('odet_fpn_topdown_merge', L.dptr(top), h, w, L.dptr(lateral), H, W, B, Cc, L.dptr(out),
+           1 if top.dtype == torch.float16 else 0, L.stream())
+    return out
+
+
 class ProfEvent:
     """HIP event for odet_roi_pool_timed (the dispatch's own begin / end timestamps)."""
 
