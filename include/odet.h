@@ -309,6 +309,14 @@ int odet_eval_detect(const float* scores, const float* deltas, const float* rois
 int odet_fpn_topdown_merge(const void* top, int h, int w, const void* lateral, int H, int W,
                            int B, int C, void* out, int f16, odet_stream_t stream);
 
+/* Convolution epilogue of the dense path, in place on an NHWC activation x [npix, C]:
+ * x = relu?((x + bias[C]) (+ residual[npix, C])) -- the frozen-BatchNormalization bias, the
+ * bottleneck's Add([shortcut, x]) and Activation('relu') of model/fpn/resnet_fpn.py:154-205
+ * (and the RpnHead's ReLU, base_fpn_model.py:393-434) in one pass.  residual may be NULL.
+ * f16 != 0: float16 tensors (float32 arithmetic, one rounding), C % 8 == 0; else float32, C % 4 == 0. */
+int odet_bias_act(void* x, const void* bias, const void* residual, long long npix, int C, int relu,
+                  int f16, odet_stream_t stream);
+
 /* ---- multi-GPU detection records ------------------------------------------------------ */
 
 /* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of

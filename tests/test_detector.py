@@ -85,6 +85,56 @@ def test_detector_neck_uses_fused_merge_and_matches_torch_formulation():
     torch.testing.assert_close(got, want, rtol=0, atol=2e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('C', [8, 64, 256])
+def test_bias_act_epilogue(C):
+    """odet_bias_act: float32 identical to the separate framework ops ((x + b) + r, then relu, NaN kept);
+    float16 = float32 arithmetic on the float16 inputs with one rounding."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(C)
+    x = torch.randn(3, 17, 19, C, device='cuda', generator=g)
+    b = torch.randn(C, device='cuda', generator=g)
+    r = torch.randn(3, 17, 19, C, device='cuda', generator=g)
+    x[0, 0, 0, 0] = float('nan')
+    for res in (None, r):
+        for relu in (False, True):
+            want = x + b
+            if res is not None:
+                want = want + res
+            if relu:
+                want = torch.relu(want)
+            got = ops.bias_act_(x.clone(), b, res, relu)
+            assert torch.equal(torch.nan_to_num(got, nan=123.0), torch.nan_to_num(want, nan=123.0))
+            x16, b16 = x.half(), b.half()
+            r16 = None if res is None else res.half()
+            w = x16.float() + b16.float()
+            if r16 is not None:
+                w = w + r16.float()
+            if relu:
+                w = torch.relu(w)
+            got16 = ops.bias_act_(x16.clone(), b16, r16, relu)
+            assert torch.equal(torch.nan_to_num(got16, nan=123.0), torch.nan_to_num(w.half(), nan=123.0))
+    with pytest.raises(TypeError):
+        ops.bias_act_(x.clone(), b.half())
+
+
+@pytest.mark.gpu
+def test_detector_block_with_fused_epilogue_matches_torch_formulation():
+    from tf_eager_object_detection_amd.model import fpn_detector as fd
+    torch.manual_seed(5)
+    blk = fd._Block(64, 32, 2, True).cuda().to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        for m in (blk.short, blk.c1, blk.c2, blk.c3):
+            m.bias.normal_(0, 0.1)
+        x = torch.randn(2, 64, 24, 30, device='cuda').contiguous(memory_format=torch.channels_last)
+        got = blk(x)
+        sc = blk.short(x)
+        y = torch.relu(blk.c1(x)); y = torch.relu(blk.c2(y)); y = blk.c3(y)
+        want = torch.relu(sc + y)
+    assert got.shape == want.shape
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
 def test_feature_map_sizes_match_anchor_grids_cpu():
     """conv arithmetic of the extractor/neck must give ceil(H/stride) x ceil(W/stride)."""
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector

@@ -1,0 +1,91 @@
+// Convolution epilogue of the dense path ("frozen-BN folded into conv"): what follows every
+// library convolution of the reference's ResNet / neck / RPN head, in ONE in-place pass over the NHWC output:
+//     y = conv + bias                        (frozen BatchNormalization folded into weight and bias)
+//     y = y + shortcut                       (bottleneck blocks, resnet_fpn.py:154-205: Add([shortcut, x]))
+//     y = max(y, 0)                          (Activation('relu'))
+// As separate framework ops this is 2-3 launches and 5-7 passes over the activation per convolution; the
+// detector spent more time in them than in the convolutions themselves.  HBM-bound: 16 B per lane, bias (C
+// values) from L1.  float32: the same operation order as the separate ops ((conv + bias) + shortcut, then
+// max) -> identical bits; float16: float32 arithmetic, one rounding at the end.
+#include <hip/hip_fp16.h>
+
+#include "odet_internal.h"
+
+struct EpiParams {
+  void* x; const void* bias; const void* res;
+  long long total;      // npix * (C / N) vectors
+  int vec_per_px, relu;
+};
+
+template <typename FT>
+__global__ void __launch_bounds__(256) k_bias_act(EpiParams p) {
+  constexpr int N = sizeof(FT) == 2 ? 8 : 4;
+  uint4* __restrict__ x = reinterpret_cast<uint4*>(p.x);
+  const uint4* __restrict__ bias = reinterpret_cast<const uint4*>(p.bias);
+  const uint4* __restrict__ res = reinterpret_cast<const uint4*>(p.res);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+    const uint4 xv = x[i];
+    const uint4 bv = bias[(int)(i % p.vec_per_px)];
+    uint4 rv = make_uint4(0, 0, 0, 0);
+    if (res) rv = res[i];
+    float a[8], b[8], r[8];
+    if (sizeof(FT) == 2) {
+      const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 t = __half22float2(*reinterpret_cast<const __half2*>(&xw[k]));
+        const float2 u = __half22float2(*reinterpret_cast<const __half2*>(&bw[k]));
+        const float2 v = __half22float2(*reinterpret_cast<const __half2*>(&rw[k]));
+        a[2 * k] = t.x; a[2 * k + 1] = t.y; b[2 * k] = u.x; b[2 * k + 1] = u.y; r[2 * k] = v.x; r[2 * k + 1] = v.y;
+      }
+    } else {
+      const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k] = __uint_as_float(xw[k]); b[k] = __uint_as_float(bw[k]); r[k] = __uint_as_float(rw[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      float y = a[k] + b[k];
+      if (res) y = y + r[k];
+      if (p.relu) y = (y < 0.0f) ? 0.0f : y;   // (a NaN stays a NaN, as in the framework's relu)
+      a[k] = y;
+    }
+    uint4 o;
+    if (sizeof(FT) == 2) {
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const __half2 t = __floats2half2_rn(a[2 * k], a[2 * k + 1]);
+        w[k] = *reinterpret_cast<const uint32_t*>(&t);
+      }
+      o = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      o = make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
+    }
+    x[i] = o;
+  }
+}
+
+extern "C" int odet_bias_act(void* x, const void* bias, const void* residual, long long npix, int C, int relu,
+                             int f16, odet_stream_t stream) {
+  ODET_REQUIRE(x && bias, "odet_bias_act: null pointer");
+  ODET_REQUIRE(npix >= 0 && C > 0, "odet_bias_act: bad sizes");
+  const int n = f16 ? 8 : 4;
+  ODET_REQUIRE(C % n == 0, "odet_bias_act: C must be a multiple of %d (got %d)", n, C);
+  if (npix == 0) return ODET_OK;
+  EpiParams p;
+  p.x = x; p.bias = bias; p.res = residual;
+  p.vec_per_px = C / n;
+  p.total = npix * p.vec_per_px;
+  p.relu = relu ? 1 : 0;
+  const long long blocks = (p.total + 255) / 256;
+  const int grid = (int)std::min<long long>(blocks, 256 * 64);
+  if (f16)
+    hipLaunchKernelGGL(k_bias_act<__half>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(k_bias_act<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}

@@ -49,6 +49,30 @@ def _fold_frozen_bn(conv):
     return conv
 
 
+def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
+    """conv (+ zero padding `pad`) -> + bias (+ extra_bias) (+ residual) -> ReLU.  On the GPU the convolution
+    runs without its bias and everything after it is ONE in-place pass of the fused HIP epilogue
+    (ops.bias_act_) over the NHWC output; the torch formulation serves the CPU shape-bookkeeping test."""
+    if pad is not None:
+        x = F.pad(x, pad)
+    bias = conv.bias if extra_bias is None else conv.bias + extra_bias
+    if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        res = None
+        if residual is not None:
+            res = residual.permute(0, 2, 3, 1)
+            if not res.is_contiguous():
+                res = res.contiguous()
+        ops.bias_act_(y.permute(0, 2, 3, 1), bias, res, relu)
+        return y
+    y = F.conv2d(x, conv.weight, bias, conv.stride, conv.padding)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
 class _Block(nn.Module):
     """reference resnet_fpn.py:154-205 block1 (bottleneck, stride on the first 1x1)."""
 
@@ -65,11 +89,15 @@ class _Block(nn.Module):
             self.c3.weight.mul_(0.2)
 
     def forward(self, x):
-        sc = x if self.short is None else self.short(x)
-        y = F.relu(self.c1(x))
-        y = F.relu(self.c2(y))
-        y = self.c3(y)
-        return F.relu(sc + y)
+        # Add([shortcut, x]) + ReLU ride on c3's epilogue; a convolutional shortcut runs without its bias,
+        # which is added to c3's instead
+        if self.short is None:
+            sc, sb = x, None
+        else:
+            sc, sb = F.conv2d(x, self.short.weight, None, self.short.stride, self.short.padding), self.short.bias
+        y = _conv_epi(self.c1, x, relu=True)
+        y = _conv_epi(self.c2, y, relu=True)
+        return _conv_epi(self.c3, y, relu=True, residual=sc, extra_bias=sb)
 
 
 def _stack(cin, filters, blocks, stride1):
@@ -153,18 +181,18 @@ class ResNetFpnDetector(nn.Module):
     def features(self, images_nhwc):
         """[B,H,W,3] -> (P2..P6), each [B,256,h,w] channels_last (= NHWC in memory)."""
         x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)                       # NHWC memory, NCHW view
-        x = F.relu(self.conv1(F.pad(x, (3, 3, 3, 3))))                           # conv1_pad + valid 7x7/2
+        x = _conv_epi(self.conv1, x, relu=True, pad=(3, 3, 3, 3))                # conv1_pad + valid 7x7/2
         x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), 3, 2)                           # pool1_pad (zeros) + 3x3/2
         c2 = self.conv2(x)
         c3 = self.conv3(c2)
         c4 = self.conv4(c3)
         c5 = self.conv5(c4)
-        p5 = self.p5(c5)
+        p5 = _conv_epi(self.p5, c5)
         p6 = p5[:, :, ::2, ::2]                                                  # MaxPooling2D(1x1, stride 2)
-        p4 = self._merge(p5, self.l4(c4))
-        p3 = self._merge(p4, self.l3(c3))
-        p2 = self._merge(p3, self.l2(c2))
-        return self.s2(p2), self.s3(p3), self.s4(p4), p5, p6
+        p4 = self._merge(p5, _conv_epi(self.l4, c4))
+        p3 = self._merge(p4, _conv_epi(self.l3, c3))
+        p2 = self._merge(p3, _conv_epi(self.l2, c2))
+        return _conv_epi(self.s2, p2), _conv_epi(self.s3, p3), _conv_epi(self.s4, p4), p5, p6
 
     @staticmethod
     def _merge(top, lateral):
@@ -181,7 +209,7 @@ class ResNetFpnDetector(nn.Module):
         (base_fpn_model.py:188-200, 427-432): scores [B, N, 2], deltas [B, N, 4]."""
         scores, deltas = [], []
         for p in p_list:
-            x = F.relu(self.rpn_conv(p))
+            x = _conv_epi(self.rpn_conv, p, relu=True)
             B = x.shape[0]
             scores.append(self.rpn_score(x).permute(0, 2, 3, 1).reshape(B, -1, 2))
             deltas.append(self.rpn_bbox(x).permute(0, 2, 3, 1).reshape(B, -1, 4))

@@ -337,6 +337,21 @@ def fpn_topdown_merge(top, lateral, out=None):
     return out
 
 
+def bias_act_(x, bias, residual=None, relu=True):
+    """In place on an NHWC (or any [..., C] contiguous) activation: x = relu?((x + bias) (+ residual)) -- the
+    convolution epilogue of the reference's ResNet blocks / RPN head (resnet_fpn.py:154-205) in one pass."""
+    if x.dtype not in (torch.float32, torch.float16) or bias.dtype != x.dtype:
+        raise TypeError('x and bias must both be float32 or both float16')
+    if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape):
+        raise ValueError('residual must match x in dtype and shape')
+    Cc = int(x.shape[-1])
+    if bias.numel() != Cc:
+        raise ValueError('bias must have %d elements' % Cc)
+    L.call('odet_bias_act', L.dptr(x), L.dptr(bias), L.dptr(residual), x.numel() // Cc, Cc, 1 if relu else 0,
+           1 if x.dtype == torch.float16 else 0, L.stream())
+    return x
+
+
 class ProfEvent:
     """HIP event for odet_roi_pool_timed (the dispatch's own begin / end timestamps)."""
 

@@ -13,7 +13,7 @@ one() {   # name flags...
   /opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
     -c tf_eager_object_detection_amd/csrc/roi.hip -o $D/roi_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/boxes.hip.o $O/sort.hip.o $O/nms.hip.o $D/roi_$name.o \
-    $O/postops.hip.o $O/neck.hip.o $O/executor.hip.o -lpthread -o $D/libodet_hip_$name.so
+    $O/postops.hip.o $O/neck.hip.o $O/epilogue.hip.o $O/executor.hip.o -lpthread -o $D/libodet_hip_$name.so
   rm -f $D/roi_$name.o
 }
 if [ $# -ge 1 ]; then one "$@"; else for k in 1 2 3 4 5; do one a$k -DODET_ROI_ABLATE=$k & done; wait; fi
