@@ -180,3 +180,29 @@ def test_detector_hot_path_state_matches_oracle():
     assert np.max(np.abs(got - want)) <= 1e-4 * max(1.0, float(np.abs(want).max()))
     boxes, labels, scores, count = out[0]
     assert int(count.item()) > 0
+
+
+@pytest.mark.gpu
+def test_detector_hip_graph_replay_matches_eager():
+    """ResNetFpnDetector.capture: the whole forward pass replayed as one HIP graph gives the eager outputs,
+    and follows its input (a second image through the same graph)."""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(3)
+    shape = (256, 352)
+    m = ResNetFpnDetector(50, 21, shape, 300, dtype=torch.float32, blind_chunks=3).prepare()
+    rng = np.random.default_rng(7)
+    imgs = [torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda() for _ in range(2)]
+    eager = []
+    for im in imgs:
+        b, l, s, c = m(im)[0]
+        eager.append((b.clone(), l.clone(), s.clone(), int(c.item())))
+    run = m.capture(1)
+    for im, (eb, el, es, ec) in zip(imgs, eager):
+        b, l, s, c = run(im)[0]
+        torch.cuda.synchronize()
+        assert int(c.item()) == ec and ec > 0
+        assert torch.equal(l[:ec], el[:ec])
+        # (library convolutions may pick another algorithm during the capture warm-up: low-bit differences)
+        torch.testing.assert_close(b[:ec], eb[:ec], rtol=1e-3, atol=1e-2)
+        torch.testing.assert_close(s[:ec], es[:ec], rtol=1e-3, atol=1e-4)
+    assert int(m._hot[0].nms_done.item()) == 1

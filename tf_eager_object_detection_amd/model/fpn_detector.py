@@ -221,6 +221,36 @@ class ResNetFpnDetector(nn.Module):
         x = F.relu(self.fc2(x))
         return self.score(x), self.bbox(x)
 
+    # ---- HIP-graph replay ---------------------------------------------------------------------------
+    def capture(self, batch, warmup=3):
+        """Captures forward() for `batch` images of self.image_shape into ONE HIP graph (the whole detector:
+        library convolutions, fused epilogues / neck merges, the sync-free hot path, the RoI head) and
+        returns `run(images_nhwc) -> outputs`: the images are copied into the graph's static input and the
+        graph is replayed -- a few hundred launches cost one host call, which is what a batch-1 latency
+        step is bound by.  Needs the sync-free proposal stage (blind_chunks >= 1: no host check inside)."""
+        if not self._hot:
+            raise RuntimeError('prepare() first')
+        dev = next(self.parameters()).device
+        static_in = torch.zeros((batch,) + self.image_shape + (3,), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):                  # MIOpen solver search + every lazy allocation
+                self.forward(static_in)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                static_out = self.forward(static_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+        def run(images_nhwc):
+            static_in.copy_(images_nhwc)
+            graph.replay()
+            return static_out
+
+        run.graph = graph
+        return run
+
     # ---- the model ----------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, images_nhwc):

@@ -19,6 +19,7 @@ ap.add_argument('--depth', type=int, default=101)
 ap.add_argument('--h', type=int, default=800)
 ap.add_argument('--w', type=int, default=1333)
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+ap.add_argument('--graph', action='store_true', help='replay the whole forward pass as one HIP graph')
 a = ap.parse_args()
 dt = {'fp16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32}[a.dtype]
 torch.backends.cudnn.benchmark = bool(a.miopen_find)
@@ -31,10 +32,15 @@ t0 = time.perf_counter()
 for _ in range(a.warmup):
     out = model(img)
 torch.cuda.synchronize()
+step = model.capture(a.batch) if a.graph else model
+if a.graph:
+    for _ in range(3):
+        out = step(img)
+    torch.cuda.synchronize()
 t_warm = time.perf_counter() - t0
 t0 = time.perf_counter()
 for _ in range(a.steps):
-    out = model(img)
+    out = step(img)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 # per-part timing (one extra pass each, synchronised)
@@ -49,5 +55,5 @@ print(json.dumps({'metric': 'end-to-end images/sec', 'value': a.steps * a.batch 
                   'model': 'ResNet-%d-FPN' % a.depth, 'image': [a.h, a.w], 'dtype': a.dtype, 'batch': a.batch,
                   'ms_per_image': el / (a.steps * a.batch) * 1e3, 'warmup_s': t_warm,
                   'ms_backbone_neck_per_batch': t_feat, 'ms_rpn_head_per_batch': t_rpn,
-                  'detections_image0': int(out[0][3].item()), 'finite': bool(torch.isfinite(p[0]).all().item()), 'miopen_find': bool(a.miopen_find),
+                  'detections_image0': int(out[0][3].item()), 'finite': bool(torch.isfinite(p[0]).all().item()), 'miopen_find': bool(a.miopen_find), 'hip_graph': bool(a.graph),
                   'nms_done': [int(h.nms_done.item()) for h in model._hot]}))
