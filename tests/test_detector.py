@@ -206,3 +206,83 @@ def test_detector_hip_graph_replay_matches_eager():
         torch.testing.assert_close(b[:ec], eb[:ec], rtol=1e-3, atol=1e-2)
         torch.testing.assert_close(s[:ec], es[:ec], rtol=1e-3, atol=1e-4)
     assert int(m._hot[0].nms_done.item()) == 1
+
+
+def test_c4_feature_map_size_matches_anchor_grid_cpu():
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector
+    m = ResNetC4Detector(50, 21, (160, 224), 50, dtype=torch.float32).eval()
+    with torch.no_grad():
+        c4 = m.features(torch.zeros((1, 160, 224, 3)))
+        sc, dl = m.rpn(c4)
+    assert tuple(c4.shape) == (1, 1024, 10, 14)
+    assert sc.shape == (1, 10 * 14, 18) and dl.shape == (1, 10 * 14 * 9, 4)
+
+
+@pytest.mark.gpu
+def test_c4_detector_hot_path_state_matches_oracle():
+    """ResNet-50 C4 Faster R-CNN (BASELINE config 2): given the tensors the dense parts produced, the hot-path
+    state (kept anchors, RoIs, 14x14 + max-pooled features) matches the oracle."""
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector
+    from oracle import oracle_np as on
+    torch.manual_seed(4)
+    shape = (256, 352)
+    m = ResNetC4Detector(50, 21, shape, 100, dtype=torch.float32, blind_chunks=4).prepare()
+    rng = np.random.default_rng(4)
+    img = torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    out = m(img)
+    torch.cuda.synchronize()
+    hot = m._hot[0]
+    assert int(hot.nms_done.item()) == 1
+    with torch.no_grad():
+        c4 = m.features(img)
+        sc, dl = m.rpn(c4)
+    fg = co.rpn_fg_frcnn(sc[0].float().cpu().numpy(), 9)
+    anchors = co.anchors_shift(hot.anchor_base, 16, hot.fh, hot.fw)
+    rois, idx = co.region_proposal(dl[0].float().cpu().numpy(), anchors, fg, shape, 100, 0.7)
+    k = int(hot.roi_count.item())
+    assert k == len(idx)
+    np.testing.assert_array_equal(hot.roi_idx[:k].cpu().numpy(), idx)
+    fmap = c4.permute(0, 2, 3, 1).float().cpu().numpy()[0]
+    want = co.roi_pool(fmap, rois, stride=16, pool=7, max_pool=True)
+    got = hot.roi_features[:k].cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 1e-4 * max(1.0, float(np.abs(want).max()))
+    boxes, labels, scores, count = out[0]
+    assert 0 < int(count.item()) <= 50
+
+
+def test_vgg16_feature_map_size_matches_anchor_grid_cpu():
+    from tf_eager_object_detection_amd.model.frcnn_detector import Vgg16Detector
+    m = Vgg16Detector(21, (150, 200), 50, dtype=torch.float32).eval()
+    with torch.no_grad():
+        f = m.features(torch.zeros((1, 150, 200, 3)))
+        sc, dl = m.rpn(f)
+    assert tuple(f.shape) == (1, 512, 10, 13)                      # ceil(150/16) x ceil(200/16)
+    assert sc.shape == (1, 130, 18) and dl.shape == (1, 130 * 9, 4)
+
+
+@pytest.mark.gpu
+def test_vgg16_detector_runs_and_pools_like_oracle():
+    """VGG16 Faster R-CNN (BASELINE config 1 shapes, reduced): RoIs and 14x14 + max pooled features vs oracle."""
+    from tf_eager_object_detection_amd.model.frcnn_detector import Vgg16Detector
+    torch.manual_seed(6)
+    shape = (240, 320)
+    m = Vgg16Detector(21, shape, 100, dtype=torch.float32, blind_chunks=4).prepare()
+    rng = np.random.default_rng(6)
+    img = torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    out = m(img)
+    torch.cuda.synchronize()
+    hot = m._hot[0]
+    assert int(hot.nms_done.item()) == 1
+    with torch.no_grad():
+        f = m.features(img)
+        sc, dl = m.rpn(f)
+    fg = co.rpn_fg_frcnn(sc[0].float().cpu().numpy(), 9)
+    anchors = co.anchors_shift(hot.anchor_base, 16, hot.fh, hot.fw)
+    rois, idx = co.region_proposal(dl[0].float().cpu().numpy(), anchors, fg, shape, 100, 0.7)
+    k = int(hot.roi_count.item())
+    np.testing.assert_array_equal(hot.roi_idx[:k].cpu().numpy(), idx)
+    fmap = f.permute(0, 2, 3, 1).float().cpu().numpy()[0]
+    want = co.roi_pool(fmap, rois, stride=16, pool=7, max_pool=True)
+    got = hot.roi_features[:k].cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 1e-4 * max(1.0, float(np.abs(want).max()))
+    assert 0 < int(out[0][3].item()) <= 50

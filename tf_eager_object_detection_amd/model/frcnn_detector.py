@@ -1,0 +1,166 @@
+"""ResNet-C4 Faster R-CNN detector assembled around the HIP hot path -- counterpart of the reference's
+model/faster_rcnn/resnet_faster_rcnn.py (ResNetFasterRcnn: extractor conv1..conv4, RoI head = conv5 stack +
+global average pool + two dense layers) + the inference branch of model/faster_rcnn/base_faster_rcnn_model.py
+(BaseFasterRcnn.call :126-198, RpnHead :309-350).  BASELINE config "ResNet-50 Faster R-CNN, 1x3x800x1333".
+
+Same arrangement as model/fpn_detector.py: the convolutions are genuine dense contractions and run through
+PyTorch-ROCm's library convolutions (NHWC, fp32 / fp16) with the fused HIP epilogue behind each of them;
+everything between them is FrcnnHotPath (anchors in registers -> [A bg | A fg] softmax -> decode / clip ->
+exact NMS over all anchors -> 14x14 crop + 2x2 max on the stride-16 map -> post_ops_prediction).  Weights are
+randomly initialised with the reference's initialisers (no checkpoints offline), frozen batch-norm folded."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..pipeline import FrcnnHotPath
+from .fpn_detector import _BLOCKS, ResNetFpnDetector, _conv, _conv_epi, _fold_frozen_bn, _stack
+
+__all__ = ['ResNetC4Detector', 'Vgg16Detector']
+
+
+class ResNetC4Detector(nn.Module):
+    """Inference-only ResNet-{50,101,152} C4 Faster R-CNN.  `forward(images)` takes NHWC float images [B,H,W,3]
+    (mean-subtracted) and returns, per image, the padded detections of post_ops_prediction + their count."""
+
+    def __init__(self, depth=50, num_classes=21, image_shape=(800, 1333), num_proposals=300, dtype=torch.float32,
+                 max_batch=1, roi_chunk=0, **hot_kwargs):
+        super().__init__()
+        b = _BLOCKS[depth]
+        self.dtype = dtype
+        self.image_shape = (int(image_shape[0]), int(image_shape[1]))
+        self.num_classes = num_classes
+        # extractor (resnet_faster_rcnn.py:104-153): conv1 .. conv4, stride 16
+        self.conv1 = _fold_frozen_bn(_conv(3, 64, 7, 2, 0))
+        self.conv2 = _stack(64, 64, b[0], 1)
+        self.conv3 = _stack(256, 128, b[1], 2)
+        self.conv4 = _stack(512, 256, b[2], 2)
+        # RPN head (base_faster_rcnn_model.py:309-350); 9 anchors per cell, scores laid out [A bg | A fg]
+        self.A = 9
+        self.rpn_conv = _conv(1024, 512, 3, 1, 1, std=0.01)
+        self.rpn_score = _conv(512, 2 * self.A, 1, std=0.01)
+        self.rpn_bbox = _conv(512, 4 * self.A, 1, std=0.001)
+        # RoI head (resnet_faster_rcnn.py:156-183): conv5 stack (stride1 = 1) on the 7x7 crops, GAP, 2 dense
+        self.conv5 = _stack(1024, 512, b[3], 1)
+        self.score = nn.Linear(2048, num_classes)
+        self.bbox = nn.Linear(2048, 4 * num_classes)
+        for m, std in ((self.score, 0.01), (self.bbox, 0.001)):
+            nn.init.normal_(m.weight, 0.0, std)
+            nn.init.zeros_(m.bias)
+        self._hot_args = (self.image_shape, num_classes, num_proposals, 1024)
+        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=True)          # roi_pooling_max_pooling_flag=True
+        self._hot_kwargs.update(hot_kwargs)
+        self._hot = []
+        self._max_batch = max_batch
+        self._roi_chunk = int(roi_chunk)
+
+    def prepare(self, device='cuda'):
+        self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
+        fd = torch.float16 if self.dtype == torch.float16 else torch.float32
+        self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs) for _ in range(self._max_batch)]
+        return self
+
+    # ---- dense parts ---------------------------------------------------------------------------
+    def features(self, images_nhwc):
+        """[B,H,W,3] -> C4 [B,1024,ceil(H/16),ceil(W/16)] channels_last (= NHWC in memory)."""
+        x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
+        x = _conv_epi(self.conv1, x, relu=True, pad=(3, 3, 3, 3))                # conv1_pad + valid 7x7/2
+        x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), 3, 2)                           # pool1_pad (zeros) + 3x3/2
+        return self.conv4(self.conv3(self.conv2(x)))
+
+    def rpn(self, c4):
+        """RpnHead: scores [B, fh*fw, 2A] ([A bg | A fg] per location), deltas [B, fh*fw*A, 4]."""
+        x = _conv_epi(self.rpn_conv, c4, relu=True)
+        B = x.shape[0]
+        scores = self.rpn_score(x).permute(0, 2, 3, 1).reshape(B, -1, 2 * self.A)
+        deltas = self.rpn_bbox(x).permute(0, 2, 3, 1).reshape(B, -1, 4)
+        return scores, deltas
+
+    def roi_head(self, roi_features):
+        """[R,7,7,1024] NHWC -> conv5 -> global average pool -> (score logits [R,C], box deltas [R,4C])."""
+        x = roi_features.permute(0, 3, 1, 2).to(self.dtype)                      # NCHW view of NHWC memory
+        R = x.shape[0]
+        step = self._roi_chunk if self._roi_chunk > 0 else R
+        outs = [self.conv5(x[i:i + step]).mean(dim=(2, 3)) for i in range(0, R, step)]
+        y = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+        return self.score(y), self.bbox(y)
+
+    capture = ResNetFpnDetector.capture          # whole forward pass as one HIP graph (generic over self.forward)
+
+    # ---- the model ----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, images_nhwc):
+        B = images_nhwc.shape[0]
+        if B > len(self._hot):
+            raise ValueError('batch %d exceeds max_batch %d' % (B, len(self._hot)))
+        c4 = self.features(images_nhwc)
+        rpn_scores, rpn_deltas = self.rpn(c4)
+        rpn_scores, rpn_deltas = rpn_scores.float().contiguous(), rpn_deltas.float().contiguous()
+        maps = c4.permute(0, 2, 3, 1)                                            # NHWC view
+        if self.dtype != torch.float16:
+            maps = maps.float()
+        outs = []
+        for b in range(B):
+            hot = self._hot[b]
+            hot.stage_proposals(rpn_scores[b], rpn_deltas[b])
+            feats = hot.stage_roi(maps[b:b + 1].contiguous())
+            logits, bbox = self.roi_head(feats)
+            cls = torch.softmax(logits.float(), dim=-1).contiguous()
+            outs.append(hot.stage_detect(cls, bbox.float().contiguous()))
+        return outs
+
+
+class Vgg16Detector(ResNetC4Detector):
+    """Inference-only VGG16 Faster R-CNN -- counterpart of model/faster_rcnn/vgg16_faster_rcnn.py
+    (Vgg16Extractor :260-342: 13 3x3 'same' convolutions + ReLU, four 2x2/2 'same' max-pools, stride 16;
+    Vgg16RoiHead :178-257: flatten(7,7,512) -> fc 4096 -> fc 4096 -> score / boxes) around FrcnnHotPath
+    (14x14 crop + 2x2 max on 512 channels).  BASELINE config "VGG16 Faster R-CNN, 1x3x600x800"."""
+
+    _CFG = ((64, 2), (128, 2), (256, 3), (512, 3), (512, 3))
+
+    def __init__(self, num_classes=21, image_shape=(600, 800), num_proposals=300, dtype=torch.float32, max_batch=1,
+                 **hot_kwargs):
+        nn.Module.__init__(self)
+        self.dtype = dtype
+        self.image_shape = (int(image_shape[0]), int(image_shape[1]))
+        self.num_classes = num_classes
+        convs, cin = [], 3
+        for cout, n in self._CFG:
+            for _ in range(n):
+                convs.append(_conv(cin, cout, 3, 1, 1))
+                cin = cout
+        self.convs = nn.ModuleList(convs)
+        self.A = 9
+        self.rpn_conv = _conv(512, 512, 3, 1, 1, std=0.01)
+        self.rpn_score = _conv(512, 2 * self.A, 1, std=0.01)
+        self.rpn_bbox = _conv(512, 4 * self.A, 1, std=0.001)
+        self.fc1 = nn.Linear(7 * 7 * 512, 4096)
+        self.fc2 = nn.Linear(4096, 4096)
+        self.score = nn.Linear(4096, num_classes)
+        self.bbox = nn.Linear(4096, 4 * num_classes)
+        for m, std in ((self.fc1, 0.01), (self.fc2, 0.01), (self.score, 0.01), (self.bbox, 0.001)):
+            nn.init.normal_(m.weight, 0.0, std)
+            nn.init.zeros_(m.bias)
+        self._hot_args = (self.image_shape, num_classes, num_proposals, 512)
+        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=True)
+        self._hot_kwargs.update(hot_kwargs)
+        self._hot = []
+        self._max_batch = max_batch
+        self._roi_chunk = 0
+
+    def features(self, images_nhwc):
+        """[B,H,W,3] -> conv5_3 [B,512,ceil(H/16),ceil(W/16)] channels_last."""
+        x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
+        i = 0
+        for bi, (_, n) in enumerate(self._CFG):
+            for _ in range(n):
+                x = _conv_epi(self.convs[i], x, relu=True)
+                i += 1
+            if bi < 4:
+                x = F.max_pool2d(x, 2, 2, ceil_mode=True)        # MaxPooling2D((2,2), 2, padding='same')
+        return x
+
+    def roi_head(self, roi_features):
+        x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)        # Flatten() of NHWC crops
+        x = F.relu(self.fc1(x))                                                   # (dropout: inference)
+        x = F.relu(self.fc2(x))
+        return self.score(x), self.bbox(x)

@@ -161,7 +161,7 @@ class FrcnnHotPath:
                  max_pooling_flag=False, extractor_stride=16, anchor_base_size=16, ratios=(0.5, 1, 2),
                  scales=(8, 16, 32), rpn_nms_iou=0.7, rpn_means=(0, 0, 0, 0), rpn_stds=(1, 1, 1, 1),
                  roi_means=(0, 0, 0, 0), roi_stds=(0.1, 0.1, 0.2, 0.2), max_per_class=50, max_per_image=50,
-                 nms_iou=0.3, score_threshold=0.0, blind_chunks=1, device=None):
+                 nms_iou=0.3, score_threshold=0.0, blind_chunks=1, device=None, feature_dtype=torch.float32):
         from .utils.anchor_generator import generate_anchor_base
         import math
         self.image_shape = [int(image_shape[0]), int(image_shape[1])]
@@ -185,7 +185,8 @@ class FrcnnHotPath:
         self.roi_idx = torch.zeros(K, dtype=torch.int32, device=dev)
         self.roi_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nms_done = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.roi_features = torch.zeros((K, pool_size, pool_size, channels), dtype=torch.float32, device=dev)
+        # float16 feature maps (a float16 backbone) are taken as they are by the pooled mode (14x14 + max)
+        self.roi_features = torch.zeros((K, pool_size, pool_size, channels), dtype=feature_dtype, device=dev)
         M = max(max_per_image, 1)
         self.det_boxes = torch.zeros((M, 4), dtype=torch.float32, device=dev)
         self.det_labels = torch.zeros(M, dtype=torch.int32, device=dev)

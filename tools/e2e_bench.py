@@ -9,6 +9,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--dtype', default='fp16')
@@ -16,6 +17,8 @@ ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--steps', type=int, default=30)
 ap.add_argument('--warmup', type=int, default=5)
 ap.add_argument('--depth', type=int, default=101)
+ap.add_argument('--model', default='fpn', choices=['fpn', 'c4', 'vgg16'],
+                help='fpn: ResNet-FPN (1000 proposals); c4: ResNet-C4 Faster R-CNN (300 proposals); vgg16: VGG16 Faster R-CNN')
 ap.add_argument('--h', type=int, default=800)
 ap.add_argument('--w', type=int, default=1333)
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
@@ -24,7 +27,12 @@ a = ap.parse_args()
 dt = {'fp16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32}[a.dtype]
 torch.backends.cudnn.benchmark = bool(a.miopen_find)
 torch.manual_seed(0)
-model = ResNetFpnDetector(a.depth, 21, (a.h, a.w), 1000, dtype=dt, max_batch=a.batch, blind_chunks=2).prepare()
+if a.model == 'fpn':
+    model = ResNetFpnDetector(a.depth, 21, (a.h, a.w), 1000, dtype=dt, max_batch=a.batch, blind_chunks=2).prepare()
+elif a.model == 'c4':
+    model = ResNetC4Detector(a.depth, 21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4).prepare()
+else:
+    model = Vgg16Detector(21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4).prepare()
 rng = np.random.default_rng(0)
 img = (rng.uniform(0, 255, (a.batch, a.h, a.w, 3)) - np.float32([103.939, 116.779, 123.68])).astype(np.float32)
 img = torch.from_numpy(img).cuda()
@@ -51,8 +59,10 @@ def timed(fn, n=5):
 with torch.no_grad():
     t_feat, p = timed(lambda: model.features(img))
     t_rpn, _ = timed(lambda: model.rpn(p))
+if not isinstance(p, (tuple, list)):
+    p = [p]
 print(json.dumps({'metric': 'end-to-end images/sec', 'value': a.steps * a.batch / el, 'unit': 'img/s',
-                  'model': 'ResNet-%d-FPN' % a.depth, 'image': [a.h, a.w], 'dtype': a.dtype, 'batch': a.batch,
+                  'model': {'fpn': 'ResNet-%d-FPN' % a.depth, 'c4': 'ResNet-%d-C4 Faster R-CNN' % a.depth, 'vgg16': 'VGG16 Faster R-CNN'}[a.model], 'image': [a.h, a.w], 'dtype': a.dtype, 'batch': a.batch,
                   'ms_per_image': el / (a.steps * a.batch) * 1e3, 'warmup_s': t_warm,
                   'ms_backbone_neck_per_batch': t_feat, 'ms_rpn_head_per_batch': t_rpn,
                   'detections_image0': int(out[0][3].item()), 'finite': bool(torch.isfinite(p[0]).all().item()), 'miopen_find': bool(a.miopen_find), 'hip_graph': bool(a.graph),
