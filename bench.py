@@ -159,6 +159,9 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='HIP streams (+ native enqueue threads) per GPU')
     ap.add_argument('--batch', type=int, default=8, help='images that share the kernel launches of a stream (1..8)')
     ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
+    ap.add_argument('--maps', choices=['f32', 'f16'], default='f32',
+                    help='feature-map / RoI-feature storage type (f32 = the metric of SURVEY 8d; f16 = BASELINE '
+                         'config 5 "fp16 feature maps": float32 lerps, float16 in / out)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; "
                     "'gloo' only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -196,8 +199,11 @@ def main():
     S, B = max(1, args.streams), max(1, min(8, args.batch))
     if args.blind_chunks != 1:
         B = 1                                                   # the NMS fallback is per image
+    fdt = torch.float16 if args.maps == 'f16' else torch.float32
     pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B,
-                         blind_chunks=args.blind_chunks)
+                         blind_chunks=args.blind_chunks, feature_dtype=fdt)
+    if fdt != torch.float32:
+        dev['feats'] = [f.to(fdt) for f in dev['feats']]
     nslots = pool.n
     rec_len = pool.slots[0].record.numel()
     records = torch.zeros((nslots, rec_len), dtype=torch.float32, device='cuda')
@@ -212,7 +218,7 @@ def main():
         pr = torch.randperm(dev['cls_scores'].shape[0], device='cuda', generator=gen)
         slot_inputs.append(dict(
             rpn_logits=dev['rpn_logits'][pa].contiguous(), rpn_deltas=dev['rpn_deltas'][pa].contiguous(),
-            feats=[torch.randn(f.shape, device='cuda', dtype=torch.float32, generator=gen) for f in dev['feats']],
+            feats=[torch.randn(f.shape, device='cuda', dtype=torch.float32, generator=gen).to(fdt) for f in dev['feats']],
             cls_scores=dev['cls_scores'][pr].contiguous(), cls_deltas=dev['cls_deltas'][pr].contiguous()))
     for k in range(nslots):
         pool.slots[k].record = records[k]                     # one contiguous block: ONE all-gather per round
@@ -315,9 +321,10 @@ def main():
         k = int(hot.roi_count.item())
         srois = hot.sorted_rois[:k].cpu().numpy()
         lv = hot.roi_level[:k].cpu().numpy()
-        algo = algorithmic_roi_bytes(srois, lv, syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS)
+        algo = algorithmic_roi_bytes(srois, lv, syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS,
+                                    elem=2 if args.maps == 'f16' else 4)
         achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
-        workload = 'fpn_hot_path_800x1333_r101fpn_%s' % args.scores
+        workload = 'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps')
         result = {
             'metric': 'images/sec', 'value': args.steps * world / elapsed, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -329,6 +336,7 @@ def main():
                                    'P2..P5x256 -> post_ops (21 classes); conv backbone/heads out of scope (their '
                                    'outputs are synthetic inputs in HBM)',
                        'images_per_step_per_gpu': 1, 'global_batch': world, 'rpn_scores': args.scores,
+                       'feature_maps': args.maps,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max)',

@@ -252,6 +252,12 @@ int odet_roi_pool_f16(const odet_level_t* levels, int num_levels, int C, const f
                       const int32_t* roi_level, int n, const int32_t* count_dev, const int32_t* order,
                       int norm_mode, int image_h, int image_w, int pool_size, int pool_mode, void* out,
                       odet_stream_t stream);
+/* the same launch with HIP events attached to the dispatch (see odet_roi_pool_timed) */
+int odet_roi_pool_f16_timed(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                            const int32_t* roi_level, int n, const int32_t* count_dev,
+                            const int32_t* order, int norm_mode, int image_h, int image_w, int pool_size,
+                            int pool_mode, void* out, odet_stream_t stream, void* start_event,
+                            void* stop_event);
 
 /* ---- detection post-processing ------------------------------------------------------- */
 
@@ -353,6 +359,7 @@ typedef struct {
   int32_t min_level, max_level, blind_chunks;
   /* roi */
   int32_t num_maps, channels, pool_size;
+  int32_t maps_f16;          /* != 0: float16 feature maps and float16 roi_features (odet_roi_pool_f16) */
   odet_level_t maps[ODET_MAX_LEVELS];
   /* detect */
   int32_t ccls, num_classes, max_per_class, max_per_image;
@@ -366,7 +373,7 @@ typedef struct {
   /* outputs / scratch (device, caller-owned) */
   float* rois; int32_t* roi_idx; int32_t* roi_count; int32_t* nms_done;
   float* sorted_rois; int32_t* roi_level; int64_t* roi_perm; int32_t* level_counts;
-  float* roi_features;
+  void* roi_features;        /* [num_proposals, pool, pool, channels] float32 (float16 when maps_f16) */
   int32_t* roi_order;        /* nullable scratch int32 [num_proposals]: spatial processing order (odet_roi_order) */
   float* det_boxes; int32_t* det_labels; float* det_scores; int32_t* det_count; float* record;
   void* ws_rpn; size_t ws_rpn_bytes;

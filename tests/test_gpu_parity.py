@@ -538,6 +538,43 @@ def test_stream_pool_matches_single_path_and_oracle():
         pool.close()
 
 
+def test_stream_pool_float16_maps_match_single_path():
+    """BASELINE config 5 ("fp16 feature maps") through the native executor: float16 slots, single launches and
+    batched launches, give the float16 single-stream result bit for bit."""
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, FpnStreamPool, synthetic_fpn_inputs
+    shape, K, ncls, ch = (320, 480), 300, 21, 64
+    sets = [synthetic_fpn_inputs(shape, ncls, K, channels=ch, seed=300 + i) for i in range(4)]
+    for _, dev in sets:
+        dev['feats'] = [f.half() for f in dev['feats']]
+    ref = FpnHotPath(shape, ncls, K, channels=ch, feature_dtype=torch.float16)
+    want = []
+    for _, dev in sets:
+        ref.step(dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        torch.cuda.synchronize()
+        want.append((ref.record.clone(), ref.roi_features.clone()))
+    assert want[0][1].dtype == torch.float16 and float(want[0][1].float().abs().max()) > 0
+    for batch in (1, 4):
+        pool = FpnStreamPool(4 // batch, shape, ncls, K, ch, batch=batch, feature_dtype=torch.float16)
+        try:
+            for k, (_, dev) in enumerate(sets):
+                pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+            if batch == 1:
+                for k in range(4):
+                    pool.submit(k)
+            else:
+                pool.submit_group(0)
+            pool.wait()
+            torch.cuda.synchronize()
+            for k in range(4):
+                assert torch.equal(pool.slots[k].roi_features, want[k][1])
+                assert torch.equal(pool.slots[k].record, want[k][0])
+            with pytest.raises(ValueError):          # float32 maps into a float16 slot
+                pool.bind(0, sets[0][1]['rpn_logits'], sets[0][1]['rpn_deltas'], [f.float() for f in sets[0][1]['feats']],
+                          sets[0][1]['cls_scores'], sets[0][1]['cls_deltas'])
+        finally:
+            pool.close()
+
+
 def test_batched_launches_match_single_path():
     """odet_fpn_step_enqueue_batch: several images in the SAME kernel launches (blockIdx.y = image) must
     give every image exactly the single-image result, stage by stage and for the whole step."""

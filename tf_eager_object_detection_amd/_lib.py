@@ -35,7 +35,7 @@ class OdetFpnStep(C.Structure):
         ('rpn_means', C.c_float * 4), ('rpn_stds', C.c_float * 4),
         ('num_proposals', C.c_int32), ('rpn_nms_iou', C.c_float),
         ('min_level', C.c_int32), ('max_level', C.c_int32), ('blind_chunks', C.c_int32),
-        ('num_maps', C.c_int32), ('channels', C.c_int32), ('pool_size', C.c_int32),
+        ('num_maps', C.c_int32), ('channels', C.c_int32), ('pool_size', C.c_int32), ('maps_f16', C.c_int32),
         ('maps', OdetLevel * MAX_LEVELS),
         ('ccls', C.c_int32), ('num_classes', C.c_int32), ('max_per_class', C.c_int32), ('max_per_image', C.c_int32),
         ('roi_means', C.c_float * 4), ('roi_stds', C.c_float * 4),
@@ -85,6 +85,7 @@ SIGNATURES = {
     'odet_roi_order': (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     'odet_roi_pool_ordered': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'odet_roi_pool_f16': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    'odet_roi_pool_f16_timed': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'odet_prof_event_create': (_i, [_vp]),
     'odet_prof_event_destroy': (_i, [_vp]),
     'odet_prof_event_elapsed_ms': (_i, [_vp, _vp, _vp]),

@@ -36,9 +36,10 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
                           s->roi_order, s->stream);
       if (rc != ODET_OK) return rc;
     }
-    rc = odet_roi_pool_ordered(s->maps, s->num_maps, s->channels, s->sorted_rois, s->roi_level, s->num_proposals,
-                               s->roi_count, s->roi_order, ODET_ROI_NORM_IMAGE, s->image_h, s->image_w, s->pool_size,
-                               ODET_ROI_POOL_MAX2, s->roi_features, s->stream, nullptr, nullptr);
+    const RoiImageIO one{s->maps, s->sorted_rois, s->roi_level, s->roi_count, s->roi_order, (float*)s->roi_features};
+    rc = odet_roi_pool_batch(&one, 1, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
+                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, (hipStream_t)s->stream,
+                             RoiEvents{nullptr, nullptr}, s->maps_f16 ? 1 : 0);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_DETECT) {
@@ -64,7 +65,7 @@ static bool same_config(const odet_fpn_step_t* a, const odet_fpn_step_t* b) {
         a->roi_stds[k] != b->roi_stds[k]) return false;
   return a->num_proposals == b->num_proposals && a->rpn_nms_iou == b->rpn_nms_iou && a->min_level == b->min_level &&
          a->max_level == b->max_level && a->blind_chunks == b->blind_chunks && a->num_maps == b->num_maps &&
-         a->channels == b->channels && a->pool_size == b->pool_size && a->ccls == b->ccls &&
+         a->channels == b->channels && a->pool_size == b->pool_size && (a->maps_f16 != 0) == (b->maps_f16 != 0) && a->ccls == b->ccls &&
          a->num_classes == b->num_classes && a->max_per_class == b->max_per_class &&
          a->max_per_image == b->max_per_image && a->nms_iou == b->nms_iou &&
          a->score_threshold == b->score_threshold && a->min_edge == b->min_edge && a->stream == b->stream;
@@ -103,7 +104,7 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
     for (int i = 0; i < count; ++i) {
       const odet_fpn_step_t* t = steps[i];
       io[i] = RoiImageIO{t->maps, t->sorted_rois, t->roi_level, t->roi_count, ordered ? t->roi_order : nullptr,
-                         t->roi_features};
+                         (float*)t->roi_features};
       oo[i] = RoiOrderIO{t->sorted_rois, t->roi_level, t->roi_count, t->roi_order};
     }
     if (ordered) {
@@ -111,7 +112,8 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
       if (rc != ODET_OK) return rc;
     }
     rc = odet_roi_pool_batch(io, count, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
-                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, st, RoiEvents{nullptr, nullptr});
+                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, st, RoiEvents{nullptr, nullptr},
+                             s->maps_f16 ? 1 : 0);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_DETECT) {

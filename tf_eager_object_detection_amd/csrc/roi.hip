@@ -782,6 +782,17 @@ extern "C" int odet_roi_pool_f16(const odet_level_t* levels, int num_levels, int
                              (hipStream_t)stream, RoiEvents{nullptr, nullptr}, 1);
 }
 
+extern "C" int odet_roi_pool_f16_timed(const odet_level_t* levels, int num_levels, int C, const float* rois,
+                                       const int32_t* roi_level, int n, const int32_t* count_dev,
+                                       const int32_t* order, int norm_mode, int image_h, int image_w, int pool_size,
+                                       int pool_mode, void* out, odet_stream_t stream, void* start_event,
+                                       void* stop_event) {
+  RoiImageIO io{levels, rois, roi_level, count_dev, order, (float*)out};
+  if (n > 0) ODET_REQUIRE(levels && rois && out, "odet_roi_pool_f16_timed: null pointer");
+  return odet_roi_pool_batch(&io, 1, num_levels, C, n, norm_mode, image_h, image_w, pool_size, pool_mode,
+                             (hipStream_t)stream, RoiEvents{(hipEvent_t)start_event, (hipEvent_t)stop_event}, 1);
+}
+
 extern "C" int odet_roi_pool(const odet_level_t* levels, int num_levels, int C, const float* rois,
                              const int32_t* roi_level, int n, const int32_t* count_dev, int norm_mode,
                              int image_h, int image_w, int pool_size, int pool_mode, float* out,

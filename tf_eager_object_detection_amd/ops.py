@@ -423,13 +423,15 @@ def roi_pool(feature_maps, rois, roi_level, norm_mode, pool_size, pool_mode, str
     if roi_level is not None and roi_level.dtype != torch.int32:
         roi_level = roi_level.to(torch.int32)
     if f16:
-        if events is not None:
-            raise ValueError('timed launches are float32 only')
         if out.dtype != torch.float16:
             raise TypeError('out must be float16 for float16 feature maps')
-        L.call('odet_roi_pool_f16', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
-               L.dptr(order, torch.int32, 'order') if order is not None else None, int(norm_mode), ih, iw, P,
-               int(pool_mode), C.c_void_p(out.data_ptr()), L.stream())
+        args = (levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
+                L.dptr(order, torch.int32, 'order') if order is not None else None, int(norm_mode), ih, iw, P,
+                int(pool_mode), C.c_void_p(out.data_ptr()), L.stream())
+        if events is None:
+            L.call('odet_roi_pool_f16', *args)
+        else:
+            L.call('odet_roi_pool_f16_timed', *(args + (events[0].handle, events[1].handle)))
     elif order is not None:
         L.call('odet_roi_pool_ordered', levels, nl, Cc, L.dptr(rois), L.dptr(roi_level), n, L.dptr(count_dev),
                L.dptr(order, torch.int32, 'order'), int(norm_mode), ih, iw, P, int(pool_mode), L.dptr(out), L.stream(),

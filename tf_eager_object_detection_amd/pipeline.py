@@ -272,10 +272,14 @@ class FpnStreamPool:
         h, st = self.slots[slot], self.steps[slot]
         nl = h.max_level - h.min_level + 1
         maps = list(p_list[:nl])
-        tensors = [rpn_logits, rpn_deltas, cls_softmax, cls_deltas] + maps
-        for t in tensors:
+        for t in (rpn_logits, rpn_deltas, cls_softmax, cls_deltas):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError('FpnStreamPool.bind needs float32 contiguous GPU tensors')
+        fdt = h.roi_features.dtype                       # float16 slots (feature_dtype) take float16 maps
+        for t in maps:
+            if not (t.is_cuda and t.dtype == fdt and t.is_contiguous()):
+                raise ValueError('FpnStreamPool.bind needs %s contiguous GPU feature maps' % fdt)
+        tensors = [rpn_logits, rpn_deltas, cls_softmax, cls_deltas] + maps
         if rpn_logits.numel() != h.N * 2 or rpn_deltas.numel() != h.N * 4:
             raise ValueError('%d anchors expected, got rpn scores %s / deltas %s'
                              % (h.N, tuple(rpn_logits.shape), tuple(rpn_deltas.shape)))
@@ -295,6 +299,7 @@ class FpnStreamPool:
         st.num_proposals, st.rpn_nms_iou = h.K, float(c['rpn_nms_iou'])
         st.min_level, st.max_level, st.blind_chunks = h.min_level, h.max_level, h.blind_chunks
         st.num_maps, st.channels, st.pool_size = nl, h.C, h.P
+        st.maps_f16 = 1 if fdt == torch.float16 else 0
         for l, fm in enumerate(maps):
             if fm.dim() != 4 or fm.shape[0] != 1 or fm.shape[3] != h.C:
                 raise ValueError('feature maps must be NHWC [1,H,W,%d]' % h.C)
