@@ -252,6 +252,12 @@ class FpnStreamPool:
             raise ValueError('batched steps need blind_chunks == 1 (the NMS fallback is per image)')
         self.n = self.n_streams * self.batch            # slots; slot k belongs to group k // batch
         self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
+        # Batched groups need ~1.4 launches per image, far below one thread's launch rate, and ONE enqueue thread
+        # issuing the groups in turn measured 3-4 % faster than one thread per stream (less contention inside the
+        # HIP runtime); single-image launches (batch < 4) keep a thread per stream for the launch rate.
+        import os
+        sw = os.environ.get('ODET_POOL_SINGLE_WORKER')
+        self._single_worker = (sw == '1') if sw is not None else self.batch >= 4
         self._group_streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
         self.streams = [self._group_streams[k // self.batch] for k in range(self.n)]
         self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
@@ -337,7 +343,8 @@ class FpnStreamPool:
         if group is None:
             group = self._rr % self.n_streams
             self._rr = (self._rr + 1) % self.n_streams
-        ops.L.check(self._lib.odet_exec_submit_batch(self._exec, group, self._groups[group], self.batch, int(stages)))
+        worker = 0 if self._single_worker else group
+        ops.L.check(self._lib.odet_exec_submit_batch(self._exec, worker, self._groups[group], self.batch, int(stages)))
         return group
 
     def wait(self):
