@@ -179,7 +179,9 @@ def main():
     local_dev = local_rank % max(ndev, 1)                     # (rehearsal with gloo: ranks may share a GPU)
     torch.cuda.set_device(local_dev)
     dist = None
-    if world > 1:
+    # (ODET_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1: the RCCL exchange path with one rank, a rehearsal)
+    use_dist = world > 1 or (os.environ.get('ODET_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.backend == 'nccl':
@@ -227,8 +229,8 @@ def main():
     hot = pool.slots[0]
     max_det = hot.cfg['max_per_image']
     comm = torch.cuda.Stream()
-    gathered = torch.zeros((S, world, B, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
-    staging = torch.zeros((S, B, rec_len), dtype=torch.float32, device='cuda') if world > 1 else None
+    gathered = torch.zeros((S, world, B, rec_len), dtype=torch.float32, device='cuda') if use_dist else None
+    staging = torch.zeros((S, B, rec_len), dtype=torch.float32, device='cuda') if use_dist else None
     gstreams = pool._group_streams
 
     # HIP events attached to the RoI kernel's dispatch, inside the timed region.  The kernel is timed
@@ -292,13 +294,13 @@ def main():
                 pool.submit(group * B)
                 done_group = group
                 i += 1
-            if world > 1:
+            if use_dist:
                 gather_group(done_group)
             group = (group + 1) % S
 
     def fence():
         drain()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -308,7 +310,7 @@ def main():
     run(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -349,7 +351,7 @@ def main():
             result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
         print(json.dumps(result))
     pool.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
