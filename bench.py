@@ -23,6 +23,7 @@ dispatch on a few steps of the timed region) and `cpu_baseline` (the C restateme
 timed on this box's host cores, kind "port"; it also carries the mAP delta of the evaluation loop).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -159,6 +160,9 @@ def main():
     ap.add_argument('--streams', type=int, default=3, help='HIP streams (+ native enqueue threads) per GPU')
     ap.add_argument('--batch', type=int, default=8, help='images that share the kernel launches of a stream (1..8)')
     ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
+    ap.add_argument('--nms-first-chunk', type=int, default=0,
+                    help='candidates of the first (sync-free) NMS chunk, 0 = auto ~1.5K; 4096 for score distributions with '
+                         'heavy suppression (--scores clustered) in batched launches')
     ap.add_argument('--maps', choices=['f32', 'f16'], default='f32',
                     help='feature-map / RoI-feature storage type (f32 = the metric of SURVEY 8d; f16 = BASELINE '
                          'config 5 "fp16 feature maps": float32 lerps, float16 in / out)')
@@ -203,7 +207,7 @@ def main():
         B = 1                                                   # the NMS fallback is per image
     fdt = torch.float16 if args.maps == 'f16' else torch.float32
     pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B,
-                         blind_chunks=args.blind_chunks, feature_dtype=fdt)
+                         blind_chunks=args.blind_chunks, feature_dtype=fdt, nms_first_chunk=args.nms_first_chunk)
     if fdt != torch.float32:
         dev['feats'] = [f.to(fdt) for f in dev['feats']]
     nslots = pool.n
@@ -270,7 +274,9 @@ def main():
         with torch.cuda.stream(mine):
             h = pool.slots[slot]
             d = slot_inputs[slot]
-            h.stage_proposals(d['rpn_logits'], d['rpn_deltas'])
+            # proposals through the slot's step descriptor (same parameters as the batched launches, e.g. the
+            # first-chunk size), on the slot's stream = `mine`
+            _lib.check(_lib.lib().odet_fpn_step_enqueue(ctypes.byref(pool.steps[slot]), 1))
             h.stage_roi(d['feats'], events=ev)                # start / stop events of the dispatch itself
             h.stage_detect(d['cls_scores'], d['cls_deltas'])
         for st in gstreams:
@@ -316,7 +322,7 @@ def main():
         elapsed = float(t.item())
     if any(int(h.nms_done.item()) != 1 for h in pool.slots):
         raise SystemExit('NMS did not complete inside the blind chunks -- result would be invalid '
-                         '(use --blind-chunks 2 for score distributions with heavy suppression)')
+                         '(use --nms-first-chunk 4096, or --blind-chunks 2, for score distributions with heavy suppression)')
 
     if rank == 0:
         roi_ms = float(np.mean([a.elapsed_ms(b) for a, b in ev_roi]))
@@ -338,7 +344,7 @@ def main():
                                    'P2..P5x256 -> post_ops (21 classes); conv backbone/heads out of scope (their '
                                    'outputs are synthetic inputs in HBM)',
                        'images_per_step_per_gpu': 1, 'global_batch': world, 'rpn_scores': args.scores,
-                       'feature_maps': args.maps,
+                       'feature_maps': args.maps, 'nms_first_chunk': args.nms_first_chunk,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max)',

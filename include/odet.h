@@ -357,6 +357,9 @@ typedef struct {
   int32_t num_proposals;
   float rpn_nms_iou;
   int32_t min_level, max_level, blind_chunks;
+  int32_t nms_first_chunk;   /* 0 = auto (~1.5 x num_proposals candidates); else candidates of the first NMS chunk,
+                                <= 4096: a wider chunk lets heavy suppression (trained-like score clusters) finish
+                                inside the one sync-free chunk of batched launches */
   /* roi */
   int32_t num_maps, channels, pool_size;
   int32_t maps_f16;          /* != 0: float16 feature maps and float16 roi_features (odet_roi_pool_f16) */

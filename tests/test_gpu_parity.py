@@ -742,3 +742,42 @@ def test_frcnn_hot_path_full_size(name, shape, channels, flag, scales):
     assert m == len(ws)
     np.testing.assert_array_equal(h(labels[:m]), wl)
     close(h(boxes[:m]), wb)
+
+
+def test_wide_first_nms_chunk_completes_clustered_scores_in_batched_launches():
+    """odet_fpn_step_t.nms_first_chunk: trained-like clustered RPN scores need more than ~1.5 K candidates to keep
+    K proposals; with a 4096-candidate first chunk the batched (sync-free, one chunk) launches complete and
+    give the oracle's proposals; with the automatic size they report nms_done = 0."""
+    from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
+    shape, K, ncls, ch = (800, 1333), 1000, 21, 8
+    sets = [synthetic_fpn_inputs(shape, ncls, K, channels=ch, seed=500 + i, score_kind='clustered') for i in range(2)]
+    anchors = co.fpn_anchors(shape)
+    for first, expect_done in ((0, False), (4096, True)):
+        pool = FpnStreamPool(1, shape, ncls, K, ch, batch=2, nms_first_chunk=first)
+        try:
+            for k, (_, dev) in enumerate(sets):
+                pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+            pool.submit_group(0)
+            pool.wait()
+            torch.cuda.synchronize()
+            for k, (host, _) in enumerate(sets):
+                slot = pool.slots[k]
+                done = int(slot.nms_done.item()) == 1
+                assert done == expect_done
+                if done:
+                    fg = co.rpn_fg_fpn(host['rpn_logits'])
+                    _, idx = co.region_proposal(host['rpn_deltas'], anchors, fg, shape, K, 0.7)
+                    m = int(slot.roi_count.item())
+                    assert m == len(idx)
+                    np.testing.assert_array_equal(h(slot.roi_idx[:m]), idx)
+        finally:
+            pool.close()
+    with pytest.raises(Exception):
+        bad = FpnStreamPool(1, shape, ncls, K, ch, batch=2, nms_first_chunk=5000)
+        try:
+            for k, (_, dev) in enumerate(sets):
+                bad.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+            bad.submit_group(0)
+            bad.wait()
+        finally:
+            bad.close()

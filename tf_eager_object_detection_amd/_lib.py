@@ -34,7 +34,7 @@ class OdetFpnStep(C.Structure):
         ('wh', C.c_float * (MAX_LEVELS * MAX_ANCHORS_PER_CELL * 2)),
         ('rpn_means', C.c_float * 4), ('rpn_stds', C.c_float * 4),
         ('num_proposals', C.c_int32), ('rpn_nms_iou', C.c_float),
-        ('min_level', C.c_int32), ('max_level', C.c_int32), ('blind_chunks', C.c_int32),
+        ('min_level', C.c_int32), ('max_level', C.c_int32), ('blind_chunks', C.c_int32), ('nms_first_chunk', C.c_int32),
         ('num_maps', C.c_int32), ('channels', C.c_int32), ('pool_size', C.c_int32), ('maps_f16', C.c_int32),
         ('maps', OdetLevel * MAX_LEVELS),
         ('ccls', C.c_int32), ('num_classes', C.c_int32), ('max_per_class', C.c_int32), ('max_per_image', C.c_int32),

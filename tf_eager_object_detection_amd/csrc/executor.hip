@@ -23,11 +23,11 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
   if (stages & ODET_STAGE_PROPOSALS) {
     int fh[ODET_MAX_LEVELS], fw[ODET_MAX_LEVELS], st[ODET_MAX_LEVELS];
     for (int l = 0; l < ODET_MAX_LEVELS; ++l) { fh[l] = s->fh[l]; fw[l] = s->fw[l]; st[l] = s->stride[l]; }
-    rc = odet_fpn_proposals(s->rpn_logits, s->rpn_deltas, s->num_levels, s->A, fh, fw, st, s->wh, s->image_h,
-                            s->image_w, s->rpn_means, s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level,
-                            s->max_level, s->rois, s->roi_idx, s->roi_count, s->sorted_rois, s->roi_level,
-                            s->roi_perm, s->level_counts, s->blind_chunks, s->nms_done, s->ws_rpn, s->ws_rpn_bytes,
-                            s->stream);
+    const FpnProposalIO one{s->rpn_logits, s->rpn_deltas, s->rois, s->roi_idx, s->roi_count, s->sorted_rois, s->roi_level,
+                            s->roi_perm, s->level_counts, s->nms_done, s->ws_rpn, s->ws_rpn_bytes};
+    rc = odet_fpn_proposals_batch(&one, 1, s->num_levels, s->A, fh, fw, st, s->wh, s->image_h, s->image_w, s->rpn_means,
+                                  s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level, s->max_level,
+                                  s->blind_chunks, (hipStream_t)s->stream, s->nms_first_chunk);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_ROI) {
@@ -64,7 +64,7 @@ static bool same_config(const odet_fpn_step_t* a, const odet_fpn_step_t* b) {
     if (a->rpn_means[k] != b->rpn_means[k] || a->rpn_stds[k] != b->rpn_stds[k] || a->roi_means[k] != b->roi_means[k] ||
         a->roi_stds[k] != b->roi_stds[k]) return false;
   return a->num_proposals == b->num_proposals && a->rpn_nms_iou == b->rpn_nms_iou && a->min_level == b->min_level &&
-         a->max_level == b->max_level && a->blind_chunks == b->blind_chunks && a->num_maps == b->num_maps &&
+         a->max_level == b->max_level && a->blind_chunks == b->blind_chunks && a->nms_first_chunk == b->nms_first_chunk && a->num_maps == b->num_maps &&
          a->channels == b->channels && a->pool_size == b->pool_size && (a->maps_f16 != 0) == (b->maps_f16 != 0) && a->ccls == b->ccls &&
          a->num_classes == b->num_classes && a->max_per_class == b->max_per_class &&
          a->max_per_image == b->max_per_image && a->nms_iou == b->nms_iou &&
@@ -93,7 +93,7 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
     }
     rc = odet_fpn_proposals_batch(io, count, s->num_levels, s->A, fh, fw, sd, s->wh, s->image_h, s->image_w,
                                   s->rpn_means, s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level,
-                                  s->max_level, s->blind_chunks, st);
+                                  s->max_level, s->blind_chunks, st, s->nms_first_chunk);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_ROI) {

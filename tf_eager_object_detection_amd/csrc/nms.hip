@@ -876,9 +876,14 @@ extern "C" size_t odet_nms_workspace_bytes(int n, int max_output) {
 
 // Candidates selected for the first chunk: with few overlaps K kept boxes need barely more than K
 // candidates, so the first bit matrix is sized ~1.5 K instead of 4096 (7x fewer IoU tiles at K = 1000).
-static int first_chunk_target(int n, int K) {
+static int first_chunk_target(int n, int K, int first_chunk) {
   long long c = ((long long)K * 3 / 2 + 63) / 64 * 64;
   if (c > 64) c -= 32;   // half a block of slack for boundary ties: K = 1000 -> 1504 -> at most 24 blocks
+  // caller's choice (odet_fpn_step_t.nms_first_chunk): a WIDER first chunk -- up to NMS_CHUNK candidates on the
+  // register-ring scan -- lets score distributions with heavy suppression finish in the one sync-free chunk that
+  // batched launches have (measured: trained-like clustered scores 20.7k img/s batched against 10.8k through
+  // the per-image two-chunk path; costs 12 % when the narrow chunk would have done)
+  if (first_chunk > 0) c = std::max<long long>(c, ((long long)first_chunk + 63) / 64 * 64 - 32);
   if (c < 256) c = 256;
   if (c > NMS_CHUNK) c = NMS_CHUNK;
   if (c > n) c = n;
@@ -912,6 +917,7 @@ struct NmsJob {
   int n, K;
   float thr;
   int blind_chunks;
+  int first_chunk;          // 0 = auto (~1.5 K candidates), else candidates of the first chunk (<= NMS_CHUNK)
   int B;                    // images in the batch (1..ODET_MAX_BATCH)
   NmsImage img[ODET_MAX_BATCH];
 };
@@ -978,7 +984,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     ODET_LAUNCH_CHECK();
   }
   // 2. select + order the first chunk
-  const uint32_t target = (uint32_t)first_chunk_target(n, K);
+  const uint32_t target = (uint32_t)first_chunk_target(n, K, J.first_chunk);
   // chunk 0 runs on the LDS-resident scan when its candidates are guaranteed to fit 24 blocks
   const bool lds0 = target <= (uint32_t)SCAN_LDS_CAND;
   const uint32_t limit = lds0 ? (uint32_t)SCAN_LDS_CAND : (uint32_t)NMS_CHUNK;
@@ -1171,8 +1177,9 @@ extern "C" size_t odet_fpn_proposals_workspace_bytes(int n, int max_output) {
 int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int A, const int* fh, const int* fw,
                              const int* stride, const float* wh, int image_h, int image_w, const float* means,
                              const float* stds, int max_output, float iou_threshold, int min_level, int max_level,
-                             int blind_chunks, hipStream_t st) {
+                             int blind_chunks, hipStream_t st, int first_chunk) {
   ODET_REQUIRE(io && fh && fw && stride && wh && means && stds, "odet_fpn_proposals: null pointer");
+  ODET_REQUIRE(first_chunk >= 0 && first_chunk <= NMS_CHUNK, "odet_fpn_proposals: nms_first_chunk %d out of range (0..%d)", first_chunk, NMS_CHUNK);
   ODET_REQUIRE(B >= 1 && B <= ODET_MAX_BATCH, "odet_fpn_proposals: batch %d out of range", B);
   ODET_REQUIRE(num_levels > 0 && num_levels <= ODET_MAX_LEVELS, "odet_fpn_proposals: num_levels %d out of range",
                num_levels);
@@ -1180,6 +1187,7 @@ int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int
   ODET_REQUIRE(image_h > 0 && image_w > 0 && max_output > 0, "odet_fpn_proposals: bad sizes");
   NmsJob J;
   job_init(&J, PREP_FPN, 0, max_output, iou_threshold, blind_chunks, B);
+  J.first_chunk = first_chunk;
   FpnAnchorParams& p = J.prep.fpn;
   p.num_levels = num_levels;
   p.A = A;
@@ -1241,7 +1249,7 @@ extern "C" int odet_fpn_proposals(const float* rpn_logits, const float* rpn_delt
   FpnProposalIO io{rpn_logits, rpn_deltas, out_rois, out_idx, out_count, out_sorted_rois, out_level, out_perm,
                    out_level_counts, out_done, workspace, workspace_bytes};
   return odet_fpn_proposals_batch(&io, 1, num_levels, A, fh, fw, stride, wh, image_h, image_w, means, stds,
-                                  max_output, iou_threshold, min_level, max_level, blind_chunks, (hipStream_t)stream);
+                                  max_output, iou_threshold, min_level, max_level, blind_chunks, (hipStream_t)stream, 0);
 }
 
 extern "C" size_t odet_frcnn_proposals_workspace_bytes(int n, int max_output) {

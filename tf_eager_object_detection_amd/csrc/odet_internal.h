@@ -325,7 +325,7 @@ struct FpnProposalIO {      // per-image arguments of the FPN proposal stage
 int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int A, const int* fh, const int* fw,
                              const int* stride, const float* wh, int image_h, int image_w, const float* means,
                              const float* stds, int max_output, float iou_threshold, int min_level, int max_level,
-                             int blind_chunks, hipStream_t st);
+                             int blind_chunks, hipStream_t st, int first_chunk = 0);
 
 struct RoiEvents { hipEvent_t start, stop; };   // optional: timestamps of the dispatch itself
 struct RoiImageIO {         // per-image arguments (order: nullable processing order, odet_roi_order)

@@ -27,7 +27,7 @@ class FpnHotPath:
                  roi_means=(0, 0, 0, 0), roi_stds=(0.1, 0.1, 0.2, 0.2), max_per_class=50, max_per_image=50,
                  nms_iou=0.3, score_threshold=0.0, min_level=2, max_level=5, strides=syn.FPN_STRIDES,
                  base_sizes=syn.FPN_BASE_SIZES, ratios=syn.FPN_RATIOS, scales=syn.FPN_SCALES,
-                 blind_chunks=1, device=None, spatial_order=True, feature_dtype=torch.float32):
+                 blind_chunks=1, device=None, spatial_order=True, feature_dtype=torch.float32, nms_first_chunk=0):
         self.image_shape = [int(image_shape[0]), int(image_shape[1])]
         self.num_classes = num_classes
         self.K = num_proposals
@@ -39,6 +39,9 @@ class FpnHotPath:
         self.min_level, self.max_level = min_level, max_level
         self.strides, self.base_sizes, self.ratios, self.scales = strides, base_sizes, ratios, scales
         self.blind_chunks = blind_chunks
+        # 0 = auto; up to 4096 candidates in the first NMS chunk for score distributions with heavy suppression (the
+        # step-descriptor path: FpnStreamPool / odet_fpn_step_enqueue*)
+        self.nms_first_chunk = int(nms_first_chunk)
         self.device = device or torch.device('cuda', torch.cuda.current_device())
         self.N = syn.num_fpn_anchors(self.image_shape, strides, len(ratios) * len(scales))
         dev = self.device
@@ -304,6 +307,7 @@ class FpnStreamPool:
             st.roi_means[k], st.roi_stds[k] = float(c['roi_means'][k]), float(c['roi_stds'][k])
         st.num_proposals, st.rpn_nms_iou = h.K, float(c['rpn_nms_iou'])
         st.min_level, st.max_level, st.blind_chunks = h.min_level, h.max_level, h.blind_chunks
+        st.nms_first_chunk = getattr(h, 'nms_first_chunk', 0)
         st.num_maps, st.channels, st.pool_size = nl, h.C, h.P
         st.maps_f16 = 1 if fdt == torch.float16 else 0
         for l, fm in enumerate(maps):
