@@ -297,3 +297,44 @@ def test_vgg16_detector_runs_and_pools_like_oracle():
     got = hot.roi_features[:k].cpu().numpy()
     assert np.max(np.abs(got - want)) <= 1e-4 * max(1.0, float(np.abs(want).max()))
     assert 0 < int(out[0][3].item()) <= 50
+
+
+@pytest.mark.gpu
+def test_detector_batched_hot_path_matches_per_image_path():
+    """ResNetFpnDetector with blind_chunks == 1: the images of a batch share the hot-path launches (FpnStepBatch)
+    and the RoI head runs on all crops at once -- same detections as the per-image path on the same dense
+    outputs."""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(8)
+    shape, K, B = (256, 352), 300, 3
+    m = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=B, blind_chunks=1, nms_first_chunk=4096).prepare()
+    assert m._steps is not None
+    rng = np.random.default_rng(8)
+    img = torch.from_numpy((rng.uniform(0, 255, (B,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    with torch.no_grad():
+        ps = m.features(img)
+        sc, dl = m.rpn(ps)
+        sc, dl = sc.float().contiguous(), dl.float().contiguous()
+        maps = [p.permute(0, 2, 3, 1).float().contiguous() for p in ps[:4]]
+        got = m._forward_batched(B, sc, dl, maps)
+        got = [tuple(t.clone() for t in g) for g in got]
+        torch.cuda.synchronize()
+        assert all(int(h.nms_done.item()) == 1 for h in m._hot)
+        from tf_eager_object_detection_amd.pipeline import FpnHotPath
+        ref = FpnHotPath(shape, 21, K, 256, blind_chunks=3)
+        for b in range(B):
+            ref.stage_proposals(sc[b], dl[b])
+            feats = ref.stage_roi([mm[b:b + 1] for mm in maps])
+            logits, bbox = m.roi_head(feats)
+            cls = torch.softmax(logits.float(), dim=-1).contiguous()
+            boxes, labels, scores, count = ref.stage_detect(cls, bbox.float().contiguous())
+            torch.cuda.synchronize()
+            c = int(count.item())
+            assert c == int(got[b][3].item()) and c > 0
+            assert torch.equal(labels[:c], got[b][1][:c])
+            torch.testing.assert_close(boxes[:c], got[b][0][:c], rtol=1e-4, atol=1e-3)
+            torch.testing.assert_close(scores[:c], got[b][2][:c], rtol=1e-4, atol=1e-5)
+    # and the public forward takes the same route
+    out = m(img)
+    torch.cuda.synchronize()
+    assert len(out) == B and all(int(o[3].item()) > 0 for o in out)

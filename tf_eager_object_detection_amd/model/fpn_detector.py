@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..pipeline import FpnHotPath
+from ..pipeline import FpnHotPath, FpnStepBatch
 
 __all__ = ['ResNetFpnDetector', 'tf_legacy_resize_bilinear']
 
@@ -172,9 +172,24 @@ class ResNetFpnDetector(nn.Module):
         self._max_batch = max_batch
 
     def prepare(self, device='cuda'):
+        """Moves the model to the GPU and allocates the hot path.  With blind_chunks == 1 (the default; widen the
+        first NMS chunk with nms_first_chunk=4096 for trained-like score clusters) the images of a batch go
+        through the hot path in the SAME kernel launches and through the RoI head as one batch (FpnStepBatch);
+        with blind_chunks > 1 every image takes the per-image path with its multi-chunk NMS fallback."""
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
         fd = torch.float16 if self.dtype == torch.float16 else torch.float32
-        self._hot = [FpnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs) for _ in range(self._max_batch)]
+        self._steps = None
+        if self._hot_kwargs.get('blind_chunks', 1) == 1 and self._max_batch <= 8:
+            self._steps = FpnStepBatch(self._max_batch, *self._hot_args, feature_dtype=fd, **self._hot_kwargs)
+            self._hot = self._steps.slots
+            K = self._hot_args[2]
+            dev = next(self.parameters()).device
+            self._cls = torch.zeros((self._max_batch, K, self.num_classes), dtype=torch.float32, device=dev)
+            self._dlt = torch.zeros((self._max_batch, K, 4 * self.num_classes), dtype=torch.float32, device=dev)
+            self._bound = False
+        else:
+            self._hot = [FpnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs)
+                         for _ in range(self._max_batch)]
         return self
 
     # ---- dense parts ---------------------------------------------------------------------------
@@ -265,6 +280,8 @@ class ResNetFpnDetector(nn.Module):
             maps = [p.permute(0, 2, 3, 1) for p in p_list[:4]]
         else:
             maps = [p.permute(0, 2, 3, 1).float() for p in p_list[:4]]
+        if self._steps is not None:
+            return self._forward_batched(B, rpn_scores, rpn_deltas, maps)
         outs = []
         for b in range(B):
             hot = self._hot[b]
@@ -275,3 +292,21 @@ class ResNetFpnDetector(nn.Module):
             boxes, labels, scores, count = hot.stage_detect(cls, bbox.float().contiguous())
             outs.append((boxes, labels, scores, count))
         return outs
+
+    def _forward_batched(self, B, rpn_scores, rpn_deltas, maps):
+        """B images in the same hot-path launches, the RoI head on all B x K crops at once."""
+        sb = self._steps
+        maps = [m if m.is_contiguous() else m.contiguous() for m in maps]
+        bind = sb.rebind if self._bound else sb.bind
+        for b in range(B):
+            bind(b, rpn_scores[b], rpn_deltas[b], [m[b:b + 1] for m in maps], self._cls[b], self._dlt[b])
+        if B == self._max_batch:
+            self._bound = True                      # every descriptor has been filled once
+        sb.enqueue(sb.STAGE_PROPOSALS | sb.STAGE_ROI, B)
+        K = self._cls.shape[1]
+        feats = sb.roi_features[:B].reshape((B * K,) + tuple(sb.roi_features.shape[2:]))
+        logits, bbox = self.roi_head(feats)
+        torch.softmax(logits.float(), dim=-1, out=self._cls[:B].view(B * K, -1))
+        self._dlt[:B].view(B * K, -1).copy_(bbox)
+        sb.enqueue(sb.STAGE_DETECT, B)
+        return [(h.det_boxes, h.det_labels, h.det_scores, h.det_count) for h in sb.slots[:B]]

@@ -228,6 +228,116 @@ class FrcnnHotPath:
         return feats, boxes, labels, scores, count
 
 
+def _fill_step(st, h, stream_handle, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
+    """Fills the odet_fpn_step_t `st` of FpnHotPath slot `h` for one image's inputs (float32 contiguous GPU
+    tensors; feature maps in the slot's feature dtype).  Returns the tensors the caller must keep alive."""
+    nl = h.max_level - h.min_level + 1
+    maps = list(p_list[:nl])
+    for t in (rpn_logits, rpn_deltas, cls_softmax, cls_deltas):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError('FpnStreamPool.bind needs float32 contiguous GPU tensors')
+    fdt = h.roi_features.dtype                       # float16 slots (feature_dtype) take float16 maps
+    for t in maps:
+        if not (t.is_cuda and t.dtype == fdt and t.is_contiguous()):
+            raise ValueError('FpnStreamPool.bind needs %s contiguous GPU feature maps' % fdt)
+    tensors = [rpn_logits, rpn_deltas, cls_softmax, cls_deltas] + maps
+    if rpn_logits.numel() != h.N * 2 or rpn_deltas.numel() != h.N * 4:
+        raise ValueError('%d anchors expected, got rpn scores %s / deltas %s'
+                         % (h.N, tuple(rpn_logits.shape), tuple(rpn_deltas.shape)))
+    if cls_softmax.dim() != 2 or cls_softmax.shape[0] != h.K or cls_deltas.numel() != cls_softmax.numel() * 4:
+        raise ValueError('class scores must be [%d, Ccls] and deltas [%d, Ccls, 4]' % (h.K, h.K))
+    c = h.cfg
+    st.image_h, st.image_w = h.image_shape
+    st.num_levels, st.A = len(h.fh), h.wh.shape[1]
+    for l in range(len(h.fh)):
+        st.fh[l], st.fw[l], st.stride[l] = h.fh[l], h.fw[l], int(h.strides[l])
+    flat = h.wh.reshape(-1)
+    for i in range(flat.shape[0]):
+        st.wh[i] = float(flat[i])
+    for k in range(4):
+        st.rpn_means[k], st.rpn_stds[k] = float(c['rpn_means'][k]), float(c['rpn_stds'][k])
+        st.roi_means[k], st.roi_stds[k] = float(c['roi_means'][k]), float(c['roi_stds'][k])
+    st.num_proposals, st.rpn_nms_iou = h.K, float(c['rpn_nms_iou'])
+    st.min_level, st.max_level, st.blind_chunks = h.min_level, h.max_level, h.blind_chunks
+    st.nms_first_chunk = getattr(h, 'nms_first_chunk', 0)
+    st.num_maps, st.channels, st.pool_size = nl, h.C, h.P
+    st.maps_f16 = 1 if fdt == torch.float16 else 0
+    for l, fm in enumerate(maps):
+        if fm.dim() != 4 or fm.shape[0] != 1 or fm.shape[3] != h.C:
+            raise ValueError('feature maps must be NHWC [1,H,W,%d]' % h.C)
+        st.maps[l].data, st.maps[l].H, st.maps[l].W, st.maps[l].stride = fm.data_ptr(), fm.shape[1], fm.shape[2], 0.0
+    st.ccls, st.num_classes = cls_softmax.shape[1], h.num_classes
+    st.max_per_class, st.max_per_image = c['max_per_class'], c['max_per_image']
+    st.nms_iou, st.score_threshold, st.min_edge = float(c['nms_iou']), float(c['score_threshold']), 16.0
+    st.rpn_logits, st.rpn_deltas = rpn_logits.data_ptr(), rpn_deltas.data_ptr()
+    st.cls_scores, st.cls_deltas = cls_softmax.data_ptr(), cls_deltas.data_ptr()
+    st.rois, st.roi_idx, st.roi_count = h.rois.data_ptr(), h.roi_idx.data_ptr(), h.roi_count.data_ptr()
+    st.nms_done, st.sorted_rois = h.nms_done.data_ptr(), h.sorted_rois.data_ptr()
+    st.roi_level, st.roi_perm = h.roi_level.data_ptr(), h.roi_perm.data_ptr()
+    st.level_counts, st.roi_features = h.level_counts.data_ptr(), h.roi_features.data_ptr()
+    st.roi_order = h.roi_order.data_ptr() if h.roi_order is not None else None
+    st.det_boxes, st.det_labels = h.det_boxes.data_ptr(), h.det_labels.data_ptr()
+    st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
+    st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
+    st.ws_post, st.ws_post_bytes = h.ws_post.data_ptr(), h.ws_post.numel()
+    st.stream = stream_handle
+    return tensors
+
+
+
+class FpnStepBatch:
+    """Up to 8 images through the FPN hot path in the SAME kernel launches (odet_fpn_step_enqueue_batch) on the
+    CURRENT stream, stage by stage -- for a model that runs its dense RoI head between the stages (the
+    assembled detectors): no enqueue thread, capturable into a HIP graph.  The RoI features of the images are
+    consecutive blocks of one buffer, so the head can take them as one [B*K, ...] batch.
+
+        sb = FpnStepBatch(8, image_shape, ...)
+        sb.bind(b, rpn_logits[b], rpn_deltas[b], maps_of_image_b, cls_softmax[b], cls_deltas[b])   # every image
+        sb.enqueue(STAGE_PROPOSALS | STAGE_ROI, B);  head on sb.roi_features[:B];  sb.enqueue(STAGE_DETECT, B)"""
+
+    STAGE_PROPOSALS, STAGE_ROI, STAGE_DETECT = 1, 2, 4
+
+    def __init__(self, max_batch, image_shape, num_classes=21, num_proposals=1000, channels=256, **kw):
+        import ctypes as C
+        if not 1 <= int(max_batch) <= 8:
+            raise ValueError('max_batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
+        if max_batch > 1 and kw.get('blind_chunks', 1) != 1:
+            raise ValueError('batched steps need blind_chunks == 1 (widen the first chunk with nms_first_chunk)')
+        self.n = int(max_batch)
+        self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
+        h0 = self.slots[0]
+        self.roi_features = torch.zeros((self.n,) + tuple(h0.roi_features.shape), dtype=h0.roi_features.dtype,
+                                        device=h0.device)
+        for b, h in enumerate(self.slots):
+            h.roi_features = self.roi_features[b]
+        self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
+        self._arr = (C.c_void_p * self.n)(*[C.addressof(st) for st in self.steps])
+        self._keep = [None] * self.n
+        self._lib = ops.L.lib()
+
+    def bind(self, b, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
+        self._keep[b] = _fill_step(self.steps[b], self.slots[b], 0, rpn_logits, rpn_deltas, p_list, cls_softmax,
+                                   cls_deltas)
+
+    def rebind(self, b, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
+        """After one bind(b, ...): only the input pointers change (same shapes, dtypes, contiguity -- not
+        re-checked here); a handful of stores instead of the whole descriptor."""
+        st = self.steps[b]
+        st.rpn_logits, st.rpn_deltas = rpn_logits.data_ptr(), rpn_deltas.data_ptr()
+        st.cls_scores, st.cls_deltas = cls_softmax.data_ptr(), cls_deltas.data_ptr()
+        for l in range(st.num_maps):
+            st.maps[l].data = p_list[l].data_ptr()
+        self._keep[b] = (rpn_logits, rpn_deltas, cls_softmax, cls_deltas) + tuple(p_list[:st.num_maps])
+
+    def enqueue(self, stages, count=None):
+        """The given stages of images 0..count-1 on the current stream (one launch sequence for all of them)."""
+        count = self.n if count is None else int(count)
+        handle = torch.cuda.current_stream().cuda_stream
+        for st in self.steps[:count]:
+            st.stream = handle
+        ops.L.check(self._lib.odet_fpn_step_enqueue_batch(self._arr, count, int(stages)))
+
+
 class FpnStreamPool:
     """Throughput arrangement: `n_streams` independent FpnHotPath slots, each with its own HIP stream
     and persistent buffers, fed by the library's native executor (one host thread per stream; a HIP
@@ -278,58 +388,8 @@ class FpnStreamPool:
 
     def bind(self, slot, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
         """Points slot `slot` at one image's inputs (float32 contiguous GPU tensors, kept alive here)."""
-        h, st = self.slots[slot], self.steps[slot]
-        nl = h.max_level - h.min_level + 1
-        maps = list(p_list[:nl])
-        for t in (rpn_logits, rpn_deltas, cls_softmax, cls_deltas):
-            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-                raise ValueError('FpnStreamPool.bind needs float32 contiguous GPU tensors')
-        fdt = h.roi_features.dtype                       # float16 slots (feature_dtype) take float16 maps
-        for t in maps:
-            if not (t.is_cuda and t.dtype == fdt and t.is_contiguous()):
-                raise ValueError('FpnStreamPool.bind needs %s contiguous GPU feature maps' % fdt)
-        tensors = [rpn_logits, rpn_deltas, cls_softmax, cls_deltas] + maps
-        if rpn_logits.numel() != h.N * 2 or rpn_deltas.numel() != h.N * 4:
-            raise ValueError('%d anchors expected, got rpn scores %s / deltas %s'
-                             % (h.N, tuple(rpn_logits.shape), tuple(rpn_deltas.shape)))
-        if cls_softmax.dim() != 2 or cls_softmax.shape[0] != h.K or cls_deltas.numel() != cls_softmax.numel() * 4:
-            raise ValueError('class scores must be [%d, Ccls] and deltas [%d, Ccls, 4]' % (h.K, h.K))
-        c = h.cfg
-        st.image_h, st.image_w = h.image_shape
-        st.num_levels, st.A = len(h.fh), h.wh.shape[1]
-        for l in range(len(h.fh)):
-            st.fh[l], st.fw[l], st.stride[l] = h.fh[l], h.fw[l], int(h.strides[l])
-        flat = h.wh.reshape(-1)
-        for i in range(flat.shape[0]):
-            st.wh[i] = float(flat[i])
-        for k in range(4):
-            st.rpn_means[k], st.rpn_stds[k] = float(c['rpn_means'][k]), float(c['rpn_stds'][k])
-            st.roi_means[k], st.roi_stds[k] = float(c['roi_means'][k]), float(c['roi_stds'][k])
-        st.num_proposals, st.rpn_nms_iou = h.K, float(c['rpn_nms_iou'])
-        st.min_level, st.max_level, st.blind_chunks = h.min_level, h.max_level, h.blind_chunks
-        st.nms_first_chunk = getattr(h, 'nms_first_chunk', 0)
-        st.num_maps, st.channels, st.pool_size = nl, h.C, h.P
-        st.maps_f16 = 1 if fdt == torch.float16 else 0
-        for l, fm in enumerate(maps):
-            if fm.dim() != 4 or fm.shape[0] != 1 or fm.shape[3] != h.C:
-                raise ValueError('feature maps must be NHWC [1,H,W,%d]' % h.C)
-            st.maps[l].data, st.maps[l].H, st.maps[l].W, st.maps[l].stride = fm.data_ptr(), fm.shape[1], fm.shape[2], 0.0
-        st.ccls, st.num_classes = cls_softmax.shape[1], h.num_classes
-        st.max_per_class, st.max_per_image = c['max_per_class'], c['max_per_image']
-        st.nms_iou, st.score_threshold, st.min_edge = float(c['nms_iou']), float(c['score_threshold']), 16.0
-        st.rpn_logits, st.rpn_deltas = rpn_logits.data_ptr(), rpn_deltas.data_ptr()
-        st.cls_scores, st.cls_deltas = cls_softmax.data_ptr(), cls_deltas.data_ptr()
-        st.rois, st.roi_idx, st.roi_count = h.rois.data_ptr(), h.roi_idx.data_ptr(), h.roi_count.data_ptr()
-        st.nms_done, st.sorted_rois = h.nms_done.data_ptr(), h.sorted_rois.data_ptr()
-        st.roi_level, st.roi_perm = h.roi_level.data_ptr(), h.roi_perm.data_ptr()
-        st.level_counts, st.roi_features = h.level_counts.data_ptr(), h.roi_features.data_ptr()
-        st.roi_order = h.roi_order.data_ptr() if h.roi_order is not None else None
-        st.det_boxes, st.det_labels = h.det_boxes.data_ptr(), h.det_labels.data_ptr()
-        st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
-        st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
-        st.ws_post, st.ws_post_bytes = h.ws_post.data_ptr(), h.ws_post.numel()
-        st.stream = self.streams[slot].cuda_stream
-        self._keep[slot] = tensors
+        self._keep[slot] = _fill_step(self.steps[slot], self.slots[slot], self.streams[slot].cuda_stream, rpn_logits,
+                                      rpn_deltas, p_list, cls_softmax, cls_deltas)
 
     def submit(self, slot=None, stages=7):
         """Enqueue one image on `slot` (round-robin when None) as a launch sequence of its own.
