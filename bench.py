@@ -203,8 +203,6 @@ def main():
     # images in flight per GPU: `streams` HIP streams (one native enqueue thread each) x `batch` images
     # that share every kernel launch of their stream (blockIdx.y = image)
     S, B = max(1, args.streams), max(1, min(8, args.batch))
-    if args.blind_chunks != 1:
-        B = 1                                                   # the NMS fallback is per image
     fdt = torch.float16 if args.maps == 'f16' else torch.float32
     pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B,
                          blind_chunks=args.blind_chunks, feature_dtype=fdt, nms_first_chunk=args.nms_first_chunk)

@@ -301,13 +301,13 @@ def test_vgg16_detector_runs_and_pools_like_oracle():
 
 @pytest.mark.gpu
 def test_detector_batched_hot_path_matches_per_image_path():
-    """ResNetFpnDetector with blind_chunks == 1: the images of a batch share the hot-path launches (FpnStepBatch)
+    """ResNetFpnDetector (default arrangement): the images of a batch share the hot-path launches (FpnStepBatch)
     and the RoI head runs on all crops at once -- same detections as the per-image path on the same dense
     outputs."""
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
     torch.manual_seed(8)
     shape, K, B = (256, 352), 300, 3
-    m = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=B, blind_chunks=1, nms_first_chunk=4096).prepare()
+    m = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=B, blind_chunks=2).prepare()
     assert m._steps is not None
     rng = np.random.default_rng(8)
     img = torch.from_numpy((rng.uniform(0, 255, (B,) + shape + (3,)) - 110).astype(np.float32)).cuda()

@@ -746,14 +746,15 @@ def test_frcnn_hot_path_full_size(name, shape, channels, flag, scales):
 
 def test_wide_first_nms_chunk_completes_clustered_scores_in_batched_launches():
     """odet_fpn_step_t.nms_first_chunk: trained-like clustered RPN scores need more than ~1.5 K candidates to keep
-    K proposals; with a 4096-candidate first chunk the batched (sync-free, one chunk) launches complete and
-    give the oracle's proposals; with the automatic size they report nms_done = 0."""
+    K proposals; with a 4096-candidate first chunk, or with a second sync-free chunk per image (blind_chunks = 2),
+    the batched launches complete and give the oracle's proposals; with one narrow chunk they report nms_done = 0."""
     from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
     shape, K, ncls, ch = (800, 1333), 1000, 21, 8
     sets = [synthetic_fpn_inputs(shape, ncls, K, channels=ch, seed=500 + i, score_kind='clustered') for i in range(2)]
     anchors = co.fpn_anchors(shape)
-    for first, expect_done in ((0, False), (4096, True)):
-        pool = FpnStreamPool(1, shape, ncls, K, ch, batch=2, nms_first_chunk=first)
+    for first, blind, expect_done in ((0, 1, False), (4096, 1, True), (0, 2, True)):
+        # (0, 2): the narrow shared chunk, then one sync-free fallback chunk per image inside the same call
+        pool = FpnStreamPool(1, shape, ncls, K, ch, batch=2, nms_first_chunk=first, blind_chunks=blind)
         try:
             for k, (_, dev) in enumerate(sets):
                 pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])

@@ -948,8 +948,8 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   }
   if (B > 1) {
     for (int i = 0; i < B; ++i)
-      if (!J.img[i].out_done || J.blind_chunks > 1)
-        return odet_set_error(ODET_E_INVALID, "odet_nms: batches need the sync-free mode with blind_chunks == 1");
+      if (!J.img[i].out_done)
+        return odet_set_error(ODET_E_INVALID, "odet_nms: batches need the sync-free mode (out_done)");
   }
   static std::once_flag once;       // (executor threads may arrive here together)
   static hipError_t once_rc = hipSuccess;
@@ -1039,46 +1039,67 @@ static int nms_run(NmsJob& J, hipStream_t st) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, B), dim3(SCAN_THREADS), 0, st, sp);
     ODET_LAUNCH_CHECK();
   }
-  if (B > 1) return ODET_OK;                   // sync-free, one chunk: the caller checks every out_done
-  // ---- single image from here on ----
-  NmsState* state = &w[0].hdr->st;
-  const NmsWorkspace& w0 = w[0];
   int blind = J.blind_chunks < 1 ? 1 : J.blind_chunks;
-  if (blind == 1) {
-    if (J.img[0].out_done) return ODET_OK;     // sync-free: the caller checks *out_done
-    NmsState h;
-    ODET_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
-    ODET_HIP(hipStreamSynchronize(st));
-    if (h.done) return ODET_OK;
-  }
-  // 5. fallback: full order, then chunks of 4096 from wherever chunk 0 stopped
-  uint32_t* sorted = nullptr;
-  int rc = odet_sort_keys_desc(n, w0.keys_a, w0.vals_a, w0.keys_b, w0.vals_b, w0.hist, &state->done, &sorted, st);
-  if (rc != ODET_OK) return rc;
-  sp.use_init = 1;
-  sp.sorted_idx = per_img<const uint32_t*>(J, [&](int) { return (const uint32_t*)sorted; });
-  const int max_chunks = (n + NMS_CHUNK - 1) / NMS_CHUNK + 1;
-  for (int c = 1; c <= max_chunks; ++c) {
-    if (c >= blind && !(c == 1 && blind == 1)) {   // (c == 1 && blind == 1: the host has just seen "not done")
-      if (J.img[0].out_done) break;
+  // 5. fallback of image i: full order, then chunks of 4096 from wherever chunk 0 stopped.  Every launch is
+  //    guarded by the image's device-side `done` word.  Batches (sync-free by construction) run exactly
+  //    blind - 1 further chunks per image, one image after the other: ~13 launches per image that exit at once
+  //    where chunk 0 has already finished -- the price of never asking the host.
+  auto fallback = [&](int i, bool host_checks) -> int {
+    NmsState* state = &w[i].hdr->st;
+    const NmsWorkspace& wi = w[i];
+    auto shift = [&](auto tbl) { auto t = tbl; for (int k = 0; k < ODET_MAX_BATCH; ++k) t.v[k] = tbl.v[i]; return t; };
+    if (host_checks && blind == 1) {
       NmsState h;
       ODET_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
       ODET_HIP(hipStreamSynchronize(st));
-      if (h.done) break;
+      if (h.done) return ODET_OK;
     }
-    const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
-    hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, state, n, cap, J.img[0].boxes, sorted,
-                       w0.sboxes, w0.sorig);
-    ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, state, w0.sboxes, w0.kept_boxes, J.thr,
-                       w0.removed_init);
-    ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap), 1), dim3(256), 0, st, cstates, csboxes, J.thr, Lts, diags, 0);
-    ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, 1), dim3(SCAN_THREADS), 0, st, sp);
-    ODET_LAUNCH_CHECK();
+    uint32_t* sorted = nullptr;
+    int rc = odet_sort_keys_desc(n, wi.keys_a, wi.vals_a, wi.keys_b, wi.vals_b, wi.hist, &state->done, &sorted, st);
+    if (rc != ODET_OK) return rc;
+    ScanParams si = sp;
+    si.st = shift(sp.st); si.Lt = shift(sp.Lt); si.diag_up = shift(sp.diag_up); si.removed_init = shift(sp.removed_init);
+    si.sboxes = shift(sp.sboxes); si.sorig = shift(sp.sorig); si.out_idx = shift(sp.out_idx);
+    si.out_boxes = shift(sp.out_boxes); si.kept_boxes = shift(sp.kept_boxes); si.out_count = shift(sp.out_count);
+    si.out_done = shift(sp.out_done); si.as_rois = shift(sp.as_rois); si.as_level = shift(sp.as_level);
+    si.as_perm = shift(sp.as_perm); si.as_counts = shift(sp.as_counts);
+    si.use_init = 1;
+    for (int k = 0; k < ODET_MAX_BATCH; ++k) si.sorted_idx.v[k] = (const uint32_t*)sorted;
+    const PerImg<const NmsState*> cst = shift(cstates);
+    const PerImg<const float4*> csb = shift(csboxes);
+    const PerImg<u64*> lt = shift(Lts), dg = shift(diags);
+    const int max_chunks = host_checks ? (n + NMS_CHUNK - 1) / NMS_CHUNK + 1 : blind - 1;
+    for (int c = 1; c <= max_chunks; ++c) {
+      if (host_checks && c >= blind && !(c == 1 && blind == 1)) {   // (c == 1 && blind == 1: just seen "not done")
+        NmsState h;
+        ODET_HIP(hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st));
+        ODET_HIP(hipStreamSynchronize(st));
+        if (h.done) break;
+      }
+      const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
+      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, state, n, cap, J.img[i].boxes, sorted,
+                         wi.sboxes, wi.sorig);
+      ODET_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, state, wi.sboxes, wi.kept_boxes, J.thr,
+                         wi.removed_init);
+      ODET_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap), 1), dim3(256), 0, st, cst, csb, J.thr, lt, dg, 0);
+      ODET_LAUNCH_CHECK();
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, 1), dim3(SCAN_THREADS), 0, st, si);
+      ODET_LAUNCH_CHECK();
+    }
+    return ODET_OK;
+  };
+  const bool sync_free = J.img[0].out_done != nullptr;    // (batches: checked above for every image)
+  if (sync_free) {
+    if (blind == 1) return ODET_OK;              // one chunk: the caller checks *out_done
+    for (int i = 0; i < B; ++i) {
+      const int rc = fallback(i, false);
+      if (rc != ODET_OK) return rc;
+    }
+    return ODET_OK;
   }
-  return ODET_OK;
+  return fallback(0, true);                      // exact mode (single image): the host follows the chunks
 }
 
 static int nms_trivial(int32_t* out_count, int32_t* out_done, hipStream_t st) {

@@ -172,14 +172,14 @@ class ResNetFpnDetector(nn.Module):
         self._max_batch = max_batch
 
     def prepare(self, device='cuda'):
-        """Moves the model to the GPU and allocates the hot path.  With blind_chunks == 1 (the default; widen the
-        first NMS chunk with nms_first_chunk=4096 for trained-like score clusters) the images of a batch go
-        through the hot path in the SAME kernel launches and through the RoI head as one batch (FpnStepBatch);
-        with blind_chunks > 1 every image takes the per-image path with its multi-chunk NMS fallback."""
+        """Moves the model to the GPU and allocates the hot path.  The images of a batch go through the hot path
+        in the SAME kernel launches and through the RoI head as one batch (FpnStepBatch; sync-free NMS with
+        `blind_chunks` chunks: the first one shared by the batch, the others per image); `batched=False` in
+        the hot-path keywords selects the per-image path (FpnHotPath per image)."""
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
         fd = torch.float16 if self.dtype == torch.float16 else torch.float32
         self._steps = None
-        if self._hot_kwargs.get('blind_chunks', 1) == 1 and self._max_batch <= 8:
+        if self._max_batch <= 8 and self._hot_kwargs.pop('batched', True):
             self._steps = FpnStepBatch(self._max_batch, *self._hot_args, feature_dtype=fd, **self._hot_kwargs)
             self._hot = self._steps.slots
             K = self._hot_args[2]

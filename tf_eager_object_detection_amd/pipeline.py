@@ -301,8 +301,6 @@ class FpnStepBatch:
         import ctypes as C
         if not 1 <= int(max_batch) <= 8:
             raise ValueError('max_batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
-        if max_batch > 1 and kw.get('blind_chunks', 1) != 1:
-            raise ValueError('batched steps need blind_chunks == 1 (widen the first chunk with nms_first_chunk)')
         self.n = int(max_batch)
         self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
         h0 = self.slots[0]
@@ -361,8 +359,6 @@ class FpnStreamPool:
         self.batch = int(batch)
         if not 1 <= self.batch <= 8:
             raise ValueError('batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
-        if self.batch > 1 and kw.get('blind_chunks', 1) != 1:
-            raise ValueError('batched steps need blind_chunks == 1 (the NMS fallback is per image)')
         self.n = self.n_streams * self.batch            # slots; slot k belongs to group k // batch
         self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
         # Batched groups need ~1.4 launches per image, far below one thread's launch rate, and ONE enqueue thread

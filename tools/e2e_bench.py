@@ -23,15 +23,14 @@ ap.add_argument('--h', type=int, default=800)
 ap.add_argument('--w', type=int, default=1333)
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
 ap.add_argument('--graph', action='store_true', help='replay the whole forward pass as one HIP graph')
-ap.add_argument('--batched', action='store_true', help='FPN: the images of a batch share the hot-path launches and the RoI head '
-                '(one wide sync-free NMS chunk: valid only if nms_done comes back 1 for every image) instead of the '
-                'per-image path with the 2-chunk NMS fallback')
+ap.add_argument('--per-image', action='store_true', help='FPN: every image through its own hot-path launches and RoI-head call '
+                'instead of the batched launches (FpnStepBatch)')
 a = ap.parse_args()
 dt = {'fp16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32}[a.dtype]
 torch.backends.cudnn.benchmark = bool(a.miopen_find)
 torch.manual_seed(0)
 if a.model == 'fpn':
-    hot_kw = dict(blind_chunks=1, nms_first_chunk=4096) if a.batched else dict(blind_chunks=2)
+    hot_kw = dict(blind_chunks=2, batched=not a.per_image)
     model = ResNetFpnDetector(a.depth, 21, (a.h, a.w), 1000, dtype=dt, max_batch=a.batch, **hot_kw).prepare()
 elif a.model == 'c4':
     model = ResNetC4Detector(a.depth, 21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4).prepare()
@@ -69,5 +68,5 @@ print(json.dumps({'metric': 'end-to-end images/sec', 'value': a.steps * a.batch 
                   'model': {'fpn': 'ResNet-%d-FPN' % a.depth, 'c4': 'ResNet-%d-C4 Faster R-CNN' % a.depth, 'vgg16': 'VGG16 Faster R-CNN'}[a.model], 'image': [a.h, a.w], 'dtype': a.dtype, 'batch': a.batch,
                   'ms_per_image': el / (a.steps * a.batch) * 1e3, 'warmup_s': t_warm,
                   'ms_backbone_neck_per_batch': t_feat, 'ms_rpn_head_per_batch': t_rpn,
-                  'detections_image0': int(out[0][3].item()), 'finite': bool(torch.isfinite(p[0]).all().item()), 'miopen_find': bool(a.miopen_find), 'hip_graph': bool(a.graph), 'hot_path': 'batched' if a.batched else 'per-image',
+                  'detections_image0': int(out[0][3].item()), 'finite': bool(torch.isfinite(p[0]).all().item()), 'miopen_find': bool(a.miopen_find), 'hip_graph': bool(a.graph), 'hot_path': 'per-image' if a.per_image else 'batched',
                   'nms_done': [int(h.nms_done.item()) for h in model._hot]}))
