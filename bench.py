@@ -240,7 +240,10 @@ def main():
     # other streams and they wait for it afterwards, so only a few steps are bracketed.
     from tf_eager_object_detection_amd import ops
     n_events = max(1, min(10, args.steps // 100))
-    ev_at = set(int(round(j * args.steps / n_events)) for j in range(n_events))
+    # (the event steps sit a whole number of B-image launches apart, so no image between them has to run as a
+    # one-image launch of its own)
+    gap = 1 + B * max(1, (args.steps // n_events - 1) // B)
+    ev_at = set(j * gap for j in range(n_events) if j * gap < args.steps)
     ev_roi = []
 
     def drain():
