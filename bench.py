@@ -137,13 +137,14 @@ def map_delta_vs_port(num_images=16):
                 data='synthetic im_detect outputs (tf_eager_object_detection_amd.synthetic.eval_image)')
 
 
-def load_traffic(workload_key):
-    """HBM bytes per launch of the RoI kernel from the committed rocprofv3 --pmc run (profiles/)."""
+def load_traffic(workload_key, images_per_launch):
+    """HBM bytes per launch of the RoI kernel from the committed rocprofv3 --pmc run (profiles/), scaled to
+    the images of the timed launch when the PMC run used another launch shape."""
     p = os.path.join(ROOT, 'profiles', 'roi_pool_traffic.json')
     try:
         d = json.load(open(p))
         if d.get('workload') == workload_key:
-            return d.get('hbm_bytes_per_launch')
+            return d.get('hbm_bytes_per_launch') / float(d.get('images_per_launch', 1)) * images_per_launch
     except Exception:
         pass
     return None
@@ -235,15 +236,15 @@ def main():
     staging = torch.zeros((S, B, rec_len), dtype=torch.float32, device='cuda') if use_dist else None
     gstreams = pool._group_streams
 
-    # HIP events attached to the RoI kernel's dispatch, inside the timed region.  The kernel is timed
-    # ALONE as a one-image launch: the step's stream first waits (on the GPU, no host sync) for the
-    # other streams and they wait for it afterwards, so only a few steps are bracketed.
+    # HIP events attached to the RoI kernel's dispatch, inside the timed region.  The dominant launch -- the
+    # B-image launch of one stream group -- is timed ALONE: the group's stream first waits (on the GPU, no host
+    # sync) for the other streams and they wait for it afterwards, so only a few launches are bracketed.  The
+    # group's maps are cold by then (the other groups' 2/3 of the 2.3 GB went through the caches since).
     from tf_eager_object_detection_amd import ops
     n_events = max(1, min(10, args.steps // 100))
-    # (the event steps sit a whole number of B-image launches apart, so no image between them has to run as a
-    # one-image launch of its own)
-    gap = 1 + B * max(1, (args.steps // n_events - 1) // B)
-    ev_at = set(j * gap for j in range(n_events) if j * gap < args.steps)
+    # (the timed launches sit a whole number of B-image launches apart)
+    gap = B * max(1, (args.steps // n_events) // B)
+    ev_at = set(j * gap for j in range(n_events) if j * gap + B <= args.steps)
     ev_roi = []
 
     def drain():
@@ -264,22 +265,22 @@ def main():
             dist.all_gather_into_tensor(gathered[g].view(world * B, rec_len), staging[g])   # concatenation form
         st.wait_event(copied)                                 # the next images of the group may overwrite the records
 
-    def timed_single_image(slot):
+    def timed_group(g):
+        """the B images of stream group g through their shared launches with nothing else on the GPU; the RoI
+        dispatch carries HIP events (odet_fpn_step_t.roi_start_event / roi_stop_event of the first step)"""
         ev = (ops.ProfEvent(), ops.ProfEvent())
         ev_roi.append(ev)
         pool.wait()                                           # every earlier image is enqueued (host side only)
-        mine = pool.streams[slot]
+        mine = gstreams[g]
         for st in gstreams:
             if st is not mine:
                 mine.wait_stream(st)
-        with torch.cuda.stream(mine):
-            h = pool.slots[slot]
-            d = slot_inputs[slot]
-            # proposals through the slot's step descriptor (same parameters as the batched launches, e.g. the
-            # first-chunk size), on the slot's stream = `mine`
-            _lib.check(_lib.lib().odet_fpn_step_enqueue(ctypes.byref(pool.steps[slot]), 1))
-            h.stage_roi(d['feats'], events=ev)                # start / stop events of the dispatch itself
-            h.stage_detect(d['cls_scores'], d['cls_deltas'])
+        first = pool.steps[g * B]
+        first.roi_start_event, first.roi_stop_event = ev[0].handle, ev[1].handle
+        try:
+            _lib.check(_lib.lib().odet_fpn_step_enqueue_batch(pool._groups[g], B, 7))      # on the steps' stream = mine
+        finally:
+            first.roi_start_event, first.roi_stop_event = None, None
         for st in gstreams:
             if st is not mine:
                 st.wait_stream(mine)
@@ -289,11 +290,11 @@ def main():
         as single images."""
         i, group = 0, 0
         while i < num_images:
-            if timed and i in ev_at:
-                timed_single_image(0)
+            if timed and i in ev_at and num_images - i >= B:
+                timed_group(0)
                 done_group = 0
-                i += 1
-            elif num_images - i >= B and not (timed and any(j in ev_at for j in range(i + 1, i + B))):
+                i += B
+            elif num_images - i >= B:
                 pool.submit_group(group)
                 done_group = group
                 i += B
@@ -328,10 +329,14 @@ def main():
     if rank == 0:
         roi_ms = float(np.mean([a.elapsed_ms(b) for a, b in ev_roi]))
         k = int(hot.roi_count.item())
-        srois = hot.sorted_rois[:k].cpu().numpy()
-        lv = hot.roi_level[:k].cpu().numpy()
-        algo = algorithmic_roi_bytes(srois, lv, syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS,
-                                    elem=2 if args.maps == 'f16' else 4)
+        # algorithmic bytes of the timed launch = the sum over the B images of stream group 0 (SURVEY 8d per image)
+        algo = None
+        for h_ in pool.slots[:B]:
+            kk = int(h_.roi_count.item())
+            a_ = algorithmic_roi_bytes(h_.sorted_rois[:kk].cpu().numpy(), h_.roi_level[:kk].cpu().numpy(),
+                                       syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS,
+                                       elem=2 if args.maps == 'f16' else 4)
+            algo = a_ if algo is None else {q: algo[q] + a_[q] for q in a_}
         achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
         workload = 'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps')
         result = {
@@ -348,9 +353,11 @@ def main():
                        'feature_maps': args.maps, 'nms_first_chunk': args.nms_first_chunk,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max)',
+            'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max), the '
+                                                   '%d-image launch of one stream group, timed alone' % B,
+                         'images_per_launch': B,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(workload),
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(workload, B),
                          'kernel_ms': roi_ms, 'kernel_ms_samples': len(ev_roi), 'algorithmic_bytes': algo['B_roi'],
                          'bytes_all_taps': algo['B_taps'], 'bytes_output': algo['out']},
         }

@@ -382,6 +382,9 @@ typedef struct {
   void* ws_rpn; size_t ws_rpn_bytes;
   void* ws_post; size_t ws_post_bytes;
   odet_stream_t stream;
+  /* profiling (nullable): HIP events (odet_prof_event_create) attached to the RoI dispatch of this step -- in a
+   * batch those of the first step bracket the one launch all its images share */
+  void* roi_start_event; void* roi_stop_event;
 } odet_fpn_step_t;
 
 size_t odet_fpn_step_sizeof(void);

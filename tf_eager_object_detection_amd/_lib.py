@@ -49,6 +49,7 @@ class OdetFpnStep(C.Structure):
         ('ws_rpn', C.c_void_p), ('ws_rpn_bytes', C.c_size_t),
         ('ws_post', C.c_void_p), ('ws_post_bytes', C.c_size_t),
         ('stream', C.c_void_p),
+        ('roi_start_event', C.c_void_p), ('roi_stop_event', C.c_void_p),
     ]
 
 

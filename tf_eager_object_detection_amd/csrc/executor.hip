@@ -39,7 +39,7 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
     const RoiImageIO one{s->maps, s->sorted_rois, s->roi_level, s->roi_count, s->roi_order, (float*)s->roi_features};
     rc = odet_roi_pool_batch(&one, 1, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
                              s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, (hipStream_t)s->stream,
-                             RoiEvents{nullptr, nullptr}, s->maps_f16 ? 1 : 0);
+                             RoiEvents{(hipEvent_t)s->roi_start_event, (hipEvent_t)s->roi_stop_event}, s->maps_f16 ? 1 : 0);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_DETECT) {
@@ -112,7 +112,8 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
       if (rc != ODET_OK) return rc;
     }
     rc = odet_roi_pool_batch(io, count, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
-                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, st, RoiEvents{nullptr, nullptr},
+                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, st,
+                             RoiEvents{(hipEvent_t)s->roi_start_event, (hipEvent_t)s->roi_stop_event},
                              s->maps_f16 ? 1 : 0);
     if (rc != ODET_OK) return rc;
   }

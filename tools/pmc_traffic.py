@@ -30,13 +30,14 @@ def main():
     ap.add_argument('--write', required=True)
     ap.add_argument('--kernel', default='k_roi_pool')
     ap.add_argument('--workload', required=True)
+    ap.add_argument('--images-per-launch', type=int, default=1, help='images sharing one launch in the profiled run (--batch)')
     ap.add_argument('--out', required=True)
     a = ap.parse_args()
     f_kib, nf = mean_counter(a.fetch, 'FETCH_SIZE', a.kernel)
     w_kib, nw = mean_counter(a.write, 'WRITE_SIZE', a.kernel)
     read_bytes = 2.0 * f_kib * 1024.0
     write_bytes = w_kib * 1024.0
-    out = dict(workload=a.workload, kernel=a.kernel, launches_fetch=nf, launches_write=nw,
+    out = dict(workload=a.workload, kernel=a.kernel, images_per_launch=a.images_per_launch, launches_fetch=nf, launches_write=nw,
                FETCH_SIZE_KiB_per_launch=f_kib, WRITE_SIZE_KiB_per_launch=w_kib,
                read_bytes_per_launch=read_bytes, write_bytes_per_launch=write_bytes,
                hbm_bytes_per_launch=read_bytes + write_bytes,
