@@ -244,7 +244,7 @@ def main():
     n_events = max(1, min(10, args.steps // 100))
     # (the timed launches sit a whole number of B-image launches apart)
     gap = B * max(1, (args.steps // n_events) // B)
-    ev_at = set(j * gap for j in range(n_events) if j * gap + B <= args.steps)
+    ev_at = set(j * gap for j in range(n_events) if j * gap < args.steps)      # (step 0 always: even --steps 1 is timed)
     ev_roi = []
 
     def drain():
@@ -265,10 +265,11 @@ def main():
             dist.all_gather_into_tensor(gathered[g].view(world * B, rec_len), staging[g])   # concatenation form
         st.wait_event(copied)                                 # the next images of the group may overwrite the records
 
-    def timed_group(g):
-        """the B images of stream group g through their shared launches with nothing else on the GPU; the RoI
-        dispatch carries HIP events (odet_fpn_step_t.roi_start_event / roi_stop_event of the first step)"""
-        ev = (ops.ProfEvent(), ops.ProfEvent())
+    def timed_group(g, count):
+        """`count` (= B unless fewer steps remain) images of stream group g through their shared launches with
+        nothing else on the GPU; the RoI dispatch carries HIP events (odet_fpn_step_t.roi_start_event /
+        roi_stop_event of the first step)"""
+        ev = (ops.ProfEvent(), ops.ProfEvent(), count)
         ev_roi.append(ev)
         pool.wait()                                           # every earlier image is enqueued (host side only)
         mine = gstreams[g]
@@ -278,7 +279,7 @@ def main():
         first = pool.steps[g * B]
         first.roi_start_event, first.roi_stop_event = ev[0].handle, ev[1].handle
         try:
-            _lib.check(_lib.lib().odet_fpn_step_enqueue_batch(pool._groups[g], B, 7))      # on the steps' stream = mine
+            _lib.check(_lib.lib().odet_fpn_step_enqueue_batch(pool._groups[g], count, 7))  # on the steps' stream = mine
         finally:
             first.roi_start_event, first.roi_stop_event = None, None
         for st in gstreams:
@@ -290,10 +291,11 @@ def main():
         as single images."""
         i, group = 0, 0
         while i < num_images:
-            if timed and i in ev_at and num_images - i >= B:
-                timed_group(0)
+            if timed and i in ev_at:
+                cnt = min(B, num_images - i)
+                timed_group(0, cnt)
                 done_group = 0
-                i += B
+                i += cnt
             elif num_images - i >= B:
                 pool.submit_group(group)
                 done_group = group
@@ -327,17 +329,22 @@ def main():
                          '(use --nms-first-chunk 4096, or --blind-chunks 2, for score distributions with heavy suppression)')
 
     if rank == 0:
-        roi_ms = float(np.mean([a.elapsed_ms(b) for a, b in ev_roi]))
         k = int(hot.roi_count.item())
-        # algorithmic bytes of the timed launch = the sum over the B images of stream group 0 (SURVEY 8d per image)
-        algo = None
+        # algorithmic bytes of a timed launch = the sum over its images (the first `count` slots of stream group 0;
+        # SURVEY 8d per image)
+        per_slot = []
         for h_ in pool.slots[:B]:
             kk = int(h_.roi_count.item())
-            a_ = algorithmic_roi_bytes(h_.sorted_rois[:kk].cpu().numpy(), h_.roi_level[:kk].cpu().numpy(),
-                                       syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS,
-                                       elem=2 if args.maps == 'f16' else 4)
-            algo = a_ if algo is None else {q: algo[q] + a_[q] for q in a_}
-        achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
+            per_slot.append(algorithmic_roi_bytes(h_.sorted_rois[:kk].cpu().numpy(), h_.roi_level[:kk].cpu().numpy(),
+                                                  syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS,
+                                                  elem=2 if args.maps == 'f16' else 4))
+        def launch_bytes(count):
+            return {q: sum(a_[q] for a_ in per_slot[:count]) for q in per_slot[0]}
+        times = [a.elapsed_ms(b) for a, b, _ in ev_roi]
+        roi_ms = float(np.mean(times))
+        timed_images = int(round(np.mean([c for _, _, c in ev_roi])))
+        algo = launch_bytes(timed_images)
+        achieved = float(np.mean([launch_bytes(c)['B_roi'] / (t * 1e-3) / 1e9 for t, (_, _, c) in zip(times, ev_roi)]))
         workload = 'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps')
         result = {
             'metric': 'images/sec', 'value': args.steps * world / elapsed, 'unit': 'img/s',
@@ -354,10 +361,10 @@ def main():
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max), the '
-                                                   '%d-image launch of one stream group, timed alone' % B,
-                         'images_per_launch': B,
+                                                   '%d-image launch of one stream group, timed alone' % timed_images,
+                         'images_per_launch': timed_images,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(workload, B),
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(workload, timed_images),
                          'kernel_ms': roi_ms, 'kernel_ms_samples': len(ev_roi), 'algorithmic_bytes': algo['B_roi'],
                          'bytes_all_taps': algo['B_taps'], 'bytes_output': algo['out']},
         }
