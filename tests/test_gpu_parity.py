@@ -782,3 +782,47 @@ def test_wide_first_nms_chunk_completes_clustered_scores_in_batched_launches():
             bad.wait()
         finally:
             bad.close()
+
+
+def test_nms_sync_free_chunks_from_selection_then_full_order():
+    """Sync-free jobs: chunk 1 comes from the ranked radix selection (no sort), chunks 2.. from the full order per
+    image; exhausted selections (massive ties: the boundary bin cannot be split) and dense suppression included."""
+    rng = np.random.default_rng(15)
+    done = torch.zeros(1, dtype=torch.int32, device='cuda')
+    # (a) dense cluster: needs > 8192 candidates -> blind 2 cannot finish (prefix exact), blind 8 does
+    n = 30000
+    base = np.float32([100, 100, 300, 260])
+    boxes = base + rng.uniform(-3, 3, (n, 4)).astype(np.float32)
+    boxes[::1000] += np.float32([500, 300, 500, 300])
+    scores = syn.scores_distinct(n, rng)
+    want, stats = co.nms(boxes, scores, 100, 0.5, True)
+    assert stats[0] > 8192
+    idx, cnt = ops.nms(g(boxes), g(scores), 100, 0.5, blind_chunks=2, done=done)
+    m = int(cnt.item())
+    assert int(done.item()) == 0 and 0 < m <= len(want)         # (not done: the order has not been walked to its end)
+    np.testing.assert_array_equal(h(idx[:m]), want[:m])
+    done.zero_()
+    idx, cnt = ops.nms(g(boxes), g(scores), 100, 0.5, blind_chunks=9, done=done)
+    assert int(done.item()) == 1
+    np.testing.assert_array_equal(h(idx[:int(cnt.item())]), want)
+    # (b) every score identical: the selection is empty, chunk 1 finds nothing, the full order decides from chunk 2
+    n = 10000
+    boxes = syn.random_boxes(n, (800, 1333), rng, 16, 200)
+    scores = np.full(n, 0.5, np.float32)
+    done.zero_()
+    idx, cnt = ops.nms(g(boxes), g(scores), 300, 0.5, blind_chunks=4, done=done)
+    assert int(done.item()) == 1
+    np.testing.assert_array_equal(h(idx[:int(cnt.item())]), co.nms(boxes, scores, 300, 0.5))
+    # (c) moderate suppression finishing inside chunk 1 (selection order), K = 1000 of 60000
+    n = 60000
+    boxes = syn.random_boxes(n, (800, 1333), rng, 40, 400)
+    scores = syn.scores_distinct(n, rng)
+    want, stats = co.nms(boxes, scores, 1000, 0.3, True)
+    done.zero_()
+    idx, cnt = ops.nms(g(boxes), g(scores), 1000, 0.3, blind_chunks=2, done=done)
+    if stats[0] <= 1536 + 4096:
+        assert int(done.item()) == 1
+        np.testing.assert_array_equal(h(idx[:int(cnt.item())]), want)
+    else:
+        m = int(cnt.item())
+        np.testing.assert_array_equal(h(idx[:m]), want[:m])

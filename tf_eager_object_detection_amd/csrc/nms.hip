@@ -43,6 +43,7 @@
 #include "odet_internal.h"
 
 #define NMS_CHUNK 4096
+#define NMS_SEL_MAX (2 * NMS_CHUNK)   // most candidates one radix selection hands over (first chunk + one more)
 #define NMS_WORDS (NMS_CHUNK / 64)
 #define SEL_BINS 4096
 #define SEL_REPL 8   // copies of the first-level histogram (hot bins: same-address atomics serialise)
@@ -327,7 +328,7 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(PerImg<NmsHeader*> hd
   __syncthreads();
   const int gb = s_base;
   for (int i = threadIdx.x; i < c; i += SEL_BLOCK)
-    if (gb + i < NMS_CHUNK) cand[gb + i] = stage[i];
+    if (gb + i < NMS_SEL_MAX) cand[gb + i] = stage[i];
 }
 
 // chunk 0: order the selected candidates by counting (all (key, index) pairs are distinct, so the
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(PerImg<NmsHeader*> hd
 // 64 candidates (lane) x 16 slices of the comparison range (wave); the pair list is staged in LDS and
 // every wave reads it as a broadcast.
 #define RANK_THREADS 1024
-__global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hdr_, int n, PerImg<const u64*> cand_,
+__global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hdr_, int n, int cap0, PerImg<const u64*> cand_,
                                                           PerImg<const float4*> boxes_, PerImg<uint32_t*> sel_idx_,
                                                           PerImg<float4*> sboxes_, PerImg<float4*> sorig_) {
   NmsHeader* hdr = hdr_.v[blockIdx.y];
@@ -347,18 +348,24 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
   __shared__ u64 all[NMS_CHUNK];
   __shared__ int part[16][64];
   NmsState* st = &hdr->st;
-  const int cnt = min(st->sel_count, NMS_CHUNK);
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->chunk_m = min(cnt, n - st->n_invalid);
+  // the selection may hold more than the first chunk takes (cap0): the rest, ranked here as well, is the next
+  // sync-free chunk's (k_nms_gather with the selection as its order)
+  const int cnt = min(st->sel_count, NMS_SEL_MAX);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->chunk_m = min(min(cnt, cap0), n - st->n_invalid);
   if (blockIdx.x * 64 >= cnt) return;
-  for (int i = threadIdx.x; i < cnt; i += RANK_THREADS) all[i] = cand[i];
-  __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
-  const u64 mine = (i < cnt) ? all[i] : ~0ull;
-  const int per = (cnt + 15) >> 4;
-  const int lo = w * per, hi = min(cnt, lo + per);
+  const u64 mine = (i < cnt) ? cand[i] : ~0ull;
   int c = 0;
-  for (int j = lo; j < hi; ++j) c += (all[j] < mine) ? 1 : 0;
+  for (int t0 = 0; t0 < cnt; t0 += NMS_CHUNK) {          // the pair list goes through LDS a tile at a time
+    const int tc = min(NMS_CHUNK, cnt - t0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < tc; k += RANK_THREADS) all[k] = cand[t0 + k];
+    __syncthreads();
+    const int per = (tc + 15) >> 4;
+    const int lo = w * per, hi = min(tc, lo + per);
+    for (int j = lo; j < hi; ++j) c += (all[j] < mine) ? 1 : 0;
+  }
   part[w][lane] = c;
   __syncthreads();
   if (w == 0 && i < cnt) {
@@ -368,18 +375,27 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
     const uint32_t idx = (uint32_t)mine;
     sel_idx[r] = idx;
     // invalid scores (key 0xFFFFFFFF) sort last; rows >= chunk_m are never read
-    const float4 bx = boxes[idx];
-    sboxes[r] = d_norm_box(bx);
-    sorig[r] = bx;
+    if (r < cap0) {
+      const float4 bx = boxes[idx];
+      sboxes[r] = d_norm_box(bx);
+      sorig[r] = bx;
+    }
   }
 }
 
 // later chunks: gather the chunk's boxes in sorted order (corner-normalised) -----------------
-__global__ void __launch_bounds__(256) k_nms_gather(NmsState* st, int n, int cap, const float4* __restrict__ boxes,
-                                                    const uint32_t* __restrict__ sorted_idx,
-                                                    float4* __restrict__ sboxes, float4* __restrict__ sorig) {
+// from_sel: the order is the ranked radix selection (sel_idx), which ends at sel_count; otherwise the full sort.
+__global__ void __launch_bounds__(256) k_nms_gather(PerImg<NmsState*> st_, int n, int cap, int from_sel,
+                                                    PerImg<const float4*> boxes_, PerImg<const uint32_t*> sorted_idx_,
+                                                    PerImg<float4*> sboxes_, PerImg<float4*> sorig_) {
+  NmsState* st = st_.v[blockIdx.y];
+  const float4* __restrict__ boxes = boxes_.v[blockIdx.y];
+  const uint32_t* __restrict__ sorted_idx = sorted_idx_.v[blockIdx.y];
+  float4* __restrict__ sboxes = sboxes_.v[blockIdx.y];
+  float4* __restrict__ sorig = sorig_.v[blockIdx.y];
   const int pos = st->pos, nv = n - st->n_invalid;
-  const int m = st->done ? 0 : min(cap, nv - pos);
+  const int lim = from_sel ? min(nv, min(st->sel_count, NMS_SEL_MAX)) : nv;
+  const int m = st->done ? 0 : max(0, min(cap, lim - pos));
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) st->chunk_m = m;
   if (i < m) {
@@ -390,9 +406,13 @@ __global__ void __launch_bounds__(256) k_nms_gather(NmsState* st, int n, int cap
 }
 
 // chunk candidates vs boxes kept by earlier chunks ---------------------------------------------
-__global__ void __launch_bounds__(256) k_nms_cross(const NmsState* st, const float4* __restrict__ sboxes,
-                                                   const float4* __restrict__ kept_boxes, float thr,
-                                                   u64* __restrict__ removed_init) {
+__global__ void __launch_bounds__(256) k_nms_cross(PerImg<const NmsState*> st_, PerImg<const float4*> sboxes_,
+                                                   PerImg<const float4*> kept_boxes_, float thr,
+                                                   PerImg<u64*> removed_init_) {
+  const NmsState* st = st_.v[blockIdx.y];
+  const float4* __restrict__ sboxes = sboxes_.v[blockIdx.y];
+  const float4* __restrict__ kept_boxes = kept_boxes_.v[blockIdx.y];
+  u64* __restrict__ removed_init = removed_init_.v[blockIdx.y];
   __shared__ float4 kb[256];
   __shared__ float ka[256];
   const int m = st->chunk_m, nk = st->kept;
@@ -584,6 +604,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
   __shared__ int lvl_tot[ODET_MAX_LEVELS];
   extern __shared__ __align__(16) u64 mat[];  // packed strictly-lower matrix (LDSMAT)
   if (st->done) return;                       // uniform: an earlier chunk finished the job
+  // a later chunk that found nothing left in its order (the ranked selection is exhausted): the state stays
+  // "not done" for whoever continues (the per-image fallback on the full order, or the caller's out_done check)
+  if (sp.use_init && st->chunk_m == 0 && st->pos < sp.n - st->n_invalid) return;
   NmsHeader* hdr = reinterpret_cast<NmsHeader*>(st);   // the state is the header's first member
   (void)hdr;
   STAMP(hdr, 0);
@@ -857,9 +880,9 @@ static size_t nms_carve(int n, int max_out, void* ws, size_t ws_bytes, NmsWorksp
   TAKE(keys_a, uint32_t, nn);
   TAKE(vals_a, uint32_t, nn);
   TAKE(keys_b, uint32_t, nn);
-  TAKE(vals_b, uint32_t, std::max(nn, (size_t)NMS_CHUNK));
+  TAKE(vals_b, uint32_t, std::max(nn, (size_t)NMS_SEL_MAX));
   TAKE(hist, uint32_t, odet_sort_hist_entries(n));
-  TAKE(cand, u64, NMS_CHUNK);
+  TAKE(cand, u64, NMS_SEL_MAX);
   TAKE(sboxes, float4, NMS_CHUNK);
   TAKE(sorig, float4, NMS_CHUNK);
   TAKE(kept_boxes, float4, kk);
@@ -987,19 +1010,26 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   const uint32_t target = (uint32_t)first_chunk_target(n, K, J.first_chunk);
   // chunk 0 runs on the LDS-resident scan when its candidates are guaranteed to fit 24 blocks
   const bool lds0 = target <= (uint32_t)SCAN_LDS_CAND;
-  const uint32_t limit = lds0 ? (uint32_t)SCAN_LDS_CAND : (uint32_t)NMS_CHUNK;
+  const uint32_t limit = lds0 ? (uint32_t)SCAN_LDS_CAND : (uint32_t)NMS_CHUNK;      // capacity of the chunk-0 scan
+  // Sync-free jobs that ask for a second chunk get it from the SAME radix selection: one NMS_CHUNK more candidates
+  // are selected and ranked, and chunk 1 runs on that order in launches shared by the whole batch -- no per-image
+  // radix sort of all anchors for it.
+  const int blind_req = J.blind_chunks < 1 ? 1 : J.blind_chunks;
+  const bool wide = J.img[0].out_done != nullptr && blind_req >= 2;
+  const uint32_t sel_target = wide ? (uint32_t)std::min<long long>(n, (long long)target + NMS_CHUNK) : target;
+  const uint32_t sel_limit = wide ? (uint32_t)NMS_SEL_MAX : limit;
   const PerImg<const float4*> nboxes = per_img<const float4*>(J, [&](int i) { return J.img[i].boxes; });
   const PerImg<float4*> sboxes = per_img<float4*>(J, [&](int i) { return w[i].sboxes; });
   const PerImg<float4*> sorig = per_img<float4*>(J, [&](int i) { return w[i].sorig; });
   {
     dim3 grid((n + SEL_TILE - 1) / SEL_TILE, B), block(SEL_BLOCK);
-    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, hdrs, keys, n, target);
+    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, hdrs, keys, n, sel_target);
     ODET_LAUNCH_CHECK();
     const PerImg<u64*> cand = per_img<u64*>(J, [&](int i) { return w[i].cand; });
-    hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, hdrs, keys, n, target, limit, cand);
+    hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, hdrs, keys, n, sel_target, sel_limit, cand);
     ODET_LAUNCH_CHECK();
-    const int rank_wgs = (std::min(n, (int)limit) + 63) / 64;
-    hipLaunchKernelGGL(k_sel_rank, dim3(rank_wgs, B), dim3(RANK_THREADS), 0, st, hdrs, n,
+    const int rank_wgs = (std::min(n, (int)sel_limit) + 63) / 64;
+    hipLaunchKernelGGL(k_sel_rank, dim3(rank_wgs, B), dim3(RANK_THREADS), 0, st, hdrs, n, (int)limit,
                        per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].cand; }), nboxes,
                        per_img<uint32_t*>(J, [&](int i) { return w[i].vals_b; }), sboxes, sorig);
     ODET_LAUNCH_CHECK();
@@ -1044,7 +1074,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   //    guarded by the image's device-side `done` word.  Batches (sync-free by construction) run exactly
   //    blind - 1 further chunks per image, one image after the other: ~13 launches per image that exit at once
   //    where chunk 0 has already finished -- the price of never asking the host.
-  auto fallback = [&](int i, bool host_checks) -> int {
+  auto fallback = [&](int i, bool host_checks, int chunks) -> int {
     NmsState* state = &w[i].hdr->st;
     const NmsWorkspace& wi = w[i];
     auto shift = [&](auto tbl) { auto t = tbl; for (int k = 0; k < ODET_MAX_BATCH; ++k) t.v[k] = tbl.v[i]; return t; };
@@ -1068,7 +1098,16 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     const PerImg<const NmsState*> cst = shift(cstates);
     const PerImg<const float4*> csb = shift(csboxes);
     const PerImg<u64*> lt = shift(Lts), dg = shift(diags);
-    const int max_chunks = host_checks ? (n + NMS_CHUNK - 1) / NMS_CHUNK + 1 : blind - 1;
+    const int max_chunks = host_checks ? (n + NMS_CHUNK - 1) / NMS_CHUNK + 1 : chunks;
+    PerImg<NmsState*> st_i;
+    PerImg<const float4*> boxes_i, kept_i;
+    PerImg<const uint32_t*> sorted_i;
+    PerImg<float4*> sb_i, so_i;
+    PerImg<u64*> ri_i;
+    for (int k = 0; k < ODET_MAX_BATCH; ++k) {
+      st_i.v[k] = state; boxes_i.v[k] = J.img[i].boxes; sorted_i.v[k] = sorted; sb_i.v[k] = wi.sboxes;
+      so_i.v[k] = wi.sorig; kept_i.v[k] = wi.kept_boxes; ri_i.v[k] = wi.removed_init;
+    }
     for (int c = 1; c <= max_chunks; ++c) {
       if (host_checks && c >= blind && !(c == 1 && blind == 1)) {   // (c == 1 && blind == 1: just seen "not done")
         NmsState h;
@@ -1077,11 +1116,10 @@ static int nms_run(NmsJob& J, hipStream_t st) {
         if (h.done) break;
       }
       const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
-      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256), dim3(256), 0, st, state, n, cap, J.img[i].boxes, sorted,
-                         wi.sboxes, wi.sorig);
+      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, 1), dim3(256), 0, st, st_i, n, cap, 0, boxes_i, sorted_i,
+                         sb_i, so_i);
       ODET_LAUNCH_CHECK();
-      hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256), dim3(256), 0, st, state, wi.sboxes, wi.kept_boxes, J.thr,
-                         wi.removed_init);
+      hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256, 1), dim3(256), 0, st, cst, csb, kept_i, J.thr, ri_i);
       ODET_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap), 1), dim3(256), 0, st, cst, csb, J.thr, lt, dg, 0);
       ODET_LAUNCH_CHECK();
@@ -1093,13 +1131,31 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   const bool sync_free = J.img[0].out_done != nullptr;    // (batches: checked above for every image)
   if (sync_free) {
     if (blind == 1) return ODET_OK;              // one chunk: the caller checks *out_done
-    for (int i = 0; i < B; ++i) {
-      const int rc = fallback(i, false);
+    // chunk 1 of every image from the ranked selection, in launches shared by the batch
+    {
+      ScanParams s1 = sp;
+      s1.use_init = 1;                           // (sorted_idx stays the ranked selection)
+      const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
+      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, B), dim3(256), 0, st, sp.st, n, cap, 1, nboxes,
+                         sp.sorted_idx, sboxes, sorig);
+      ODET_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256, B), dim3(256), 0, st, cstates, csboxes,
+                         per_img<const float4*>(J, [&](int i) { return (const float4*)w[i].kept_boxes; }), J.thr,
+                         per_img<u64*>(J, [&](int i) { return w[i].removed_init; }));
+      ODET_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap), B), dim3(256), 0, st, cstates, csboxes, J.thr, Lts, diags, 0);
+      ODET_LAUNCH_CHECK();
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, B), dim3(SCAN_THREADS), 0, st, s1);
+      ODET_LAUNCH_CHECK();
+    }
+    // chunks 2.. (rarely asked for): per image, on the full order
+    for (int i = 0; i < B && blind > 2; ++i) {
+      const int rc = fallback(i, false, blind - 2);
       if (rc != ODET_OK) return rc;
     }
     return ODET_OK;
   }
-  return fallback(0, true);                      // exact mode (single image): the host follows the chunks
+  return fallback(0, true, 0);                   // exact mode (single image): the host follows the chunks
 }
 
 static int nms_trivial(int32_t* out_count, int32_t* out_done, hipStream_t st) {
