@@ -30,7 +30,9 @@ dt = {'fp16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32}[a.dt
 torch.backends.cudnn.benchmark = bool(a.miopen_find)
 torch.manual_seed(0)
 if a.model == 'fpn':
-    hot_kw = dict(blind_chunks=2, batched=not a.per_image)
+    # chunk 0 + chunk 1 from the ranked selection + one per-image chunk on the full order: the float16 logits of the
+    # random-init RPN tie in thousands, which the selection cannot split
+    hot_kw = dict(blind_chunks=3, batched=not a.per_image)
     model = ResNetFpnDetector(a.depth, 21, (a.h, a.w), 1000, dtype=dt, max_batch=a.batch, **hot_kw).prepare()
 elif a.model == 'c4':
     model = ResNetC4Detector(a.depth, 21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4).prepare()
