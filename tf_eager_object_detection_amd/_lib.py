@@ -11,6 +11,8 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libodet_hip.so')
+if os.environ.get('ODET_LIB_PATH'):          # diagnostic builds of the same ABI (tools/): never a fallback
+    LIB_PATH = os.environ['ODET_LIB_PATH']
 
 _lib = None
 

@@ -243,16 +243,21 @@ __device__ __forceinline__ void sel_find(const uint32_t* __restrict__ hist, uint
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n,
-                                                         uint32_t target) {
+// First-level threshold bin, once per image: a thousand blocks each re-deriving it from the 8 histogram replicas
+// (128 KB per block, 1 GB of L2 reads per 8-image batch) cost more than this launch.
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_find1(PerImg<NmsHeader*> hdr_, uint32_t target) {
   NmsHeader* hdr = hdr_.v[blockIdx.y];
-  const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
-  __shared__ uint32_t h[SEL_BINS];
   __shared__ uint32_t res[3];
   __shared__ int lds17[17];
   sel_find<SEL_REPL>(&hdr->hist1[0][0], target, res, lds17);
-  const uint32_t b1 = res[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->st.sel_b1 = (int32_t)b1; hdr->st.sel_below1 = res[1]; }
+  if (threadIdx.x == 0) { hdr->st.sel_b1 = (int32_t)res[0]; hdr->st.sel_below1 = res[1]; }
+}
+
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n) {
+  NmsHeader* hdr = hdr_.v[blockIdx.y];
+  const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
+  __shared__ uint32_t h[SEL_BINS];
+  const uint32_t b1 = (uint32_t)hdr->st.sel_b1;
   uint32_t key[SEL_ITEMS];
   bool match = false;
 #pragma unroll
@@ -1023,7 +1028,9 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   const PerImg<float4*> sorig = per_img<float4*>(J, [&](int i) { return w[i].sorig; });
   {
     dim3 grid((n + SEL_TILE - 1) / SEL_TILE, B), block(SEL_BLOCK);
-    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, hdrs, keys, n, sel_target);
+    hipLaunchKernelGGL(k_sel_find1, dim3(1, B), block, 0, st, hdrs, sel_target);
+    ODET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, hdrs, keys, n);
     ODET_LAUNCH_CHECK();
     const PerImg<u64*> cand = per_img<u64*>(J, [&](int i) { return w[i].cand; });
     hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, hdrs, keys, n, sel_target, sel_limit, cand);
