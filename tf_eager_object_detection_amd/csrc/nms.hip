@@ -123,14 +123,49 @@ __global__ void __launch_bounds__(256) k_zero_headers(PerImg<NmsHeader*> hdr_) {
   if (i < (int)(sizeof(NmsHeader) / 16)) d[i] = make_uint4(0, 0, 0, 0);
 }
 
+// Box of candidate e of image img -- decoded LAZILY: the order key needs only the score, and of the 267 069
+// anchors of a pyramid only the few thousand candidates the selection hands to NMS ever need their box
+// (anchor in registers, 16 B of deltas, decode + clip: the same device functions, the same bits as a full
+// decode pass, which cost 32 of the 44 bytes per anchor of this stage and a float64 exp pair per anchor).
+template <int MODE>
+__device__ __forceinline__ float4 d_prep_box(const PrepParams& p, int img, int e) {
+  if (MODE == PREP_NMS) return p.boxes_in.v[img][e];
+  float4 a;
+  if (MODE == PREP_FPN) {
+    a = d_fpn_anchor(p.fpn, e);                                    // base_fpn_model.py:220 / :163-186
+  } else if (MODE == PREP_FRCNN) {
+    // anchor_generator.py:46-60 generate_by_anchor_base_tf, in registers
+    const int ai = e % p.fpn.A, cell = e / p.fpn.A;
+    const int x = cell % p.fpn.fw[0], y = cell / p.fpn.fw[0];
+    const float sx = (float)(x * p.fpn.stride[0]), sy = (float)(y * p.fpn.stride[0]);
+    a = make_float4(p.fpn.wh[ai * 4 + 0] + sx, p.fpn.wh[ai * 4 + 1] + sy, p.fpn.wh[ai * 4 + 2] + sx,
+                    p.fpn.wh[ai * 4 + 3] + sy);
+  } else {
+    a = p.boxes_in.v[img][e];                                      // PREP_RP: anchors given
+  }
+  const float4 d = reinterpret_cast<const float4*>(p.deltas.v[img])[e];
+  const float d0 = d.x * p.stds.v[0] + p.means.v[0];               // bbox_transform.py:37
+  const float d1 = d.y * p.stds.v[1] + p.means.v[1];
+  const float d2 = d.z * p.stds.v[2] + p.means.v[2];
+  const float d3 = d.w * p.stds.v[3] + p.means.v[3];
+  float4 b = d_decode_box(a, d0, d1, d2, d3);                      // region_proposal.py:59
+  return d_clip_box(b, 0.0f, p.wmax, p.hmax);                      // :63
+}
+
+__device__ __forceinline__ float4 d_candidate_box(const PrepParams& p, int mode, int img, int e) {
+  switch (mode) {
+    case PREP_NMS: return d_prep_box<PREP_NMS>(p, img, e);
+    case PREP_RP: return d_prep_box<PREP_RP>(p, img, e);
+    case PREP_FRCNN: return d_prep_box<PREP_FRCNN>(p, img, e);
+    default: return d_prep_box<PREP_FPN>(p, img, e);
+  }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
   const int img = blockIdx.y;
-  const float4* __restrict__ in_boxes = p.boxes_in.v[img];
-  const float* __restrict__ in_deltas = p.deltas.v[img];
   const float* __restrict__ in_scores = p.scores.v[img];
   const float2* __restrict__ in_logits = p.logits.v[img];
-  float4* __restrict__ out_boxes_ = p.boxes_out.v[img];
   uint32_t* __restrict__ out_keys = p.keys.v[img];
   NmsHeader* hdr = p.hdr.v[img];
   __shared__ uint32_t h[SEL_BINS];
@@ -138,7 +173,6 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
   // all loads of the tile first (independent, in flight together), then the arithmetic
   float sc[PREP_ITEMS];
   float2 lg[PREP_ITEMS];
-  float4 an[PREP_ITEMS], dl[PREP_ITEMS];
 #pragma unroll
   for (int it = 0; it < PREP_ITEMS; ++it) {
     const int e = blockIdx.x * PREP_TILE + it * 256 + threadIdx.x;
@@ -154,8 +188,6 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
     } else {
       sc[it] = in_scores[ee];
     }
-    if (MODE == PREP_RP) an[it] = in_boxes[ee];
-    if (MODE != PREP_NMS) dl[it] = reinterpret_cast<const float4*>(in_deltas)[ee];
   }
   __syncthreads();
   int invalid = 0;
@@ -166,29 +198,6 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
       float s;
       if (MODE == PREP_FPN || MODE == PREP_FRCNN) s = d_fg_prob(lg[it].x, lg[it].y);   // base_fpn_model.py:223
       else s = sc[it];
-      if (MODE != PREP_NMS) {
-        float4 a;
-        if (MODE == PREP_FPN) {
-          a = d_fpn_anchor(p.fpn, e);                              // :220 / :163-186
-        } else if (MODE == PREP_FRCNN) {
-          // anchor_generator.py:46-60 generate_by_anchor_base_tf, in registers
-          const int ai = e % p.fpn.A, cell = e / p.fpn.A;
-          const int x = cell % p.fpn.fw[0], y = cell / p.fpn.fw[0];
-          const float sx = (float)(x * p.fpn.stride[0]), sy = (float)(y * p.fpn.stride[0]);
-          a = make_float4(p.fpn.wh[ai * 4 + 0] + sx, p.fpn.wh[ai * 4 + 1] + sy, p.fpn.wh[ai * 4 + 2] + sx,
-                          p.fpn.wh[ai * 4 + 3] + sy);
-        } else {
-          a = an[it];
-        }
-        const float4 d = dl[it];
-        const float d0 = d.x * p.stds.v[0] + p.means.v[0];         // bbox_transform.py:37
-        const float d1 = d.y * p.stds.v[1] + p.means.v[1];
-        const float d2 = d.z * p.stds.v[2] + p.means.v[2];
-        const float d3 = d.w * p.stds.v[3] + p.means.v[3];
-        float4 b = d_decode_box(a, d0, d1, d2, d3);                // region_proposal.py:59
-        b = d_clip_box(b, 0.0f, p.wmax, p.hmax);                   // :63
-        out_boxes_[e] = b;
-      }
       const bool valid = s > -3.402823466e+38f;   // NonMaxSuppressionV3: score > score_threshold (= lowest)
       const uint32_t k = valid ? ~d_float_asc_key(s) : 0xFFFFFFFFu;
       out_keys[e] = k;
@@ -342,11 +351,10 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(PerImg<NmsHeader*> hd
 // every wave reads it as a broadcast.
 #define RANK_THREADS 1024
 __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hdr_, int n, int cap0, PerImg<const u64*> cand_,
-                                                          PerImg<const float4*> boxes_, PerImg<uint32_t*> sel_idx_,
+                                                          PrepParams prep, int mode, PerImg<uint32_t*> sel_idx_,
                                                           PerImg<float4*> sboxes_, PerImg<float4*> sorig_) {
   NmsHeader* hdr = hdr_.v[blockIdx.y];
   const u64* __restrict__ cand = cand_.v[blockIdx.y];
-  const float4* __restrict__ boxes = boxes_.v[blockIdx.y];
   uint32_t* __restrict__ sel_idx = sel_idx_.v[blockIdx.y];
   float4* __restrict__ sboxes = sboxes_.v[blockIdx.y];
   float4* __restrict__ sorig = sorig_.v[blockIdx.y];
@@ -381,7 +389,7 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
     sel_idx[r] = idx;
     // invalid scores (key 0xFFFFFFFF) sort last; rows >= chunk_m are never read
     if (r < cap0) {
-      const float4 bx = boxes[idx];
+      const float4 bx = d_candidate_box(prep, mode, blockIdx.y, (int)idx);
       sboxes[r] = d_norm_box(bx);
       sorig[r] = bx;
     }
@@ -391,10 +399,9 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
 // later chunks: gather the chunk's boxes in sorted order (corner-normalised) -----------------
 // from_sel: the order is the ranked radix selection (sel_idx), which ends at sel_count; otherwise the full sort.
 __global__ void __launch_bounds__(256) k_nms_gather(PerImg<NmsState*> st_, int n, int cap, int from_sel,
-                                                    PerImg<const float4*> boxes_, PerImg<const uint32_t*> sorted_idx_,
+                                                    PrepParams prep, int mode, PerImg<const uint32_t*> sorted_idx_,
                                                     PerImg<float4*> sboxes_, PerImg<float4*> sorig_) {
   NmsState* st = st_.v[blockIdx.y];
-  const float4* __restrict__ boxes = boxes_.v[blockIdx.y];
   const uint32_t* __restrict__ sorted_idx = sorted_idx_.v[blockIdx.y];
   float4* __restrict__ sboxes = sboxes_.v[blockIdx.y];
   float4* __restrict__ sorig = sorig_.v[blockIdx.y];
@@ -404,7 +411,7 @@ __global__ void __launch_bounds__(256) k_nms_gather(PerImg<NmsState*> st_, int n
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) st->chunk_m = m;
   if (i < m) {
-    const float4 bx = boxes[sorted_idx[pos + i]];
+    const float4 bx = d_candidate_box(prep, mode, blockIdx.y, (int)sorted_idx[pos + i]);
     sboxes[i] = d_norm_box(bx);
     sorig[i] = bx;
   }
@@ -1037,7 +1044,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     ODET_LAUNCH_CHECK();
     const int rank_wgs = (std::min(n, (int)sel_limit) + 63) / 64;
     hipLaunchKernelGGL(k_sel_rank, dim3(rank_wgs, B), dim3(RANK_THREADS), 0, st, hdrs, n, (int)limit,
-                       per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].cand; }), nboxes,
+                       per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].cand; }), J.prep, J.mode,
                        per_img<uint32_t*>(J, [&](int i) { return w[i].vals_b; }), sboxes, sorig);
     ODET_LAUNCH_CHECK();
   }
@@ -1106,6 +1113,8 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     const PerImg<const float4*> csb = shift(csboxes);
     const PerImg<u64*> lt = shift(Lts), dg = shift(diags);
     const int max_chunks = host_checks ? (n + NMS_CHUNK - 1) / NMS_CHUNK + 1 : chunks;
+    PrepParams prep_i = J.prep;                 // image i at entry 0 (grid.y == 1)
+    prep_i.boxes_in = shift(J.prep.boxes_in); prep_i.deltas = shift(J.prep.deltas);
     PerImg<NmsState*> st_i;
     PerImg<const float4*> boxes_i, kept_i;
     PerImg<const uint32_t*> sorted_i;
@@ -1123,8 +1132,8 @@ static int nms_run(NmsJob& J, hipStream_t st) {
         if (h.done) break;
       }
       const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
-      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, 1), dim3(256), 0, st, st_i, n, cap, 0, boxes_i, sorted_i,
-                         sb_i, so_i);
+      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, 1), dim3(256), 0, st, st_i, n, cap, 0, prep_i, J.mode,
+                         sorted_i, sb_i, so_i);
       ODET_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256, 1), dim3(256), 0, st, cst, csb, kept_i, J.thr, ri_i);
       ODET_LAUNCH_CHECK();
@@ -1143,7 +1152,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
       ScanParams s1 = sp;
       s1.use_init = 1;                           // (sorted_idx stays the ranked selection)
       const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
-      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, B), dim3(256), 0, st, sp.st, n, cap, 1, nboxes,
+      hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, B), dim3(256), 0, st, sp.st, n, cap, 1, J.prep, J.mode,
                          sp.sorted_idx, sboxes, sorig);
       ODET_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256, B), dim3(256), 0, st, cstates, csboxes,
