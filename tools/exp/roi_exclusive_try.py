@@ -46,7 +46,24 @@ def round_mutex(first):
         enqueue(g, 1)
         sec[g].record(st)
         enqueue(g, 2)
-fn = {'exclusive': round_exclusive, 'plain': round_plain, 'mutex': round_mutex}[mode]
+hi = [torch.cuda.Stream(priority=-1) for _ in range(S)]
+lo = [torch.cuda.Stream(priority=0) for _ in range(S)]
+e1 = [torch.cuda.Event() for _ in range(S)]
+e2 = [torch.cuda.Event() for _ in range(S)]
+def enqueue_on(g, stages, stream):
+    for k in range(g * B, (g + 1) * B):
+        pool.steps[k].stream = stream.cuda_stream
+    enqueue(g, stages)
+def round_prio(first):
+    """small kernels (proposals, detect) on a high-priority stream per group, the RoI launch on a normal one"""
+    for g in range(S):
+        enqueue_on(g, 1, hi[g]); e1[g].record(hi[g])
+        lo[g].wait_event(e1[g]); enqueue_on(g, 2, lo[g]); e2[g].record(lo[g])
+        hi[g].wait_event(e2[g]); enqueue_on(g, 4, hi[g])
+def round_plain2(first):
+    for g in range(S):
+        enqueue_on(g, 7, lo[g])
+fn = {'exclusive': round_exclusive, 'plain': round_plain, 'mutex': round_mutex, 'prio': round_prio, 'plain2': round_plain2}[mode]
 for i in range(10): fn(i == 0)
 torch.cuda.synchronize()
 t0 = time.perf_counter(); R = 80
