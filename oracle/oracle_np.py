@@ -19,7 +19,8 @@ PARITY PIN STATUS
 * PINNED against the reference's own code (executed in the build container, vectors in
   ``tests/golden/ref_numpy_vectors.npz``, generator ``tests/golden/make_ref_vectors.py``):
   ``generate_anchor_base`` (+helpers), ``generate_by_anchor_base_np``, the +1 IoU formula
-  (against ``utils/bbox_np.py``), ``voc_ap``.
+  (against ``utils/bbox_np.py``), ``voc_ap`` and ``voc_eval_arrays`` (against the reference's ``voc_eval`` run on a
+  synthetic dataset in the VOC devkit's file formats: rec / prec / AP of both metrics, bit for bit).
 * PARITY UNPINNED for everything that the reference delegates to TensorFlow ops
   (NMS, crop_and_resize, top_k, softmax, exp/log): TensorFlow is not installable in the
   build container and the reference has no tests / fixtures.  Those parts restate the

@@ -251,7 +251,7 @@ def test_c4_detector_hot_path_state_matches_oracle():
     assert k == len(idx)
     np.testing.assert_array_equal(hot.roi_idx[:k].cpu().numpy(), idx)
     fmap = c4.permute(0, 2, 3, 1).float().cpu().numpy()[0]
-    want = co.roi_pool(fmap, rois, stride=16, pool=7, max_pool=True)
+    want = co.roi_pool(fmap, rois, stride=16, pool=7, max_pool=False)       # resnet_roi_pooling_max_pooling_flag: False
     got = hot.roi_features[:k].cpu().numpy()
     assert np.max(np.abs(got - want)) <= 1e-4 * max(1.0, float(np.abs(want).max()))
     boxes, labels, scores, count = out[0]

@@ -133,3 +133,34 @@ def test_map_delta_on_synthetic_set_is_zero():
         m_ref, _ = pe.evaluate_detections(dets_ref, gtb, gtl, use_07_metric=flag)
         assert m_ref > 0.3                                  # the synthetic detector is a sensible one
         assert abs(m_gpu - m_ref) <= 0.002
+
+
+def _ve_case(golden, c):
+    """dataset of tests/golden/ref_numpy_vectors.npz (the reference's own voc_eval ran on it) as the list-of-arrays
+    form of voc_eval_arrays, for class c"""
+    n_img = int(golden['ve_num_images'])
+    d = golden['ve_dets_%d' % c]                      # rows (image, x1, y1, x2, y2, score) in file order
+    g = golden['ve_gts']                              # rows (image, class, x1, y1, x2, y2, difficult)
+    dets = [d[d[:, 0] == i][:, 1:6] for i in range(n_img)]
+    gt_boxes = [g[(g[:, 0] == i) & (g[:, 1] == c)][:, 2:6].astype(np.float64) for i in range(n_img)]
+    gt_diff = [g[(g[:, 0] == i) & (g[:, 1] == c)][:, 6].astype(bool) for i in range(n_img)]
+    return dets, gt_boxes, gt_diff
+
+
+def test_voc_eval_pinned_by_the_references_own_voc_eval():
+    """PIN: evaluation/detectron_pascal_evaluation_utils.py voc_eval (:86-222), executed by
+    tests/golden/make_ref_vectors.py on a synthetic VOC-format dataset -- the oracle restatement and the product's
+    evaluation.pascal_eval.voc_eval_arrays reproduce its rec / prec / AP (both metrics) exactly."""
+    import os
+    from tf_eager_object_detection_amd.evaluation import pascal_eval as pe
+    golden = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_numpy_vectors.npz'))
+    assert int(golden['ve_num_classes']) == 3
+    for c in range(3):
+        dets, gt_boxes, gt_diff = _ve_case(golden, c)
+        for fn in (on.voc_eval_arrays, pe.voc_eval_arrays):
+            rec, prec, ap07 = fn(dets, gt_boxes, gt_diff, 0.5, True)
+            np.testing.assert_array_equal(rec, golden['ve_rec_%d' % c])
+            np.testing.assert_array_equal(prec, golden['ve_prec_%d' % c])
+            assert ap07 == float(golden['ve_ap07_%d' % c])
+            _, _, ap = fn(dets, gt_boxes, gt_diff, 0.5, False)
+            assert ap == float(golden['ve_aparea_%d' % c])

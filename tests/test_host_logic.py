@@ -108,3 +108,39 @@ def test_synthetic_shapes():
     rng = np.random.default_rng(0)
     s = syn.scores_distinct(1000, rng)
     assert len(np.unique(s)) == 1000 and s.dtype == np.float32
+
+
+def test_hot_path_defaults_pinned_by_reference_configs():
+    """PIN: the default hyper-parameters of the hot-path classes against the reference's own config dictionaries
+    (config/fpn_config.py, config/faster_rcnn_config.py, dumped by tests/golden/make_ref_vectors.py)."""
+    import inspect, json, os
+    from tf_eager_object_detection_amd import synthetic as syn
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, FrcnnHotPath
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'ref_configs.json')))
+    fpn = cfg['fpn.get_default_pascal_faster_rcnn_config']
+    d = {k: v.default for k, v in inspect.signature(FpnHotPath.__init__).parameters.items()}
+    assert d['num_classes'] == fpn['num_classes'] and d['num_proposals'] == fpn['rpn_proposal_test_after_nms_sample_number']
+    assert d['channels'] == fpn['top_down_dims'] == fpn['resnet_roi_feature_size'][2] and d['pool_size'] == fpn['roi_pooling_size']
+    assert d['rpn_nms_iou'] == fpn['rpn_proposal_nms_iou_threshold']
+    assert list(d['rpn_means']) == fpn['rpn_proposal_means'] and list(d['rpn_stds']) == fpn['rpn_proposal_stds']
+    assert list(d['roi_means']) == fpn['roi_proposal_means'] and list(d['roi_stds']) == fpn['roi_proposal_stds']
+    assert d['max_per_class'] == fpn['max_objects_per_class_per_image'] and d['max_per_image'] == fpn['max_objects_per_image']
+    assert d['nms_iou'] == fpn['prediction_nms_iou_threshold'] and d['score_threshold'] == fpn['prediction_score_threshold']
+    assert d['min_level'] == fpn['min_level'] and d['max_level'] == fpn['max_level']
+    assert list(syn.FPN_STRIDES) == fpn['anchor_stride_list'] and list(syn.FPN_BASE_SIZES) == fpn['base_anchor_size_list']
+    assert list(syn.FPN_RATIOS) == fpn['ratios'] and list(syn.FPN_SCALES) == fpn['scales']
+    assert fpn['roi_pooling_max_pooling_flag'] is True              # FpnHotPath: 14x14 crop + 2x2 max
+    fr = cfg['faster_rcnn.get_default_pascal_faster_rcnn_config']
+    d = {k: v.default for k, v in inspect.signature(FrcnnHotPath.__init__).parameters.items()}
+    assert d['num_classes'] == fr['num_classes'] and d['num_proposals'] == fr['rpn_proposal_test_after_nms_sample_number']
+    assert d['pool_size'] == fr['roi_pooling_size'] and d['extractor_stride'] == fr['extractor_stride']
+    assert list(d['ratios']) == fr['ratios'] and list(d['scales']) == fr['scales']
+    assert d['rpn_nms_iou'] == fr['rpn_proposal_nms_iou_threshold']
+    assert list(d['rpn_means']) == fr['rpn_proposal_means'] and list(d['rpn_stds']) == fr['rpn_proposal_stds']
+    assert list(d['roi_means']) == fr['roi_proposal_means'] and list(d['roi_stds']) == fr['roi_proposal_stds']
+    assert d['max_per_class'] == fr['max_objects_per_class_per_image'] and d['max_per_image'] == fr['max_objects_per_image']
+    assert d['nms_iou'] == fr['prediction_nms_iou_threshold'] and d['score_threshold'] == fr['prediction_score_threshold']
+    assert d['max_pooling_flag'] == fr['resnet_roi_pooling_max_pooling_flag']
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
+    assert ResNetC4Detector(50, 21, (64, 64), 10)._hot_kwargs['max_pooling_flag'] == fr['resnet_roi_pooling_max_pooling_flag']
+    assert Vgg16Detector(21, (64, 64), 10)._hot_kwargs['max_pooling_flag'] == fr['vgg16_roi_pooling_max_pooling_flag']

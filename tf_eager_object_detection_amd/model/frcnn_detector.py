@@ -6,7 +6,8 @@ global average pool + two dense layers) + the inference branch of model/faster_r
 Same arrangement as model/fpn_detector.py: the convolutions are genuine dense contractions and run through
 PyTorch-ROCm's library convolutions (NHWC, fp32 / fp16) with the fused HIP epilogue behind each of them;
 everything between them is FrcnnHotPath (anchors in registers -> [A bg | A fg] softmax -> decode / clip ->
-exact NMS over all anchors -> 14x14 crop + 2x2 max on the stride-16 map -> post_ops_prediction).  Weights are
+exact NMS over all anchors -> 7x7 crop (ResNet) / 14x14 crop + 2x2 max (VGG16) on the stride-16 map ->
+post_ops_prediction).  Weights are
 randomly initialised with the reference's initialisers (no checkpoints offline), frozen batch-norm folded."""
 import torch
 import torch.nn as nn
@@ -47,7 +48,9 @@ class ResNetC4Detector(nn.Module):
             nn.init.normal_(m.weight, 0.0, std)
             nn.init.zeros_(m.bias)
         self._hot_args = (self.image_shape, num_classes, num_proposals, 1024)
-        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=True)          # roi_pooling_max_pooling_flag=True
+        # config/faster_rcnn_config.py: 'resnet_roi_pooling_max_pooling_flag': False (7x7 crop, no pool) -- what
+        # model_factory.py:117 passes, overriding the class default
+        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=False)
         self._hot_kwargs.update(hot_kwargs)
         self._hot = []
         self._max_batch = max_batch
@@ -55,7 +58,10 @@ class ResNetC4Detector(nn.Module):
 
     def prepare(self, device='cuda'):
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
-        fd = torch.float16 if self.dtype == torch.float16 else torch.float32
+        # float16 maps go straight into the pooled RoI mode (14x14 + max); the un-pooled 7x7 crop takes float32
+        pooled = bool(self._hot_kwargs.get('max_pooling_flag', False))
+        fd = torch.float16 if (self.dtype == torch.float16 and pooled) else torch.float32
+        self._feature_dtype = fd
         self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs) for _ in range(self._max_batch)]
         return self
 
@@ -96,8 +102,8 @@ class ResNetC4Detector(nn.Module):
         rpn_scores, rpn_deltas = self.rpn(c4)
         rpn_scores, rpn_deltas = rpn_scores.float().contiguous(), rpn_deltas.float().contiguous()
         maps = c4.permute(0, 2, 3, 1)                                            # NHWC view
-        if self.dtype != torch.float16:
-            maps = maps.float()
+        if maps.dtype != self._feature_dtype:
+            maps = maps.to(self._feature_dtype)
         outs = []
         for b in range(B):
             hot = self._hot[b]
