@@ -53,11 +53,15 @@ def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
     """conv (+ zero padding `pad`) -> + bias (+ extra_bias) (+ residual) -> ReLU.  On the GPU the convolution
     runs without its bias and everything after it is ONE in-place pass of the fused HIP epilogue
     (ops.bias_act_) over the NHWC output; the torch formulation serves the CPU shape-bookkeeping test."""
+    padding = conv.padding
     if pad is not None:
-        x = F.pad(x, pad)
+        if pad[0] == pad[1] == pad[2] == pad[3] and tuple(conv.padding) == (0, 0):
+            padding = (pad[0], pad[0])           # symmetric ZeroPadding2D + 'valid' == the convolution's own zero padding
+        else:
+            x = F.pad(x, pad)
     bias = conv.bias if extra_bias is None else conv.bias + extra_bias
     if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+        y = F.conv2d(x, conv.weight, None, conv.stride, padding)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
         res = None
@@ -67,7 +71,7 @@ def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
                 res = res.contiguous()
         ops.bias_act_(y.permute(0, 2, 3, 1), bias, res, relu)
         return y
-    y = F.conv2d(x, conv.weight, bias, conv.stride, conv.padding)
+    y = F.conv2d(x, conv.weight, bias, conv.stride, padding)
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
@@ -197,7 +201,8 @@ class ResNetFpnDetector(nn.Module):
         """[B,H,W,3] -> (P2..P6), each [B,256,h,w] channels_last (= NHWC in memory)."""
         x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)                       # NHWC memory, NCHW view
         x = _conv_epi(self.conv1, x, relu=True, pad=(3, 3, 3, 3))                # conv1_pad + valid 7x7/2
-        x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), 3, 2)                           # pool1_pad (zeros) + 3x3/2
+        # pool1_pad (zeros) + 3x3/2: x >= 0 after the ReLU, so the pooling's own (-inf) padding gives the same maxima
+        x = F.max_pool2d(x, 3, 2, padding=1)
         c2 = self.conv2(x)
         c3 = self.conv3(c2)
         c4 = self.conv4(c3)

@@ -70,7 +70,8 @@ class ResNetC4Detector(nn.Module):
         """[B,H,W,3] -> C4 [B,1024,ceil(H/16),ceil(W/16)] channels_last (= NHWC in memory)."""
         x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
         x = _conv_epi(self.conv1, x, relu=True, pad=(3, 3, 3, 3))                # conv1_pad + valid 7x7/2
-        x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), 3, 2)                           # pool1_pad (zeros) + 3x3/2
+        # pool1_pad (zeros) + 3x3/2: x >= 0 after the ReLU, so the pooling's own (-inf) padding gives the same maxima
+        x = F.max_pool2d(x, 3, 2, padding=1)
         return self.conv4(self.conv3(self.conv2(x)))
 
     def rpn(self, c4):
