@@ -633,6 +633,37 @@ def fpn_topdown_merge(top, lateral):
 
 
 # --------------------------------------------------------------------------------------
+# model/anchor_target.py, model/proposal_target.py -- the deterministic parts
+# --------------------------------------------------------------------------------------
+def anchor_target_labels(gt_bboxes, image_shape, all_anchors, pos_iou_threshold=0.7, neg_iou_threshold=0.3):
+    """model/anchor_target.py:53-69 up to (not including) the random sub-sampling:
+    -> (selected_anchor_idx, labels int32 in {-1,0,1} on the selected anchors, argmax_overlaps)."""
+    idx = bboxes_range_filter(all_anchors, image_shape[0], image_shape[1])                 # :54
+    anchors = f32(all_anchors)[idx]
+    overlaps = pairwise_iou(anchors, gt_bboxes)                                            # :60
+    argmax = np.argmax(overlaps, axis=1)                                                   # :61
+    mx = overlaps.max(axis=1)                                                              # :62
+    gt_max = overlaps.max(axis=0)                                                          # :63
+    gt_argmax = np.nonzero(overlaps == gt_max[None, :])[0]                                 # :64
+    labels = -np.ones(anchors.shape[0], np.int32)
+    labels[mx < F32(neg_iou_threshold)] = 0                                                # :67
+    labels[gt_argmax] = 1                                                                  # :68
+    labels[mx >= F32(pos_iou_threshold)] = 1                                               # :69
+    return idx, labels, argmax
+
+
+def proposal_target_assign(rois, gt_bboxes, gt_labels, pos_iou_threshold=0.5, neg_iou_threshold=0.5):
+    """model/proposal_target.py:55-63: -> (labels per RoI, gt_assignment, fg_inds, bg_inds)."""
+    iou = pairwise_iou(rois, gt_bboxes)
+    mx = iou.max(axis=1)
+    ga = np.argmax(iou, axis=1)
+    labels = np.asarray(gt_labels)[ga]
+    fg = np.nonzero(mx >= F32(pos_iou_threshold))[0]
+    bg = np.nonzero((mx < F32(pos_iou_threshold)) & (mx >= F32(neg_iou_threshold)))[0]
+    return labels, ga, fg, bg
+
+
+# --------------------------------------------------------------------------------------
 # evaluation/detectron_pascal_evaluation_utils.py
 # --------------------------------------------------------------------------------------
 def voc_ap(rec, prec, use_07_metric=False):
