@@ -63,6 +63,11 @@ class ResNetC4Detector(nn.Module):
         fd = torch.float16 if (self.dtype == torch.float16 and pooled) else torch.float32
         self._feature_dtype = fd
         self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs) for _ in range(self._max_batch)]
+        # the images' RoI features are consecutive blocks of one buffer: the RoI head takes the whole batch at once
+        h0 = self._hot[0]
+        self._roi_feat_all = torch.zeros((self._max_batch,) + tuple(h0.roi_features.shape), dtype=fd, device=h0.device)
+        for b, h in enumerate(self._hot):
+            h.roi_features = self._roi_feat_all[b]
         return self
 
     # ---- dense parts ---------------------------------------------------------------------------
@@ -105,15 +110,16 @@ class ResNetC4Detector(nn.Module):
         maps = c4.permute(0, 2, 3, 1)                                            # NHWC view
         if maps.dtype != self._feature_dtype:
             maps = maps.to(self._feature_dtype)
-        outs = []
         for b in range(B):
             hot = self._hot[b]
             hot.stage_proposals(rpn_scores[b], rpn_deltas[b])
-            feats = hot.stage_roi(maps[b:b + 1].contiguous())
-            logits, bbox = self.roi_head(feats)
-            cls = torch.softmax(logits.float(), dim=-1).contiguous()
-            outs.append(hot.stage_detect(cls, bbox.float().contiguous()))
-        return outs
+            hot.stage_roi(maps[b:b + 1].contiguous())
+        K = self._roi_feat_all.shape[1]
+        feats = self._roi_feat_all[:B].reshape((B * K,) + tuple(self._roi_feat_all.shape[2:]))
+        logits, bbox = self.roi_head(feats)                                      # one head pass for the whole batch
+        cls = torch.softmax(logits.float(), dim=-1).reshape(B, K, -1)
+        bbox = bbox.float().reshape(B, K, -1)
+        return [self._hot[b].stage_detect(cls[b].contiguous(), bbox[b].contiguous()) for b in range(B)]
 
 
 class Vgg16Detector(ResNetC4Detector):
