@@ -323,6 +323,13 @@ int odet_fpn_topdown_merge(const void* top, int h, int w, const void* lateral, i
 int odet_bias_act(void* x, const void* bias, const void* residual, long long npix, int C, int relu,
                   int f16, odet_stream_t stream);
 
+/* RPN head epilogue (model/fpn/base_fpn_model.py:188-200,427-432): one pyramid level's 1x1
+ * convolution output level_out [B, pixels, ch] (NHWC, ch = 2A scores or 4A deltas, float32 or float16, WITHOUT
+ * its bias) -> + bias[ch] -> float32 at out[b * out_image_stride + out_offset + ...]: the level's slice of the
+ * concatenated [B, N, 2] / [B, N, 4] arrays the proposal stage reads (tf.reshape + tf.concat of the reference). */
+int odet_rpn_pack(const void* level_out, const void* bias, long long pixels, int ch, int B, float* out,
+                  long long out_image_stride, long long out_offset, int f16, odet_stream_t stream);
+
 /* ---- multi-GPU detection records ------------------------------------------------------ */
 
 /* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of

@@ -338,3 +338,48 @@ def test_detector_batched_hot_path_matches_per_image_path():
     out = m(img)
     torch.cuda.synchronize()
     assert len(out) == B and all(int(o[3].item()) > 0 for o in out)
+
+
+@pytest.mark.gpu
+def test_rpn_pack_and_detector_rpn_match_torch_formulation():
+    """odet_rpn_pack: bias + float32 + the level's slice of the concatenated arrays (base_fpn_model.py:188-200,
+    427-432) -- exact against reshape / concat of the biased convolution outputs."""
+    from tf_eager_object_detection_amd import ops
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    g = torch.Generator(device='cuda'); g.manual_seed(9)
+    B, A = 2, 3
+    shapes = [(12, 17), (6, 9), (3, 5)]
+    n = sum(h * w for h, w in shapes) * A
+    for dt in (torch.float32, torch.float16):
+        outs = torch.zeros((B, n, 2), dtype=torch.float32, device='cuda')
+        outd = torch.zeros((B, n, 4), dtype=torch.float32, device='cuda')
+        want_s, want_d, off = [], [], 0
+        bs = torch.randn(2 * A, device='cuda', generator=g).to(dt)
+        bd = torch.randn(4 * A, device='cuda', generator=g).to(dt)
+        for h, w in shapes:
+            s = torch.randn(B, h, w, 2 * A, device='cuda', generator=g).to(dt)
+            d = torch.randn(B, h, w, 4 * A, device='cuda', generator=g).to(dt)
+            ops.rpn_pack(s, bs, outs, off * 2)
+            ops.rpn_pack(d, bd, outd, off * 4)
+            want_s.append((s.float() + bs.float()).reshape(B, -1, 2))
+            want_d.append((d.float() + bd.float()).reshape(B, -1, 4))
+            off += h * w * A
+        assert torch.equal(outs, torch.cat(want_s, 1)) and torch.equal(outd, torch.cat(want_d, 1))
+    with pytest.raises(Exception):
+        ops.rpn_pack(torch.zeros(1, 2, 2, 6, device='cuda'), torch.zeros(6, device='cuda'),
+                     torch.zeros(1, 10, 2, device='cuda'), 0)                       # 24 values do not fit 20
+    torch.manual_seed(10)
+    m = ResNetFpnDetector(50, 21, (128, 160), 50, dtype=torch.float32).prepare()
+    with torch.no_grad():
+        for c in (m.rpn_score, m.rpn_bbox):
+            c.bias.normal_(0, 0.1)
+        ps = [torch.randn(2, 256, h, w, device='cuda').contiguous(memory_format=torch.channels_last)
+              for h, w in ((32, 40), (16, 20), (8, 10), (4, 5), (2, 3))]
+        sc, dl = m.rpn(ps)
+        ws, wd = [], []
+        for p in ps:
+            x = torch.relu(m.rpn_conv(p))
+            ws.append(m.rpn_score(x).permute(0, 2, 3, 1).reshape(2, -1, 2))
+            wd.append(m.rpn_bbox(x).permute(0, 2, 3, 1).reshape(2, -1, 4))
+    torch.testing.assert_close(sc, torch.cat(ws, 1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dl, torch.cat(wd, 1), rtol=1e-5, atol=1e-5)

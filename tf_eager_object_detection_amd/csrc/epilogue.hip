@@ -89,3 +89,50 @@ extern "C" int odet_bias_act(void* x, const void* bias, const void* residual, lo
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
+
+// ---- RPN head epilogue ---------------------------------------------------------------
+// base_fpn_model.py:188-200,427-432: the shared RpnHead runs on every pyramid level, its 1x1 convolutions emit
+// [h,w,2A] scores and [h,w,4A] box deltas, reshaped to [-1,2] / [-1,4] and concatenated P2 -> P6.  In NHWC the
+// reshape is the identity, so the "re-layout" is: add the bias, widen to float32, write at the level's offset of
+// the concatenated arrays the proposal stage reads -- one pass per level instead of two bias adds, two casts and
+// a share of two concatenations.
+struct RpnPackParams {
+  const void* in; const void* bias; float* out;
+  long long per_image;        // h * w * ch values of one image of this level
+  long long out_image_stride; // values of one image in the concatenated array (N * 2 or N * 4)
+  long long out_offset;       // this level's first value inside an image
+  long long total;            // B * per_image
+  int ch;                     // 2A or 4A
+};
+
+template <typename FT>
+__global__ void __launch_bounds__(256) k_rpn_pack(RpnPackParams p) {
+  const FT* __restrict__ in = reinterpret_cast<const FT*>(p.in);
+  const FT* __restrict__ bias = reinterpret_cast<const FT*>(p.bias);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+    const long long b = i / p.per_image, r = i - b * p.per_image;
+    const float v = (float)in[i] + (float)bias[(int)(r % p.ch)];
+    p.out[b * p.out_image_stride + p.out_offset + r] = v;
+  }
+}
+
+extern "C" int odet_rpn_pack(const void* level_out, const void* bias, long long pixels, int ch, int B, float* out,
+                             long long out_image_stride, long long out_offset, int f16, odet_stream_t stream) {
+  ODET_REQUIRE(level_out && bias && out, "odet_rpn_pack: null pointer");
+  ODET_REQUIRE(pixels >= 0 && ch > 0 && B >= 0 && out_image_stride >= 0 && out_offset >= 0, "odet_rpn_pack: bad sizes");
+  ODET_REQUIRE(out_offset + pixels * ch <= out_image_stride, "odet_rpn_pack: level does not fit the concatenated array");
+  RpnPackParams p;
+  p.in = level_out; p.bias = bias; p.out = out;
+  p.per_image = pixels * ch;
+  p.out_image_stride = out_image_stride; p.out_offset = out_offset;
+  p.total = (long long)B * p.per_image;
+  p.ch = ch;
+  if (p.total == 0) return ODET_OK;
+  const int grid = (int)std::min<long long>((p.total + 255) / 256, 256 * 16);
+  if (f16)
+    hipLaunchKernelGGL(k_rpn_pack<__half>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(k_rpn_pack<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}

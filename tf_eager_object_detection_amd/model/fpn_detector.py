@@ -227,6 +227,22 @@ class ResNetFpnDetector(nn.Module):
     def rpn(self, p_list):
         """shared RpnHead on every level; outputs concatenated P2->P6 in (y, x, anchor) order
         (base_fpn_model.py:188-200, 427-432): scores [B, N, 2], deltas [B, N, 4]."""
+        if p_list[0].is_cuda and p_list[0].dtype in (torch.float32, torch.float16):
+            # GPU: the 1x1 convolutions run without their bias and ONE pass per level (ops.rpn_pack) adds it, widens
+            # to float32 and writes the level's slice of the concatenated arrays the proposal stage reads
+            B = p_list[0].shape[0]
+            n = sum(int(p.shape[2]) * int(p.shape[3]) for p in p_list) * self.A
+            scores = torch.empty((B, n, 2), dtype=torch.float32, device=p_list[0].device)
+            deltas = torch.empty((B, n, 4), dtype=torch.float32, device=p_list[0].device)
+            off = 0
+            for p in p_list:
+                x = _conv_epi(self.rpn_conv, p, relu=True)
+                s = F.conv2d(x, self.rpn_score.weight, None).permute(0, 2, 3, 1)
+                d = F.conv2d(x, self.rpn_bbox.weight, None).permute(0, 2, 3, 1)
+                ops.rpn_pack(s if s.is_contiguous() else s.contiguous(), self.rpn_score.bias, scores, off * 2)
+                ops.rpn_pack(d if d.is_contiguous() else d.contiguous(), self.rpn_bbox.bias, deltas, off * 4)
+                off += int(p.shape[2]) * int(p.shape[3]) * self.A
+            return scores, deltas
         scores, deltas = [], []
         for p in p_list:
             x = _conv_epi(self.rpn_conv, p, relu=True)

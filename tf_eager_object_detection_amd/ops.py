@@ -352,6 +352,23 @@ def bias_act_(x, bias, residual=None, relu=True):
     return x
 
 
+def rpn_pack(level_out, bias, out, out_offset):
+    """One level of the RPN head's output into the concatenated arrays: ``level_out`` [B,h,w,ch] NHWC (float32 /
+    float16, the 1x1 convolution WITHOUT its bias), ``bias`` [ch] of the same dtype, ``out`` float32 [B, N, 2 or 4]
+    contiguous; ``out_offset`` = the level's first VALUE (anchor offset x 2 or 4) inside an image."""
+    if level_out.dim() != 4 or not level_out.is_contiguous():
+        raise ValueError('level_out must be a contiguous NHWC [B,h,w,ch] tensor')
+    if level_out.dtype not in (torch.float32, torch.float16) or bias.dtype != level_out.dtype:
+        raise TypeError('level_out and bias must both be float32 or both float16')
+    B, h, w, ch = (int(v) for v in level_out.shape)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[0] != B:
+        raise ValueError('out must be a contiguous float32 [B, N, k] tensor')
+    stride = out.numel() // max(B, 1)
+    L.call('odet_rpn_pack', L.dptr(level_out), L.dptr(bias), h * w, ch, B, L.dptr(out), stride, int(out_offset),
+           1 if level_out.dtype == torch.float16 else 0, L.stream())
+    return out
+
+
 class ProfEvent:
     """HIP event for odet_roi_pool_timed (the dispatch's own begin / end timestamps)."""
 
