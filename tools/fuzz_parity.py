@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Seeded parity sweep of the hot path against the C oracle beyond the fixed cases of tests/: random image shapes,
+proposal counts, score distributions (distinct / clustered / tied / quantised), RoIs in and out of range, class
+scores.  Prints one line per case; exits non-zero on the first mismatch.
+
+    python tools/fuzz_parity.py [--seconds 120] [--seed 0]"""
+import argparse, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, '/root/repo')
+from oracle import c_oracle as co
+from tf_eager_object_detection_amd import ops
+from tf_eager_object_detection_amd import synthetic as syn
+from tf_eager_object_detection_amd.pipeline import FpnHotPath
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--seconds', type=float, default=120)
+ap.add_argument('--seed', type=int, default=0)
+a = ap.parse_args()
+g = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+t_end = time.time() + a.seconds
+case = 0
+rng0 = np.random.default_rng(a.seed)
+while time.time() < t_end:
+    seed = int(rng0.integers(0, 2 ** 31))
+    rng = np.random.default_rng(seed)
+    shape = (int(rng.integers(200, 900)), int(rng.integers(200, 1400)))
+    K = int(rng.choice([100, 300, 1000, 2000]))
+    ch = int(rng.choice([8, 64, 256]))
+    kind = str(rng.choice(['distinct', 'clustered', 'tied', 'quantised']))
+    anchors = co.fpn_anchors(shape)
+    n = anchors.shape[0]
+    deltas = syn.rpn_deltas(n, rng, float(rng.choice([0.05, 0.1, 0.3])))
+    if kind == 'distinct':
+        prob = syn.scores_distinct(n, rng)
+    elif kind == 'clustered':
+        prob = syn.scores_clustered(anchors, shape, rng)
+    elif kind == 'tied':
+        prob = syn.scores_tied(n, rng, int(rng.integers(2, 50)))
+    else:
+        prob = (np.round(syn.scores_distinct(n, rng) * 1024) / 1024).astype(np.float32)       # fp16-like plateaus
+    logits = syn.logits_from_prob(prob, rng)
+    fg = co.rpn_fg_fpn(logits)
+    want_rois, want_idx = co.region_proposal(deltas, anchors, fg, shape, K, 0.7)
+    hot = FpnHotPath(shape, 21, K, ch, blind_chunks=int(rng.choice([1, 2, 3, 6])))
+    blind = hot.blind_chunks
+    hot.stage_proposals(g(logits), g(deltas))
+    torch.cuda.synchronize()
+    done = int(hot.nms_done.item())
+    m = int(hot.roi_count.item())
+    got_idx = hot.roi_idx[:m].cpu().numpy()
+    ok = np.array_equal(got_idx, want_idx[:m]) and (not done or m == len(want_idx))
+    status = 'done' if done else 'prefix(%d/%d)' % (m, len(want_idx))
+    if ok and done:
+        lv, perm, cnt = co.assign_levels(want_rois)
+        ok = ok and np.array_equal(hot.roi_perm[:m].cpu().numpy(), perm)
+        feats = syn.features(syn.fpn_level_shapes(shape)[:4], ch, rng)
+        got = hot.stage_roi([g(f) for f in feats])[:m].cpu().numpy()
+        srois = want_rois[perm]
+        for l in range(4):
+            sel = lv[perm] == l + 2
+            if np.any(sel):
+                w = co.roi_pool(feats[l], srois[sel], image_shape=shape, pool=7)
+                ok = ok and np.array_equal(got[sel], w)
+        S, D = syn.class_scores(K, 21, rng), syn.class_deltas(K, 21, rng)
+        Sg, Dg = g(S), g(D)
+        b, lab, sc, c = hot.stage_detect(Sg, Dg)
+        torch.cuda.synchronize()
+        wb = co.post_ops(S[:m], D[:m], srois, shape, [0] * 4, [.1, .1, .2, .2], 50, 50, 0.3, 0.0, 16, 21)
+        c = int(c.item())
+        if wb[0] is None:
+            ok = ok and c == 0
+        else:
+            ok = ok and c == len(wb[2]) and np.array_equal(lab[:c].cpu().numpy(), wb[1]) and \
+                np.allclose(sc[:c].cpu().numpy(), wb[2], rtol=0, atol=1e-6) and np.allclose(b[:c].cpu().numpy(), wb[0], rtol=1e-4, atol=1e-3)
+    case += 1
+    print('case %3d seed %10d shape %s K %4d C %3d %-9s blind %d: %s %s' % (case, seed, shape, K, ch, kind, blind, status, 'OK' if ok else 'MISMATCH'), flush=True)
+    if not ok:
+        sys.exit(1)
+print('all %d cases OK' % case)
