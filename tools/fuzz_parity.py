@@ -11,7 +11,7 @@ sys.path.insert(0, '/root/repo')
 from oracle import c_oracle as co
 from tf_eager_object_detection_amd import ops
 from tf_eager_object_detection_amd import synthetic as syn
-from tf_eager_object_detection_amd.pipeline import FpnHotPath
+from tf_eager_object_detection_amd.pipeline import FpnHotPath, FrcnnHotPath
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
@@ -21,9 +21,42 @@ g = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 t_end = time.time() + a.seconds
 case = 0
 rng0 = np.random.default_rng(a.seed)
+def frcnn_case(seed, rng):
+    """single-level Faster R-CNN path (VGG16 / ResNet-C4 shapes): anchors from the base table, [A bg | A fg] scores,
+    stride-normalised crops, pooled or not"""
+    shape = (int(rng.integers(200, 700)), int(rng.integers(200, 900)))
+    K = int(rng.choice([50, 300]))
+    ch = int(rng.choice([8, 512, 1024]))
+    flag = bool(rng.integers(0, 2))
+    scales = (8, 16, 32) if rng.integers(0, 2) else (4, 8, 16, 32)
+    hot = FrcnnHotPath(shape, 21, K, ch, 7, flag, scales=scales, blind_chunks=int(rng.choice([1, 3])))
+    A, fh, fw = hot.A, hot.fh, hot.fw
+    anchors = co.anchors_shift(hot.anchor_base, 16, fh, fw)
+    logits = rng.normal(0, 2.0, (fh * fw, 2 * A)).astype(np.float32)
+    deltas = syn.rpn_deltas(fh * fw * A, rng, 0.1)
+    fg = co.rpn_fg_frcnn(logits, A)
+    want_rois, want_idx = co.region_proposal(deltas, anchors, fg, shape, K, 0.7)
+    hot.stage_proposals(g(logits), g(deltas))
+    torch.cuda.synchronize()
+    done, m = int(hot.nms_done.item()), int(hot.roi_count.item())
+    ok = np.array_equal(hot.roi_idx[:m].cpu().numpy(), want_idx[:m]) and (not done or m == len(want_idx))
+    if ok and done:
+        feat = rng.standard_normal((1, fh, fw, ch), dtype=np.float32)
+        got = hot.stage_roi(g(feat))[:m].cpu().numpy()
+        ok = np.array_equal(got, co.roi_pool(feat[0], want_rois, stride=16, pool=7, max_pool=flag))
+    return 'frcnn shape %s K %d C %d pool %d A %d blind %d: %s' % (shape, K, ch, flag, A, hot.blind_chunks, 'done' if done else 'prefix'), ok
+
+
 while time.time() < t_end:
     seed = int(rng0.integers(0, 2 ** 31))
     rng = np.random.default_rng(seed)
+    if rng.integers(0, 4) == 0:
+        desc, ok = frcnn_case(seed, rng)
+        case += 1
+        print('case %3d seed %10d %s %s' % (case, seed, desc, 'OK' if ok else 'MISMATCH'), flush=True)
+        if not ok:
+            sys.exit(1)
+        continue
     shape = (int(rng.integers(200, 900)), int(rng.integers(200, 1400)))
     K = int(rng.choice([100, 300, 1000, 2000]))
     ch = int(rng.choice([8, 64, 256]))
