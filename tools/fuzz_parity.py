@@ -11,7 +11,7 @@ sys.path.insert(0, '/root/repo')
 from oracle import c_oracle as co
 from tf_eager_object_detection_amd import ops
 from tf_eager_object_detection_amd import synthetic as syn
-from tf_eager_object_detection_amd.pipeline import FpnHotPath, FrcnnHotPath
+from tf_eager_object_detection_amd.pipeline import FpnHotPath, FpnStepBatch, FrcnnHotPath, synthetic_fpn_inputs
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=120)
@@ -47,9 +47,44 @@ def frcnn_case(seed, rng):
     return 'frcnn shape %s K %d C %d pool %d A %d blind %d: %s' % (shape, K, ch, flag, A, hot.blind_chunks, 'done' if done else 'prefix'), ok
 
 
+def batched_case(seed, rng):
+    """B images in the same launches (FpnStepBatch) == each image through the single path, bit for bit"""
+    shape = (int(rng.integers(200, 600)), int(rng.integers(200, 800)))
+    K, ch, B = int(rng.choice([100, 300, 1000])), int(rng.choice([8, 64])), int(rng.choice([2, 3, 4, 8]))
+    kind = str(rng.choice(['distinct', 'clustered']))
+    blind = int(rng.choice([1, 2, 3]))
+    first = int(rng.choice([0, 4096]))
+    sets = [synthetic_fpn_inputs(shape, 21, K, channels=ch, seed=seed + i, score_kind=kind)[1] for i in range(B)]
+    sb = FpnStepBatch(B, shape, 21, K, ch, blind_chunks=blind, nms_first_chunk=first)
+    for b, d in enumerate(sets):
+        sb.bind(b, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
+    sb.enqueue(7, B)
+    torch.cuda.synchronize()
+    ref = FpnHotPath(shape, 21, K, ch, blind_chunks=6)
+    ok = True
+    for b, d in enumerate(sets):
+        ref.step(d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
+        torch.cuda.synchronize()
+        h = sb.slots[b]
+        if int(h.nms_done.item()) == 1:
+            ok = ok and torch.equal(h.record, ref.record) and torch.equal(h.roi_features, ref.roi_features) and \
+                torch.equal(h.roi_idx, ref.roi_idx)
+        else:                                   # not finished inside its chunks: the kept prefix must still be exact
+            m = int(h.roi_count.item())
+            ok = ok and m <= int(ref.roi_count.item()) and torch.equal(h.roi_idx[:m], ref.roi_idx[:m])
+    return 'batched B %d shape %s K %d C %d %s blind %d first %d' % (B, shape, K, ch, kind, blind, first), ok
+
+
 while time.time() < t_end:
     seed = int(rng0.integers(0, 2 ** 31))
     rng = np.random.default_rng(seed)
+    if rng.integers(0, 5) == 0:
+        desc, ok = batched_case(seed, rng)
+        case += 1
+        print('case %3d seed %10d %s %s' % (case, seed, desc, 'OK' if ok else 'MISMATCH'), flush=True)
+        if not ok:
+            sys.exit(1)
+        continue
     if rng.integers(0, 4) == 0:
         desc, ok = frcnn_case(seed, rng)
         case += 1
