@@ -79,6 +79,21 @@ def main():
     b1 = torch.from_numpy(syn.random_boxes(4096, shape, rng, 16, 400)).cuda()
     b2 = torch.from_numpy(syn.random_boxes(64, shape, rng, 16, 400)).cuda()
     add('odet_pairwise_iou (4096 x 64)', timeit(lambda: ops.pairwise_iou(b1, b2)), 4096 * 64 * 4)
+    # dense-path glue kernels at the ResNet-101-FPN 800x1333 shapes, float16 NHWC, batch 4
+    B = 4
+    g16 = lambda *sh: torch.randn(*sh, device='cuda', dtype=torch.float16)
+    x = g16(B, 200, 334, 256); bias = g16(256); res = g16(B, 200, 334, 256)
+    add('odet_bias_act (conv2 block output: bias + shortcut + ReLU, fp16, batch 4)', timeit(lambda: ops.bias_act_(x, bias, res, True)),
+        3 * x.numel() * 2, 'activation in + shortcut in + out')
+    x2 = g16(B, 200, 334, 64); bias2 = g16(64)
+    add('odet_bias_act (conv2 1x1 output: bias + ReLU, fp16, batch 4)', timeit(lambda: ops.bias_act_(x2, bias2, None, True)),
+        2 * x2.numel() * 2, 'activation in + out')
+    top, lat = g16(B, 100, 167, 256), g16(B, 200, 334, 256)
+    outm = torch.empty_like(lat)
+    add('odet_fpn_topdown_merge (P3 -> P2, fp16, batch 4)', timeit(lambda: ops.fpn_topdown_merge(top, lat, out=outm)),
+        (2 * lat.numel() + top.numel()) * 2, 'lateral in + out + coarse map')
+    sc = g16(B, 200, 334, 6); so = torch.empty((B, 200 * 334 * 3, 2), dtype=torch.float32, device='cuda'); bs = g16(6)
+    add('odet_rpn_pack (P2 scores, fp16 -> fp32, batch 4)', timeit(lambda: ops.rpn_pack(sc, bs, so, 0)), sc.numel() * 6, 'fp16 in + fp32 out')
     for r in rows:
         print('%-58s %8.1f us %s %s' % (r['entry'], r['us'], ('%8.1f GB/s' % r['GBps']) if r['GBps'] else ' ' * 13, r['note']))
     if a.json:
