@@ -10,7 +10,7 @@ D=tools/exp/_ablate
 mkdir -p $D
 one() {   # name flags...
   local name=$1; shift
-  /opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+  /opt/rocm/bin/hipcc "$@" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
     -c tf_eager_object_detection_amd/csrc/roi.hip -o $D/roi_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $O/boxes.hip.o $O/sort.hip.o $O/nms.hip.o $D/roi_$name.o \
     $O/postops.hip.o $O/neck.hip.o $O/epilogue.hip.o $O/executor.hip.o -lpthread -o $D/libodet_hip_$name.so
