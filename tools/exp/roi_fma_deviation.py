@@ -1,0 +1,11 @@
+import sys, numpy as np, torch
+sys.path.insert(0,'/root/repo')
+from oracle import c_oracle as co
+from tf_eager_object_detection_amd import ops, synthetic as syn
+rng=np.random.default_rng(0)
+feat=rng.standard_normal((1,50,84,256),dtype=np.float32)
+rois=syn.random_boxes(500,(800,1333),rng,16,600)
+got=ops.roi_pool([torch.from_numpy(feat).cuda()], torch.from_numpy(rois).cuda(), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_MAX2, strides=[16.0]).cpu().numpy()
+want=co.roi_pool(feat, rois, stride=16, pool=7, max_pool=True)
+d=np.abs(got-want)
+print('max abs dev %.3g, rel-to-max(1,|x|) %.3g, fraction differing %.3f' % (d.max(), (d/np.maximum(1,np.abs(want))).max(), float((d>0).mean())))
