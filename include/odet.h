@@ -330,6 +330,13 @@ int odet_bias_act(void* x, const void* bias, const void* residual, long long npi
 int odet_rpn_pack(const void* level_out, const void* bias, long long pixels, int ch, int B, float* out,
                   long long out_image_stride, long long out_offset, int f16, odet_stream_t stream);
 
+/* Same, for the RpnHead's two 1x1 convolutions run as ONE contraction (output channels = 2A scores then 4A
+ * deltas, weights concatenated): level_out [B, pixels, 6A] + bias[6A] -> the level's slices of BOTH arrays
+ * (scores [B, N, 2] at scores_offset values, deltas [B, N, 4] at deltas_offset values inside an image). */
+int odet_rpn_pack_pair(const void* level_out, const void* bias, long long pixels, int A, int B, float* scores,
+                       long long scores_image_stride, long long scores_offset, float* deltas,
+                       long long deltas_image_stride, long long deltas_offset, int f16, odet_stream_t stream);
+
 /* ---- multi-GPU detection records ------------------------------------------------------ */
 
 /* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of

@@ -353,18 +353,28 @@ def test_rpn_pack_and_detector_rpn_match_torch_formulation():
     for dt in (torch.float32, torch.float16):
         outs = torch.zeros((B, n, 2), dtype=torch.float32, device='cuda')
         outd = torch.zeros((B, n, 4), dtype=torch.float32, device='cuda')
-        want_s, want_d, off = [], [], 0
+        want_s, want_d, pairs, off = [], [], [], 0
         bs = torch.randn(2 * A, device='cuda', generator=g).to(dt)
         bd = torch.randn(4 * A, device='cuda', generator=g).to(dt)
         for h, w in shapes:
             s = torch.randn(B, h, w, 2 * A, device='cuda', generator=g).to(dt)
             d = torch.randn(B, h, w, 4 * A, device='cuda', generator=g).to(dt)
+            pairs.append(torch.cat([s, d], 3).contiguous())
             ops.rpn_pack(s, bs, outs, off * 2)
             ops.rpn_pack(d, bd, outd, off * 4)
             want_s.append((s.float() + bs.float()).reshape(B, -1, 2))
             want_d.append((d.float() + bd.float()).reshape(B, -1, 4))
             off += h * w * A
         assert torch.equal(outs, torch.cat(want_s, 1)) and torch.equal(outd, torch.cat(want_d, 1))
+        # the two convolutions as one contraction: [B,h,w,6A] = scores then deltas along the channel
+        outs2, outd2, off = torch.zeros_like(outs), torch.zeros_like(outd), 0
+        for (h, w), sd in zip(shapes, pairs):
+            ops.rpn_pack_pair(sd, torch.cat([bs, bd]), A, outs2, outd2, off)
+            off += h * w * A
+        assert torch.equal(outs2, outs) and torch.equal(outd2, outd)
+    with pytest.raises(Exception):
+        ops.rpn_pack_pair(torch.zeros(1, 2, 2, 18, device='cuda'), torch.zeros(18, device='cuda'), 3,
+                          torch.zeros(1, 10, 2, device='cuda'), torch.zeros(1, 12, 4, device='cuda'), 0)   # 12 anchors, 10 slots
     with pytest.raises(Exception):
         ops.rpn_pack(torch.zeros(1, 2, 2, 6, device='cuda'), torch.zeros(6, device='cuda'),
                      torch.zeros(1, 10, 2, device='cuda'), 0)                       # 24 values do not fit 20

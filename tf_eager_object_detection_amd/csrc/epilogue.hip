@@ -136,3 +136,55 @@ extern "C" int odet_rpn_pack(const void* level_out, const void* bias, long long 
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
+
+// The RpnHead's two 1x1 convolutions as ONE contraction (weights concatenated along the output channel: 2A
+// score channels then 4A delta channels): the 512-channel activation is read once instead of twice, and this
+// pass splits the [B, pixels, 6A] result into the two concatenated arrays.
+struct RpnPackPairParams {
+  const void* in; const void* bias; float* scores; float* deltas;
+  long long per_image;            // pixels * 6A
+  long long scores_image_stride, scores_offset, deltas_image_stride, deltas_offset;
+  long long total;
+  int A;
+};
+
+template <typename FT>
+__global__ void __launch_bounds__(256) k_rpn_pack_pair(RpnPackPairParams p) {
+  const FT* __restrict__ in = reinterpret_cast<const FT*>(p.in);
+  const FT* __restrict__ bias = reinterpret_cast<const FT*>(p.bias);
+  const int ch = 6 * p.A, sc = 2 * p.A;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+    const long long b = i / p.per_image, r = i - b * p.per_image;
+    const long long px = r / ch;
+    const int c = (int)(r - px * ch);
+    const float v = (float)in[i] + (float)bias[c];
+    if (c < sc)
+      p.scores[b * p.scores_image_stride + p.scores_offset + px * sc + c] = v;
+    else
+      p.deltas[b * p.deltas_image_stride + p.deltas_offset + px * (ch - sc) + (c - sc)] = v;
+  }
+}
+
+extern "C" int odet_rpn_pack_pair(const void* level_out, const void* bias, long long pixels, int A, int B, float* scores,
+                                  long long scores_image_stride, long long scores_offset, float* deltas,
+                                  long long deltas_image_stride, long long deltas_offset, int f16, odet_stream_t stream) {
+  ODET_REQUIRE(level_out && bias && scores && deltas, "odet_rpn_pack_pair: null pointer");
+  ODET_REQUIRE(pixels >= 0 && A > 0 && B >= 0 && scores_offset >= 0 && deltas_offset >= 0, "odet_rpn_pack_pair: bad sizes");
+  ODET_REQUIRE(scores_offset + pixels * 2 * A <= scores_image_stride && deltas_offset + pixels * 4 * A <= deltas_image_stride,
+               "odet_rpn_pack_pair: level does not fit the concatenated arrays");
+  RpnPackPairParams p;
+  p.in = level_out; p.bias = bias; p.scores = scores; p.deltas = deltas;
+  p.per_image = pixels * 6 * A;
+  p.scores_image_stride = scores_image_stride; p.scores_offset = scores_offset;
+  p.deltas_image_stride = deltas_image_stride; p.deltas_offset = deltas_offset;
+  p.total = (long long)B * p.per_image;
+  p.A = A;
+  if (p.total == 0) return ODET_OK;
+  const int grid = (int)std::min<long long>((p.total + 255) / 256, 256 * 16);
+  if (f16)
+    hipLaunchKernelGGL(k_rpn_pack_pair<__half>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(k_rpn_pack_pair<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}

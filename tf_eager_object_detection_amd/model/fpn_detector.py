@@ -173,6 +173,7 @@ class ResNetFpnDetector(nn.Module):
         self._hot_args = (self.image_shape, num_classes, num_proposals, 256)
         self._hot_kwargs = hot_kwargs
         self._hot = []
+        self._rpn_pair = None
         self._max_batch = max_batch
 
     def prepare(self, device='cuda'):
@@ -182,6 +183,7 @@ class ResNetFpnDetector(nn.Module):
         the hot-path keywords selects the per-image path (FpnHotPath per image)."""
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
         fd = torch.float16 if self.dtype == torch.float16 else torch.float32
+        self._rpn_pair = None
         self._steps = None
         if self._max_batch <= 8 and self._hot_kwargs.pop('batched', True):
             self._steps = FpnStepBatch(self._max_batch, *self._hot_args, feature_dtype=fd, **self._hot_kwargs)
@@ -228,8 +230,10 @@ class ResNetFpnDetector(nn.Module):
         """shared RpnHead on every level; outputs concatenated P2->P6 in (y, x, anchor) order
         (base_fpn_model.py:188-200, 427-432): scores [B, N, 2], deltas [B, N, 4]."""
         if p_list[0].is_cuda and p_list[0].dtype in (torch.float32, torch.float16):
-            # GPU: the 1x1 convolutions run without their bias and ONE pass per level (ops.rpn_pack) adds it, widens
-            # to float32 and writes the level's slice of the concatenated arrays the proposal stage reads
+            # GPU: the two 1x1 convolutions run as ONE contraction (weights concatenated: the 512-channel activation
+            # is read once) without bias, and ONE pass per level (ops.rpn_pack_pair) adds the bias, widens to float32
+            # and writes the level's slices of the concatenated arrays the proposal stage reads
+            w, b = self._rpn_pair_weights()
             B = p_list[0].shape[0]
             n = sum(int(p.shape[2]) * int(p.shape[3]) for p in p_list) * self.A
             scores = torch.empty((B, n, 2), dtype=torch.float32, device=p_list[0].device)
@@ -237,10 +241,8 @@ class ResNetFpnDetector(nn.Module):
             off = 0
             for p in p_list:
                 x = _conv_epi(self.rpn_conv, p, relu=True)
-                s = F.conv2d(x, self.rpn_score.weight, None).permute(0, 2, 3, 1)
-                d = F.conv2d(x, self.rpn_bbox.weight, None).permute(0, 2, 3, 1)
-                ops.rpn_pack(s if s.is_contiguous() else s.contiguous(), self.rpn_score.bias, scores, off * 2)
-                ops.rpn_pack(d if d.is_contiguous() else d.contiguous(), self.rpn_bbox.bias, deltas, off * 4)
+                sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
+                ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, off)
                 off += int(p.shape[2]) * int(p.shape[3]) * self.A
             return scores, deltas
         scores, deltas = [], []
@@ -250,6 +252,17 @@ class ResNetFpnDetector(nn.Module):
             scores.append(self.rpn_score(x).permute(0, 2, 3, 1).reshape(B, -1, 2))
             deltas.append(self.rpn_bbox(x).permute(0, 2, 3, 1).reshape(B, -1, 4))
         return torch.cat(scores, 1), torch.cat(deltas, 1)
+
+    def _rpn_pair_weights(self):
+        """[6A, 512, 1, 1] weight and [6A] bias of rpn_score and rpn_bbox concatenated along the output channel;
+        rebuilt when either parameter was modified (weight loading, an optimiser step)."""
+        ver = tuple(t._version for t in (self.rpn_score.weight, self.rpn_score.bias, self.rpn_bbox.weight, self.rpn_bbox.bias))
+        if self._rpn_pair is None or self._rpn_pair[0] != ver or self._rpn_pair[1].device != self.rpn_score.weight.device:
+            with torch.no_grad():
+                w = torch.cat([self.rpn_score.weight, self.rpn_bbox.weight], 0).contiguous(memory_format=torch.channels_last)
+                b = torch.cat([self.rpn_score.bias, self.rpn_bbox.bias], 0).contiguous()
+            self._rpn_pair = (ver, w, b)
+        return self._rpn_pair[1], self._rpn_pair[2]
 
     def roi_head(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)

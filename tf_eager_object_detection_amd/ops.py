@@ -369,6 +369,27 @@ def rpn_pack(level_out, bias, out, out_offset):
     return out
 
 
+def rpn_pack_pair(level_out, bias, num_anchors, scores, deltas, anchor_offset):
+    """rpn_pack for the RpnHead's two 1x1 convolutions run as one contraction: ``level_out`` [B,h,w,6A] (2A score
+    channels then 4A delta channels, no bias), ``bias`` [6A]; writes the level's slices of ``scores`` [B,N,2] and
+    ``deltas`` [B,N,4] (float32) starting at anchor ``anchor_offset``."""
+    if level_out.dim() != 4 or not level_out.is_contiguous():
+        raise ValueError('level_out must be a contiguous NHWC [B,h,w,6A] tensor')
+    if level_out.dtype not in (torch.float32, torch.float16) or bias.dtype != level_out.dtype:
+        raise TypeError('level_out and bias must both be float32 or both float16')
+    B, h, w, ch = (int(v) for v in level_out.shape)
+    A = int(num_anchors)
+    if ch != 6 * A or bias.numel() != ch:
+        raise ValueError('level_out / bias must have 6 * num_anchors channels')
+    for t, k in ((scores, 2), (deltas, 4)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 3 or t.shape[0] != B or t.shape[2] != k:
+            raise ValueError('scores / deltas must be contiguous float32 [B, N, 2] / [B, N, 4] tensors')
+    L.call('odet_rpn_pack_pair', L.dptr(level_out), L.dptr(bias), h * w, A, B, L.dptr(scores),
+           scores.numel() // max(B, 1), int(anchor_offset) * 2, L.dptr(deltas), deltas.numel() // max(B, 1),
+           int(anchor_offset) * 4, 1 if level_out.dtype == torch.float16 else 0, L.stream())
+    return scores, deltas
+
+
 class ProfEvent:
     """HIP event for odet_roi_pool_timed (the dispatch's own begin / end timestamps)."""
 
