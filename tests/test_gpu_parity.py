@@ -826,3 +826,37 @@ def test_nms_sync_free_chunks_from_selection_then_full_order():
     else:
         m = int(cnt.item())
         np.testing.assert_array_equal(h(idx[:m]), want[:m])
+
+
+@pytest.mark.parametrize('name', ['config1_vgg16_600x800', 'config2_resnet_c4_800x1333', 'config3_resnet101_fpn_800x1333',
+                                  'config5_resnet101_fpn_1333x1333_81_classes'])
+def test_full_size_hashes_from_the_hip_path(name):
+    """SURVEY.md 8(c) full-size fixtures: the HIP hot path (through the C ABI) reproduces the committed SHA-256
+    digests of every discrete output at the BASELINE.json shapes -- kept anchor indices of the NMS over all
+    anchors, level assignment, detection labels (tests/golden/full_size_hashes.json, written by the oracle)."""
+    import full_size_cases as fs
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, FrcnnHotPath
+    c = fs.CASES[name]
+    inp = fs.make_inputs(name)
+    want = fs.load_golden()[name]
+    assert inp['num_anchors'] == want['num_anchors']
+    gen = torch.Generator(device='cuda'); gen.manual_seed(5)
+    if c['kind'] == 'fpn':
+        hot = FpnHotPath(c['shape'], c['ncls'], c['K'], c['channels'], max_per_class=c['per_class'],
+                         max_per_image=c['per_image'], blind_chunks=4)
+        feats = [torch.randn((1, fh, fw, c['channels']), device='cuda', generator=gen)
+                 for fh, fw in syn.fpn_level_shapes(c['shape'])[:4]]
+    else:
+        hot = FrcnnHotPath(c['shape'], c['ncls'], c['K'], c['channels'], max_pooling_flag=c['max_pool'], blind_chunks=4)
+        feats = torch.randn((1, hot.fh, hot.fw, c['channels']), device='cuda', generator=gen)
+    assert hot.N == want['num_anchors']
+    _, _, labels, _, count = hot.step(g(inp['rpn_logits']), g(inp['rpn_deltas']), feats, g(inp['cls_scores']),
+                                      g(inp['cls_deltas']))
+    torch.cuda.synchronize()
+    assert int(hot.nms_done.item()) == 1
+    k = int(hot.roi_count.item())
+    got = dict(kept_anchor_idx=h(hot.roi_idx[:k]), det_labels=h(labels[:int(count.item())]))
+    if c['kind'] == 'fpn':
+        got['roi_level'] = h(hot.roi_level[:k]) + 2
+        got['level_perm'] = h(hot.roi_perm[:k])
+    assert fs.digests(got) == {k_: v for k_, v in want.items() if k_ != 'num_anchors'}
