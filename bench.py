@@ -368,6 +368,10 @@ def main():
                          'kernel_ms': roi_ms, 'kernel_ms_samples': len(ev_roi), 'algorithmic_bytes': algo['B_roi'],
                          'bytes_all_taps': algo['B_taps'], 'bytes_output': algo['out']},
         }
+        # the same launch priced on the HBM bytes the PMC counters saw (cross-RoI reuse served from L2 / Infinity
+        # Cache is not in them, SURVEY 8d's algorithmic bytes count every RoI's cells): the plain bandwidth figure
+        tr = result['roofline']['traffic']
+        result['roofline']['measured_traffic_GBps'] = (tr / (roi_ms * 1e-3) / 1e9) if (tr and roi_ms) else None
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
         print(json.dumps(result))

@@ -135,6 +135,22 @@ def tf_legacy_resize_bilinear(x, out_hw):
     return t + (b - t) * wy
 
 
+def rpn_pair_weights(m):
+    """[6A, 512, 1, 1] weight and [6A] bias of m.rpn_score and m.rpn_bbox concatenated along the output channel
+    (the RpnHead's two 1x1 convolutions as one contraction); cached on the module, rebuilt when either parameter
+    was modified (weight loading, an optimiser step) or moved."""
+    ps = (m.rpn_score.weight, m.rpn_score.bias, m.rpn_bbox.weight, m.rpn_bbox.bias)
+    key = tuple((t._version, t.data_ptr(), t.dtype) for t in ps)
+    cached = getattr(m, '_rpn_pair', None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            w = torch.cat([ps[0], ps[2]], 0).contiguous(memory_format=torch.channels_last)
+            b = torch.cat([ps[1], ps[3]], 0).contiguous()
+        cached = (key, w, b)
+        m._rpn_pair = cached
+    return cached[1], cached[2]
+
+
 class ResNetFpnDetector(nn.Module):
     """Inference-only ResNet-{50,101,152}-FPN detector.  `forward(images)` takes NHWC float images
     [B,H,W,3] (already mean-subtracted, as the reference's input pipeline delivers them) and returns,
@@ -254,15 +270,7 @@ class ResNetFpnDetector(nn.Module):
         return torch.cat(scores, 1), torch.cat(deltas, 1)
 
     def _rpn_pair_weights(self):
-        """[6A, 512, 1, 1] weight and [6A] bias of rpn_score and rpn_bbox concatenated along the output channel;
-        rebuilt when either parameter was modified (weight loading, an optimiser step)."""
-        ver = tuple(t._version for t in (self.rpn_score.weight, self.rpn_score.bias, self.rpn_bbox.weight, self.rpn_bbox.bias))
-        if self._rpn_pair is None or self._rpn_pair[0] != ver or self._rpn_pair[1].device != self.rpn_score.weight.device:
-            with torch.no_grad():
-                w = torch.cat([self.rpn_score.weight, self.rpn_bbox.weight], 0).contiguous(memory_format=torch.channels_last)
-                b = torch.cat([self.rpn_score.bias, self.rpn_bbox.bias], 0).contiguous()
-            self._rpn_pair = (ver, w, b)
-        return self._rpn_pair[1], self._rpn_pair[2]
+        return rpn_pair_weights(self)
 
     def roi_head(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)

@@ -13,8 +13,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..pipeline import FrcnnHotPath
-from .fpn_detector import _BLOCKS, ResNetFpnDetector, _conv, _conv_epi, _fold_frozen_bn, _stack
+from .fpn_detector import _BLOCKS, ResNetFpnDetector, _conv, _conv_epi, _fold_frozen_bn, _stack, rpn_pair_weights
 
 __all__ = ['ResNetC4Detector', 'Vgg16Detector']
 
@@ -83,6 +84,16 @@ class ResNetC4Detector(nn.Module):
         """RpnHead: scores [B, fh*fw, 2A] ([A bg | A fg] per location), deltas [B, fh*fw*A, 4]."""
         x = _conv_epi(self.rpn_conv, c4, relu=True)
         B = x.shape[0]
+        if x.is_cuda and x.dtype in (torch.float32, torch.float16):
+            # the two 1x1 convolutions as one contraction, then ONE pass: + bias, float32, split (ops.rpn_pack_pair;
+            # [fh*fw, 2A] and [fh*fw*A, 2] are the same memory)
+            w, b = rpn_pair_weights(self)
+            sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
+            n = int(sd.shape[1]) * int(sd.shape[2]) * self.A
+            scores = torch.empty((B, n, 2), dtype=torch.float32, device=x.device)
+            deltas = torch.empty((B, n, 4), dtype=torch.float32, device=x.device)
+            ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, 0)
+            return scores.view(B, -1, 2 * self.A), deltas
         scores = self.rpn_score(x).permute(0, 2, 3, 1).reshape(B, -1, 2 * self.A)
         deltas = self.rpn_bbox(x).permute(0, 2, 3, 1).reshape(B, -1, 4)
         return scores, deltas

@@ -1,7 +1,7 @@
 """How long the three top-down merges of the FPN neck (TF1 legacy bilinear resize + 0.5/0.5 fusion, torch ops)
 take inside the detector: decides whether a fused HIP kernel is worth writing."""
-import sys, torch
-sys.path.insert(0, '/root/repo')
+import sys, torch, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tf_eager_object_detection_amd.model.fpn_detector import tf_legacy_resize_bilinear
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dt = torch.float16

@@ -2,9 +2,9 @@
 their small kernels).  Here the RoI launches are serialised across the groups with HIP events (one RoI kernel
 at a time at full speed, the other groups' small kernels beside it); driven from one Python thread through
 odet_fpn_step_enqueue_batch with stage masks."""
-import sys, time, ctypes as C
+import sys, time, ctypes as C, os
 import torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tf_eager_object_detection_amd import _lib
 from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
 S, B = int(sys.argv[1]) if len(sys.argv) > 1 else 3, 8

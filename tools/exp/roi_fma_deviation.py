@@ -1,5 +1,5 @@
-import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+import sys, numpy as np, torch, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import c_oracle as co
 from tf_eager_object_detection_amd import ops, synthetic as syn
 rng=np.random.default_rng(0)

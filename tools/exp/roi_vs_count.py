@@ -1,8 +1,8 @@
 """RoI-kernel time against the number of RoIs (one image, bench shapes), warm and with flushed caches: tells a
 throughput bound (time proportional to the RoIs) from a latency / rounds bound (steps at multiples of the 512
 workgroups the chip holds)."""
-import sys, torch
-sys.path.insert(0, '/root/repo')
+import sys, torch, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tf_eager_object_detection_amd.pipeline import FpnHotPath, synthetic_fpn_inputs
 from tf_eager_object_detection_amd import ops
 flush = torch.empty(1 << 28, dtype=torch.float32, device='cuda')

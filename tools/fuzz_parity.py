@@ -4,10 +4,10 @@ proposal counts, score distributions (distinct / clustered / tied / quantised), 
 scores.  Prints one line per case; exits non-zero on the first mismatch.
 
     python tools/fuzz_parity.py [--seconds 120] [--seed 0]"""
-import argparse, sys, time
+import argparse, os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import c_oracle as co
 from tf_eager_object_detection_amd import ops
 from tf_eager_object_detection_amd import synthetic as syn

@@ -1,6 +1,6 @@
 """Throughput of the stream pool per stage subset: where does the chip time of an image go?"""
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+import sys, time, torch, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
 host, dev = synthetic_fpn_inputs((800, 1333), 21, 1000, 256, seed=1234)
 S = 8

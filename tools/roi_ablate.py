@@ -2,8 +2,8 @@
 flushed by sweeping a 1 GiB buffer between launches).  Diagnostic builds: `tools/roi_ablate_build.sh`
 makes libodet_hip_a{1..4}.so with -DODET_ROI_ABLATE=k (no loads / no lerps / no stores / prologue only);
 pass the library path as argv[1] to time one of them."""
-import sys, torch
-sys.path.insert(0, '/root/repo')
+import sys, torch, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tf_eager_object_detection_amd import _lib
 if len(sys.argv) > 1:
     _lib.LIB_PATH = sys.argv[1]
