@@ -49,6 +49,54 @@ def _fold_frozen_bn(conv):
     return conv
 
 
+# 1x1 stride-1 convolutions in NHWC are plain GEMMs on the [pixels, channels] view: hipBLASLt applies bias (+ ReLU)
+# in the GEMM's own epilogue, which saves the separate pass over the output -- most of these layers are bound by
+# HBM traffic, not by MFMA throughput (tools/exp/conv1x1_gemm.py).  Which of the two wins depends on the shape
+# (the library convolution is ahead on 256 -> 64 at 200x334), so the route is measured once per shape.
+_GEMM_ROUTE = {}
+
+
+def _gemm_1x1(conv, x, bias, relu):
+    B, cin, h, w = x.shape
+    x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)
+    w2 = conv.weight.view(conv.out_channels, cin).t()
+    y2 = torch._addmm_activation(bias, x2, w2, use_gelu=False) if relu else torch.addmm(bias, x2, w2)
+    return y2.view(B, h, w, conv.out_channels).permute(0, 3, 1, 2)
+
+
+def _conv_1x1(conv, x, bias, relu):
+    y = F.conv2d(x, conv.weight, None)
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    ops.bias_act_(y.permute(0, 2, 3, 1), bias, None, relu)
+    return y
+
+
+def _time_route(fn, reps=5):
+    for _ in range(2):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b)
+
+
+def _route_1x1(conv, x, bias, relu):
+    """'gemm' or 'conv' for this layer shape; measured at the first call outside a stream capture."""
+    key = (tuple(x.shape), conv.out_channels, x.dtype, bool(relu))
+    r = _GEMM_ROUTE.get(key)
+    if r is None:
+        if torch.cuda.is_current_stream_capturing():
+            return 'conv'
+        r = 'gemm' if _time_route(lambda: _gemm_1x1(conv, x, bias, relu)) < \
+            _time_route(lambda: _conv_1x1(conv, x, bias, relu)) else 'conv'
+        _GEMM_ROUTE[key] = r
+    return r
+
+
 def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
     """conv (+ zero padding `pad`) -> + bias (+ extra_bias) (+ residual) -> ReLU.  On the GPU the convolution
     runs without its bias and everything after it is ONE in-place pass of the fused HIP epilogue
@@ -61,6 +109,10 @@ def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
             x = F.pad(x, pad)
     bias = conv.bias if extra_bias is None else conv.bias + extra_bias
     if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
+        if (residual is None and pad is None and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
+                and tuple(conv.padding) == (0, 0) and x.is_contiguous(memory_format=torch.channels_last)
+                and _route_1x1(conv, x, bias, relu) == 'gemm'):
+            return _gemm_1x1(conv, x, bias, relu)
         y = F.conv2d(x, conv.weight, None, conv.stride, padding)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
