@@ -1,13 +1,15 @@
-// EXPERIMENT, not built into libodet_hip.so.  Measured on MI355X (batch 8 at 800x1333, float16 NHWC) against what
-// the detectors do (library convolution without bias + ops.bias_act_ with the shortcut):
-//     64 -> 256  at 200x334 : 237 us (2.6 TB/s of its 615 MB)  vs 219 us
-//     128 -> 512 at 100x167 : 174 us                           vs 107 us
-//     256 -> 1024 at 50x84  : 111 us                           vs  63 us   (154 MB: served by the Infinity Cache)
-// Exact on integer data (fragment maps and the row permutation below are right: 5 shapes incl. ragged pixel
-// counts), but every wave runs load-x -> load-W -> MFMA -> load-shortcut -> store as one dependent sequence and
-// the shortcut's HBM latency is exposed once per 64-channel group; the upside even at the HBM floor is ~1.5 % of
-// the detector's time (the frequent 50x84 layers are cache-resident), so it was not developed further.
-// To try it: copy to tf_eager_object_detection_amd/csrc/, add to _build.SOURCES, declare odet_conv1x1_f16.
+// EXPERIMENT, not built into libodet_hip.so (tools/exp/conv1x1_mfma_build.sh + conv1x1_mfma_bench.py build and run it).
+// Measured on MI355X (batch 8 at 800x1333, float16 NHWC) against what the detectors do (library convolution without
+// bias + ops.bias_act_ with the shortcut):
+//     64 -> 256  at 200x334 : 219 us (2.8 TB/s of its 615 MB)  vs 224 us
+//     128 -> 512 at 100x167 : 151 us                           vs 111 us
+//     256 -> 1024 at 50x84  : 117 us                           vs  65 us   (154 MB: served by the Infinity Cache)
+// (first version, shortcut loaded after the MFMAs: 237 / 174 / 111 us).  Exact on integer data (fragment maps and the
+// row permutation below are right: 6 shapes incl. ragged pixel counts).  Without the shortcut it still takes 139 /
+// 108 / 103 us: every wave re-reads its weight rows from L2 for each 32-pixel slab (550 MB of L2 traffic on the
+// 50x84 layer) and feeds them straight into the MFMAs at 2-3 waves per SIMD -- the next step would be a workgroup
+// tile of 128+ pixels with the weight group staged once in LDS.  The upside even at the HBM floor is a few percent
+// of the detector's time (the frequent 50x84 layers are cache-resident), so it was not developed further.
 //
 // 1x1 stride-1 convolution of the dense path with its whole epilogue, on the matrix cores (SURVEY 8(f) rank 3:
 // "Backbone + FPN neck on MFMA ... frozen-BN folded into conv"): the third convolution of every bottleneck block
@@ -48,6 +50,48 @@ struct Conv1x1Params {
 
 __device__ __forceinline__ h8 ldg16(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
 
+// one 64-channel group of a wave's tile: weights -> 2 x KSTEPS MFMAs -> bias + shortcut (already in `cur`) -> store;
+// the NEXT group's shortcut is requested into `nxt` before the weights
+template <int KSTEPS>
+__device__ __forceinline__ void conv1x1_group(const Conv1x1Params& p, const h8 (&xa)[KSTEPS], int n0, int n_end, int perm,
+                                              int h, long long mc, bool store, const h8 (&cur)[4], h8 (&nxt)[4]) {
+  const int K = p.K, N = p.N;
+  const _Float16* w0 = p.w + (long long)(n0 + perm) * K + 8 * h;
+  const _Float16* w1 = w0 + 16 * K;
+  const int c0 = n0 + 32 * h;
+  const long long off = mc * N + c0;
+  if (p.res && n0 + 64 < n_end) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = ldg16(p.res + off + 64 + 8 * q);
+  }
+  f16v acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const h8 a0 = ldg16(w0 + 16 * s);
+    const h8 a1 = ldg16(w1 + 16 * s);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xa[s], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[s], acc1, 0, 0, 0);
+  }
+  // lane (pixel r, half h): channels n0 + 32 h + [0, 32): acc0 -> +0..15, acc1 -> +16..31
+  const _Float16* bp = p.bias + c0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const h8 bv = ldg16(bp + 8 * q);
+    h8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = (q & 1) * 8 + e;
+      float v = (q < 2 ? acc0[idx] : acc1[idx]) + (float)bv[e];
+      if (p.res) v = v + (float)cur[q][e];
+      if (p.relu) v = (v < 0.0f) ? 0.0f : v;
+      ov[e] = (_Float16)v;
+    }
+    if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
+  }
+}
+
 // KSTEPS = K / 16 (4, 8 or 16): the pixel fragments of the whole K live in registers
 template <int KSTEPS>
 __global__ void __launch_bounds__(256) k_conv1x1_f16(Conv1x1Params p) {
@@ -69,40 +113,17 @@ __global__ void __launch_bounds__(256) k_conv1x1_f16(Conv1x1Params p) {
 
   // A operand rows: MFMA row r <-> channel (of a 64-channel group) perm(r) + 16 j
   const int perm = 32 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
-  const int n_begin = tn * p.nt;
-  for (int n0 = n_begin; n0 < n_begin + p.nt; n0 += 64) {
-    const _Float16* w0 = p.w + (long long)(n0 + perm) * K + 8 * h;
-    const _Float16* w1 = w0 + 16 * K;
-    f16v acc0, acc1;
+  const int n_begin = tn * p.nt, n_end = n_begin + p.nt;
+  // the shortcut of a group is requested one group AHEAD (two register buffers, the loop handles two groups per
+  // trip): its HBM latency is covered by the previous group's weight loads, MFMAs and stores
+  h8 ra[4], rb[4];
+  if (p.res) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      const h8 a0 = ldg16(w0 + 16 * s);
-      const h8 a1 = ldg16(w1 + 16 * s);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xa[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[s], acc1, 0, 0, 0);
-    }
-    // lane (pixel r, half h): channels n0 + 32 h + [0, 32): acc0 -> +0..15, acc1 -> +16..31
-    const int c0 = n0 + 32 * h;
-    const _Float16* bp = p.bias + c0;
-    const long long off = mc * N + c0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const h8 bv = ldg16(bp + 8 * q);
-      h8 rv;
-      if (p.res) rv = ldg16(p.res + off + 8 * q);
-      h8 ov;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int idx = (q & 1) * 8 + e;
-        float v = (q < 2 ? acc0[idx] : acc1[idx]) + (float)bv[e];
-        if (p.res) v = v + (float)rv[e];
-        if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-        ov[e] = (_Float16)v;
-      }
-      if (m < p.M) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
-    }
+    for (int q = 0; q < 4; ++q) ra[q] = ldg16(p.res + mc * N + n_begin + 32 * h + 8 * q);
+  }
+  for (int n0 = n_begin; n0 < n_end; n0 += 128) {
+    conv1x1_group<KSTEPS>(p, xa, n0, n_end, perm, h, mc, m < p.M, ra, rb);
+    if (n0 + 64 < n_end) conv1x1_group<KSTEPS>(p, xa, n0 + 64, n_end, perm, h, mc, m < p.M, rb, ra);
   }
 }
 
