@@ -393,3 +393,38 @@ def test_rpn_pack_and_detector_rpn_match_torch_formulation():
             wd.append(m.rpn_bbox(x).permute(0, 2, 3, 1).reshape(2, -1, 4))
     torch.testing.assert_close(sc, torch.cat(ws, 1), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dl, torch.cat(wd, 1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K,N', [(1007, 64, 256), (96, 128, 512), (33, 256, 1024), (2500, 256, 64), (64, 64, 320),
+                                   (5000, 128, 128)])
+def test_conv1x1_mfma_kernel_exact_on_integer_data_and_close_on_random(M, K, N):
+    """odet_conv1x1_f16 (1x1 convolution + bias + shortcut + ReLU on the matrix cores, resnet_fpn.py:154-205):
+    EXACT on small-integer data with asymmetric operands (catches any fragment / permutation / row-column slip),
+    within float16 rounding of the float32 formulation on random data; pixel counts that do not fill a tile."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(M + K + N)
+    ri = lambda lo, hi, *sh: torch.randint(lo, hi, sh, device='cuda', generator=g).to(torch.float16)
+    x, w, b, r = ri(-3, 4, M, K), ri(-2, 3, N, K), ri(-8, 9, N), ri(-16, 17, M, N)
+    w[:, 0] += torch.arange(N, device='cuda').remainder(5).to(torch.float16)           # every channel distinct-ish
+    x[:, 1] += torch.arange(M, device='cuda').remainder(7).to(torch.float16)           # every pixel distinct-ish
+    for res, relu in ((r, True), (None, True), (r, False), (None, False)):
+        want = x.float() @ w.float().t() + b.float()
+        if res is not None:
+            want = want + res.float()
+        if relu:
+            want = torch.relu(want)
+        assert float(want.abs().max()) < 2048                                          # exactly representable
+        got = ops.conv1x1_f16(x, w.view(N, K, 1, 1), b, res, relu)
+        assert torch.equal(got.float(), want)
+    x, w, b, r = (torch.randn(s, device='cuda', generator=g).to(torch.float16) for s in ((M, K), (N, K), (N,), (M, N)))
+    w = (w.float() / K ** 0.5).to(torch.float16)
+    want = torch.relu(x.float() @ w.float().t() + b.float() + r.float())
+    got = ops.conv1x1_f16(x, w, b, r, True)
+    torch.testing.assert_close(got.float(), want, rtol=2e-3, atol=2e-3)
+    # in place on the shortcut, NHWC leading dims
+    r2 = r.clone().view(1, M, 1, N)
+    out = ops.conv1x1_f16(x.view(1, M, 1, K), w, b, r2, True, out=r2)
+    assert out.data_ptr() == r2.data_ptr() and torch.equal(out.view(M, N), got)
+    with pytest.raises(Exception):
+        ops.conv1x1_f16(x[:, :48].contiguous(), w[:, :48].contiguous(), b, None, True)  # 48 input channels

@@ -1,16 +1,3 @@
-// EXPERIMENT, not built into libodet_hip.so (tools/exp/conv1x1_mfma_build.sh + conv1x1_mfma_bench.py build and run it).
-// Measured on MI355X (batch 8 at 800x1333, float16 NHWC) against what the detectors do (library convolution without
-// bias + ops.bias_act_ with the shortcut):
-//     64 -> 256  at 200x334 : 219 us (2.8 TB/s of its 615 MB)  vs 224 us
-//     128 -> 512 at 100x167 : 151 us                           vs 111 us
-//     256 -> 1024 at 50x84  : 117 us                           vs  65 us   (154 MB: served by the Infinity Cache)
-// (first version, shortcut loaded after the MFMAs: 237 / 174 / 111 us).  Exact on integer data (fragment maps and the
-// row permutation below are right: 6 shapes incl. ragged pixel counts).  Without the shortcut it still takes 139 /
-// 108 / 103 us: every wave re-reads its weight rows from L2 for each 32-pixel slab (550 MB of L2 traffic on the
-// 50x84 layer) and feeds them straight into the MFMAs at 2-3 waves per SIMD -- the next step would be a workgroup
-// tile of 128+ pixels with the weight group staged once in LDS.  The upside even at the HBM floor is a few percent
-// of the detector's time (the frequent 50x84 layers are cache-resident), so it was not developed further.
-//
 // 1x1 stride-1 convolution of the dense path with its whole epilogue, on the matrix cores (SURVEY 8(f) rank 3:
 // "Backbone + FPN neck on MFMA ... frozen-BN folded into conv"): the third convolution of every bottleneck block
 // (resnet_fpn.py:154-205) and what follows it,
@@ -20,19 +7,27 @@
 // epilogue next to the shortcut); these layers are bound by that traffic, not by the contraction (K = 64 .. 256:
 // 32 .. 128 FLOP per output byte), so the kernel is built around the streams, not around the MFMA rate:
 //
-//  * one WAVE owns a tile of 32 pixels x NT channels and v_mfma_f32_32x32x16_f16 computes it TRANSPOSED
-//    (D = W_tile . x_tile^T): the MFMA's A operand is 32 rows of W, its B operand 32 pixels of x.  Both fragments
-//    are "8 consecutive k of one row" = one 16-byte global load per lane straight into the operand registers,
-//    no LDS and no shuffles; the x fragments of the whole K stay in registers across the channel loop, so x is
-//    read from HBM exactly once.  W (<= 512 KB) is served by L1 / L2.
+//  * a WORKGROUP (4 waves) owns 128 pixels x NT channels; wave w computes its 32 pixels TRANSPOSED with
+//    v_mfma_f32_32x32x16_f16 (D = W_tile . x_tile^T): the MFMA's A operand is 32 rows of W, its B operand 32
+//    pixels of x.  A fragment is "8 consecutive k of one row": the x fragments are one 16-byte global load per
+//    lane straight into the operand registers and stay there for the whole channel loop (x is read from HBM
+//    exactly once); the weights of a 64-channel group ([64, K], <= 32 KB) are staged once per workgroup in LDS
+//    (double buffer: the next group travels global -> registers while this one computes, registers -> LDS after
+//    it, one barrier per group; rows padded by 16 bytes so that ds_read_b128 of 16 consecutive rows covers all
+//    64 banks: SQ_LDS_BANK_CONFLICT = 0).
 //  * in the transposed result a lane holds ONE pixel and 16 channels per 32x32 block.  The rows of W are fed in a
 //    permuted order (row i of the MFMA = channel 32*((i>>2)&1) + 16*j + 4*(i>>3) + (i&3) of the 64-channel group,
 //    j = block 0 / 1), which makes those 16 registers 16 CONSECUTIVE channels and the two blocks of a group 32
 //    consecutive channels: the shortcut is read and the output written with 16-byte accesses, 64 contiguous bytes
 //    per lane, a full 128-byte line per pixel from the two lane halves.
+//  * bias and shortcut START the accumulators (acc = bias + shortcut, then += W.x) and are requested one group
+//    ahead, so their latency is covered by the previous group's MFMAs and nothing but ReLU + one rounding + the
+//    store follows the contraction.
 //
-// HBM bytes per call: M*K*2 (x) + M*N*2 (shortcut) + M*N*2 (y) -- the algorithmic minimum.
-#include <cstdlib>
+// HBM bytes per call: M*K*2 (x) + M*N*2 (shortcut) + M*N*2 (y) -- the algorithmic minimum.  Measured (batch 8 at
+// 800x1333; library convolution + epilogue pass beside it): 64 -> 256 at 200x334 157 us = 3.9 TB/s (225 us);
+// 128 -> 512 at 100x167 91 us (110 us); 256 -> 1024 at 50x84 57 us (64 us); 256 -> 64 at 200x334 without
+// shortcut 77 us (89 us).  History and the direct-to-register first versions: tools/exp/conv1x1_mfma.hip.
 #include <hip/hip_fp16.h>
 
 #include "odet_internal.h"
@@ -44,9 +39,8 @@ struct Conv1x1Params {
   const _Float16* x; const _Float16* w; const _Float16* bias; const _Float16* res; _Float16* y;
   long long M;
   int K, N, relu;
-  int tiles_n;      // N / NT
-  int nt;           // channels per wave tile (multiple of 64)
-  long long waves;  // ceil(M / 32) * tiles_n
+  int tiles_n;      // N / nt
+  int nt;           // channels per workgroup tile (multiple of 64)
 };
 
 __device__ __forceinline__ h8 ldg16(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
@@ -191,9 +185,7 @@ extern "C" int odet_conv1x1_f16(const void* x, const void* w, const void* bias, 
   // channels per wave tile: the whole row up to 256 channels; wider outputs are split so that small feature maps
   // still give the chip enough waves (the waves of a pixel slab sit in one workgroup and share its x lines in L1)
   p.nt = cout <= 256 ? cout : (cout % 256 == 0 ? 256 : 64);
-  if (const char* e = getenv("ODET_CONV1X1_NT")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0 && cout % v == 0) p.nt = v; }
   p.tiles_n = cout / p.nt;
-  p.waves = 0;
   const long long blocks = ((npix + 127) / 128) * p.tiles_n;
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv1x1_f16: too many workgroups");
   dim3 grid((unsigned)blocks), block(256);

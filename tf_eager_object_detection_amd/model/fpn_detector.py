@@ -49,10 +49,11 @@ def _fold_frozen_bn(conv):
     return conv
 
 
-# 1x1 stride-1 convolutions in NHWC are plain GEMMs on the [pixels, channels] view: hipBLASLt applies bias (+ ReLU)
-# in the GEMM's own epilogue, which saves the separate pass over the output -- most of these layers are bound by
-# HBM traffic, not by MFMA throughput (tools/exp/conv1x1_gemm.py).  Which of the two wins depends on the shape
-# (the library convolution is ahead on 256 -> 64 at 200x334), so the route is measured once per shape.
+# 1x1 stride-1 convolutions in NHWC are plain GEMMs on the [pixels, channels] view and most of them are bound by HBM
+# traffic, not by MFMA throughput (tools/exp/conv1x1_gemm.py).  Three routes, measured once per layer shape:
+#   'conv' library convolution without bias + the fused epilogue pass (ops.bias_act_)
+#   'gemm' hipBLASLt GEMM with bias (+ ReLU) in its own epilogue (no shortcut)
+#   'mfma' ops.conv1x1_f16: the hand-written MFMA kernel with bias + shortcut + ReLU fused (float16, cin <= 256)
 _GEMM_ROUTE = {}
 
 
@@ -64,12 +65,16 @@ def _gemm_1x1(conv, x, bias, relu):
     return y2.view(B, h, w, conv.out_channels).permute(0, 3, 1, 2)
 
 
-def _conv_1x1(conv, x, bias, relu):
+def _conv_1x1(conv, x, bias, relu, res):
     y = F.conv2d(x, conv.weight, None)
     if not y.is_contiguous(memory_format=torch.channels_last):
         y = y.contiguous(memory_format=torch.channels_last)
-    ops.bias_act_(y.permute(0, 2, 3, 1), bias, None, relu)
+    ops.bias_act_(y.permute(0, 2, 3, 1), bias, res, relu)
     return y
+
+
+def _mfma_1x1(conv, x, bias, relu, res):
+    return ops.conv1x1_f16(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu).permute(0, 3, 1, 2)
 
 
 def _time_route(fn, reps=5):
@@ -84,15 +89,20 @@ def _time_route(fn, reps=5):
     return a.elapsed_time(b)
 
 
-def _route_1x1(conv, x, bias, relu):
-    """'gemm' or 'conv' for this layer shape; measured at the first call outside a stream capture."""
-    key = (tuple(x.shape), conv.out_channels, x.dtype, bool(relu))
+def _route_1x1(conv, x, bias, relu, res):
+    """'conv', 'gemm' or 'mfma' for this layer shape; measured at the first call outside a stream capture."""
+    key = (tuple(x.shape), conv.out_channels, x.dtype, bool(relu), res is not None)
     r = _GEMM_ROUTE.get(key)
     if r is None:
         if torch.cuda.is_current_stream_capturing():
             return 'conv'
-        r = 'gemm' if _time_route(lambda: _gemm_1x1(conv, x, bias, relu)) < \
-            _time_route(lambda: _conv_1x1(conv, x, bias, relu)) else 'conv'
+        cand = {'conv': lambda: _conv_1x1(conv, x, bias, relu, res)}
+        if res is None:
+            cand['gemm'] = lambda: _gemm_1x1(conv, x, bias, relu)
+        if x.dtype == torch.float16 and conv.in_channels in (64, 128, 256) and conv.out_channels % 64 == 0:
+            cand['mfma'] = lambda: _mfma_1x1(conv, x, bias, relu, res)
+        times = {k: _time_route(f) for k, f in cand.items()}
+        r = min(times, key=times.get)
         _GEMM_ROUTE[key] = r
     return r
 
@@ -109,10 +119,19 @@ def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
             x = F.pad(x, pad)
     bias = conv.bias if extra_bias is None else conv.bias + extra_bias
     if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
-        if (residual is None and pad is None and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
-                and tuple(conv.padding) == (0, 0) and x.is_contiguous(memory_format=torch.channels_last)
-                and _route_1x1(conv, x, bias, relu) == 'gemm'):
-            return _gemm_1x1(conv, x, bias, relu)
+        if (pad is None and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
+                and tuple(conv.padding) == (0, 0) and x.is_contiguous(memory_format=torch.channels_last)):
+            res = None
+            if residual is not None:
+                res = residual.permute(0, 2, 3, 1)
+                if not res.is_contiguous():
+                    res = res.contiguous()
+            route = _route_1x1(conv, x, bias, relu, res)
+            if route == 'gemm':
+                return _gemm_1x1(conv, x, bias, relu)
+            if route == 'mfma':
+                return _mfma_1x1(conv, x, bias, relu, res)
+            return _conv_1x1(conv, x, bias, relu, res)
         y = F.conv2d(x, conv.weight, None, conv.stride, padding)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)

@@ -369,6 +369,36 @@ def rpn_pack(level_out, bias, out, out_offset):
     return out
 
 
+def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None):
+    """1x1 stride-1 convolution + bias (+ residual) (+ ReLU) in ONE kernel on the matrix cores: ``x`` [..., cin]
+    NHWC float16 contiguous (any leading dims), ``weight`` [cout, cin(, 1, 1)], ``bias`` [cout], ``residual`` /
+    ``out`` [..., cout] (``out`` may be ``residual``).  cin in {64, 128, 256}, cout % 64 == 0."""
+    if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
+        raise ValueError('x must be a contiguous float16 GPU tensor [..., cin]')
+    cin = int(x.shape[-1])
+    cout = int(weight.shape[0])
+    if weight.dtype != torch.float16 or weight.numel() != cout * cin:
+        raise ValueError('weight must be a float16 [cout, cin] (or [cout, cin, 1, 1]) tensor')
+    w = weight.reshape(cout, cin)       # (a channels_last [cout, cin, 1, 1] weight is the same memory: a view)
+    if not w.is_contiguous():
+        w = w.contiguous()
+    if bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous():
+        raise ValueError('bias must be a contiguous float16 [cout] tensor')
+    shape = tuple(x.shape[:-1]) + (cout,)
+    if residual is not None and (residual.dtype != torch.float16 or tuple(residual.shape) != shape
+                                 or not residual.is_contiguous()):
+        raise ValueError('residual must be a contiguous float16 tensor shaped like the output')
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor shaped like the output')
+    if out.data_ptr() == x.data_ptr():
+        raise ValueError('out must not alias x')
+    L.call('odet_conv1x1_f16', L.dptr(x), L.dptr(w), L.dptr(bias), L.dptr(residual) if residual is not None else None,
+           L.dptr(out), x.numel() // cin, cin, cout, 1 if relu else 0, L.stream())
+    return out
+
+
 def rpn_pack_pair(level_out, bias, num_anchors, scores, deltas, anchor_offset):
     """rpn_pack for the RpnHead's two 1x1 convolutions run as one contraction: ``level_out`` [B,h,w,6A] (2A score
     channels then 4A delta channels, no bias), ``bias`` [6A]; writes the level's slices of ``scores`` [B,N,2] and
