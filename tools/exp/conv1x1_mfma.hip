@@ -1,15 +1,15 @@
-// EXPERIMENT, not built into libodet_hip.so (tools/exp/conv1x1_mfma_build.sh + conv1x1_mfma_bench.py build and run it).
-// Measured on MI355X (batch 8 at 800x1333, float16 NHWC) against what the detectors do (library convolution without
-// bias + ops.bias_act_ with the shortcut):
-//     64 -> 256  at 200x334 : 219 us (2.8 TB/s of its 615 MB)  vs 224 us
-//     128 -> 512 at 100x167 : 151 us                           vs 111 us
-//     256 -> 1024 at 50x84  : 117 us                           vs  65 us   (154 MB: served by the Infinity Cache)
-// (first version, shortcut loaded after the MFMAs: 237 / 174 / 111 us).  Exact on integer data (fragment maps and the
-// row permutation below are right: 6 shapes incl. ragged pixel counts).  Without the shortcut it still takes 139 /
+// EXPERIMENT, not built into libodet_hip.so: the DIRECT-TO-REGISTER first versions of csrc/conv1x1.hip (every wave
+// loads its weight fragments from global memory / L2 itself; no LDS).  tools/exp/conv1x1_mfma_build.sh +
+// conv1x1_mfma_bench.py build and run it as odet_conv1x1_f16_direct next to the product kernel.
+// Measured on MI355X (batch 8 at 800x1333, float16 NHWC), with shortcut; library = convolution + epilogue pass:
+//                               library   direct v1   direct v2 (this file)   LDS-staged (product)
+//     64 -> 256  at 200x334 :   224 us     237 us         219 us                  157 us
+//     128 -> 512 at 100x167 :   110 us     174 us         151 us                   91 us
+//     256 -> 1024 at 50x84  :    64 us     111 us         117 us                   57 us
+// v1 loaded the shortcut after the MFMAs; v2 requests it a group ahead.  Without the shortcut v2 still takes 139 /
 // 108 / 103 us: every wave re-reads its weight rows from L2 for each 32-pixel slab (550 MB of L2 traffic on the
-// 50x84 layer) and feeds them straight into the MFMAs at 2-3 waves per SIMD -- the next step would be a workgroup
-// tile of 128+ pixels with the weight group staged once in LDS.  The upside even at the HBM floor is a few percent
-// of the detector's time (the frequent 50x84 layers are cache-resident), so it was not developed further.
+// 50x84 layer) and feeds them straight into the MFMAs at 2-3 waves per SIMD -- which is what the workgroup tile
+// with the weight group staged once in LDS (the product kernel) removes.
 //
 // 1x1 stride-1 convolution of the dense path with its whole epilogue, on the matrix cores (SURVEY 8(f) rank 3:
 // "Backbone + FPN neck on MFMA ... frozen-BN folded into conv"): the third convolution of every bottleneck block
@@ -32,7 +32,6 @@
 //    per lane, a full 128-byte line per pixel from the two lane halves.
 //
 // HBM bytes per call: M*K*2 (x) + M*N*2 (shortcut) + M*N*2 (y) -- the algorithmic minimum.
-#include <cstdlib>
 #include <hip/hip_fp16.h>
 
 #include "odet_internal.h"
@@ -40,7 +39,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-struct Conv1x1Params {
+struct Conv1x1DirectParams {
   const _Float16* x; const _Float16* w; const _Float16* bias; const _Float16* res; _Float16* y;
   long long M;
   int K, N, relu;
@@ -51,156 +50,108 @@ struct Conv1x1Params {
 
 __device__ __forceinline__ h8 ldg16(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
 
-// WORKGROUP tile: 128 pixels (4 waves x 32) x nt channels, walked in groups of 64 channels.  The group's weights
-// ([64, K], rows in MFMA order = permuted channels) are staged ONCE per workgroup in LDS (two buffers: the next
-// group's rows travel global -> registers while this group computes, registers -> LDS after it, one barrier per
-// group); rows are padded by 16 bytes so that the ds_read_b128 of 16 consecutive rows covers all 64 banks.
+// one 64-channel group of a wave's tile: weights -> 2 x KSTEPS MFMAs -> bias + shortcut (already in `cur`) -> store;
+// the NEXT group's shortcut is requested into `nxt` before the weights
 template <int KSTEPS>
-__global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
-  constexpr int K = 16 * KSTEPS;
-  constexpr int LDW = K + 8;                       // LDS row stride in halfs (2K + 16 bytes)
-  constexpr int CHUNKS = (64 * K / 8) / 256;       // 16-byte chunks of a weight group per thread: 2, 4, 8
-  __shared__ __align__(16) _Float16 wl[2][64 * LDW];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long long blk = blockIdx.x;
-  const long long slab = blk / p.tiles_n;
-  const int tn = (int)(blk - slab * p.tiles_n);
-  const int r = lane & 31, h = lane >> 5;
-  const int N = p.N;
-  const long long m = slab * 128 + wv * 32 + r;
-  const long long mc = m < p.M ? m : p.M - 1;      // rows past the end re-read the last pixel, never stored
-  const bool store = m < p.M;
+__device__ __forceinline__ void conv1x1_direct_group(const Conv1x1DirectParams& p, const h8 (&xa)[KSTEPS], int n0, int n_end, int perm,
+                                              int h, long long mc, bool store, const h8 (&cur)[4], h8 (&nxt)[4]) {
+  const int K = p.K, N = p.N;
+  const _Float16* w0 = p.w + (long long)(n0 + perm) * K + 8 * h;
+  const _Float16* w1 = w0 + 16 * K;
+  const int c0 = n0 + 32 * h;
+  const long long off = mc * N + c0;
+  if (p.res && n0 + 64 < n_end) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = ldg16(p.res + off + 64 + 8 * q);
+  }
+  f16v acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const h8 a0 = ldg16(w0 + 16 * s);
+    const h8 a1 = ldg16(w1 + 16 * s);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xa[s], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[s], acc1, 0, 0, 0);
+  }
+  // lane (pixel r, half h): channels n0 + 32 h + [0, 32): acc0 -> +0..15, acc1 -> +16..31
+  const _Float16* bp = p.bias + c0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const h8 bv = ldg16(bp + 8 * q);
+    h8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = (q & 1) * 8 + e;
+      float v = (q < 2 ? acc0[idx] : acc1[idx]) + (float)bv[e];
+      if (p.res) v = v + (float)cur[q][e];
+      if (p.relu) v = (v < 0.0f) ? 0.0f : v;
+      ov[e] = (_Float16)v;
+    }
+    if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
+  }
+}
 
-  // B operand: pixel r, k = 16 s + 8 h .. + 7 (kept for the whole channel loop: x is read from HBM once)
+// KSTEPS = K / 16 (4, 8 or 16): the pixel fragments of the whole K live in registers
+template <int KSTEPS>
+__global__ void __launch_bounds__(256) k_conv1x1_f16_direct(Conv1x1DirectParams p) {
+  const int lane = threadIdx.x & 63;
+  const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= p.waves) return;                       // (whole waves leave; no barrier in this kernel)
+  const long long slab = gw / p.tiles_n;
+  const int tn = (int)(gw - slab * p.tiles_n);
+  const int r = lane & 31, h = lane >> 5;
+  const int K = p.K, N = p.N;
+  const long long m = slab * 32 + r;
+  const long long mc = m < p.M ? m : p.M - 1;      // rows past the end re-read the last pixel, never stored
+
+  // B operand: pixel r, k = 16 s + 8 h .. + 7
   h8 xa[KSTEPS];
   const _Float16* xrow = p.x + mc * K + 8 * h;
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) xa[s] = ldg16(xrow + 16 * s);
 
+  // A operand rows: MFMA row r <-> channel (of a 64-channel group) perm(r) + 16 j
+  const int perm = 32 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
   const int n_begin = tn * p.nt, n_end = n_begin + p.nt;
-  // this thread's chunks of a weight group: LDS row lr (MFMA row lr & 31 of block lr >> 5) <- channel perm
-  int goff[CHUNKS], loff[CHUNKS];
+  // the shortcut of a group is requested one group AHEAD (two register buffers, the loop handles two groups per
+  // trip): its HBM latency is covered by the previous group's weight loads, MFMAs and stores
+  h8 ra[4], rb[4];
+  if (p.res) {
 #pragma unroll
-  for (int i = 0; i < CHUNKS; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    const int lr = c / (K / 8), cc = c - lr * (K / 8);
-    const int ri = lr & 31, j = lr >> 5;
-    const int ch = 32 * ((ri >> 2) & 1) + 16 * j + 4 * (ri >> 3) + (ri & 3);
-    goff[i] = ch * K + 8 * cc;
-    loff[i] = lr * LDW + 8 * cc;
+    for (int q = 0; q < 4; ++q) ra[q] = ldg16(p.res + mc * N + n_begin + 32 * h + 8 * q);
   }
-  h8 wreg[CHUNKS];
-#pragma unroll
-  for (int i = 0; i < CHUNKS; ++i) wreg[i] = ldg16(p.w + (long long)n_begin * K + goff[i]);
-  // bias and shortcut of a group start its accumulators (acc = bias + shortcut, then += W.x); they are requested
-  // one group AHEAD into `pre`, converted at the group's start -- which frees `pre` for the group after
-  h8 pre_b[4], pre_r[4];
-  const long long row_off = mc * N + 32 * h;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    pre_b[q] = ldg16(p.bias + n_begin + 32 * h + 8 * q);
-    if (p.res) pre_r[q] = ldg16(p.res + row_off + n_begin + 8 * q);
-  }
-#pragma unroll
-  for (int i = 0; i < CHUNKS; ++i) *reinterpret_cast<h8*>(&wl[0][loff[i]]) = wreg[i];
-  __syncthreads();
-
-  int b = 0;
-  for (int n0 = n_begin; n0 < n_end; n0 += 64, b ^= 1) {     // (n_end - n_begin is the same for every wave)
-    const bool more = n0 + 64 < n_end;
-    f16v acc0, acc1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = (float)pre_b[q][e];
-        if (p.res) v = v + (float)pre_r[q][e];
-        const int idx = (q & 1) * 8 + e;
-        if (q < 2) acc0[idx] = v; else acc1[idx] = v;
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < CHUNKS; ++i) wreg[i] = ldg16(p.w + (long long)(n0 + 64) * K + goff[i]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pre_b[q] = ldg16(p.bias + n0 + 64 + 32 * h + 8 * q);
-        if (p.res) pre_r[q] = ldg16(p.res + row_off + n0 + 64 + 8 * q);
-      }
-    }
-    const _Float16* l0 = &wl[b][r * LDW + 8 * h];
-    const _Float16* l1 = l0 + 32 * LDW;
-    if constexpr (KSTEPS <= 8) {
-      // weight fragments two k-steps ahead of the MFMAs that use them (LDS latency ~ two MFMA pairs)
-      h8 f0[3], f1[3];
-      f0[0] = *reinterpret_cast<const h8*>(l0); f1[0] = *reinterpret_cast<const h8*>(l1);
-      f0[1] = *reinterpret_cast<const h8*>(l0 + 16); f1[1] = *reinterpret_cast<const h8*>(l1 + 16);
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        if (s + 2 < KSTEPS) {
-          f0[(s + 2) % 3] = *reinterpret_cast<const h8*>(l0 + 16 * (s + 2));
-          f1[(s + 2) % 3] = *reinterpret_cast<const h8*>(l1 + 16 * (s + 2));
-        }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[s % 3], xa[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[s % 3], xa[s], acc1, 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        const h8 a0 = *reinterpret_cast<const h8*>(l0 + 16 * s);
-        const h8 a1 = *reinterpret_cast<const h8*>(l1 + 16 * s);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xa[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[s], acc1, 0, 0, 0);
-      }
-    }
-    // lane (pixel r, half h): channels n0 + 32 h + [0, 32): acc0 -> +0..15, acc1 -> +16..31
-    const long long off = mc * N + n0 + 32 * h;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      h8 ov;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int idx = (q & 1) * 8 + e;
-        float v = q < 2 ? acc0[idx] : acc1[idx];
-        if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-        ov[e] = (_Float16)v;
-      }
-      if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < CHUNKS; ++i) *reinterpret_cast<h8*>(&wl[b ^ 1][loff[i]]) = wreg[i];
-    }
-    __syncthreads();     // buffer b is free for the group after next; buffer b ^ 1 is complete
+  for (int n0 = n_begin; n0 < n_end; n0 += 128) {
+    conv1x1_direct_group<KSTEPS>(p, xa, n0, n_end, perm, h, mc, m < p.M, ra, rb);
+    if (n0 + 64 < n_end) conv1x1_direct_group<KSTEPS>(p, xa, n0 + 64, n_end, perm, h, mc, m < p.M, rb, ra);
   }
 }
 
-extern "C" int odet_conv1x1_f16(const void* x, const void* w, const void* bias, const void* residual, void* y,
+extern "C" int odet_conv1x1_f16_direct(const void* x, const void* w, const void* bias, const void* residual, void* y,
                                 long long npix, int cin, int cout, int relu, odet_stream_t stream) {
-  ODET_REQUIRE(x && w && bias && y, "odet_conv1x1_f16: null pointer");
-  ODET_REQUIRE(npix >= 0 && npix < (1ll << 40), "odet_conv1x1_f16: bad pixel count");
-  ODET_REQUIRE(cin == 64 || cin == 128 || cin == 256, "odet_conv1x1_f16: input channels must be 64, 128 or 256 (got %d)", cin);
-  ODET_REQUIRE(cout > 0 && cout % 64 == 0, "odet_conv1x1_f16: output channels must be a multiple of 64 (got %d)", cout);
+  ODET_REQUIRE(x && w && bias && y, "odet_conv1x1_f16_direct: null pointer");
+  ODET_REQUIRE(npix >= 0 && npix < (1ll << 40), "odet_conv1x1_f16_direct: bad pixel count");
+  ODET_REQUIRE(cin == 64 || cin == 128 || cin == 256, "odet_conv1x1_f16_direct: input channels must be 64, 128 or 256 (got %d)", cin);
+  ODET_REQUIRE(cout > 0 && cout % 64 == 0, "odet_conv1x1_f16_direct: output channels must be a multiple of 64 (got %d)", cout);
   ODET_REQUIRE(((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)y) % 16 == 0,
-               "odet_conv1x1_f16: pointers must be 16-byte aligned");
+               "odet_conv1x1_f16_direct: pointers must be 16-byte aligned");
   if (npix == 0) return ODET_OK;
-  Conv1x1Params p;
+  Conv1x1DirectParams p;
   p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = (const _Float16*)bias;
   p.res = (const _Float16*)residual; p.y = (_Float16*)y;
   p.M = npix; p.K = cin; p.N = cout; p.relu = relu ? 1 : 0;
   // channels per wave tile: the whole row up to 256 channels; wider outputs are split so that small feature maps
   // still give the chip enough waves (the waves of a pixel slab sit in one workgroup and share its x lines in L1)
   p.nt = cout <= 256 ? cout : (cout % 256 == 0 ? 256 : 64);
-  if (const char* e = getenv("ODET_CONV1X1_NT")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0 && cout % v == 0) p.nt = v; }
   p.tiles_n = cout / p.nt;
-  p.waves = 0;
-  const long long blocks = ((npix + 127) / 128) * p.tiles_n;
-  ODET_REQUIRE(blocks < (1ll << 31), "odet_conv1x1_f16: too many workgroups");
+  p.waves = ((npix + 31) / 32) * p.tiles_n;
+  const long long blocks = (p.waves + 3) / 4;
+  ODET_REQUIRE(blocks < (1ll << 31), "odet_conv1x1_f16_direct: too many workgroups");
   dim3 grid((unsigned)blocks), block(256);
   switch (cin) {
-    case 64: hipLaunchKernelGGL(k_conv1x1_f16<4>, grid, block, 0, (hipStream_t)stream, p); break;
-    case 128: hipLaunchKernelGGL(k_conv1x1_f16<8>, grid, block, 0, (hipStream_t)stream, p); break;
-    default: hipLaunchKernelGGL(k_conv1x1_f16<16>, grid, block, 0, (hipStream_t)stream, p); break;
+    case 64: hipLaunchKernelGGL(k_conv1x1_f16_direct<4>, grid, block, 0, (hipStream_t)stream, p); break;
+    case 128: hipLaunchKernelGGL(k_conv1x1_f16_direct<8>, grid, block, 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL(k_conv1x1_f16_direct<16>, grid, block, 0, (hipStream_t)stream, p); break;
   }
   ODET_LAUNCH_CHECK();
   return ODET_OK;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Checks and times the experimental odet_conv1x1_f16 (tools/exp/conv1x1_mfma.hip) against the detectors' route
-(library convolution + ops.bias_act_ with the shortcut).  Needs a library that contains the kernel:
+"""Checks and times the MFMA 1x1 convolutions -- the product's odet_conv1x1_f16 (csrc/conv1x1.hip) and, when the loaded
+library has it, the experimental direct-to-register odet_conv1x1_f16_direct (tools/exp/conv1x1_mfma.hip) -- against
+the library route (convolution + ops.bias_act_ with the shortcut).  For the experimental kernel:
 
     bash tools/exp/conv1x1_mfma_build.sh && ODET_LIB_PATH=tools/exp/_ablate/libodet_hip_conv1x1.so \\
         python tools/exp/conv1x1_mfma_bench.py"""
@@ -11,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from tf_eager_object_detection_amd import _lib, ops
 
 lib = _lib.lib()
-fn = lib.odet_conv1x1_f16
+name = 'odet_conv1x1_f16_direct' if (hasattr(lib, 'odet_conv1x1_f16_direct') and '--product' not in sys.argv) else 'odet_conv1x1_f16'
+print('kernel:', name)
+fn = getattr(lib, name)
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One layer shape through the experimental odet_conv1x1_f16 a few times (for rocprofv3 --pmc passes):
-    ODET_LIB_PATH=... python tools/exp/conv1x1_mfma_one.py H W CIN COUT [reps]"""
+"""One layer shape through odet_conv1x1_f16 a few times (for rocprofv3 --pmc passes):
+    python tools/exp/conv1x1_mfma_one.py H W CIN COUT [reps]"""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
