@@ -20,14 +20,14 @@
 //    j = block 0 / 1), which makes those 16 registers 16 CONSECUTIVE channels and the two blocks of a group 32
 //    consecutive channels: the shortcut is read and the output written with 16-byte accesses, 64 contiguous bytes
 //    per lane, a full 128-byte line per pixel from the two lane halves.
-//  * bias and shortcut START the accumulators (acc = bias + shortcut, then += W.x) and are requested one group
-//    ahead, so their latency is covered by the previous group's MFMAs and nothing but ReLU + one rounding + the
-//    store follows the contraction.
+//  * the shortcut STARTS the accumulators (acc = shortcut, then += W.x) and is requested TWO groups ahead (a
+//    wave's 64-channel groups are short next to an HBM round trip); the tile's bias slice sits in LDS; bias +
+//    ReLU + one rounding + the store follow the contraction.
 //
 // HBM bytes per call: M*K*2 (x) + M*N*2 (shortcut) + M*N*2 (y) -- the algorithmic minimum.  Measured (batch 8 at
-// 800x1333; library convolution + epilogue pass beside it): 64 -> 256 at 200x334 157 us = 3.9 TB/s (225 us);
-// 128 -> 512 at 100x167 91 us (110 us); 256 -> 1024 at 50x84 57 us (64 us); 256 -> 64 at 200x334 without
-// shortcut 77 us (89 us).  History and the direct-to-register first versions: tools/exp/conv1x1_mfma.hip.
+// 800x1333; library convolution + epilogue pass beside it): 64 -> 256 at 200x334 146 us = 4.2 TB/s (225 us);
+// 128 -> 512 at 100x167 88 us (110 us); 256 -> 1024 at 50x84 56 us (64 us); 256 -> 64 at 200x334 without
+// shortcut 78 us (89 us).  History and the direct-to-register first versions: tools/exp/conv1x1_mfma.hip.
 #include <hip/hip_fp16.h>
 
 #include "odet_internal.h"
@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
   constexpr int LDW = K + 8;                       // LDS row stride in halfs (2K + 16 bytes)
   constexpr int CHUNKS = (64 * K / 8) / 256;       // 16-byte chunks of a weight group per thread: 2, 4, 8
   __shared__ __align__(16) _Float16 wl[2][64 * LDW];
+  __shared__ __align__(16) _Float16 bl[256];          // the tile's bias slice (nt <= 256)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const long long blk = blockIdx.x;
   const long long slab = blk / p.tiles_n;
@@ -86,86 +87,108 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
   h8 wreg[CHUNKS];
 #pragma unroll
   for (int i = 0; i < CHUNKS; ++i) wreg[i] = ldg16(p.w + (long long)n_begin * K + goff[i]);
-  // bias and shortcut of a group start its accumulators (acc = bias + shortcut, then += W.x); they are requested
-  // one group AHEAD into `pre`, converted at the group's start -- which frees `pre` for the group after
-  h8 pre_b[4], pre_r[4];
+  // The shortcut of a group STARTS its accumulators (acc = shortcut, then += W.x) and is requested TWO groups
+  // ahead (buffers ra / rb, two groups per loop trip; a buffer is refilled right after its conversion): a wave's
+  // groups are short next to an HBM round trip, and with one group of lead every group waited for one.  The
+  // tile's bias slice sits in LDS and joins in the epilogue.
+  h8 ra[4], rb[4];
   const long long row_off = mc * N + 32 * h;
+  if (p.res) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    pre_b[q] = ldg16(p.bias + n_begin + 32 * h + 8 * q);
-    if (p.res) pre_r[q] = ldg16(p.res + row_off + n_begin + 8 * q);
+    for (int q = 0; q < 4; ++q) ra[q] = ldg16(p.res + row_off + n_begin + 8 * q);
+    if (n_begin + 64 < n_end) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rb[q] = ldg16(p.res + row_off + n_begin + 64 + 8 * q);
+    }
   }
+  if ((int)threadIdx.x * 8 < p.nt) *reinterpret_cast<h8*>(&bl[threadIdx.x * 8]) = ldg16(p.bias + n_begin + threadIdx.x * 8);
 #pragma unroll
   for (int i = 0; i < CHUNKS; ++i) *reinterpret_cast<h8*>(&wl[0][loff[i]]) = wreg[i];
   __syncthreads();
 
-  int b = 0;
-  for (int n0 = n_begin; n0 < n_end; n0 += 64, b ^= 1) {     // (n_end - n_begin is the same for every wave)
+  auto group = [&](const int n0, const int b, h8 (&pre)[4]) {
     const bool more = n0 + 64 < n_end;
     f16v acc0, acc1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float v = (float)pre_b[q][e];
-        if (p.res) v = v + (float)pre_r[q][e];
+        const float v = p.res ? (float)pre[q][e] : 0.0f;
         const int idx = (q & 1) * 8 + e;
         if (q < 2) acc0[idx] = v; else acc1[idx] = v;
       }
     }
+#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 2      /* diagnostic: the weight group is loaded once */
+    if (more && n0 == n_begin) {
+#else
     if (more) {
+#endif
 #pragma unroll
       for (int i = 0; i < CHUNKS; ++i) wreg[i] = ldg16(p.w + (long long)(n0 + 64) * K + goff[i]);
+    }
+#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 3      /* diagnostic: the shortcut is loaded once */
+    if (p.res && n0 + 128 < n_end && n0 == n_begin) {
+#else
+    if (p.res && n0 + 128 < n_end) {
+#endif
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        pre_b[q] = ldg16(p.bias + n0 + 64 + 32 * h + 8 * q);
-        if (p.res) pre_r[q] = ldg16(p.res + row_off + n0 + 64 + 8 * q);
-      }
+      for (int q = 0; q < 4; ++q) pre[q] = ldg16(p.res + row_off + n0 + 128 + 8 * q);
     }
     const _Float16* l0 = &wl[b][r * LDW + 8 * h];
     const _Float16* l1 = l0 + 32 * LDW;
-    if constexpr (KSTEPS <= 8) {
-      // weight fragments two k-steps ahead of the MFMAs that use them (LDS latency ~ two MFMA pairs)
-      h8 f0[3], f1[3];
-      f0[0] = *reinterpret_cast<const h8*>(l0); f1[0] = *reinterpret_cast<const h8*>(l1);
-      f0[1] = *reinterpret_cast<const h8*>(l0 + 16); f1[1] = *reinterpret_cast<const h8*>(l1 + 16);
+    // weight fragments two k-steps AHEAD of the MFMAs that use them; the scheduling barriers keep hipcc from
+    // sinking the reads back next to their uses (read -> wait -> MFMA per step otherwise)
+    h8 f0[3], f1[3];
+    f0[0] = *reinterpret_cast<const h8*>(l0); f1[0] = *reinterpret_cast<const h8*>(l1);
+    f0[1] = *reinterpret_cast<const h8*>(l0 + 16); f1[1] = *reinterpret_cast<const h8*>(l1 + 16);
+#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 5      /* diagnostic: no k-loop (no LDS reads, no MFMAs) */
+    for (int s = 0; s < (p.relu == 77 ? KSTEPS : 0); ++s) {
+#else
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        if (s + 2 < KSTEPS) {
-          f0[(s + 2) % 3] = *reinterpret_cast<const h8*>(l0 + 16 * (s + 2));
-          f1[(s + 2) % 3] = *reinterpret_cast<const h8*>(l1 + 16 * (s + 2));
-        }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[s % 3], xa[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[s % 3], xa[s], acc1, 0, 0, 0);
+    for (int s = 0; s < KSTEPS; ++s) {
+#endif
+      if (s + 2 < KSTEPS) {
+        f0[(s + 2) % 3] = *reinterpret_cast<const h8*>(l0 + 16 * (s + 2));
+        f1[(s + 2) % 3] = *reinterpret_cast<const h8*>(l1 + 16 * (s + 2));
       }
-    } else {
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        const h8 a0 = *reinterpret_cast<const h8*>(l0 + 16 * s);
-        const h8 a1 = *reinterpret_cast<const h8*>(l1 + 16 * s);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xa[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xa[s], acc1, 0, 0, 0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 4      /* diagnostic: LDS reads but no MFMAs */
+      acc0[s & 15] += (float)f0[s % 3][0]; acc1[s & 15] += (float)f1[s % 3][1];
+#else
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[s % 3], xa[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[s % 3], xa[s], acc1, 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
     // lane (pixel r, half h): channels n0 + 32 h + [0, 32): acc0 -> +0..15, acc1 -> +16..31
     const long long off = mc * N + n0 + 32 * h;
+    const _Float16* bp = &bl[n0 - n_begin + 32 * h];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      const h8 bv = *reinterpret_cast<const h8*>(bp + 8 * q);
       h8 ov;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int idx = (q & 1) * 8 + e;
-        float v = q < 2 ? acc0[idx] : acc1[idx];
+        float v = (q < 2 ? acc0[idx] : acc1[idx]) + (float)bv[e];
         if (p.relu) v = (v < 0.0f) ? 0.0f : v;
         ov[e] = (_Float16)v;
       }
+#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 1      /* diagnostic: no output stores */
+      if (store && ov[0] == (_Float16)12345.0f) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
+#else
       if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
+#endif
     }
     if (more) {
 #pragma unroll
       for (int i = 0; i < CHUNKS; ++i) *reinterpret_cast<h8*>(&wl[b ^ 1][loff[i]]) = wreg[i];
     }
     __syncthreads();     // buffer b is free for the group after next; buffer b ^ 1 is complete
+  };
+  for (int n0 = n_begin; n0 < n_end; n0 += 128) {     // (n_end - n_begin is the same for every wave: uniform trips)
+    group(n0, 0, ra);
+    if (n0 + 64 < n_end) group(n0 + 64, 1, rb);
   }
 }
 
