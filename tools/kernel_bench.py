@@ -94,6 +94,13 @@ def main():
         (2 * lat.numel() + top.numel()) * 2, 'lateral in + out + coarse map')
     sc = g16(B, 200, 334, 6); so = torch.empty((B, 200 * 334 * 3, 2), dtype=torch.float32, device='cuda'); bs = g16(6)
     add('odet_rpn_pack (P2 scores, fp16 -> fp32, batch 4)', timeit(lambda: ops.rpn_pack(sc, bs, so, 0)), sc.numel() * 6, 'fp16 in + fp32 out')
+    # the bottleneck blocks' last 1x1 convolution + bias + shortcut + ReLU on MFMA (batch 8, float16 NHWC)
+    for (h_, w_, cin, cout) in ((200, 334, 64, 256), (100, 167, 128, 512), (50, 84, 256, 1024)):
+        xx = g16(8, h_, w_, cin); ww = g16(cout, cin) * 0.05; bb = g16(cout); rr = g16(8, h_, w_, cout)
+        oo = torch.empty_like(rr)
+        add('odet_conv1x1_f16 (%d -> %d at %dx%d + shortcut + ReLU, fp16, batch 8)' % (cin, cout, h_, w_),
+            timeit(lambda: ops.conv1x1_f16(xx, ww, bb, rr, True, out=oo), warm=5, reps=50),
+            8 * h_ * w_ * (cin + 2 * cout) * 2, 'x + shortcut + y once; %.1f GFLOP' % (2e-9 * 8 * h_ * w_ * cin * cout))
     for r in rows:
         print('%-58s %8.1f us %s %s' % (r['entry'], r['us'], ('%8.1f GB/s' % r['GBps']) if r['GBps'] else ' ' * 13, r['note']))
     if a.json:
