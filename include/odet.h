@@ -346,6 +346,17 @@ int odet_rpn_pack_pair(const void* level_out, const void* bias, long long pixels
                        long long scores_image_stride, long long scores_offset, float* deltas,
                        long long deltas_image_stride, long long deltas_offset, int f16, odet_stream_t stream);
 
+/* The whole RpnHead after its 3x3 convolution in one pass (base_fpn_model.py:393-434, 188-200):
+ * conv_out [B, pixels, 512] = the 3x3 convolution WITHOUT its bias (float16 NHWC), conv_bias [512];
+ * t = relu(conv_out + conv_bias); scores = t . w[0:2A]^T + bias[0:2A]; deltas = t . w[2A:6A]^T + bias[2A:6A]
+ * (w [6A, 512] float16 = rpn_score's rows then rpn_bbox's, bias [6A] float16), written as float32 into the level's
+ * slices of the concatenated [B, N, 2] / [B, N, 4] arrays (offsets / strides in VALUES, as odet_rpn_pack_pair).
+ * Matrix cores, float32 accumulation; 1 <= A <= 4. */
+int odet_rpn_head_tail_f16(const void* conv_out, const void* conv_bias, const void* w, const void* bias,
+                           long long pixels, int A, int B, float* scores, long long scores_image_stride,
+                           long long scores_offset, float* deltas, long long deltas_image_stride,
+                           long long deltas_offset, odet_stream_t stream);
+
 /* ---- multi-GPU detection records ------------------------------------------------------ */
 
 /* Native addition (the reference has no multi-GPU path): packs the padded post-ops outputs of

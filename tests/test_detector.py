@@ -428,3 +428,46 @@ def test_conv1x1_mfma_kernel_exact_on_integer_data_and_close_on_random(M, K, N):
     assert out.data_ptr() == r2.data_ptr() and torch.equal(out.view(M, N), got)
     with pytest.raises(Exception):
         ops.conv1x1_f16(x[:, :48].contiguous(), w[:, :48].contiguous(), b, None, True)  # 48 input channels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('A', [3, 4, 1])
+def test_rpn_head_tail_mfma_kernel(A):
+    """odet_rpn_head_tail_f16 (RpnHead after its 3x3 convolution, base_fpn_model.py:393-434 + the reshape / concat of
+    :188-200): exact on integer data (fragment maps, the row order that puts deltas / scores into consecutive
+    registers, the level offsets), within float16 rounding of the float32 formulation on random data."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(40 + A)
+    B, shapes = 2, [(13, 17), (7, 9), (3, 5)]                    # 221 / 63 / 15 pixels: none fills a 128-pixel slab evenly
+    n = sum(h * w for h, w in shapes) * A
+    for kind in ('int', 'randn'):
+        scores = torch.full((B, n, 2), -7.0, dtype=torch.float32, device='cuda')
+        deltas = torch.full((B, n, 4), -7.0, dtype=torch.float32, device='cuda')
+        if kind == 'int':
+            ri = lambda lo, hi, *sh: torch.randint(lo, hi, sh, device='cuda', generator=g).to(torch.float16)
+            b1, w, b2 = ri(-2, 3, 512), ri(-2, 3, 6 * A, 512), ri(-8, 9, 6 * A)
+            w[:, 0] += torch.arange(6 * A, device='cuda').to(torch.float16)          # every output channel distinct
+        else:
+            rn = lambda *sh: torch.randn(sh, device='cuda', generator=g).to(torch.float16)
+            b1, w, b2 = rn(512), (rn(6 * A, 512).float() / 512 ** 0.5).to(torch.float16), rn(6 * A)
+        want_s, want_d, off = [], [], 0
+        for h, w_ in shapes:
+            c = (torch.randint(-3, 4, (B, h, w_, 512), device='cuda', generator=g).to(torch.float16) if kind == 'int'
+                 else torch.randn((B, h, w_, 512), device='cuda', generator=g).to(torch.float16))
+            if kind == 'int':
+                c[..., 1] += torch.arange(h * w_, device='cuda').remainder(5).view(1, h, w_).to(torch.float16)
+            ops.rpn_head_tail(c, b1, w.view(6 * A, 512, 1, 1), b2, A, scores, deltas, off)
+            t = torch.relu(c.float() + b1.float()).to(torch.float16).float()
+            o = t.reshape(B, -1, 512) @ w.float().t() + b2.float()
+            want_s.append(o[..., :2 * A].reshape(B, -1, 2))
+            want_d.append(o[..., 2 * A:].reshape(B, -1, 4))
+            off += h * w_ * A
+        ws, wd = torch.cat(want_s, 1), torch.cat(want_d, 1)
+        if kind == 'int':
+            assert torch.equal(scores, ws) and torch.equal(deltas, wd)
+        else:
+            torch.testing.assert_close(scores, ws, rtol=2e-3, atol=2e-3)
+            torch.testing.assert_close(deltas, wd, rtol=2e-3, atol=2e-3)
+    with pytest.raises(Exception):
+        ops.rpn_head_tail(torch.zeros(1, 2, 2, 512, device='cuda', dtype=torch.float16), b1, w, b2, A,
+                          torch.zeros(1, 3 * A, 2, device='cuda'), torch.zeros(1, 3 * A, 4, device='cuda'), 0)   # 4 px, 3 fit

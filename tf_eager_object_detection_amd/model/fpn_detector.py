@@ -326,10 +326,19 @@ class ResNetFpnDetector(nn.Module):
             scores = torch.empty((B, n, 2), dtype=torch.float32, device=p_list[0].device)
             deltas = torch.empty((B, n, 4), dtype=torch.float32, device=p_list[0].device)
             off = 0
+            fused = p_list[0].dtype == torch.float16 and self.rpn_conv.out_channels == 512 and self.A <= 4
             for p in p_list:
-                x = _conv_epi(self.rpn_conv, p, relu=True)
-                sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
-                ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, off)
+                if fused:
+                    # float16: the 3x3 convolution without bias, then ONE MFMA pass does bias + ReLU + both 1x1
+                    # convolutions + their biases + the float32 re-layout (ops.rpn_head_tail)
+                    c = F.conv2d(p, self.rpn_conv.weight, None, 1, self.rpn_conv.padding)
+                    if not c.is_contiguous(memory_format=torch.channels_last):
+                        c = c.contiguous(memory_format=torch.channels_last)
+                    ops.rpn_head_tail(c.permute(0, 2, 3, 1), self.rpn_conv.bias, w, b, self.A, scores, deltas, off)
+                else:
+                    x = _conv_epi(self.rpn_conv, p, relu=True)
+                    sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
+                    ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, off)
                 off += int(p.shape[2]) * int(p.shape[3]) * self.A
             return scores, deltas
         scores, deltas = [], []

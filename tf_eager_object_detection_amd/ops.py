@@ -369,6 +369,32 @@ def rpn_pack(level_out, bias, out, out_offset):
     return out
 
 
+def rpn_head_tail(conv_out, conv_bias, weight, bias, num_anchors, scores, deltas, anchor_offset):
+    """Everything of the RpnHead after its 3x3 convolution for one level, in one MFMA pass: ``conv_out`` [B,h,w,512]
+    float16 NHWC contiguous (the 3x3 convolution WITHOUT its bias), ``conv_bias`` [512], ``weight`` [6A,512(,1,1)]
+    (2A score rows then 4A delta rows), ``bias`` [6A]; relu(conv_out + conv_bias) . weight^T + bias -> the level's
+    slices of ``scores`` [B,N,2] / ``deltas`` [B,N,4] (float32) starting at anchor ``anchor_offset``."""
+    A = int(num_anchors)
+    if conv_out.dim() != 4 or conv_out.dtype != torch.float16 or not conv_out.is_contiguous() or conv_out.shape[3] != 512:
+        raise ValueError('conv_out must be a contiguous float16 NHWC [B,h,w,512] tensor')
+    if weight.dtype != torch.float16 or weight.numel() != 6 * A * 512:
+        raise ValueError('weight must be a float16 [6A, 512] tensor')
+    w = weight.reshape(6 * A, 512)
+    if not w.is_contiguous():
+        w = w.contiguous()
+    for t, n_ in ((conv_bias, 512), (bias, 6 * A)):
+        if t.dtype != torch.float16 or t.numel() != n_ or not t.is_contiguous():
+            raise ValueError('conv_bias [512] / bias [6A] must be contiguous float16 tensors')
+    B, h, w_ = (int(v) for v in conv_out.shape[:3])
+    for t, k in ((scores, 2), (deltas, 4)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 3 or t.shape[0] != B or t.shape[2] != k:
+            raise ValueError('scores / deltas must be contiguous float32 [B, N, 2] / [B, N, 4] tensors')
+    L.call('odet_rpn_head_tail_f16', L.dptr(conv_out), L.dptr(conv_bias), L.dptr(w), L.dptr(bias), h * w_, A, B,
+           L.dptr(scores), scores.numel() // max(B, 1), int(anchor_offset) * 2, L.dptr(deltas),
+           deltas.numel() // max(B, 1), int(anchor_offset) * 4, L.stream())
+    return scores, deltas
+
+
 def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None):
     """1x1 stride-1 convolution + bias (+ residual) (+ ReLU) in ONE kernel on the matrix cores: ``x`` [..., cin]
     NHWC float16 contiguous (any leading dims), ``weight`` [cout, cin(, 1, 1)], ``bias`` [cout], ``residual`` /
