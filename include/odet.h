@@ -325,12 +325,14 @@ int odet_bias_act(void* x, const void* bias, const void* residual, long long npi
 
 /* 1x1 stride-1 convolution with its whole epilogue on the matrix cores (the third convolution
  * of a bottleneck block + Add([shortcut, x]) + Activation('relu'), model/fpn/resnet_fpn.py:154-205, frozen
- * BatchNormalization folded into w / bias): y[npix, cout] = relu?(x[npix, cin] . w[cout, cin]^T + bias[cout]
+ * BatchNormalization folded into w / bias): y[npix, cout] = relu?(x'[npix, cin] . w[cout, cin]^T + bias[cout]
  * (+ residual[npix, cout])), all float16 NHWC (w = the convolution's [cout, cin, 1, 1] weight), float32
- * accumulation, one rounding.  cin in {64, 128, 256}, cout % 64 == 0, 16-byte aligned pointers; residual may be
- * NULL; y must not alias x (it may alias residual). */
-int odet_conv1x1_f16(const void* x, const void* w, const void* bias, const void* residual, void* y,
-                     long long npix, int cin, int cout, int relu, odet_stream_t stream);
+ * accumulation, one rounding.  x' = x, or relu(x + in_bias[cin]) when in_bias != NULL (x is then the preceding
+ * convolution WITHOUT its bias and ReLU: the block's 3x3 convolution; its epilogue pass disappears).
+ * cin in {64, 128, 256}, cout % 64 == 0, 16-byte aligned pointers; in_bias / residual may be NULL; y must not
+ * alias x (it may alias residual). */
+int odet_conv1x1_f16(const void* x, const void* in_bias, const void* w, const void* bias, const void* residual,
+                     void* y, long long npix, int cin, int cout, int relu, odet_stream_t stream);
 
 /* RPN head epilogue (model/fpn/base_fpn_model.py:188-200,427-432): one pyramid level's 1x1
  * convolution output level_out [B, pixels, ch] (NHWC, ch = 2A scores or 4A deltas, float32 or float16, WITHOUT

@@ -422,6 +422,10 @@ def test_conv1x1_mfma_kernel_exact_on_integer_data_and_close_on_random(M, K, N):
     want = torch.relu(x.float() @ w.float().t() + b.float() + r.float())
     got = ops.conv1x1_f16(x, w, b, r, True)
     torch.testing.assert_close(got.float(), want, rtol=2e-3, atol=2e-3)
+    # the producer's epilogue on load: x is a convolution without bias / ReLU
+    ib = torch.randn(K, device='cuda', generator=g).to(torch.float16)
+    xin = torch.relu(x.float() + ib.float()).to(torch.float16)
+    assert torch.equal(ops.conv1x1_f16(x, w, b, r, True, in_bias=ib), ops.conv1x1_f16(xin, w, b, r, True))
     # in place on the shortcut, NHWC leading dims
     r2 = r.clone().view(1, M, 1, N)
     out = ops.conv1x1_f16(x.view(1, M, 1, K), w, b, r2, True, out=r2)

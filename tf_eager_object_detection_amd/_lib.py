@@ -106,7 +106,7 @@ SIGNATURES = {
     'odet_rpn_pack': (_i, [_vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp]),
     'odet_rpn_head_tail_f16': (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _vp,
                                     C.c_longlong, C.c_longlong, _vp]),
-    'odet_conv1x1_f16': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _vp]),
+    'odet_conv1x1_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _vp]),
     'odet_rpn_pack_pair': (_i, [_vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _vp, C.c_longlong,
                                 C.c_longlong, _i, _vp]),
     'odet_fpn_step_enqueue': (_i, [_vp, _i]),

@@ -24,6 +24,9 @@
 //    wave's 64-channel groups are short next to an HBM round trip); the tile's bias slice sits in LDS; bias +
 //    ReLU + one rounding + the store follow the contraction.
 //
+//  * optionally the PRODUCER's epilogue rides on the operand load (in_bias: x is the preceding 3x3 convolution without
+//    bias / ReLU; relu(x + in_bias) is applied to the fragments once per pixel), which removes that layer's pass.
+//
 // HBM bytes per call: M*K*2 (x) + M*N*2 (shortcut) + M*N*2 (y) -- the algorithmic minimum.  Measured (batch 8 at
 // 800x1333; library convolution + epilogue pass beside it): 64 -> 256 at 200x334 146 us = 4.2 TB/s (225 us);
 // 128 -> 512 at 100x167 88 us (110 us); 256 -> 1024 at 50x84 56 us (64 us); 256 -> 64 at 200x334 without
@@ -37,6 +40,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 struct Conv1x1Params {
   const _Float16* x; const _Float16* w; const _Float16* bias; const _Float16* res; _Float16* y;
+  const _Float16* in_bias;   // nullable: x is a convolution WITHOUT its bias / ReLU; relu(x + in_bias) is applied on load
   long long M;
   int K, N, relu;
   int tiles_n;      // N / nt
@@ -71,6 +75,20 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
   const _Float16* xrow = p.x + mc * K + 8 * h;
 #pragma unroll
   for (int s = 0; s < KSTEPS; ++s) xa[s] = ldg16(xrow + 16 * s);
+  if (p.in_bias) {
+    // the producer's epilogue on the way in (the 3x3 convolution before this one ran without bias / ReLU):
+    // bias_act's arithmetic -- float32 add, ReLU, one rounding -- on the operand fragments, once per pixel
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const h8 bv = ldg16(p.in_bias + 16 * s + 8 * h);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = (float)xa[s][e] + (float)bv[e];
+        v = (v < 0.0f) ? 0.0f : v;
+        xa[s][e] = (_Float16)v;
+      }
+    }
+  }
 
   const int n_begin = tn * p.nt, n_end = n_begin + p.nt;
   // this thread's chunks of a weight group: LDS row lr (MFMA row lr & 31 of block lr >> 5) <- channel perm
@@ -192,18 +210,18 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
   }
 }
 
-extern "C" int odet_conv1x1_f16(const void* x, const void* w, const void* bias, const void* residual, void* y,
-                                long long npix, int cin, int cout, int relu, odet_stream_t stream) {
+extern "C" int odet_conv1x1_f16(const void* x, const void* in_bias, const void* w, const void* bias, const void* residual,
+                                void* y, long long npix, int cin, int cout, int relu, odet_stream_t stream) {
   ODET_REQUIRE(x && w && bias && y, "odet_conv1x1_f16: null pointer");
   ODET_REQUIRE(npix >= 0 && npix < (1ll << 40), "odet_conv1x1_f16: bad pixel count");
   ODET_REQUIRE(cin == 64 || cin == 128 || cin == 256, "odet_conv1x1_f16: input channels must be 64, 128 or 256 (got %d)", cin);
   ODET_REQUIRE(cout > 0 && cout % 64 == 0, "odet_conv1x1_f16: output channels must be a multiple of 64 (got %d)", cout);
-  ODET_REQUIRE(((uintptr_t)x | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)y) % 16 == 0,
+  ODET_REQUIRE(((uintptr_t)x | (uintptr_t)in_bias | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)y) % 16 == 0,
                "odet_conv1x1_f16: pointers must be 16-byte aligned");
   if (npix == 0) return ODET_OK;
   Conv1x1Params p;
   p.x = (const _Float16*)x; p.w = (const _Float16*)w; p.bias = (const _Float16*)bias;
-  p.res = (const _Float16*)residual; p.y = (_Float16*)y;
+  p.res = (const _Float16*)residual; p.y = (_Float16*)y; p.in_bias = (const _Float16*)in_bias;
   p.M = npix; p.K = cin; p.N = cout; p.relu = relu ? 1 : 0;
   // channels per wave tile: the whole row up to 256 channels; wider outputs are split so that small feature maps
   // still give the chip enough waves (the waves of a pixel slab sit in one workgroup and share its x lines in L1)

@@ -73,8 +73,8 @@ def _conv_1x1(conv, x, bias, relu, res):
     return y
 
 
-def _mfma_1x1(conv, x, bias, relu, res):
-    return ops.conv1x1_f16(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu).permute(0, 3, 1, 2)
+def _mfma_1x1(conv, x, bias, relu, res, in_bias=None):
+    return ops.conv1x1_f16(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu, in_bias=in_bias).permute(0, 3, 1, 2)
 
 
 def _time_route(fn, reps=5):
@@ -171,6 +171,20 @@ class _Block(nn.Module):
         else:
             sc, sb = F.conv2d(x, self.short.weight, None, self.short.stride, self.short.padding), self.short.bias
         y = _conv_epi(self.c1, x, relu=True)
+        if y.is_cuda and y.dtype == torch.float16 and self.c3.in_channels in (64, 128, 256):
+            # c2 (3x3) runs WITHOUT bias / ReLU; if c3 takes the MFMA route for this shape, c2's epilogue is applied
+            # to c3's operand fragments as they are loaded (ops.conv1x1_f16(in_bias=...)) and its pass disappears
+            y2 = F.conv2d(y, self.c2.weight, None, self.c2.stride, self.c2.padding)
+            if not y2.is_contiguous(memory_format=torch.channels_last):
+                y2 = y2.contiguous(memory_format=torch.channels_last)
+            res = sc.permute(0, 2, 3, 1)
+            if not res.is_contiguous():
+                res = res.contiguous()
+            b3 = self.c3.bias if sb is None else self.c3.bias + sb
+            if _route_1x1(self.c3, y2, b3, True, res) == 'mfma':
+                return _mfma_1x1(self.c3, y2, b3, True, res, in_bias=self.c2.bias)
+            ops.bias_act_(y2.permute(0, 2, 3, 1), self.c2.bias, None, True)
+            return _conv_epi(self.c3, y2, relu=True, residual=sc, extra_bias=sb)
         y = _conv_epi(self.c2, y, relu=True)
         return _conv_epi(self.c3, y, relu=True, residual=sc, extra_bias=sb)
 

@@ -395,10 +395,11 @@ def rpn_head_tail(conv_out, conv_bias, weight, bias, num_anchors, scores, deltas
     return scores, deltas
 
 
-def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None):
+def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None, in_bias=None):
     """1x1 stride-1 convolution + bias (+ residual) (+ ReLU) in ONE kernel on the matrix cores: ``x`` [..., cin]
     NHWC float16 contiguous (any leading dims), ``weight`` [cout, cin(, 1, 1)], ``bias`` [cout], ``residual`` /
-    ``out`` [..., cout] (``out`` may be ``residual``).  cin in {64, 128, 256}, cout % 64 == 0."""
+    ``out`` [..., cout] (``out`` may be ``residual``).  cin in {64, 128, 256}, cout % 64 == 0.  ``in_bias`` [cin]:
+    ``x`` is the preceding convolution without its bias and ReLU; relu(x + in_bias) is applied on load."""
     if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
         raise ValueError('x must be a contiguous float16 GPU tensor [..., cin]')
     cin = int(x.shape[-1])
@@ -420,7 +421,10 @@ def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None):
         raise ValueError('out must be a contiguous float16 tensor shaped like the output')
     if out.data_ptr() == x.data_ptr():
         raise ValueError('out must not alias x')
-    L.call('odet_conv1x1_f16', L.dptr(x), L.dptr(w), L.dptr(bias), L.dptr(residual) if residual is not None else None,
+    if in_bias is not None and (in_bias.dtype != torch.float16 or in_bias.numel() != cin or not in_bias.is_contiguous()):
+        raise ValueError('in_bias must be a contiguous float16 [cin] tensor')
+    L.call('odet_conv1x1_f16', L.dptr(x), L.dptr(in_bias) if in_bias is not None else None, L.dptr(w), L.dptr(bias),
+           L.dptr(residual) if residual is not None else None,
            L.dptr(out), x.numel() // cin, cin, cout, 1 if relu else 0, L.stream())
     return out
 

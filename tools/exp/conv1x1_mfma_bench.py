@@ -16,13 +16,14 @@ name = 'odet_conv1x1_f16_direct' if (hasattr(lib, 'odet_conv1x1_f16_direct') and
 print('kernel:', name)
 fn = getattr(lib, name)
 fn.restype = C.c_int
-fn.argtypes = [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+product = name == 'odet_conv1x1_f16'          # (the product entry point has an in_bias pointer after x)
+fn.argtypes = [C.c_void_p] * (6 if product else 5) + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
 
 
 def conv1x1(x, w, b, res, relu=True, out=None):
     cin, cout = x.shape[-1], w.shape[0]
     out = torch.empty(tuple(x.shape[:-1]) + (cout,), dtype=torch.float16, device='cuda') if out is None else out
-    _lib.check(fn(x.data_ptr(), w.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
+    _lib.check(fn(x.data_ptr(), *([None] if product else []), w.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
                   x.numel() // cin, cin, cout, 1 if relu else 0, _lib.stream()))
     return out
 
