@@ -323,6 +323,14 @@ int odet_fpn_topdown_merge(const void* top, int h, int w, const void* lateral, i
 int odet_bias_act(void* x, const void* bias, const void* residual, long long npix, int C, int relu,
                   int f16, odet_stream_t stream);
 
+/* Convolution epilogue + max-pooling in one pass (model/fpn/resnet_fpn.py:228-259 conv1 -> relu -> pool1;
+ * model/faster_rcnn/vgg16_faster_rcnn.py:260-342 conv -> relu -> MaxPooling2D((2,2), 2, 'same')):
+ * out[B, OH, OW, C] = maxpool_{kernel, stride, pad}(relu(x[B, H, W, C] + bias[C])), NHWC, x = the convolution
+ * WITHOUT its bias.  Window taps outside the map are skipped (= zero padding after a ReLU, = TF 'same').
+ * Bit-identical to the separate passes (bias and ReLU commute with the maximum).  f16: C % 8 == 0; else C % 4. */
+int odet_bias_relu_maxpool(const void* x, const void* bias, void* out, int B, int H, int W, int C, int OH, int OW,
+                           int kernel, int stride, int pad, int f16, odet_stream_t stream);
+
 /* 1x1 stride-1 convolution with its whole epilogue on the matrix cores (the third convolution
  * of a bottleneck block + Add([shortcut, x]) + Activation('relu'), model/fpn/resnet_fpn.py:154-205, frozen
  * BatchNormalization folded into w / bias): y[npix, cout] = relu?(x'[npix, cin] . w[cout, cin]^T + bias[cout]

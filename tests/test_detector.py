@@ -4,6 +4,7 @@ dense parts produced."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import c_oracle as co
 from tf_eager_object_detection_amd import synthetic as syn
@@ -475,3 +476,24 @@ def test_rpn_head_tail_mfma_kernel(A):
     with pytest.raises(Exception):
         ops.rpn_head_tail(torch.zeros(1, 2, 2, 512, device='cuda', dtype=torch.float16), b1, w, b2, A,
                           torch.zeros(1, 3 * A, 2, device='cuda'), torch.zeros(1, 3 * A, 4, device='cuda'), 0)   # 4 px, 3 fit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float16, torch.float32])
+def test_bias_relu_maxpool_identical_to_separate_passes(dt):
+    """odet_bias_relu_maxpool == max_pool2d(relu(x + bias)) bit for bit: the ResNet stem (resnet_fpn.py:228-259: pad 1 +
+    3x3/2) and VGG16's MaxPooling2D((2,2), 2, 'same') (odd sizes: ceil mode)."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    for (B, H, W, C, k, s, pad, ceil) in ((2, 41, 67, 64, 3, 2, 1, False), (1, 400, 667, 64, 3, 2, 1, False),
+                                           (2, 75, 100, 128, 2, 2, 0, True), (1, 38, 51, 512, 2, 2, 0, True),
+                                           (1, 8, 8, 8, 2, 2, 0, False)):
+        x = torch.randn(B, H, W, C, device='cuda', generator=g).to(dt)
+        b = torch.randn(C, device='cuda', generator=g).to(dt)
+        got = ops.bias_relu_maxpool(x, b, k, s, pad, ceil)
+        y = torch.relu((x.float() + b.float())).to(dt) if dt == torch.float16 else torch.relu(x + b)
+        want = F.max_pool2d(y.permute(0, 3, 1, 2), k, s, padding=pad, ceil_mode=ceil).permute(0, 2, 3, 1)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        assert torch.equal(got, want.contiguous())
+    with pytest.raises(Exception):
+        ops.bias_relu_maxpool(torch.zeros(1, 4, 4, 6, device='cuda'), torch.zeros(6, device='cuda'), 2, 2)     # C % 4

@@ -104,6 +104,7 @@ SIGNATURES = {
     'odet_fpn_topdown_merge': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'odet_bias_act': (_i, [_vp, _vp, _vp, C.c_longlong, _i, _i, _i, _vp]),
     'odet_rpn_pack': (_i, [_vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _i, _vp]),
+    'odet_bias_relu_maxpool': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_rpn_head_tail_f16': (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _vp,
                                     C.c_longlong, C.c_longlong, _vp]),
     'odet_conv1x1_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _vp]),

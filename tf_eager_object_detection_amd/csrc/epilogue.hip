@@ -90,6 +90,104 @@ extern "C" int odet_bias_act(void* x, const void* bias, const void* residual, lo
   return ODET_OK;
 }
 
+// ---- convolution epilogue + max-pooling in one pass -------------------------------------------------------
+// resnet_fpn.py:228-259 (conv1 -> bn -> relu -> pool1_pad + 3x3/2 max-pool) and vgg16_faster_rcnn.py:260-342
+// (conv + relu, then MaxPooling2D((2,2), 2, 'same') after each stage): out = maxpool(relu(conv + bias)).
+// Bias is per channel and ReLU / rounding are monotone, so maxpool(relu(x + b)) == relu(max(x) + b) bit for bit:
+// the window maximum is taken over the RAW convolution output, one pass reads it once and writes the pooled map
+// (1/4 of the pixels) -- instead of an epilogue pass (read + write of the full map) followed by a pooling pass.
+// Window taps outside the map are skipped; with values >= 0 after the ReLU that equals the reference's zero
+// padding (ZeroPadding2D + 'valid') and TF's 'same' pooling alike.
+struct PoolEpiParams {
+  const void* x; const void* bias; void* out;
+  int B, H, W, C, OH, OW, k, stride, pad;
+  long long total;            // B * OH * OW * (C / N) vectors
+};
+
+template <typename FT>
+__global__ void __launch_bounds__(256) k_bias_relu_maxpool(PoolEpiParams p) {
+  constexpr int N = sizeof(FT) == 2 ? 8 : 4;
+  const uint4* __restrict__ x = reinterpret_cast<const uint4*>(p.x);
+  const uint4* __restrict__ bias = reinterpret_cast<const uint4*>(p.bias);
+  uint4* __restrict__ out = reinterpret_cast<uint4*>(p.out);
+  const int vpp = p.C / N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (long long)gridDim.x * 256) {
+    const int v = (int)(i % vpp);
+    long long t = i / vpp;
+    const int ox = (int)(t % p.OW); t /= p.OW;
+    const int oy = (int)(t % p.OH);
+    const int b = (int)(t / p.OH);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int ky = 0; ky < p.k; ++ky) {
+      const int iy = oy * p.stride - p.pad + ky;
+      if (iy < 0 || iy >= p.H) continue;
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int ix = ox * p.stride - p.pad + kx;
+        if (ix < 0 || ix >= p.W) continue;
+        const uint4 xv = x[(((long long)b * p.H + iy) * p.W + ix) * vpp + v];
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (sizeof(FT) == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&xw[q]));
+            m[2 * q] = fmaxf(m[2 * q], f.x); m[2 * q + 1] = fmaxf(m[2 * q + 1], f.y);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], __uint_as_float(xw[q]));
+        }
+      }
+    }
+    const uint4 bv = bias[v];
+    const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
+    uint4 o;
+    if (sizeof(FT) == 2) {
+      uint32_t w[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&bw[q]));
+        float a0 = m[2 * q] + f.x, a1 = m[2 * q + 1] + f.y;
+        a0 = (a0 < 0.0f) ? 0.0f : a0; a1 = (a1 < 0.0f) ? 0.0f : a1;
+        const __half2 hh = __floats2half2_rn(a0, a1);
+        w[q] = *reinterpret_cast<const uint32_t*>(&hh);
+      }
+      o = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      float a[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a[q] = m[q] + __uint_as_float(bw[q]); a[q] = (a[q] < 0.0f) ? 0.0f : a[q]; }
+      o = make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
+    }
+    out[i] = o;
+  }
+}
+
+extern "C" int odet_bias_relu_maxpool(const void* x, const void* bias, void* out, int B, int H, int W, int C, int OH,
+                                      int OW, int kernel, int stride, int pad, int f16, odet_stream_t stream) {
+  ODET_REQUIRE(x && bias && out, "odet_bias_relu_maxpool: null pointer");
+  ODET_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "odet_bias_relu_maxpool: bad sizes");
+  ODET_REQUIRE(kernel >= 1 && kernel <= 4 && stride >= 1 && pad >= 0 && pad < kernel, "odet_bias_relu_maxpool: bad window");
+  // every output window must hold at least one pixel of the map
+  ODET_REQUIRE((long long)(OH - 1) * stride - pad < H && (long long)(OW - 1) * stride - pad < W,
+               "odet_bias_relu_maxpool: output larger than the pooled map");
+  const int n = f16 ? 8 : 4;
+  ODET_REQUIRE(C % n == 0, "odet_bias_relu_maxpool: C must be a multiple of %d (got %d)", n, C);
+  if (B == 0) return ODET_OK;
+  PoolEpiParams p;
+  p.x = x; p.bias = bias; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.k = kernel; p.stride = stride; p.pad = pad;
+  p.total = (long long)B * OH * OW * (C / n);
+  const int grid = (int)std::min<long long>((p.total + 255) / 256, 256 * 64);
+  if (f16)
+    hipLaunchKernelGGL(k_bias_relu_maxpool<__half>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(k_bias_relu_maxpool<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
 // ---- RPN head epilogue ---------------------------------------------------------------
 // base_fpn_model.py:188-200,427-432: the shared RpnHead runs on every pyramid level, its 1x1 convolutions emit
 // [h,w,2A] scores and [h,w,4A] box deltas, reshaped to [-1,2] / [-1,4] and concatenated P2 -> P6.  In NHWC the

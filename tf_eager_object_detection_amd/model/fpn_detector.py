@@ -107,6 +107,24 @@ def _route_1x1(conv, x, bias, relu, res):
     return r
 
 
+def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=None):
+    """max_pool(relu(conv(x) + bias)): on the GPU the convolution runs without its bias and ONE pass
+    (ops.bias_relu_maxpool) reads its output once and writes the pooled map; torch formulation elsewhere."""
+    if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
+        padding = conv.padding
+        if pad is not None:
+            if pad[0] == pad[1] == pad[2] == pad[3] and tuple(conv.padding) == (0, 0):
+                padding = (pad[0], pad[0])
+            else:
+                x = F.pad(x, pad)
+        y = F.conv2d(x, conv.weight, None, conv.stride, padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        return ops.bias_relu_maxpool(y.permute(0, 2, 3, 1), conv.bias, kernel, stride, pool_pad, ceil_mode).permute(0, 3, 1, 2)
+    y = _conv_epi(conv, x, relu=True, pad=pad)
+    return F.max_pool2d(y, kernel, stride, padding=pool_pad, ceil_mode=ceil_mode)
+
+
 def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
     """conv (+ zero padding `pad`) -> + bias (+ extra_bias) (+ residual) -> ReLU.  On the GPU the convolution
     runs without its bias and everything after it is ONE in-place pass of the fused HIP epilogue
@@ -303,9 +321,9 @@ class ResNetFpnDetector(nn.Module):
     def features(self, images_nhwc):
         """[B,H,W,3] -> (P2..P6), each [B,256,h,w] channels_last (= NHWC in memory)."""
         x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)                       # NHWC memory, NCHW view
-        x = _conv_epi(self.conv1, x, relu=True, pad=(3, 3, 3, 3))                # conv1_pad + valid 7x7/2
-        # pool1_pad (zeros) + 3x3/2: x >= 0 after the ReLU, so the pooling's own (-inf) padding gives the same maxima
-        x = F.max_pool2d(x, 3, 2, padding=1)
+        # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 -- the last three in one pass; x >= 0 after
+        # the ReLU, so skipping the window taps outside the map gives the same maxima as the zero padding
+        x = _conv_relu_pool(self.conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
         c2 = self.conv2(x)
         c3 = self.conv3(c2)
         c4 = self.conv4(c3)

@@ -15,7 +15,8 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pipeline import FrcnnHotPath
-from .fpn_detector import _BLOCKS, ResNetFpnDetector, _conv, _conv_epi, _fold_frozen_bn, _stack, rpn_pair_weights
+from .fpn_detector import _BLOCKS, ResNetFpnDetector, _conv, _conv_epi, _conv_relu_pool, _fold_frozen_bn, _stack, \
+    rpn_pair_weights
 
 __all__ = ['ResNetC4Detector', 'Vgg16Detector']
 
@@ -75,9 +76,8 @@ class ResNetC4Detector(nn.Module):
     def features(self, images_nhwc):
         """[B,H,W,3] -> C4 [B,1024,ceil(H/16),ceil(W/16)] channels_last (= NHWC in memory)."""
         x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
-        x = _conv_epi(self.conv1, x, relu=True, pad=(3, 3, 3, 3))                # conv1_pad + valid 7x7/2
-        # pool1_pad (zeros) + 3x3/2: x >= 0 after the ReLU, so the pooling's own (-inf) padding gives the same maxima
-        x = F.max_pool2d(x, 3, 2, padding=1)
+        # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 (the last three in one pass on the GPU)
+        x = _conv_relu_pool(self.conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
         return self.conv4(self.conv3(self.conv2(x)))
 
     def rpn(self, c4):
@@ -176,11 +176,13 @@ class Vgg16Detector(ResNetC4Detector):
         x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
         i = 0
         for bi, (_, n) in enumerate(self._CFG):
-            for _ in range(n):
-                x = _conv_epi(self.convs[i], x, relu=True)
+            for k in range(n):
+                if k == n - 1 and bi < 4:
+                    # the stage's last convolution: bias + ReLU + MaxPooling2D((2,2), 2, padding='same') in one pass
+                    x = _conv_relu_pool(self.convs[i], x, 2, 2, ceil_mode=True)
+                else:
+                    x = _conv_epi(self.convs[i], x, relu=True)
                 i += 1
-            if bi < 4:
-                x = F.max_pool2d(x, 2, 2, ceil_mode=True)        # MaxPooling2D((2,2), 2, padding='same')
         return x
 
     def roi_head(self, roi_features):

@@ -369,6 +369,29 @@ def rpn_pack(level_out, bias, out, out_offset):
     return out
 
 
+def bias_relu_maxpool(x, bias, kernel, stride, pad=0, ceil_mode=False):
+    """maxpool(relu(x + bias)) in one pass: ``x`` NHWC [B,H,W,C] contiguous (float32 / float16; a convolution WITHOUT
+    its bias), ``bias`` [C]; window ``kernel`` x ``kernel``, ``stride``, ``pad`` skipped taps on every side;
+    ``ceil_mode`` as torch's max_pool2d (TF 'same' pooling for kernel == stride).  Returns NHWC [B,OH,OW,C]."""
+    if x.dim() != 4 or not x.is_cuda or not x.is_contiguous() or x.dtype not in (torch.float32, torch.float16):
+        raise ValueError('x must be a contiguous NHWC float32 / float16 GPU tensor')
+    B, H, W, Cn = (int(v) for v in x.shape)
+    if bias.dtype != x.dtype or bias.numel() != Cn or not bias.is_contiguous():
+        raise ValueError('bias must be a contiguous [C] tensor of the same dtype')
+
+    def osz(n):
+        a = n + 2 * pad - kernel
+        o = (-(-a // stride) if ceil_mode else a // stride) + 1
+        if ceil_mode and (o - 1) * stride >= n + pad:        # torch: the last window must start inside the map
+            o -= 1
+        return o
+    OH, OW = osz(H), osz(W)
+    out = torch.empty((B, OH, OW, Cn), dtype=x.dtype, device=x.device)
+    L.call('odet_bias_relu_maxpool', L.dptr(x), L.dptr(bias), L.dptr(out), B, H, W, Cn, OH, OW, int(kernel), int(stride),
+           int(pad), 1 if x.dtype == torch.float16 else 0, L.stream())
+    return out
+
+
 def rpn_head_tail(conv_out, conv_bias, weight, bias, num_anchors, scores, deltas, anchor_offset):
     """Everything of the RpnHead after its 3x3 convolution for one level, in one MFMA pass: ``conv_out`` [B,h,w,512]
     float16 NHWC contiguous (the 3x3 convolution WITHOUT its bias), ``conv_bias`` [512], ``weight`` [6A,512(,1,1)]
