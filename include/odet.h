@@ -337,7 +337,7 @@ int odet_bias_relu_maxpool(const void* x, const void* bias, void* out, int B, in
  * (+ residual[npix, cout])), all float16 NHWC (w = the convolution's [cout, cin, 1, 1] weight), float32
  * accumulation, one rounding.  x' = x, or relu(x + in_bias[cin]) when in_bias != NULL (x is then the preceding
  * convolution WITHOUT its bias and ReLU: the block's 3x3 convolution; its epilogue pass disappears).
- * cin in {64, 128, 256}, cout % 64 == 0, 16-byte aligned pointers; in_bias / residual may be NULL; y must not
+ * cin in {64, 128, 256, 512}, cout % 64 == 0, 16-byte aligned pointers; in_bias / residual may be NULL; y must not
  * alias x (it may alias residual). */
 int odet_conv1x1_f16(const void* x, const void* in_bias, const void* w, const void* bias, const void* residual,
                      void* y, long long npix, int cin, int cout, int relu, odet_stream_t stream);

@@ -30,7 +30,7 @@
 // HBM bytes per call: M*K*2 (x) + M*N*2 (shortcut) + M*N*2 (y) -- the algorithmic minimum.  Measured (batch 8 at
 // 800x1333; library convolution + epilogue pass beside it): 64 -> 256 at 200x334 146 us = 4.2 TB/s (225 us);
 // 128 -> 512 at 100x167 88 us (110 us); 256 -> 1024 at 50x84 56 us (64 us); 256 -> 64 at 200x334 without
-// shortcut 78 us (89 us).  History and the direct-to-register first versions: tools/exp/conv1x1_mfma.hip.
+// shortcut 78 us (89 us); K = 512 form: 512 -> 2048 over the C4 RoI head's 117 600 pixels 447 us (609 us).  History and the direct-to-register first versions: tools/exp/conv1x1_mfma.hip.
 #include <hip/hip_fp16.h>
 
 #include "odet_internal.h"
@@ -210,11 +210,129 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
   }
 }
 
+// K = 512 (a bottleneck's last convolution in conv5: 512 -> 2048): the pixel fragments take 128 registers, so the
+// channel loop walks groups of 32 channels (ONE 32x32 MFMA block; a lane owns 16 consecutive channels, the two
+// lane halves of a pixel 64 contiguous bytes) and a weight group is [32, 512] = 33 KB per LDS buffer.  Same
+// schedule as above: weights double-buffered through LDS, shortcut two groups ahead, bias slice in LDS.
+__global__ void __launch_bounds__(256, 2) k_conv1x1_f16_k512(Conv1x1Params p) {
+  constexpr int KSTEPS = 32, K = 512, LDW = K + 8;
+  constexpr int CHUNKS = (32 * K / 8) / 256;       // 8
+  __shared__ __align__(16) _Float16 wl[2][32 * LDW];
+  __shared__ __align__(16) _Float16 bl[256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long long blk = blockIdx.x;
+  const long long slab = blk / p.tiles_n;
+  const int tn = (int)(blk - slab * p.tiles_n);
+  const int r = lane & 31, h = lane >> 5;
+  const int N = p.N;
+  const long long m = slab * 128 + wv * 32 + r;
+  const long long mc = m < p.M ? m : p.M - 1;
+  const bool store = m < p.M;
+  h8 xa[KSTEPS];
+  const _Float16* xrow = p.x + mc * K + 8 * h;
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) xa[s] = ldg16(xrow + 16 * s);
+  if (p.in_bias) {
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const h8 bv = ldg16(p.in_bias + 16 * s + 8 * h);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = (float)xa[s][e] + (float)bv[e];
+        v = (v < 0.0f) ? 0.0f : v;
+        xa[s][e] = (_Float16)v;
+      }
+    }
+  }
+  const int n_begin = tn * p.nt, n_end = n_begin + p.nt;
+  // MFMA row i <-> channel 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3) of the 32-channel group
+  int goff[CHUNKS], loff[CHUNKS];
+#pragma unroll
+  for (int i = 0; i < CHUNKS; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    const int lr = c / (K / 8), cc = c - lr * (K / 8);
+    const int ch = 16 * ((lr >> 2) & 1) + 4 * (lr >> 3) + (lr & 3);
+    goff[i] = ch * K + 8 * cc;
+    loff[i] = lr * LDW + 8 * cc;
+  }
+  h8 wreg[CHUNKS];
+#pragma unroll
+  for (int i = 0; i < CHUNKS; ++i) wreg[i] = ldg16(p.w + (long long)n_begin * K + goff[i]);
+  h8 ra[2], rb[2];
+  const long long row_off = mc * N + 16 * h;
+  if (p.res) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ra[q] = ldg16(p.res + row_off + n_begin + 8 * q);
+    if (n_begin + 32 < n_end) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) rb[q] = ldg16(p.res + row_off + n_begin + 32 + 8 * q);
+    }
+  }
+  if ((int)threadIdx.x * 8 < p.nt) *reinterpret_cast<h8*>(&bl[threadIdx.x * 8]) = ldg16(p.bias + n_begin + threadIdx.x * 8);
+#pragma unroll
+  for (int i = 0; i < CHUNKS; ++i) *reinterpret_cast<h8*>(&wl[0][loff[i]]) = wreg[i];
+  __syncthreads();
+
+  auto group = [&](const int n0, const int b, h8 (&pre)[2]) {
+    const bool more = n0 + 32 < n_end;
+    f16v acc;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[8 * q + e] = p.res ? (float)pre[q][e] : 0.0f;
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < CHUNKS; ++i) wreg[i] = ldg16(p.w + (long long)(n0 + 32) * K + goff[i]);
+    }
+    if (p.res && n0 + 64 < n_end) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) pre[q] = ldg16(p.res + row_off + n0 + 64 + 8 * q);
+    }
+    const _Float16* l0 = &wl[b][r * LDW + 8 * h];
+    h8 f0[3];
+    f0[0] = *reinterpret_cast<const h8*>(l0);
+    f0[1] = *reinterpret_cast<const h8*>(l0 + 16);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + 2 < KSTEPS) f0[(s + 2) % 3] = *reinterpret_cast<const h8*>(l0 + 16 * (s + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[s % 3], xa[s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // lane (pixel r, half h): channels n0 + 16 h + [0, 16)
+    const long long off = mc * N + n0 + 16 * h;
+    const _Float16* bp = &bl[n0 - n_begin + 16 * h];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const h8 bv = *reinterpret_cast<const h8*>(bp + 8 * q);
+      h8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = acc[8 * q + e] + (float)bv[e];
+        if (p.relu) v = (v < 0.0f) ? 0.0f : v;
+        ov[e] = (_Float16)v;
+      }
+      if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < CHUNKS; ++i) *reinterpret_cast<h8*>(&wl[b ^ 1][loff[i]]) = wreg[i];
+    }
+    __syncthreads();
+  };
+  for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+    group(n0, 0, ra);
+    if (n0 + 32 < n_end) group(n0 + 32, 1, rb);
+  }
+}
+
 extern "C" int odet_conv1x1_f16(const void* x, const void* in_bias, const void* w, const void* bias, const void* residual,
                                 void* y, long long npix, int cin, int cout, int relu, odet_stream_t stream) {
   ODET_REQUIRE(x && w && bias && y, "odet_conv1x1_f16: null pointer");
   ODET_REQUIRE(npix >= 0 && npix < (1ll << 40), "odet_conv1x1_f16: bad pixel count");
-  ODET_REQUIRE(cin == 64 || cin == 128 || cin == 256, "odet_conv1x1_f16: input channels must be 64, 128 or 256 (got %d)", cin);
+  ODET_REQUIRE(cin == 64 || cin == 128 || cin == 256 || cin == 512,
+               "odet_conv1x1_f16: input channels must be 64, 128, 256 or 512 (got %d)", cin);
   ODET_REQUIRE(cout > 0 && cout % 64 == 0, "odet_conv1x1_f16: output channels must be a multiple of 64 (got %d)", cout);
   ODET_REQUIRE(((uintptr_t)x | (uintptr_t)in_bias | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)y) % 16 == 0,
                "odet_conv1x1_f16: pointers must be 16-byte aligned");
@@ -233,6 +351,7 @@ extern "C" int odet_conv1x1_f16(const void* x, const void* in_bias, const void* 
   switch (cin) {
     case 64: hipLaunchKernelGGL(k_conv1x1_f16<4>, grid, block, 0, (hipStream_t)stream, p); break;
     case 128: hipLaunchKernelGGL(k_conv1x1_f16<8>, grid, block, 0, (hipStream_t)stream, p); break;
+    case 512: hipLaunchKernelGGL(k_conv1x1_f16_k512, grid, block, 0, (hipStream_t)stream, p); break;
     default: hipLaunchKernelGGL(k_conv1x1_f16<16>, grid, block, 0, (hipStream_t)stream, p); break;
   }
   ODET_LAUNCH_CHECK();

@@ -99,7 +99,7 @@ def _route_1x1(conv, x, bias, relu, res):
         cand = {'conv': lambda: _conv_1x1(conv, x, bias, relu, res)}
         if res is None:
             cand['gemm'] = lambda: _gemm_1x1(conv, x, bias, relu)
-        if x.dtype == torch.float16 and conv.in_channels in (64, 128, 256) and conv.out_channels % 64 == 0:
+        if x.dtype == torch.float16 and conv.in_channels in (64, 128, 256, 512) and conv.out_channels % 64 == 0:
             cand['mfma'] = lambda: _mfma_1x1(conv, x, bias, relu, res)
         times = {k: _time_route(f) for k, f in cand.items()}
         r = min(times, key=times.get)
@@ -189,7 +189,7 @@ class _Block(nn.Module):
         else:
             sc, sb = F.conv2d(x, self.short.weight, None, self.short.stride, self.short.padding), self.short.bias
         y = _conv_epi(self.c1, x, relu=True)
-        if y.is_cuda and y.dtype == torch.float16 and self.c3.in_channels in (64, 128, 256):
+        if y.is_cuda and y.dtype == torch.float16 and self.c3.in_channels in (64, 128, 256, 512):
             # c2 (3x3) runs WITHOUT bias / ReLU; if c3 takes the MFMA route for this shape, c2's epilogue is applied
             # to c3's operand fragments as they are loaded (ops.conv1x1_f16(in_bias=...)) and its pass disappears
             y2 = F.conv2d(y, self.c2.weight, None, self.c2.stride, self.c2.padding)

@@ -421,7 +421,7 @@ def rpn_head_tail(conv_out, conv_bias, weight, bias, num_anchors, scores, deltas
 def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None, in_bias=None):
     """1x1 stride-1 convolution + bias (+ residual) (+ ReLU) in ONE kernel on the matrix cores: ``x`` [..., cin]
     NHWC float16 contiguous (any leading dims), ``weight`` [cout, cin(, 1, 1)], ``bias`` [cout], ``residual`` /
-    ``out`` [..., cout] (``out`` may be ``residual``).  cin in {64, 128, 256}, cout % 64 == 0.  ``in_bias`` [cin]:
+    ``out`` [..., cout] (``out`` may be ``residual``).  cin in {64, 128, 256, 512}, cout % 64 == 0.  ``in_bias`` [cin]:
     ``x`` is the preceding convolution without its bias and ReLU; relu(x + in_bias) is applied on load."""
     if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous():
         raise ValueError('x must be a contiguous float16 GPU tensor [..., cin]')

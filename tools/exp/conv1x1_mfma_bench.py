@@ -55,7 +55,10 @@ for M, K, N in ((1007, 64, 256), (96, 128, 512), (33, 256, 1024), (2500, 256, 64
 print('exact on integer data')
 torch.backends.cudnn.benchmark = True
 B = 8
-for h, w_, cin, cout in ((200, 334, 64, 256), (100, 167, 128, 512), (50, 84, 256, 1024), (200, 334, 256, 64)):
+SHAPES = ((200, 334, 64, 256), (100, 167, 128, 512), (50, 84, 256, 1024), (200, 334, 256, 64))
+if product:
+    SHAPES += ((25, 42, 512, 2048), (100, 167, 512, 128), (120, 123, 512, 2048))   # conv5 / conv3 c1 / the C4 RoI head (2400 crops of 7x7 = 14760 px x 8)
+for h, w_, cin, cout in SHAPES:
     x = torch.randn(B, cin, h, w_, device='cuda', dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     wt = (torch.randn(cout, cin, 1, 1, device='cuda', dtype=torch.float16) * 0.05).contiguous(memory_format=torch.channels_last)
     bias = torch.randn(cout, device='cuda', dtype=torch.float16)
