@@ -25,7 +25,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 tot = collections.defaultdict(float)
 for d in ids:
     n = names[d]
-    fam = ('mfma_conv_gemm' if any(k in n for k in ('igemm', 'ck16', 'Cijk', 'gemm', 'conv', 'Conv')) and 'naive' not in n else
+    fam = ('odet_mfma' if ('k_conv1x1' in n or 'k_rpn_tail' in n) else
+           'mfma_conv_gemm' if any(k in n for k in ('igemm', 'ck16', 'Cijk', 'gemm', 'conv', 'Conv')) and 'naive' not in n else
            'odet_hip' if (n.startswith('k_') or 'k_roi' in n or 'k_rp_' in n or 'k_nms' in n or 'k_fpn' in n or 'k_bias' in n) else 'other')
     for c, v in per[d].items():
         agg[fam][c] += v
