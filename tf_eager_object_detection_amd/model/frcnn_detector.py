@@ -70,7 +70,29 @@ class ResNetC4Detector(nn.Module):
         self._roi_feat_all = torch.zeros((self._max_batch,) + tuple(h0.roi_features.shape), dtype=fd, device=h0.device)
         for b, h in enumerate(self._hot):
             h.roi_features = self._roi_feat_all[b]
+        # one stream per image: the hot path of an image is a chain of small launches (~130 us), the images'
+        # chains run beside each other
+        self._streams = [torch.cuda.Stream(device=h0.device) for _ in range(self._max_batch)]
         return self
+
+    def _per_image(self, B, fn):
+        """fn(b) for every image on its own stream; the current stream forks before and joins after (events, no host
+        sync -- capturable into a HIP graph).  The tensors fn touches stay referenced by the caller past the join."""
+        if B == 1:
+            return [fn(0)]
+        cur = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        out = []
+        for b in range(B):
+            st = self._streams[b]
+            st.wait_event(fork)
+            with torch.cuda.stream(st):
+                out.append(fn(b))
+            done = torch.cuda.Event()
+            done.record(st)
+            cur.wait_event(done)
+        return out
 
     # ---- dense parts ---------------------------------------------------------------------------
     def features(self, images_nhwc):
@@ -121,16 +143,19 @@ class ResNetC4Detector(nn.Module):
         maps = c4.permute(0, 2, 3, 1)                                            # NHWC view
         if maps.dtype != self._feature_dtype:
             maps = maps.to(self._feature_dtype)
-        for b in range(B):
+        def proposals_and_crops(b):
             hot = self._hot[b]
             hot.stage_proposals(rpn_scores[b], rpn_deltas[b])
-            hot.stage_roi(maps[b:b + 1].contiguous())
+            hot.stage_roi(maps[b:b + 1])
+        maps = maps.contiguous()
+        self._per_image(B, proposals_and_crops)
         K = self._roi_feat_all.shape[1]
         feats = self._roi_feat_all[:B].reshape((B * K,) + tuple(self._roi_feat_all.shape[2:]))
         logits, bbox = self.roi_head(feats)                                      # one head pass for the whole batch
         cls = torch.softmax(logits.float(), dim=-1).reshape(B, K, -1)
-        bbox = bbox.float().reshape(B, K, -1)
-        return [self._hot[b].stage_detect(cls[b].contiguous(), bbox[b].contiguous()) for b in range(B)]
+        bbox = bbox.float().reshape(B, K, -1).contiguous()
+        cls = cls.contiguous()
+        return self._per_image(B, lambda b: self._hot[b].stage_detect(cls[b], bbox[b]))
 
 
 class Vgg16Detector(ResNetC4Detector):
