@@ -29,7 +29,7 @@
 //
 // HBM bytes per call: M*K*2 (x) + M*N*2 (shortcut) + M*N*2 (y) -- the algorithmic minimum.  Measured (batch 8 at
 // 800x1333; library convolution + epilogue pass beside it): 64 -> 256 at 200x334 146 us = 4.2 TB/s (225 us);
-// 128 -> 512 at 100x167 88 us (110 us); 256 -> 1024 at 50x84 56 us (64 us); 256 -> 64 at 200x334 without
+// 128 -> 512 at 100x167 88 us (110 us); 256 -> 1024 at 50x84 53 us (64 us); 256 -> 64 at 200x334 without
 // shortcut 78 us (89 us); K = 512 form: 512 -> 2048 over the C4 RoI head's 117 600 pixels 447 us (609 us).  History and the direct-to-register first versions: tools/exp/conv1x1_mfma.hip.
 #include <hip/hip_fp16.h>
 
@@ -61,9 +61,14 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
   __shared__ __align__(16) _Float16 wl[2][64 * LDW];
   __shared__ __align__(16) _Float16 bl[256];          // the tile's bias slice (nt <= 256)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // XCD-aware order: hardware deals consecutive workgroups round-robin over the 8 XCDs (one L2 each).  The
+  // tiles_n channel tiles of a pixel slab read the same x rows, so they are consecutive workgroups of ONE XCD:
+  // x comes over the fabric once per slab instead of once per channel tile.
   const long long blk = blockIdx.x;
-  const long long slab = blk / p.tiles_n;
-  const int tn = (int)(blk - slab * p.tiles_n);
+  const long long q = blk >> 3;
+  const long long slab = (blk & 7) + 8 * (q / p.tiles_n);
+  const int tn = (int)(q % p.tiles_n);
+  if (slab * 128 >= p.M) return;                   // (padding workgroups of the last group of 8 slabs; whole workgroup)
   const int r = lane & 31, h = lane >> 5;
   const int N = p.N;
   const long long m = slab * 128 + wv * 32 + r;
@@ -220,9 +225,14 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16_k512(Conv1x1Params p) {
   __shared__ __align__(16) _Float16 wl[2][32 * LDW];
   __shared__ __align__(16) _Float16 bl[256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // XCD-aware order: hardware deals consecutive workgroups round-robin over the 8 XCDs (one L2 each).  The
+  // tiles_n channel tiles of a pixel slab read the same x rows, so they are consecutive workgroups of ONE XCD:
+  // x comes over the fabric once per slab instead of once per channel tile.
   const long long blk = blockIdx.x;
-  const long long slab = blk / p.tiles_n;
-  const int tn = (int)(blk - slab * p.tiles_n);
+  const long long q = blk >> 3;
+  const long long slab = (blk & 7) + 8 * (q / p.tiles_n);
+  const int tn = (int)(q % p.tiles_n);
+  if (slab * 128 >= p.M) return;                   // (padding workgroups of the last group of 8 slabs; whole workgroup)
   const int r = lane & 31, h = lane >> 5;
   const int N = p.N;
   const long long m = slab * 128 + wv * 32 + r;
@@ -344,8 +354,11 @@ extern "C" int odet_conv1x1_f16(const void* x, const void* in_bias, const void* 
   // channels per wave tile: the whole row up to 256 channels; wider outputs are split so that small feature maps
   // still give the chip enough waves (the waves of a pixel slab sit in one workgroup and share its x lines in L1)
   p.nt = cout <= 256 ? cout : (cout % 256 == 0 ? 256 : 64);
+#ifdef ODET_C1_NT                                    /* diagnostic builds: channels per workgroup tile */
+  if (cout % ODET_C1_NT == 0 && ODET_C1_NT <= 256) p.nt = ODET_C1_NT;
+#endif
   p.tiles_n = cout / p.nt;
-  const long long blocks = ((npix + 127) / 128) * p.tiles_n;
+  const long long blocks = (((npix + 127) / 128 + 7) / 8) * 8 * p.tiles_n;      // slabs padded to the 8 XCDs
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv1x1_f16: too many workgroups");
   dim3 grid((unsigned)blocks), block(256);
   switch (cin) {
