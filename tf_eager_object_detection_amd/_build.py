@@ -11,7 +11,7 @@ CSRC = os.path.join(PKG, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(PKG), 'include')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libodet_hip.so')
-SOURCES = ['boxes.hip', 'sort.hip', 'nms.hip', 'roi.hip', 'postops.hip', 'neck.hip', 'epilogue.hip', 'conv1x1.hip', 'rpn_tail.hip',
+SOURCES = ['boxes.hip', 'sort.hip', 'nms.hip', 'roi.hip', 'roi_half.hip', 'postops.hip', 'neck.hip', 'epilogue.hip', 'conv1x1.hip', 'rpn_tail.hip',
            'executor.hip']
 HEADERS = [os.path.join(CSRC, 'odet_internal.h'), os.path.join(INCLUDE, 'odet.h')]
 
@@ -26,6 +26,8 @@ HIPCC_FLAGS = EXTRA + ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-
 # (which the SLP vectoriser produces, plus the v_mov shuffles to feed them) issue slower than two plain ones:
 # -1.5 % kernel time, +1.2 % throughput (same-box A/B); results are the same IEEE operations either way
 PER_SOURCE_FLAGS = {'roi.hip': ['-fno-slp-vectorize']}
+# sources that #include another source: rebuilt when that one changes
+EXTRA_DEPS = {'roi_half.hip': ['roi.hip']}
 
 
 def _hipcc():
@@ -51,7 +53,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, src + '.o')
         objs.append(o)
-        if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
+        if force or _stale(o, [s] + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])] + HEADERS + [os.path.abspath(__file__)]):
             cmd = [hipcc] + HIPCC_FLAGS + PER_SOURCE_FLAGS.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))

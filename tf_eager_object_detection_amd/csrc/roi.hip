@@ -569,6 +569,26 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   }   // FT == float
 }
 
+// The float16 instantiations live in their own translation unit (roi_half.hip = this file with ODET_ROI_HALF_TU):
+// roi.hip is compiled with -fno-slp-vectorize (hipcc's SLP pass packs the float32 lerps into v_pk_*_f32, which
+// issue slower than the scalar forms: +1.2 % for the float32 kernel), but the same flag costs the float16 kernel
+// its packed conversions (357 instead of 237 us for the 8-image launch), so that one is built with SLP.
+#define ODET_ROI_HALF_KERNELS(X)                                                                               \
+  X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_STRIDE) X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_IMAGE)                       \
+  X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_TP_ALIGN) X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_TP_ALIGN_NOPAD)            \
+  X(ODET_ROI_POOL_MAX2, ODET_ROI_NORM_STRIDE) X(ODET_ROI_POOL_MAX2, ODET_ROI_NORM_IMAGE)                       \
+  X(ODET_ROI_POOL_MAX2, ODET_ROI_NORM_TP_ALIGN) X(ODET_ROI_POOL_MAX2, ODET_ROI_NORM_TP_ALIGN_NOPAD)            \
+  X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_STRIDE) X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_IMAGE)                       \
+  X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_TP_ALIGN) X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_TP_ALIGN_NOPAD)
+#ifdef ODET_ROI_HALF_TU
+#define ODET_ROI_X(POOL, NORM) template __global__ void k_roi_pool<POOL, NORM, false, __half>(RoiParams);
+ODET_ROI_HALF_KERNELS(ODET_ROI_X)
+#undef ODET_ROI_X
+#else
+#define ODET_ROI_X(POOL, NORM) extern template __global__ void k_roi_pool<POOL, NORM, false, __half>(RoiParams);
+ODET_ROI_HALF_KERNELS(ODET_ROI_X)
+#undef ODET_ROI_X
+
 // A/B switches for profiling, read once (function-local static: thread-safe initialisation).
 //   ODET_ROI_STAGE=1   the LDS-staged tile path.  OFF by default: every bilinear tap still has to be read
 //                      once from LDS (128 B/clk/CU, only 2x the vector L1's 64 B/clk/CU) behind a
@@ -838,3 +858,4 @@ extern "C" int odet_prof_event_elapsed_ms(void* start, void* stop, float* ms) {
   ODET_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
   return ODET_OK;
 }
+#endif   // !ODET_ROI_HALF_TU
