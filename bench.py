@@ -5,11 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric "images/sec ResNet-101-FPN @ 800x1333", configs[2]): a step = one image
+Workload (BASELINE.json metric "images/sec ResNet-101-FPN @ 800x1333", configs[2]): every image goes
 through region_proposal -> roi_pooling -> prediction (+ anchor generation, fg softmax, level assignment)
 at the ResNet-101-FPN shapes: 267 069 anchors, 1000 proposals, P2..P5 x 256 channels, 21 classes.  The
 dense conv parts of the model (backbone, neck, RPN head, RoI head) are NOT part of this path (SURVEY.md
 section 8): their outputs are the synthetic inputs, resident in HBM before the timed region.
+
+A STEP = `--rounds-per-step` (32) rounds over the `streams` x `batch` (3 x 8 = 24) in-flight image slots of a
+GPU = 768 images per GPU (`config.images_per_step_per_gpu`), so the driver's `--steps 20 --warmup 5` times
+15 360 images (~0.5 s), not 20.
 
 Serving arrangement: images are independent, so `--streams` HIP streams (each fed by a native enqueue
 thread of the library) carry `--batch` images each whose kernels share their launches (one grid dimension
@@ -17,10 +21,19 @@ thread of the library) carry `--batch` images each whose kernels share their lau
 step); with N > 1 every round of streams x batch images ends with ONE RCCL all-gather of the fixed-size
 detection records.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel = the fused
-RoI crop+pool kernel, HBM bound; timed alone, as a one-image launch, with HIP events attached to its
-dispatch on a few steps of the timed region) and `cpu_baseline` (the C restatement of the reference path
-timed on this box's host cores, kind "port"; it also carries the mAP delta of the evaluation loop).
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  `roofline`     dominant kernel = the fused RoI crop+pool kernel (HBM bound), the 8-image launch of one stream
+                 group: >= 10 launches in a short phase AFTER the timed region, each alone on the GPU with cold
+                 maps, HIP events attached to the dispatch.  Those launches run under their own kernel name
+                 (k_roi_pool<..., 1>, same code), so the kernel-stats summary of a profiled run of this command
+                 (profiles/) has a row whose average IS `kernel_ms`.  `frac` prices SURVEY 8(d)'s algorithmic
+                 bytes B_roi (no credit for reuse between RoIs); `hbm_frac_measured` prices the HBM bytes the PMC
+                 counters saw (profiles/roi_pool_traffic.json); `B_min` / `B_taps` bracket B_roi.
+  `cpu_baseline` the C restatement of the reference path timed on this box's host cores (kind "port"); it also
+                 carries the mAP delta of the evaluation loop.
+  `e2e`          (N = 1) a second, separately labelled record: the assembled ResNet-101-FPN detector end to end
+                 (library convolutions + hand-written kernels around the hot path), fp32 = the reference's
+                 precision, fp16 = throughput mode (narrower than the reference).
 """
 import argparse
 import ctypes
@@ -46,11 +59,12 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB
 def algorithmic_roi_bytes(sorted_rois, levels, level_shapes, image_shape, channels, pool=7, elem=4):
     """B_roi = sum_r U_r*C*s + R*P*P*C*s + R*16, U_r = unique feature cells tapped by
     RoI r on its level (first/last in-bounds sample coordinate of the 2P x 2P grid, FPN normalisation
-    of model/roi_pooling.py:30-35 + TF crop_and_resize)."""
+    of model/roi_pooling.py:30-35 + TF crop_and_resize); B_min = sum_k min(sum_{r in k} U_r, H_k*W_k)*C*s + out
+    + rois (perfect reuse between RoIs); B_taps = R*crop^2*4*C*s + out (every tap fetched)."""
     crop = 2 * pool
     H_img, W_img = np.float32(image_shape[0]), np.float32(image_shape[1])
     total_cells = 0
-    taps = 0
+    per_level = {}
     for r, l in zip(sorted_rois, levels):
         Hk, Wk = level_shapes[int(l)]
         spans = []
@@ -66,11 +80,13 @@ def algorithmic_roi_bytes(sorted_rois, levels, level_shapes, image_shape, channe
                 first, last = ok.min(), ok.max()
                 spans.append(int(min(np.ceil(last), dim - 1) - max(np.floor(first), 0) + 1))
         total_cells += spans[0] * spans[1]
-        taps += crop * crop * 4
+        per_level[int(l)] = per_level.get(int(l), 0) + spans[0] * spans[1]
     R = len(sorted_rois)
     out_bytes = R * pool * pool * channels * elem
+    min_cells = sum(min(c, level_shapes[l][0] * level_shapes[l][1]) for l, c in per_level.items())
     return dict(B_roi=total_cells * channels * elem + out_bytes + R * 16,
-                B_taps=taps * channels * elem + out_bytes, out=out_bytes, unique_cells=total_cells)
+                B_min=min_cells * channels * elem + out_bytes + R * 16,
+                B_taps=R * crop * crop * 4 * channels * elem + out_bytes, out=out_bytes, unique_cells=total_cells)
 
 
 def cpu_baseline(host, image_shape, budget_s=20.0, max_images=8):
@@ -150,15 +166,59 @@ def load_traffic(workload_key, images_per_launch):
     return None
 
 
+def e2e_record(dtype_name, batch, budget_s=8.0):
+    """The assembled ResNet-101-FPN detector end to end on synthetic 800x1333 images (random-init weights):
+    backbone + neck + RPN head + hot path + RoI head + post-ops; not the headline metric (that one is the hot
+    path): a second, separately labelled record.  fp32 = the reference's precision (parity mode)."""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    dt = {'fp32': torch.float32, 'fp16': torch.float16}[dtype_name]
+    torch.backends.cudnn.benchmark = True                 # MIOpen find mode (its default solver is naive on some shapes)
+    torch.manual_seed(0)
+    model = ResNetFpnDetector(101, NUM_CLASSES, IMAGE_SHAPE, NUM_PROPOSALS, dtype=dt, max_batch=batch,
+                              blind_chunks=3, batched=True).prepare()
+    rng = np.random.default_rng(0)
+    img = (rng.uniform(0, 255, (batch,) + IMAGE_SHAPE + (3,)) - np.float32([103.939, 116.779, 123.68])).astype(np.float32)
+    img = torch.from_numpy(img).cuda()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = model(img)
+    torch.cuda.synchronize()
+    warm_s = time.perf_counter() - t0
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        out = model(img)
+        steps += 1
+        if steps >= 5 and (steps % 5) == 0:
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 > budget_s or steps >= 200:
+                break
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    done = [int(h.nms_done.item()) for h in model._hot]
+    rec = dict(value=steps * batch / el, unit='img/s', batch=batch, steps=steps, ms_per_image=el / (steps * batch) * 1e3,
+               dtype=dtype_name, model='ResNet-101-FPN', image=list(IMAGE_SHAPE), weights='random init', data='synthetic',
+               conv_path='MIOpen / hipBLASLt library convolutions (find mode) + hand-written HIP epilogues, 1x1 MFMA '
+                         'convolutions, neck merges, RPN tail (fp16) around the HIP hot path',
+               warmup_s=warm_s, nms_done=done, detections_image0=int(out[0][3].item()))
+    del model
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
+    # (before anything initialises HSA: dmabuf IPC is the only kind the host driver supports)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--rounds-per-step', type=int, default=32,
+                    help='a step = this many rounds over the streams x batch in-flight image slots')
     ap.add_argument('--scores', choices=['distinct', 'clustered'], default='distinct',
                     help='RPN score distribution (SURVEY 8d: distinct; clustered = trained-like)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--streams', type=int, default=3, help='HIP streams (+ native enqueue threads) per GPU')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end detector record')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams (stream groups) per GPU')
     ap.add_argument('--batch', type=int, default=8, help='images that share the kernel launches of a stream (1..8)')
     ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
     ap.add_argument('--nms-first-chunk', type=int, default=0,
@@ -167,6 +227,7 @@ def main():
     ap.add_argument('--maps', choices=['f32', 'f16'], default='f32',
                     help='feature-map / RoI-feature storage type (f32 = the metric of SURVEY 8d; f16 = BASELINE '
                          'config 5 "fp16 feature maps": float32 lerps, float16 in / out)')
+    ap.add_argument('--roofline-samples', type=int, default=12, help='isolated RoI launches timed after the timed region')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; "
                     "'gloo' only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -188,7 +249,6 @@ def main():
     use_dist = world > 1 or (os.environ.get('ODET_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
     if use_dist:
         import torch.distributed as dist
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev))
         else:
@@ -201,9 +261,10 @@ def main():
 
     host, dev = synthetic_fpn_inputs(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, seed=1234 + rank,
                                      score_kind=args.scores)
-    # images in flight per GPU: `streams` HIP streams (one native enqueue thread each) x `batch` images
-    # that share every kernel launch of their stream (blockIdx.y = image)
+    # images in flight per GPU: `streams` stream groups x `batch` images that share every kernel launch of their
+    # stream (one grid dimension = image)
     S, B = max(1, args.streams), max(1, min(8, args.batch))
+    R = max(1, args.rounds_per_step)
     fdt = torch.float16 if args.maps == 'f16' else torch.float32
     pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B,
                          blind_chunks=args.blind_chunks, feature_dtype=fdt, nms_first_chunk=args.nms_first_chunk)
@@ -226,98 +287,38 @@ def main():
             feats=[torch.randn(f.shape, device='cuda', dtype=torch.float32, generator=gen).to(fdt) for f in dev['feats']],
             cls_scores=dev['cls_scores'][pr].contiguous(), cls_deltas=dev['cls_deltas'][pr].contiguous()))
     for k in range(nslots):
-        pool.slots[k].record = records[k]                     # one contiguous block: ONE all-gather per round
+        pool.slots[k].record = records[k]                     # one contiguous block per group: ONE all-gather per group
         d = slot_inputs[k]
         pool.bind(k, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
     hot = pool.slots[0]
-    max_det = hot.cfg['max_per_image']
-    comm = torch.cuda.Stream()
-    gathered = torch.zeros((S, world, B, rec_len), dtype=torch.float32, device='cuda') if use_dist else None
-    staging = torch.zeros((S, B, rec_len), dtype=torch.float32, device='cuda') if use_dist else None
     gstreams = pool._group_streams
-
-    # HIP events attached to the RoI kernel's dispatch, inside the timed region.  The dominant launch -- the
-    # B-image launch of one stream group -- is timed ALONE: the group's stream first waits (on the GPU, no host
-    # sync) for the other streams and they wait for it afterwards, so only a few launches are bracketed.  The
-    # group's maps are cold by then (the other groups' 2/3 of the 2.3 GB went through the caches since).
-    from tf_eager_object_detection_amd import ops
-    n_events = max(1, min(10, args.steps // 100))
-    # (the timed launches sit a whole number of B-image launches apart)
-    gap = B * max(1, (args.steps // n_events) // B)
-    ev_at = set(j * gap for j in range(n_events) if j * gap < args.steps)      # (step 0 always: even --steps 1 is timed)
-    ev_roi = []
+    exchange = parallel.GroupExchange(S, B, rec_len, 'cuda') if use_dist else None
 
     def drain():
         pool.wait()
         torch.cuda.synchronize()
 
-    def gather_group(g):
-        """image-parallel exchange: the records of stream group g (B images) of every rank in ONE RCCL
-        all-gather.  Only group g's stream is involved and it only waits for a 10 KB staging copy, so the
-        collective overlaps the other streams and the group's own next images."""
-        pool.wait()                                           # host: the group's launches are enqueued
-        st = gstreams[g]
-        comm.wait_stream(st)
-        with torch.cuda.stream(comm):
-            staging[g].copy_(records[g * B:(g + 1) * B])
-            copied = torch.cuda.Event()
-            copied.record(comm)
-            dist.all_gather_into_tensor(gathered[g].view(world * B, rec_len), staging[g])   # concatenation form
-        st.wait_event(copied)                                 # the next images of the group may overwrite the records
-
-    def timed_group(g, count):
-        """`count` (= B unless fewer steps remain) images of stream group g through their shared launches with
-        nothing else on the GPU; the RoI dispatch carries HIP events (odet_fpn_step_t.roi_start_event /
-        roi_stop_event of the first step)"""
-        ev = (ops.ProfEvent(), ops.ProfEvent(), count)
-        ev_roi.append(ev)
-        pool.wait()                                           # every earlier image is enqueued (host side only)
-        mine = gstreams[g]
-        for st in gstreams:
-            if st is not mine:
-                mine.wait_stream(st)
-        first = pool.steps[g * B]
-        first.roi_start_event, first.roi_stop_event = ev[0].handle, ev[1].handle
-        try:
-            _lib.check(_lib.lib().odet_fpn_step_enqueue_batch(pool._groups[g], count, 7))  # on the steps' stream = mine
-        finally:
-            first.roi_start_event, first.roi_stop_event = None, None
-        for st in gstreams:
-            if st is not mine:
-                st.wait_stream(mine)
-
-    def run(num_images, timed):
-        """num_images steps: groups of B images share their launches; event steps and the remainder run
-        as single images."""
-        i, group = 0, 0
-        while i < num_images:
-            if timed and i in ev_at:
-                cnt = min(B, num_images - i)
-                timed_group(0, cnt)
-                done_group = 0
-                i += cnt
-            elif num_images - i >= B:
-                pool.submit_group(group)
-                done_group = group
-                i += B
-            else:
-                pool.submit(group * B)
-                done_group = group
-                i += 1
-            if use_dist:
-                gather_group(done_group)
-            group = (group + 1) % S
+    def run_steps(nsteps):
+        """nsteps steps of R rounds: in every round each of the S stream groups sends its B images through their
+        shared launches; with N > 1 ranks each group's records then go through one all-gather (parallel.GroupExchange)."""
+        for _ in range(nsteps * R):
+            for g in range(S):
+                pool.submit_group(g)
+                if use_dist:
+                    pool.wait()                               # host: the group's launches are enqueued
+                    exchange.gather(g, records[g * B:(g + 1) * B], producer_stream=gstreams[g])
 
     def fence():
         drain()
         if use_dist:
+            exchange.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(max(args.warmup, nslots), False)                      # (at least one pass over every slot)
+    run_steps(max(args.warmup, 1))                            # (at least one pass over every slot)
     fence()
     t0 = time.perf_counter()
-    run(args.steps, True)
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -327,55 +328,100 @@ def main():
     if any(int(h.nms_done.item()) != 1 for h in pool.slots):
         raise SystemExit('NMS did not complete inside the blind chunks -- result would be invalid '
                          '(use --nms-first-chunk 4096, or --blind-chunks 2, for score distributions with heavy suppression)')
+    images_per_step = R * S * B
 
     if rank == 0:
+        # ---- roofline phase (untimed): the B-image RoI launch of stream group 0, ALONE on the GPU, cold maps.  Before
+        # every sample the other groups run once (their 2/3 of the 2.3 GB of inputs go through the caches; with one
+        # group a 1 GiB buffer is written instead), then group 0's stream waits (on the GPU) for the others.
+        from tf_eager_object_detection_amd import ops
+        flush = torch.empty(1 << 28, dtype=torch.float32, device='cuda') if S == 1 else None
+        ev_roi = []
+        for _ in range(max(3, args.roofline_samples)):
+            if S > 1:
+                for g in range(1, S):
+                    pool.submit_group(g)
+                pool.wait()
+            else:
+                with torch.cuda.stream(gstreams[0]):
+                    flush.fill_(1.0)
+            mine = gstreams[0]
+            for st in gstreams[1:]:
+                mine.wait_stream(st)
+            ev = (ops.ProfEvent(), ops.ProfEvent())
+            first = pool.steps[0]
+            first.roi_start_event, first.roi_stop_event = ev[0].handle, ev[1].handle
+            try:
+                _lib.check(_lib.lib().odet_fpn_step_enqueue_batch(pool._groups[0], B, 7))    # on the group's stream
+            finally:
+                first.roi_start_event, first.roi_stop_event = None, None
+            torch.cuda.synchronize()
+            ev_roi.append(ev)
+        times = [a.elapsed_ms(b) for a, b in ev_roi][2:]      # (the first two settle clocks / caches)
+        roi_ms = float(np.mean(times))
+
         k = int(hot.roi_count.item())
-        # algorithmic bytes of a timed launch = the sum over its images (the first `count` slots of stream group 0;
-        # SURVEY 8d per image)
+        # algorithmic bytes of the timed launch = the sum over its images (the slots of stream group 0; SURVEY 8d per image)
         per_slot = []
         for h_ in pool.slots[:B]:
             kk = int(h_.roi_count.item())
             per_slot.append(algorithmic_roi_bytes(h_.sorted_rois[:kk].cpu().numpy(), h_.roi_level[:kk].cpu().numpy(),
                                                   syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS,
                                                   elem=2 if args.maps == 'f16' else 4))
-        def launch_bytes(count):
-            return {q: sum(a_[q] for a_ in per_slot[:count]) for q in per_slot[0]}
-        times = [a.elapsed_ms(b) for a, b, _ in ev_roi]
-        roi_ms = float(np.mean(times))
-        timed_images = int(round(np.mean([c for _, _, c in ev_roi])))
-        algo = launch_bytes(timed_images)
-        achieved = float(np.mean([launch_bytes(c)['B_roi'] / (t * 1e-3) / 1e9 for t, (_, _, c) in zip(times, ev_roi)]))
+        algo = {q: sum(a_[q] for a_ in per_slot) for q in per_slot[0]}
+        achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
         workload = 'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps')
+        traffic = load_traffic(workload, B)
+        ft = 'float' if args.maps == 'f32' else '__half'
         result = {
-            'metric': 'images/sec', 'value': args.steps * world / elapsed, 'unit': 'img/s',
+            'metric': 'images/sec', 'value': args.steps * images_per_step * world / elapsed, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': args.maps, 'data': 'synthetic',
             'config': {'workload': 'ResNet-101-FPN @ 800x1333 detection hot path: anchors(267069, generated in '
                                    'registers) -> fg softmax -> RegionProposal (decode+clip+exact NMS over all '
                                    'anchors, 1000 proposals) -> assign_levels -> RoI crop14x14+maxpool over '
                                    'P2..P5x256 -> post_ops (21 classes); conv backbone/heads out of scope (their '
                                    'outputs are synthetic inputs in HBM)',
-                       'images_per_step_per_gpu': 1, 'global_batch': world, 'rpn_scores': args.scores,
-                       'feature_maps': args.maps, 'nms_first_chunk': args.nms_first_chunk,
+                       'step': '%d rounds over the %d x %d in-flight image slots of a GPU' % (R, S, B),
+                       'images_per_step_per_gpu': images_per_step, 'global_batch': images_per_step * world,
+                       'timed_images': args.steps * images_per_step * world, 'timed_region_s': elapsed,
+                       'rpn_scores': args.scores, 'feature_maps': args.maps, 'nms_first_chunk': args.nms_first_chunk,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2> (fused crop_and_resize 14x14 + 2x2 max), the '
-                                                   '%d-image launch of one stream group, timed alone' % timed_images,
-                         'images_per_launch': timed_images,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2, NORM_IMAGE> (fused crop_and_resize 14x14 + 2x2 max), the '
+                                                   '%d-image launch of one stream group, alone on the GPU, cold maps' % B,
+                         'rocprof_kernel_name': 'void k_roi_pool<1, 1, %s, 1>(RoiParams)' % ft,
+                         'images_per_launch': B,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': load_traffic(workload, timed_images),
-                         'kernel_ms': roi_ms, 'kernel_ms_samples': len(ev_roi), 'algorithmic_bytes': algo['B_roi'],
-                         'bytes_all_taps': algo['B_taps'], 'bytes_output': algo['out']},
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel_ms': roi_ms, 'kernel_ms_samples': len(times), 'kernel_ms_min': float(np.min(times)),
+                         'kernel_ms_max': float(np.max(times)), 'algorithmic_bytes': algo['B_roi'],
+                         'B_min': algo['B_min'], 'B_taps': algo['B_taps'], 'bytes_output': algo['out']},
         }
-        # the same launch priced on the HBM bytes the PMC counters saw (cross-RoI reuse served from L2 / Infinity
-        # Cache is not in them, SURVEY 8d's algorithmic bytes count every RoI's cells): the plain bandwidth figure
-        tr = result['roofline']['traffic']
-        result['roofline']['measured_traffic_GBps'] = (tr / (roi_ms * 1e-3) / 1e9) if (tr and roi_ms) else None
+        # the same launch priced on the HBM bytes the PMC counters saw (reuse between RoIs served from L2 / Infinity
+        # Cache is not in them; SURVEY 8d's algorithmic bytes count every RoI's cells): the plain bandwidth figure
+        rf = result['roofline']
+        rf['measured_traffic_GBps'] = (traffic / (roi_ms * 1e-3) / 1e9) if (traffic and roi_ms) else None
+        rf['hbm_frac_measured'] = (rf['measured_traffic_GBps'] / HBM_PEAK_GBS) if rf['measured_traffic_GBps'] else None
+        rf['frac_on_B_min'] = algo['B_min'] / (roi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        pool.close()
+        del pool
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
+        if not args.no_e2e and world == 1:
+            e2e = {}
+            for name, b in (('fp32', 4), ('fp16', 8)):
+                try:
+                    e2e[name] = e2e_record(name, b)
+                except Exception as ex:               # the headline record must not depend on the second one
+                    e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+            e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
+                           'mode (the reference computes in float32), fp16 = throughput mode, narrower than the reference')
+            result['e2e'] = e2e
         print(json.dumps(result))
-    pool.close()
+    else:
+        pool.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -136,7 +136,12 @@ size_t odet_nms_workspace_bytes(int n, int max_output);
  *    `stream` once per further chunk until the device reports completion.  Always exact.
  *  - out_done != NULL  (sync-free mode, graph-capturable): exactly blind_chunks chunks run;
  *    *out_done (device int32) = 1 when the result is complete, 0 when max_output was not
- *    reached within them (caller re-runs in exact mode). */
+ *    reached within them; odet_nms / odet_region_proposal then hold the exact PREFIX found so far
+ *    (out_count of it), the caller re-runs in exact mode.  The fused stages whose count feeds further
+ *    kernels on the device (odet_fpn_proposals, odet_frcnn_proposals, the step descriptor) report an
+ *    incomplete result as ZERO proposals (*out_count = 0, level counts 0, *out_done = 0): nothing
+ *    downstream ever runs on a partial or stale RoI list -- an image that did not complete yields no
+ *    detections and says so. */
 int odet_nms(const float* boxes, const float* scores, int n, int max_output, float iou_threshold,
              int32_t* out_idx, float* out_boxes, int32_t* out_count, int blind_chunks,
              int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream);
@@ -436,7 +441,9 @@ int odet_fpn_step_enqueue(const odet_fpn_step_t* step, int stages);
 /* `count` (<= ODET_MAX_STEP_BATCH) images whose steps agree in every shape, parameter and the stream,
  * processed by the SAME kernel launches (one grid dimension = image): per-launch costs are paid once
  * per batch and the single-workgroup stages of the images run side by side.  Needs the sync-free NMS
- * mode (nms_done != NULL) with blind_chunks == 1. */
+ * mode (nms_done != NULL); blind_chunks >= 1 (chunk 1 comes from the same ranked selection in launches
+ * shared by the batch, chunks 2.. per image on the full order).  An image whose NMS did not complete
+ * inside its chunks reports zero proposals and nms_done = 0 (see odet_nms). */
 #define ODET_MAX_STEP_BATCH 8
 int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, int count, int stages);
 

@@ -499,3 +499,117 @@ def test_bias_relu_maxpool_identical_to_separate_passes(dt):
         assert torch.equal(got, want.contiguous())
     with pytest.raises(Exception):
         ops.bias_relu_maxpool(torch.zeros(1, 4, 4, 6, device='cuda'), torch.zeros(6, device='cuda'), 2, 2)     # C % 4
+
+
+# ---- a18: model-level im_detect + the mAP-producing loop, end to end ---------------------------------------------
+def _gt_from_detections(dets, rng, num_classes=21, keep=0.6):
+    """synthetic ground truth that makes AP non-trivial: a random subset of the oracle's detections, jittered"""
+    boxes, labels = [], []
+    for j in range(1, num_classes):
+        for row in dets[j]:
+            if rng.uniform() < keep:
+                jit = rng.normal(0, 0.02, 4).astype(np.float32) * (row[2:4] - row[0:2]).repeat(2)[[0, 2, 1, 3]]
+                boxes.append(row[:4] + jit)                  # (2 % of the box size: IoU stays far above 0.5)
+                labels.append(j)
+    if not boxes:
+        return np.zeros((0, 4), np.float32), np.zeros(0, np.int32)
+    return np.stack(boxes).astype(np.float32), np.asarray(labels, np.int32)
+
+
+def _im_detect_eval(model, shapes_scales, seed, rois_attr):
+    """detector.im_detect -> pascal_eval.detect_image -> evaluate_detections on the GPU path, and the restated
+    reference loop (oracle_np.eval_detect_image, pascal_eval_files_utils.py:76-106) on the SAME dense-part outputs."""
+    from oracle import oracle_np as on
+    from tf_eager_object_detection_amd.evaluation import pascal_eval as pe
+    rng = np.random.default_rng(seed)
+    kw = dict(score_threshold=0.0, iou_threshold=0.5, max_objects_per_class=50, max_objects_per_image=50, min_size=10)
+    dg, dr, gb, gl = [], [], [], []
+    shape = model.image_shape
+    for scale in shapes_scales:
+        img = torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+        scores, deltas, rois = model.im_detect(img, scale)[0]
+        hot = model._hot[0]
+        k = int(hot.roi_count.item())
+        assert scores.shape == (k, 21) and deltas.shape == (k, 84) and rois.shape == (k, 4) and k > 0
+        raw = getattr(hot, rois_attr)[:k]
+        # rois / tf.to_float(img_scale) (base_fpn_model.py:390): a true float32 division
+        np.testing.assert_array_equal(rois.cpu().numpy(), (raw.cpu().numpy() / np.float32(scale)).astype(np.float32))
+        np.testing.assert_allclose(scores.sum(dim=1).cpu().numpy(), 1.0, rtol=0, atol=1e-5)
+        raw_h, raw_w = int(round(shape[0] / scale)), int(round(shape[1] / scale))
+        dg.append(pe.detect_image(scores, deltas, rois, 1.0, raw_h, raw_w, **kw))        # (already divided)
+        dr.append(on.eval_detect_image(scores.cpu().numpy(), deltas.cpu().numpy(), raw.cpu().numpy(), scale, raw_h,
+                                       raw_w, **kw))
+        b, l = _gt_from_detections(dr[-1], rng)
+        gb.append(b)
+        gl.append(l)
+    for a, b in zip(dg, dr):
+        for j in range(1, 21):
+            assert a[j].shape == b[j].shape
+            np.testing.assert_array_equal(a[j], b[j])                       # identical rows, class by class
+    m_gpu, aps_gpu = pe.evaluate_detections(dg, gb, gl, use_07_metric=True)
+    m_ref, aps_ref = pe.evaluate_detections(dr, gb, gl, use_07_metric=True)
+    assert abs(m_gpu - m_ref) <= 0.002                                      # BASELINE.json: mAP within +-0.002
+    assert aps_gpu == aps_ref
+    # the synthetic ground truth is hit (a random-init head puts all its detections into one or two classes; the
+    # classes without detections and without ground truth score 0 and pull the MEAN down, so look at the best class)
+    assert max(aps_ref) > 0.3
+    return m_gpu, m_ref
+
+
+@pytest.mark.gpu
+def test_fpn_im_detect_eval_loop_matches_reference_loop():
+    """fp32 ResNet-FPN detector -> im_detect (base_fpn_model.py:364-390) -> the per-image
+    evaluation loop -> VOC07 mAP, against the restated reference loop on the same dense-part outputs."""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(11)
+    m = ResNetFpnDetector(50, 21, (256, 352), 300, dtype=torch.float32).prepare()
+    _im_detect_eval(m, [1.0, 1.6, 0.8, 1.25], 5, 'sorted_rois')
+    # level-sorted rows with empty levels dropped (:384-388) == the hot path's sorted RoI list
+    hot = m._hot[0]
+    k = int(hot.roi_count.item())
+    lv = hot.roi_level[:k].cpu().numpy()
+    assert np.all(np.diff(lv) >= 0) and int(hot.level_counts.sum().item()) == k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['c4', 'vgg16'])
+def test_frcnn_im_detect_eval_loop_matches_reference_loop(kind):
+    """base_faster_rcnn_model.py:279-306 im_detect on the single-level detectors, same check."""
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
+    torch.manual_seed(12)
+    if kind == 'c4':
+        m = ResNetC4Detector(50, 21, (256, 352), 100, dtype=torch.float32).prepare()
+    else:
+        m = Vgg16Detector(21, (256, 352), 100, dtype=torch.float32).prepare()
+    _im_detect_eval(m, [1.0, 1.6], 6, 'rois')
+
+
+@pytest.mark.gpu
+def test_detector_incomplete_nms_is_flagged_never_silent():
+    """a detector must never run its later stages on a partial / stale RoI list.  With too few sync-free
+    NMS chunks for a heavily clustered score map the image is reported EMPTY and forward() raises; with the detector's
+    default chunk count the same inputs complete and match the oracle."""
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, synthetic_fpn_inputs
+    shape, K = (800, 1333), 1000
+    host, dev = synthetic_fpn_inputs(shape, 21, K, channels=8, seed=500, score_kind='clustered')
+    narrow = FpnHotPath(shape, 21, K, 8, blind_chunks=1)
+    narrow.step(dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+    torch.cuda.synchronize()
+    assert int(narrow.nms_done.item()) == 0
+    assert int(narrow.roi_count.item()) == 0 and int(narrow.det_count.item()) == 0
+    assert float(narrow.roi_features.abs().max().item()) == 0.0
+    from tf_eager_object_detection_amd.model.fpn_detector import DEFAULT_BLIND_CHUNKS, _NmsCompleteness
+
+    class Probe(_NmsCompleteness):
+        _hot = [narrow]
+    with pytest.raises(RuntimeError, match='did not complete'):
+        Probe()._after_pass(1, None)
+    safe = FpnHotPath(shape, 21, K, 8, blind_chunks=DEFAULT_BLIND_CHUNKS)
+    safe.step(dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+    torch.cuda.synchronize()
+    assert int(safe.nms_done.item()) == 1
+    fg = co.rpn_fg_fpn(host['rpn_logits'])
+    _, idx = co.region_proposal(host['rpn_deltas'], co.fpn_anchors(shape), fg, shape, K, 0.7)
+    k = int(safe.roi_count.item())
+    assert k == len(idx)
+    np.testing.assert_array_equal(safe.roi_idx[:k].cpu().numpy(), idx)

@@ -646,9 +646,10 @@ def test_roi_pool_float16_feature_maps_bit_exact():
                               axis=1).astype(np.float32), np.zeros(int(np.sum(slv == l)), np.int32), (14, 14))))
                 for l in range(4) if np.any(slv == l)], axis=0).astype(np.float16)
             np.testing.assert_array_equal(h(got).view(np.uint16), want.view(np.uint16))
-    # un-pooled / padded modes are float32 only
-    with pytest.raises(Exception):
-        ops.roi_pool([g(feats16[0])], g(srois[:4]), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_NONE, strides=[4.0])
+    # the un-pooled 7 x 7 crop (ResNet-C4 form, roi_pooling.py:85-90) on float16 maps
+    got = ops.roi_pool([g(feats16[0])], g(srois[:64]), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_NONE, strides=[4.0])
+    want = co.roi_pool(feats16[0].astype(np.float32), srois[:64], stride=4, pool=7, max_pool=False).astype(np.float16)
+    np.testing.assert_array_equal(h(got).view(np.uint16), want.view(np.uint16))
 
 
 def test_executor_reports_job_errors_and_recovers():
@@ -771,6 +772,13 @@ def test_wide_first_nms_chunk_completes_clustered_scores_in_batched_launches():
                     m = int(slot.roi_count.item())
                     assert m == len(idx)
                     np.testing.assert_array_equal(h(slot.roi_idx[:m]), idx)
+                else:
+                    # an incomplete image is reported EMPTY (odet.h, odet_nms): no stage ever runs on a partial or
+                    # stale RoI list -- zero proposals, zero RoI features, zero detections, nms_done = 0
+                    assert int(slot.roi_count.item()) == 0 and int(slot.det_count.item()) == 0
+                    assert int(h(slot.level_counts).sum()) == 0
+                    assert float(slot.roi_features.abs().max().item()) == 0.0
+                    assert float(slot.record[-1].item()) == 0.0
         finally:
             pool.close()
     with pytest.raises(Exception):

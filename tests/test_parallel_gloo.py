@@ -113,3 +113,76 @@ def test_all_gather_detections_world2_gloo():
             np.testing.assert_array_equal(gb, b[:m])
             np.testing.assert_array_equal(gl, l[:m])
             np.testing.assert_array_equal(gs, s[:m])
+
+
+# ---- the exchange bench.py times: stream groups of B images, [S, world, B, rec_len], ragged tail ----------------
+def _group_worker(rank, world, port, S, B, rounds, num_images, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        rec_len = MAX_DET * 6 + 1
+        ex = parallel.GroupExchange(S, B, rec_len, 'cpu')
+        mine = parallel.shard_images(num_images, rank, world)
+        got = {}
+        k = 0                                     # next local image
+        for rd in range(rounds):
+            for g in range(S):
+                block = torch.zeros((B, rec_len))
+                valid = 0
+                for j in range(B):
+                    if k + j < len(mine):
+                        b, l, sc, m = _fake_detections(mine[k + j])
+                        block[j] = parallel.pack_detections(torch.from_numpy(b), torch.from_numpy(l),
+                                                            torch.from_numpy(sc), torch.tensor([m], dtype=torch.int32),
+                                                            MAX_DET)
+                        valid += 1
+                    else:
+                        block[j] = 123.0          # stale slot contents: must never reach another rank
+                out = ex.gather(g, block, valid=valid)
+                assert out.shape == (world, B, rec_len)
+                for r in range(world):
+                    for j in range(B):
+                        local = k + j             # local index on rank r
+                        img = r + local * world
+                        cnt = int(out[r, j, -1].item())
+                        if img < num_images:
+                            got[img] = [t.numpy().copy() for t in parallel.unpack_detections(out[r, j], MAX_DET)]
+                        else:
+                            assert cnt == 0 and torch.all(out[r, j, :-1].view(-1, 6)[:, 4] == -1.0)
+                k += B
+        q.put((rank, got))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_group_exchange_world2_gloo_ragged():
+    world, S, B, rounds = 2, 3, 4, 2
+    num_images = 41                   # 2 ranks x 24 slots; rank 1's last group is ragged, the one after empty
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, S, B, rounds, num_images, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got in results:
+        assert sorted(got) == list(range(num_images))           # every rank ends with every image's record
+        for img in range(num_images):
+            b, l, s, m = _fake_detections(img)
+            gb, gl, gs = got[img]
+            np.testing.assert_array_equal(gb, b[:m])
+            np.testing.assert_array_equal(gl, l[:m])
+            np.testing.assert_array_equal(gs, s[:m])
+
+
+def test_group_exchange_single_rank_cpu():
+    ex = parallel.GroupExchange(2, 3, MAX_DET * 6 + 1, 'cpu')
+    block = torch.arange(3 * (MAX_DET * 6 + 1), dtype=torch.float32).view(3, -1)
+    out = ex.gather(1, block, valid=2)
+    assert out.shape == (1, 3, MAX_DET * 6 + 1)
+    assert torch.equal(out[0, :2], block[:2])
+    assert float(out[0, 2, -1]) == 0.0 and torch.all(out[0, 2, :-1].view(-1, 6)[:, 4] == -1.0)

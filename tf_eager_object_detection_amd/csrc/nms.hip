@@ -584,7 +584,18 @@ struct ScanParams {          // pointer tables: one entry per image of the batch
   PerImg<int64_t*> as_perm;
   PerImg<int32_t*> as_counts;
   int n, use_init, K, min_level, max_level;
+  int fail_empty;      // last sync-free chunk of a job whose outputs feed further kernels through out_count (the fused
+                       // proposal stages): an INCOMPLETE result is reported as zero proposals (+ *out_done = 0), so
+                       // that nothing downstream runs on a partial / stale RoI list
 };
+
+// the job could not be completed inside its sync-free chunks: empty result (thread 0 of the workgroup)
+__device__ __forceinline__ void scan_fail_empty(int32_t* out_count, int32_t* out_done, int32_t* level_counts, int nl) {
+  *out_count = 0;
+  if (out_done) *out_done = 0;
+  if (level_counts)
+    for (int L = 0; L < nl; ++L) level_counts[L] = 0;
+}
 
 template <bool LDSMAT>
 __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
@@ -618,7 +629,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
   if (st->done) return;                       // uniform: an earlier chunk finished the job
   // a later chunk that found nothing left in its order (the ranked selection is exhausted): the state stays
   // "not done" for whoever continues (the per-image fallback on the full order, or the caller's out_done check)
-  if (sp.use_init && st->chunk_m == 0 && st->pos < sp.n - st->n_invalid) return;
+  if (sp.use_init && st->chunk_m == 0 && st->pos < sp.n - st->n_invalid) {
+    if (sp.fail_empty && threadIdx.x == 0) scan_fail_empty(out_count, out_done, ao.counts, ao.max_level - ao.min_level + 1);
+    return;
+  }
   NmsHeader* hdr = reinterpret_cast<NmsHeader*>(st);   // the state is the header's first member
   (void)hdr;
   STAMP(hdr, 0);
@@ -830,8 +844,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     st->kept = nkf;
     st->pos = np;
     st->done = done;
-    *out_count = nkf;
-    if (out_done) *out_done = done;
+    if (sp.fail_empty && !done) {
+      scan_fail_empty(out_count, out_done, ao.counts, nl);
+    } else {
+      *out_count = nkf;
+      if (out_done) *out_done = done;
+    }
   }
   STAMP(hdr, 4);
   if (fused_lv) {
@@ -952,6 +970,7 @@ struct NmsJob {
   int n, K;
   float thr;
   int blind_chunks;
+  int fail_empty;           // sync-free jobs: report an incomplete result as zero proposals (ScanParams::fail_empty)
   int first_chunk;          // 0 = auto (~1.5 K candidates), else candidates of the first chunk (<= NMS_CHUNK)
   int B;                    // images in the batch (1..ODET_MAX_BATCH)
   NmsImage img[ODET_MAX_BATCH];
@@ -1071,6 +1090,9 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   sp.as_perm = per_img<int64_t*>(J, [&](int i) { return J.img[i].assign.perm; });
   sp.as_counts = per_img<int32_t*>(J, [&](int i) { return J.img[i].assign.counts; });
   sp.n = n; sp.use_init = 0; sp.K = K;
+  const int blind_n = J.blind_chunks < 1 ? 1 : J.blind_chunks;
+  const bool fail_empty = J.fail_empty && J.img[0].out_done != nullptr;
+  sp.fail_empty = (fail_empty && blind_n == 1) ? 1 : 0;         // (set on the LAST sync-free chunk only)
   sp.min_level = J.img[0].assign.min_level; sp.max_level = J.img[0].assign.max_level;
   {
     const int cap0 = std::min((int)limit, (n + 63) / 64 * 64);
@@ -1108,6 +1130,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     si.out_done = shift(sp.out_done); si.as_rois = shift(sp.as_rois); si.as_level = shift(sp.as_level);
     si.as_perm = shift(sp.as_perm); si.as_counts = shift(sp.as_counts);
     si.use_init = 1;
+    si.fail_empty = 0;
     for (int k = 0; k < ODET_MAX_BATCH; ++k) si.sorted_idx.v[k] = (const uint32_t*)sorted;
     const PerImg<const NmsState*> cst = shift(cstates);
     const PerImg<const float4*> csb = shift(csboxes);
@@ -1139,6 +1162,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
       ODET_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap), 1), dim3(256), 0, st, cst, csb, J.thr, lt, dg, 0);
       ODET_LAUNCH_CHECK();
+      si.fail_empty = (!host_checks && fail_empty && c == max_chunks) ? 1 : 0;
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, 1), dim3(SCAN_THREADS), 0, st, si);
       ODET_LAUNCH_CHECK();
     }
@@ -1151,6 +1175,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     {
       ScanParams s1 = sp;
       s1.use_init = 1;                           // (sorted_idx stays the ranked selection)
+      s1.fail_empty = (fail_empty && blind == 2) ? 1 : 0;
       const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
       hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, B), dim3(256), 0, st, sp.st, n, cap, 1, J.prep, J.mode,
                          sp.sorted_idx, sboxes, sorig);
@@ -1191,6 +1216,8 @@ static void no_assign(AssignOut* a) {
 static void job_init(NmsJob* J, int mode, int n, int K, float thr, int blind_chunks, int B) {
   memset(J, 0, sizeof(*J));
   J->mode = mode; J->n = n; J->K = K; J->thr = thr; J->blind_chunks = blind_chunks; J->B = B;
+  // the fused proposal stages feed further kernels through out_count: incomplete sync-free results are reported empty
+  J->fail_empty = (mode == PREP_FPN || mode == PREP_FRCNN) ? 1 : 0;
   for (int i = 0; i < ODET_MAX_BATCH; ++i) no_assign(&J->img[i].assign);
 }
 

@@ -1,42 +1,47 @@
 // RoI feature extraction: tf.image.crop_and_resize (bilinear, extrapolation 0) fused with the
-// reference's 2x2 max / avg pooling, over all pyramid levels in one launch.
+// reference's 2x2 max / avg pooling, over all pyramid levels (and up to 8 images) in one launch.
 //
 //   model/roi_pooling.py:45-90   RoiPoolingCropAndResize   (NORM_STRIDE, POOL_MAX2 | POOL_NONE)
 //   model/roi_pooling.py:8-42    RoiPoolingCropAndResize2  (NORM_IMAGE,  POOL_MAX2)   <- FPN
 //   model/roi_pooling.py:93-177  crop_and_resize/roi_align/RoiPoolingRoiAlign
-//                                                          (NORM_TP_ALIGN, POOL_AVG2)
+//                                                          (NORM_TP_ALIGN[_NOPAD], POOL_AVG2 | POOL_NONE)
 //
-// The reference materialises the [R,14,14,C] crops (200 MB at R=1000, C=256) and pools them in
-// a second op.  Here one workgroup produces one output ROW (P bins x C channels) of one RoI:
+// The reference materialises the [R,2P,2P,C] crops (200 MB at R = 1000, C = 256) and pools them in a
+// second op; here the pooled [R,P,P,C] features are the only thing written.
 //
-//   * the sampling arithmetic (box normalisation, per-sample coordinates) is evaluated once per
-//     workgroup instead of once per bin;
-//   * LDS-staged RoI tile: when the feature cells tapped by the row's S x (P*S) samples form a
-//     small bounding tile (<= ROI_LDS_BYTES, i.e. sample spacing below ~1 cell -- the RoIs whose
-//     bilinear taps overlap), the tile is loaded ONCE (NHWC: a cell's C channels are contiguous,
-//     64 lanes x float4 = 1 KiB coalesced per cell) into LDS and all taps of the row are served
-//     from there: 4-5x less L2 traffic than fetching every tap.  RoIs with wider spacing share no
-//     taps; they read their taps straight from L2 (coalesced 1 KiB per tap).
-//   * lerps in the exact TF operation order (no FMA), 2x2 max / avg reduced in registers -- max
-//     is exact and the avg uses the same row-major sum, so results are bit-identical to the
-//     un-fused form.
+// Work split: ONE WAVE = ONE OUTPUT ROW of one RoI (P bins), a lane = 4 consecutive channels of a cell
+// (NHWC: a cell's C channels are contiguous, 64 lanes x 16 B = 1 KiB coalesced per cell and wave).  A
+// workgroup is the P waves of one RoI (they tap the same cells, so they share the CU's L1).
 //
-// Workgroup = 4 waves; wave w computes bins w, w+4, ... of the row, lane = 4 channels.
-// Consecutive rows / (level-sorted) RoIs are mapped to the same XCD so that each XCD's L2 mostly
-// holds one neighbourhood of one pyramid level.
-#include <stdlib.h>
-
-#include <algorithm>
-#include <mutex>
-
+//   * Everything about the sample ROWS of the wave's output row (the tapped cell rows, their lerp
+//     weights, how the two sample rows of a bin share cell rows) is wave-uniform and loop-invariant: it
+//     lives in scalar registers.  The sample COLUMNS are computed once, lane px = bin column px, and a bin
+//     fetches its column descriptor with four v_readlane.
+//   * Cells are read with buffer loads whose address is split the way the data is: the per-lane part
+//     (lane * 16 B, + a column step) never changes, the per-cell part is a scalar byte offset (soffset) --
+//     a bin costs a handful of scalar adds and no vector address arithmetic.
+//   * Cells tapped by both samples of a bin along an axis are DEDUPLICATED IN REGISTERS: along an axis
+//     the two samples tap cells (lo0, lo0+1) and (lo1, lo1+1); D = lo1 - lo0 in {0, 1} means they share
+//     cells, so only 2 + D distinct rows / columns are loaded (4, 6 or 9 cells instead of 16 taps -- every
+//     RoI whose sample spacing is below one cell); D = 2 is the general form (lo0, hi0, lo1, hi1 as they
+//     are).  Same values, same lerp arithmetic -> bit-identical to the 16-tap form.  The row class is fixed
+//     per wave (three loop variants), the column class is switched per bin.
+//   * Lerps in the exact TF operation order (no FMA: the library is built with -ffp-contract=off), the
+//     2x2 max / avg reduced in registers -- max is exact and avg uses the same row-major sum, so results
+//     are bit-identical to the un-fused form.  Pooled features are written once with non-temporal stores.
+//   * XCD-aware placement: consecutive (spatially ordered, odet_roi_order) RoIs go to the same XCD, and in
+//     a batch of 2 / 4 / 8 images every image gets 4 / 2 / 1 XCDs of its own, so an XCD's L2 holds one
+//     neighbourhood of one pyramid level of one image.
+//
+// Measured alternatives that lost (LDS-staged RoI tiles, LDS-DMA prefetch ring, packed float32 lerps,
+// row sharing between bins) are recorded in DESIGN.md section 3.2 and tools/exp/*.patch.
 #include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "odet_internal.h"
-
-#define ROI_LDS_BYTES (40 * 1024)   // staged tile budget: 4 workgroups per CU
 
 struct RoiParams {
   const void* data[ODET_MAX_BATCH][ODET_MAX_LEVELS];    // [image of the batch][pyramid level]; float32 or float16
@@ -48,16 +53,13 @@ struct RoiParams {
   int H[ODET_MAX_LEVELS];
   int W[ODET_MAX_LEVELS];
   float stride[ODET_MAX_LEVELS];
-  int C, n, norm_mode, P, pool_mode, num_levels;
+  int C, n, P, num_levels;
   float image_h, image_w;
-  int nblocks;        // logical workgroups (before padding the grid to a multiple of 8)
+  int nblocks;        // logical workgroups per image (before padding the grid to a multiple of 8)
   int blocks_per_xcd;
-  int rows_per_wg;    // output rows of one RoI per workgroup
-  int groups_per_roi; // ceil(P / rows_per_wg)
-  int use_desc;       // whole-RoI descriptor form (roi_bins_desc)
+  int waves;          // waves (= output rows) per workgroup; == P: a workgroup is one RoI
   int xcd_images;     // 1: the image is derived from the XCD slot (batch of 2 / 4 / 8), 0: blockIdx.y
   int xcds_per_img;   // XCDs that serve one image (8 / batch)
-  int f16;            // float16 feature maps / output
 };
 
 struct Axis {
@@ -77,20 +79,16 @@ __device__ __forceinline__ Axis make_axis(float lo_n, float hi_n, int dim, int c
   return a;
 }
 
-__device__ __forceinline__ float axis_coord(const Axis& a, int i, int crop) {
-  return (crop > 1) ? a.start + (float)i * a.scale : a.single;
-}
-
-struct Tap {      // one sample along one axis (wave-uniform)
+struct Tap {      // one sample along one axis
   bool ok;        // TF: not extrapolated (0 <= in <= dim-1; NaN fails)
-  int lo, hi;     // floor / ceil cell (after the SYMMETRIC-pad remap for the tensorpack modes)
+  int lo, hi;     // floor / ceil cell (after the SYMMETRIC-pad remap for the padded tensorpack mode)
   float lerp;
 };
 
 template <bool PAD>
 __device__ __forceinline__ Tap make_tap(const Axis& a, int i, int crop, int dim) {
   Tap t;
-  const float in = axis_coord(a, i, crop);
+  const float in = (crop > 1) ? a.start + (float)i * a.scale : a.single;
   // TF: extrapolate when (in < 0 || in > dim-1).  Written as the positive test so that a NaN
   // coordinate can never turn into a tap index.
   t.ok = (in >= 0.0f && in <= a.limit);
@@ -101,6 +99,7 @@ __device__ __forceinline__ Tap make_tap(const Axis& a, int i, int crop, int dim)
     lo = min(max(lo - 1, 0), dim - 1);
     hi = min(max(hi - 1, 0), dim - 1);
   }
+  if (!t.ok) { lo = 0; hi = 0; }     // never an address
   t.lo = lo; t.hi = hi;
   return t;
 }
@@ -134,347 +133,259 @@ __device__ __forceinline__ float4 pool4(const float4 (&v)[2][2]) {
   return o;
 }
 
-// 4 consecutive channels of a cell: float32 maps as they are, float16 maps (BASELINE config 5) widened
-// to float32 for the lerps and rounded to nearest-even on the way out
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 ld4(const __half* p) {
-  const uint2 u = *reinterpret_cast<const uint2*>(p);
-  const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
-  const float2 fa = __half22float2(a), fb = __half22float2(b);
-  return make_float4(fa.x, fa.y, fb.x, fb.y);
-}
-// Pooled features are written once and not read again by this path: non-temporal stores keep the 50 MB per
-// image out of L2 / Infinity Cache, where they would evict the feature-map lines neighbouring RoIs share
-// (measured in the bench: one-image launch 44-47 us -> 37-40 us with the maps streaming from HBM).
-typedef float f4v __attribute__((ext_vector_type(4)));
+// ---- cell I/O through buffer descriptors -------------------------------------------------------------------
+// address = descriptor base + soffset (scalar, bytes) + voffset (per lane, bytes).  float32 maps as they are,
+// float16 maps (BASELINE config 5) widened to float32 for the lerps and rounded to nearest-even on the way out.
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void st4(float* p, float4 v) {
-  const f4v t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(p));
-}
-__device__ __forceinline__ void st4(__half* p, float4 v) {
-  const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
-  u2v u;
-  u.x = *reinterpret_cast<const uint32_t*>(&a);
-  u.y = *reinterpret_cast<const uint32_t*>(&b);
-  *reinterpret_cast<u2v*>(p) = u;      // (float16 outputs: plain stores; non-temporal measured neutral end to end)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+template <typename FT> struct Cell;
+template <> struct Cell<float> {
+  static constexpr uint32_t LANE_BYTES = 16;
+  static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u4v u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+  }
+  // Pooled features are written once and not read again by this path: non-temporal stores keep the 50 MB per
+  // image out of L2 / Infinity Cache, where they would evict the feature-map lines neighbouring RoIs share.
+  static __device__ __forceinline__ void store(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
+    const u4v u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, /*nt*/ 2);
+  }
+};
+template <> struct Cell<__half> {
+  static constexpr uint32_t LANE_BYTES = 8;
+  static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u2v u = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    const uint32_t ux = u.x, uy = u.y;
+    const __half2 a = *reinterpret_cast<const __half2*>(&ux), b = *reinterpret_cast<const __half2*>(&uy);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    return make_float4(fa.x, fa.y, fb.x, fb.y);
+  }
+  static __device__ __forceinline__ void store(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
+    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+    u2v u;
+    u.x = *reinterpret_cast<const uint32_t*>(&a);
+    u.y = *reinterpret_cast<const uint32_t*>(&b);
+    __builtin_amdgcn_raw_buffer_store_b64(u, r, (int)voff, (int)soff, 0);   // (float16 features are read back by the RoI head)
+  }
+};
+
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t rl_u(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+__device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t rfl_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float rfl_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
 
-// One bin whose 2 x 2 samples are all inside the map, with its tapped cells DEDUPLICATED IN REGISTERS:
-// along an axis the two samples tap cells (lo0, lo0+1) and (lo1, lo1+1); D = lo1 - lo0 in {0, 1} means
-// they share cells, so only 2 + D distinct rows / columns are loaded (4, 6 or 9 cells instead of 16
-// taps -- the RoIs whose sample spacing is below one cell, i.e. most of them).  D = 2 is the general
-// form: (lo0, hi0, lo1, hi1) taken as they are, no sharing assumed.  Same values, same lerp
-// arithmetic as the 16-tap form -> bit-identical results.
+// sharing class of the two samples of a bin along one axis: 0 / 1 = they share cells (lo1 - lo0), 2 = general
+__device__ __forceinline__ int share_class(const Tap& t0, const Tap& t1) {
+  const int d = t1.lo - t0.lo;
+  return (t0.hi == t0.lo + 1 && t1.hi == t1.lo + 1 && (d == 0 || d == 1)) ? d : 2;
+}
+
+// What a wave knows about its output row (scalar registers): byte offsets of the four tapped cell rows
+// (lo0, hi0, lo1, hi1; for the sharing classes row[i] = row[0] + i * row pitch), the y lerp weights, the maps'
+// descriptor, and the per-lane byte offset.
+struct RowCtx {
+  rsrc_t feat;
+  uint32_t row[4];
+  float yw[2];
+  uint32_t vlane;     // lane * bytes per lane (+ channel chunk)
+  uint32_t cellB;     // bytes per cell = C * sizeof(FT)
+};
+
+// One bin whose 2 x 2 samples are all inside the map.  DY / DX: sharing class per axis.  c0: byte offset of the
+// bin's first cell column; crel[k]: byte offsets of the columns (lo0, hi0, lo1, hi1) relative to c0 (DX == 2).
 template <int POOL, int DY, int DX, typename FT>
-__device__ __forceinline__ float4 roi_bin_shared(const FT* base, uint32_t C, uint32_t c, const uint32_t (&rowoff)[4],
-                                                 const uint32_t (&col)[4], const float (&xw)[2],
-                                                 const float (&yw)[2]) {
+__device__ __forceinline__ float4 roi_bin(const RowCtx& rc, uint32_t c0, const uint32_t (&crel)[4], const float (&xw)[2]) {
   constexpr int NR = (DY == 2) ? 4 : 2 + DY, NC = (DX == 2) ? 4 : 2 + DX;
+  uint32_t soff[NR], voff[NC];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) soff[i] = rc.row[i] + c0;                              // scalar
+#pragma unroll
+  for (int j = 0; j < NC; ++j) voff[j] = rc.vlane + ((DX == 2) ? crel[j] : (uint32_t)j * rc.cellB);
   float4 blk[NR][NC];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-#if defined(ODET_ROI_ABLATE) && (ODET_ROI_ABLATE == 1 || ODET_ROI_ABLATE == 5)   /* diagnostic: no loads (5: nor stores) */
-      blk[i][j] = make_float4((float)(rowoff[i] + col[j]), xw[0], yw[0], (float)c);
-#else
-      blk[i][j] = ld4(base + (rowoff[i] + col[j]) * C + c);
-#endif
+      blk[i][j] = Cell<FT>::load(rc.feat, voff[j], soff[i]);
     }
   }
-#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 2     /* diagnostic: loads, no lerp arithmetic */
-  {
-    float4 acc = blk[0][0];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-#pragma unroll
-      for (int j = 0; j < NC; ++j) acc.x = fmaxf(acc.x, blk[i][j].y + blk[i][j].z + blk[i][j].w + blk[i][j].x);
-    }
-    return acc;
-  }
-#endif
   float4 v[2][2];
 #pragma unroll
   for (int sy = 0; sy < 2; ++sy) {
 #pragma unroll
     for (int sx = 0; sx < 2; ++sx) {
-      constexpr int dummy = 0;
-      (void)dummy;
       const int rt = (DY == 2) ? 2 * sy : sy * DY, rb = rt + 1;
       const int cl = (DX == 2) ? 2 * sx : sx * DX, cr = cl + 1;
-      v[sy][sx] = lerp_tap(blk[rt][cl], blk[rt][cr], blk[rb][cl], blk[rb][cr], xw[sx], yw[sy]);
+      v[sy][sx] = lerp_tap(blk[rt][cl], blk[rt][cr], blk[rb][cl], blk[rb][cr], xw[sx], rc.yw[sy]);
     }
   }
   return pool4<POOL>(v);
 }
 
-// Bins w, w+4, ... of `nrows` consecutive output rows starting at row0 (w = wave).  The taps of ALL
-// sample rows / columns were computed once, one per lane (tyl / txl: lane i = sample i); a bin fetches
-// its S x S taps with v_readlane.  A tap (row y, col x) lives at float offset
-// ((y - r0) * rs + (x - c0)) * C + c from `base` -- the feature map itself (r0 = c0 = 0, rs = W) or
-// the LDS tile.
-template <int POOL, bool PAD, bool LANE_TAPS>
-__device__ __forceinline__ void roi_bins(const float* base, int rs, int r0, int c0, int C, int P, int crop,
-                                         int Hdim, int Wdim, const Axis& ay, const Axis& ax, const Tap& tyl,
-                                         const Tap& txl, int row0, int nrows, float* __restrict__ orow0) {
-  constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
+// The bins of one output row whose row class is DY, every sample of the row inside the map.  FULL: C is a
+// multiple of 256 (no lane is ever idle).
+template <int POOL, int DY, bool FULL, typename FT>
+__device__ __forceinline__ void roi_row(const RowCtx& rc0, rsrc_t out, int P, int C, uint32_t xcls_l, uint32_t c0_l,
+                                        const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
+  RowCtx rc = rc0;
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int txok = txl.ok ? 1 : 0, tyok = tyl.ok ? 1 : 0;
-#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 4        /* diagnostic: prologue only */
-  const int nbins = (tyl.lerp == 1.2345e30f) ? nrows * P : 0;
-#else
-  const int nbins = nrows * P;
-#endif
-  for (int b = w; b < nbins; b += 4) {
-    const int pr = b / P;
-    const int px = b - pr * P;
-    const int py = row0 + pr;
-    Tap tx[2], ty[2];
+  for (int px = 0; px < P; ++px) {
+    const int xc = rl_i((int)xcls_l, px);
+    const uint32_t c0 = rl_u(c0_l, px);
+    const float xw[2] = {rl_f(xw0_l, px), rl_f(xw1_l, px)};
+    uint32_t crel[4] = {0, 0, 0, 0};
+    if (xc == 2) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int xx = px * S + (s < S ? s : 0), yy = py * S + (s < S ? s : 0);
-      if (LANE_TAPS) {
-        tx[s].ok = rl_i(txok, xx) != 0; tx[s].lo = rl_i(txl.lo, xx); tx[s].hi = rl_i(txl.hi, xx);
-        tx[s].lerp = rl_f(txl.lerp, xx);
-        ty[s].ok = rl_i(tyok, yy) != 0; ty[s].lo = rl_i(tyl.lo, yy); ty[s].hi = rl_i(tyl.hi, yy);
-        ty[s].lerp = rl_f(tyl.lerp, yy);
-      } else {
-        tx[s] = make_tap<PAD>(ax, xx, crop, Wdim);
-        ty[s] = make_tap<PAD>(ay, yy, crop, Hdim);
-        ty[s].lo = __builtin_amdgcn_readfirstlane(ty[s].lo);
-        ty[s].hi = __builtin_amdgcn_readfirstlane(ty[s].hi);
-      }
+      for (int k = 1; k < 4; ++k) crel[k] = rl_u(crel_l[k], px);
     }
-    // row offsets (in cells) of the S sample rows, wave-uniform
-    int rowlo[2], rowhi[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) { rowlo[s] = (ty[s].lo - r0) * rs; rowhi[s] = (ty[s].hi - r0) * rs; }
-    float* __restrict__ obin = orow0 + ((size_t)pr * P + px) * C;
-    if (S == 2 && !PAD && ty[0].ok && ty[1].ok && tx[0].ok && tx[1].ok) {
-      // all four samples inside the map: deduplicated loads.  Register-sharing class per axis:
-      // 0 / 1 = the two samples share cells, 2 = general
-      int dy = 2, dx = 2;
-      {
-        const int d = ty[1].lo - ty[0].lo;
-        if (ty[0].hi == ty[0].lo + 1 && ty[1].hi == ty[1].lo + 1 && (d == 0 || d == 1)) dy = d;
-        const int e = tx[1].lo - tx[0].lo;
-        if (tx[0].hi == tx[0].lo + 1 && tx[1].hi == tx[1].lo + 1 && (e == 0 || e == 1)) dx = e;
-      }
-      uint32_t rowoff[4], col[4];
-      if (dy == 2) {
-        rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = (uint32_t)rowhi[0];
-        rowoff[2] = (uint32_t)rowlo[1]; rowoff[3] = (uint32_t)rowhi[1];
-      } else {
-        rowoff[0] = (uint32_t)rowlo[0]; rowoff[1] = rowoff[0] + (uint32_t)rs;
-        rowoff[2] = rowoff[1] + (uint32_t)rs; rowoff[3] = rowoff[2];
-      }
-      if (dx == 2) {
-        col[0] = (uint32_t)(tx[0].lo - c0); col[1] = (uint32_t)(tx[0].hi - c0);
-        col[2] = (uint32_t)(tx[1].lo - c0); col[3] = (uint32_t)(tx[1].hi - c0);
-      } else {
-        col[0] = (uint32_t)(tx[0].lo - c0); col[1] = col[0] + 1; col[2] = col[0] + 2; col[3] = col[2];
-      }
-      const float xw[2] = {tx[0].lerp, tx[1].lerp};
-      const float yw[2] = {ty[0].lerp, ty[1].lerp};
-      const int cls = dy * 3 + dx;
-      for (int c = lane * 4; c < C; c += 256) {
+    const uint32_t so_out = (uint32_t)px * rc.cellB;
+    for (int ch = 0; ch < C; ch += 256) {
+      rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
+      if (FULL || lane * 4 + ch < C) {
         float4 o;
-        switch (cls) {
-          case 0: o = roi_bin_shared<POOL, 0, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 1: o = roi_bin_shared<POOL, 0, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 2: o = roi_bin_shared<POOL, 0, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 3: o = roi_bin_shared<POOL, 1, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 4: o = roi_bin_shared<POOL, 1, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 5: o = roi_bin_shared<POOL, 1, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 6: o = roi_bin_shared<POOL, 2, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 7: o = roi_bin_shared<POOL, 2, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          default: o = roi_bin_shared<POOL, 2, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-        }
-#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 3      /* diagnostic: no stores */
-        if (o.x == 1.2345e30f) st4(obin + c, o);
-#else
-        st4(obin + c, o);
-#endif
+        if (xc == 0) o = roi_bin<POOL, DY, 0, FT>(rc, c0, crel, xw);
+        else if (xc == 1) o = roi_bin<POOL, DY, 1, FT>(rc, c0, crel, xw);
+        else o = roi_bin<POOL, DY, 2, FT>(rc, c0, crel, xw);
+        Cell<FT>::store(out, rc.vlane, so_out, o);
       }
-      continue;
-    }
-    // general form: every sample guarded (extrapolated samples are 0), 4 taps each
-    for (int c = lane * 4; c < C; c += 256) {
-      float4 v[2][2];
-#pragma unroll
-      for (int sy = 0; sy < S; ++sy) {
-#pragma unroll
-        for (int sx = 0; sx < S; ++sx) {
-          float4 res = make_float4(0, 0, 0, 0);
-          if (ty[sy].ok && tx[sx].ok) {
-            const uint32_t xl = (uint32_t)(tx[sx].lo - c0), xr = (uint32_t)(tx[sx].hi - c0);
-            const uint32_t otl = ((uint32_t)rowlo[sy] + xl) * (uint32_t)C + (uint32_t)c;
-            const uint32_t otr = ((uint32_t)rowlo[sy] + xr) * (uint32_t)C + (uint32_t)c;
-            const uint32_t obl = ((uint32_t)rowhi[sy] + xl) * (uint32_t)C + (uint32_t)c;
-            const uint32_t obr = ((uint32_t)rowhi[sy] + xr) * (uint32_t)C + (uint32_t)c;
-            const float4 tl = *reinterpret_cast<const float4*>(base + otl);
-            const float4 tr = *reinterpret_cast<const float4*>(base + otr);
-            const float4 bl = *reinterpret_cast<const float4*>(base + obl);
-            const float4 br = *reinterpret_cast<const float4*>(base + obr);
-            res = lerp_tap(tl, tr, bl, br, tx[sx].lerp, ty[sy].lerp);
-          }
-          v[sy][sx] = res;
-        }
-      }
-      st4(obin + c, pool4<POOL>(v));
     }
   }
 }
 
-// Whole-RoI form for the pooled modes with P*P <= 64 bins (un-padded): every lane first builds the
-// DESCRIPTOR of one bin -- its four taps, the register-sharing class, the cell offsets of the rows /
-// columns it loads and the lerp weights -- so the per-bin scalar bookkeeping is done once, 64 bins in
-// parallel on the vector unit; a wave then walks its bins (wave, wave + nwaves, ...) and only fetches a
-// descriptor with v_readlane before loading / lerping / storing.
+// An output row with extrapolated samples (TF: such a sample is 0): every sample guarded, 4 taps each; rc.row
+// holds the four tapped rows (lo0, hi0, lo1, hi1) as they are.  Rare (boxes are clipped to the image).
 template <int POOL, typename FT>
-__device__ __forceinline__ void roi_bins_desc(const FT* base, int W, int C, int P, int crop, const Axis& ay,
-                                              const Axis& ax, FT* __restrict__ oroi) {
+__device__ __forceinline__ void roi_row_guarded(const RowCtx& rc0, rsrc_t out, int P, int C, const uint32_t (&cabs_l)[4],
+                                             uint32_t xok_l, float xw0_l, float xw1_l, uint32_t yok) {
+  RowCtx rc = rc0;
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nwaves = blockDim.x >> 6;
-  const int nbins = P * P;
-  // ---- descriptor of bin `lane`
-  const int bpy = lane / P, bpx = lane - bpy * P;
-  const Tap ty0 = make_tap<false>(ay, min(2 * bpy, crop - 1), crop, 0);
-  const Tap ty1 = make_tap<false>(ay, min(2 * bpy + 1, crop - 1), crop, 0);
-  const Tap tx0 = make_tap<false>(ax, min(2 * bpx, crop - 1), crop, 0);
-  const Tap tx1 = make_tap<false>(ax, min(2 * bpx + 1, crop - 1), crop, 0);
-  const int okbits = (ty0.ok ? 1 : 0) | (ty1.ok ? 2 : 0) | (tx0.ok ? 4 : 0) | (tx1.ok ? 8 : 0);
-  int dy = 2, dx = 2;
-  {
-    const int d = ty1.lo - ty0.lo;
-    if (ty0.hi == ty0.lo + 1 && ty1.hi == ty1.lo + 1 && (d == 0 || d == 1)) dy = d;
-    const int e = tx1.lo - tx0.lo;
-    if (tx0.hi == tx0.lo + 1 && tx1.hi == tx1.lo + 1 && (e == 0 || e == 1)) dx = e;
-  }
-  const int cls_l = (okbits == 15) ? dy * 3 + dx : 9;          // 9 = general guarded form
-  int ro0 = ty0.lo * W, ro1 = ty0.hi * W, ro2 = ty1.lo * W, ro3 = ty1.hi * W;
-  int co0 = tx0.lo, co1 = tx0.hi, co2 = tx1.lo, co3 = tx1.hi;
-  if (cls_l != 9) {
-    if (dy != 2) { ro1 = ro0 + W; ro2 = ro1 + W; ro3 = ro2; }
-    if (dx != 2) { co1 = co0 + 1; co2 = co0 + 2; co3 = co2; }
-  }
-  const float xw0 = tx0.lerp, xw1 = tx1.lerp, yw0 = ty0.lerp, yw1 = ty1.lerp;
-
-#if defined(ODET_ROI_ABLATE) && ODET_ROI_ABLATE == 4        /* diagnostic: prologue + descriptors only */
-  const int nb_run = (xw0 == 1.2345e30f) ? nbins : 0;
-#else
-  const int nb_run = nbins;
-#endif
-  for (int b = w; b < nb_run; b += nwaves) {
-    const int cls = rl_i(cls_l, b);
-    const uint32_t rowoff[4] = {(uint32_t)rl_i(ro0, b), (uint32_t)rl_i(ro1, b), (uint32_t)rl_i(ro2, b),
-                                (uint32_t)rl_i(ro3, b)};
-    const uint32_t col[4] = {(uint32_t)rl_i(co0, b), (uint32_t)rl_i(co1, b), (uint32_t)rl_i(co2, b),
-                             (uint32_t)rl_i(co3, b)};
-    const float xw[2] = {rl_f(xw0, b), rl_f(xw1, b)};
-    const float yw[2] = {rl_f(yw0, b), rl_f(yw1, b)};
-    FT* __restrict__ obin = oroi + (size_t)b * C;
-    if (cls != 9) {
-      for (int c = lane * 4; c < C; c += 256) {
-        float4 o;
-        switch (cls) {
-          case 0: o = roi_bin_shared<POOL, 0, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 1: o = roi_bin_shared<POOL, 0, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 2: o = roi_bin_shared<POOL, 0, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 3: o = roi_bin_shared<POOL, 1, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 4: o = roi_bin_shared<POOL, 1, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 5: o = roi_bin_shared<POOL, 1, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 6: o = roi_bin_shared<POOL, 2, 0>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          case 7: o = roi_bin_shared<POOL, 2, 1>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-          default: o = roi_bin_shared<POOL, 2, 2>(base, (uint32_t)C, (uint32_t)c, rowoff, col, xw, yw); break;
-        }
-#if defined(ODET_ROI_ABLATE) && (ODET_ROI_ABLATE == 3 || ODET_ROI_ABLATE == 5)     /* diagnostic: no stores */
-        if (o.x == 1.2345e30f) st4(obin + c, o);
-#else
-        st4(obin + c, o);
-#endif
-      }
-    } else {
-      // general form: every sample guarded (extrapolated samples are 0), 4 taps each
-      const int ok = rl_i(okbits, b);
-      for (int c = lane * 4; c < C; c += 256) {
+  for (int px = 0; px < P; ++px) {
+    uint32_t cabs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cabs[k] = rl_u(cabs_l[k], px);
+    const uint32_t xok = rl_u(xok_l, px);
+    const float xw[2] = {rl_f(xw0_l, px), rl_f(xw1_l, px)};
+    const uint32_t so_out = (uint32_t)px * rc.cellB;
+    for (int ch = 0; ch < C; ch += 256) {
+      rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
+      if (lane * 4 + ch < C) {
         float4 v[2][2];
 #pragma unroll
         for (int sy = 0; sy < 2; ++sy) {
 #pragma unroll
           for (int sx = 0; sx < 2; ++sx) {
             float4 res = make_float4(0, 0, 0, 0);
-            if (((ok >> sy) & 1) && ((ok >> (2 + sx)) & 1)) {
-              const uint32_t otl = (rowoff[2 * sy] + col[2 * sx]) * (uint32_t)C + (uint32_t)c;
-              const uint32_t otr = (rowoff[2 * sy] + col[2 * sx + 1]) * (uint32_t)C + (uint32_t)c;
-              const uint32_t obl = (rowoff[2 * sy + 1] + col[2 * sx]) * (uint32_t)C + (uint32_t)c;
-              const uint32_t obr = (rowoff[2 * sy + 1] + col[2 * sx + 1]) * (uint32_t)C + (uint32_t)c;
-              const float4 tl = ld4(base + otl);
-              const float4 tr = ld4(base + otr);
-              const float4 bl = ld4(base + obl);
-              const float4 br = ld4(base + obr);
-              res = lerp_tap(tl, tr, bl, br, xw[sx], yw[sy]);
+            if (((yok >> sy) & 1) && ((xok >> sx) & 1)) {
+              const float4 tl = Cell<FT>::load(rc.feat, rc.vlane, rc.row[2 * sy] + cabs[2 * sx]);
+              const float4 tr = Cell<FT>::load(rc.feat, rc.vlane, rc.row[2 * sy] + cabs[2 * sx + 1]);
+              const float4 bl = Cell<FT>::load(rc.feat, rc.vlane, rc.row[2 * sy + 1] + cabs[2 * sx]);
+              const float4 br = Cell<FT>::load(rc.feat, rc.vlane, rc.row[2 * sy + 1] + cabs[2 * sx + 1]);
+              res = lerp_tap(tl, tr, bl, br, xw[sx], rc.yw[sy]);
             }
             v[sy][sx] = res;
           }
         }
-        st4(obin + c, pool4<POOL>(v));
+        Cell<FT>::store(out, rc.vlane, so_out, pool4<POOL>(v));
       }
     }
   }
 }
 
-// NORM: ODET_ROI_NORM_*; STAGE: allow the LDS-staged tile path.
-template <int POOL, int NORM, bool STAGE, typename FT>
-__global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
-  extern __shared__ __align__(16) float tile[];
+// The un-pooled form (one sample per bin): 4 taps, guarded.
+template <typename FT>
+__device__ __forceinline__ void roi_row_single(const RowCtx& rc0, rsrc_t out, int P, int C, const uint32_t (&cabs_l)[4],
+                                               uint32_t xok_l, float xw0_l, uint32_t yok) {
+  RowCtx rc = rc0;
+  const int lane = threadIdx.x & 63;
+  for (int px = 0; px < P; ++px) {
+    const uint32_t cl = rl_u(cabs_l[0], px), cr = rl_u(cabs_l[1], px);
+    const uint32_t xok = rl_u(xok_l, px);
+    const float xw = rl_f(xw0_l, px);
+    const uint32_t so_out = (uint32_t)px * rc.cellB;
+    const bool ok = (yok & 1) && (xok & 1);
+    for (int ch = 0; ch < C; ch += 256) {
+      rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
+      if (lane * 4 + ch < C) {
+        float4 o = make_float4(0, 0, 0, 0);
+        if (ok) {
+          const float4 tl = Cell<FT>::load(rc.feat, rc.vlane, rc.row[0] + cl);
+          const float4 tr = Cell<FT>::load(rc.feat, rc.vlane, rc.row[0] + cr);
+          const float4 bl = Cell<FT>::load(rc.feat, rc.vlane, rc.row[1] + cl);
+          const float4 br = Cell<FT>::load(rc.feat, rc.vlane, rc.row[1] + cr);
+          o = lerp_tap(tl, tr, bl, br, xw, rc.yw[0]);
+        }
+        Cell<FT>::store(out, rc.vlane, so_out, o);
+      }
+    }
+  }
+}
+
+// TAG: 0 = the product launches; 1 = the SAME code under a second kernel name, launched when HIP events are
+// attached to the dispatch (bench.py's roofline samples, timed alone on the GPU): a kernel-stats summary of a
+// profiled run then lists those launches as a row of their own (k_roi_pool<.., 1>) instead of averaging them with
+// the launches that share the chip with other streams' kernels.
+template <int POOL, int NORM, typename FT, int TAG>
+__global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
   constexpr bool PAD = (NORM == ODET_ROI_NORM_TP_ALIGN);
+  constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
   // XCD-aware remap: hardware deals workgroups round-robin over the 8 XCDs (each has its own L2).
   // A batch of 1 / 2 / 4 / 8 images gives every image 8 / 4 / 2 / 1 XCDs of its own, so that an XCD's L2
-  // only ever holds lines of one image's maps; inside an image consecutive (level-sorted) RoIs share an XCD.
+  // only ever holds lines of one image's maps; inside an image consecutive (spatially ordered) RoIs share an XCD.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int img = p.xcd_images ? xcd / p.xcds_per_img : blockIdx.y;
   const int sub = p.xcd_images ? xcd - img * p.xcds_per_img : xcd;
   const int lb = sub * p.blocks_per_xcd + slot;
   if (slot >= p.blocks_per_xcd || lb >= p.nblocks) return;
+  const int lane = threadIdx.x & 63;
+  const int w = rfl_i(threadIdx.x >> 6);
+  const int P = p.P, C = p.C;
+  int ri, py;       // this wave: output row py of the ri-th RoI of the processing order
+  if (p.waves == P) {
+    ri = lb; py = w;
+  } else {
+    const int u = lb * p.waves + w;
+    ri = u / P; py = u - ri * P;
+  }
+  if (ri >= p.n) return;
   const float4* __restrict__ rois = p.rois.v[img];
   const int32_t* __restrict__ roi_level = p.roi_level.v[img];
   const int32_t* __restrict__ count_dev = p.count_dev.v[img];
-  FT* __restrict__ out = reinterpret_cast<FT*>(p.out.v[img]);
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int P = p.P, C = p.C;
-  const int gpr = p.groups_per_roi;                 // workgroups per RoI (row groups of p.rows_per_wg rows)
   const int32_t* __restrict__ order = p.order.v[img];
-  const int ri = lb / gpr;
   const int r = order ? min(max(order[ri], 0), p.n - 1) : ri;
-  const int row0 = (lb - ri * gpr) * p.rows_per_wg;
-  const int nrows = min(p.rows_per_wg, P - row0);
-  FT* __restrict__ orow = out + ((size_t)r * P + row0) * P * C;
-
-  // the three loads of the prologue are independent (r < n always addresses valid rows): one memory
-  // latency instead of a chain of three
+  // (independent loads: r < n always addresses valid rows)
   const int cnt_raw = count_dev ? *count_dev : p.n;
   const int lvl_raw = roi_level ? roi_level[r] : 0;
   const float4 roi = rois[r];
   const int cnt = min(cnt_raw, p.n);
-  if (r >= cnt) {
-    for (int i = threadIdx.x * 4; i < nrows * P * C; i += blockDim.x * 4) st4(orow + i, make_float4(0, 0, 0, 0));
+
+  const uint32_t cellB = (uint32_t)C * (uint32_t)sizeof(FT);
+  FT* orow = reinterpret_cast<FT*>(p.out.v[img]) + ((size_t)r * P + py) * P * C;
+  const rsrc_t out = make_rsrc(orow, (uint32_t)P * cellB);
+  const uint32_t vlane0 = (uint32_t)lane * Cell<FT>::LANE_BYTES;
+  if (r >= cnt) {      // padded rows of the static-shape output are zero
+    for (int px = 0; px < P; ++px)
+      for (int c = lane * 4, ch = 0; ch < C; c += 256, ch += 256)
+        if (c < C)
+          Cell<FT>::store(out, vlane0 + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4), (uint32_t)px * cellB,
+                          make_float4(0, 0, 0, 0));
     return;
   }
 
-  const int lvl = min(max(lvl_raw, 0), p.num_levels - 1);
-  const FT* __restrict__ feat = reinterpret_cast<const FT*>(p.data[img][lvl]);
+  const int lvl = rfl_i(min(max(lvl_raw, 0), p.num_levels - 1));
   const int H = p.H[lvl], W = p.W[lvl];
-  constexpr int S = (POOL == ODET_ROI_POOL_NONE) ? 1 : 2;
   const int crop = P * S;
 
   // normalised box (y1,x1,y2,x2) exactly as the reference builds it
@@ -508,71 +419,60 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   const Axis ax = make_axis(x1n, x2n, Ws, crop);
   const int Hdim = PAD ? H : Hs, Wdim = PAD ? W : Ws;
 
-  if (!STAGE && !PAD && S == 2 && p.use_desc) {
-    // whole RoI per workgroup, per-bin descriptors built lane-parallel (P*P <= 64 checked on the host)
-    roi_bins_desc<POOL, FT>(feat, W, C, P, crop, ay, ax, orow);
+  // ---- the wave's sample rows (uniform) and, in lane px, the sample columns of bin column px
+  const Tap ty0 = make_tap<PAD>(ay, py * S, crop, Hdim);
+  const Tap ty1 = make_tap<PAD>(ay, py * S + (S - 1), crop, Hdim);
+  const int bx = min(lane, P - 1);
+  const Tap tx0 = make_tap<PAD>(ax, bx * S, crop, Wdim);
+  const Tap tx1 = make_tap<PAD>(ax, bx * S + (S - 1), crop, Wdim);
+
+  RowCtx rc;
+  rc.feat = make_rsrc(p.data[img][lvl], (uint32_t)H * (uint32_t)W * cellB);
+  const uint32_t rowB = (uint32_t)W * cellB;
+  rc.yw[0] = rfl_f(ty0.lerp); rc.yw[1] = rfl_f(ty1.lerp);
+  rc.vlane = vlane0;
+  rc.cellB = cellB;
+  const uint32_t yok = rfl_u((ty0.ok ? 1u : 0u) | (ty1.ok ? 2u : 0u));
+  const uint32_t xok_l = (tx0.ok ? 1u : 0u) | (tx1.ok ? 2u : 0u);
+  const uint32_t cabs_l[4] = {(uint32_t)tx0.lo * cellB, (uint32_t)tx0.hi * cellB, (uint32_t)tx1.lo * cellB,
+                              (uint32_t)tx1.hi * cellB};
+  const float xw0_l = tx0.lerp, xw1_l = tx1.lerp;
+  // the four tapped rows as they are
+  rc.row[0] = rfl_u((uint32_t)ty0.lo * rowB); rc.row[1] = rfl_u((uint32_t)ty0.hi * rowB);
+  rc.row[2] = rfl_u((uint32_t)ty1.lo * rowB); rc.row[3] = rfl_u((uint32_t)ty1.hi * rowB);
+
+  if (S == 1) {
+    roi_row_single<FT>(rc, out, P, C, cabs_l, xok_l, xw0_l, yok);
     return;
   }
-  if constexpr (!std::is_same<FT, float>::value) {
-    return;     // float16 maps are only served by the descriptor form (checked on the host)
-  } else {
-
-  // ALL sample rows and columns, one per lane
-  const bool lane_taps = crop <= 64;
-  const Tap txl = make_tap<PAD>(ax, min(lane, crop - 1), crop, Wdim);
-  const Tap tyl = make_tap<PAD>(ay, min(lane, crop - 1), crop, Hdim);
-
-  // bounding tile of the cells this row taps; staged when it is small (only for the un-padded modes:
-  // the tensorpack modes read through the clamped indices straight from the map)
-  bool staged = false;
-  int r0 = 0, c0 = 0, ncols = 0, trows = 0;
-  if (STAGE && !PAD && nrows == 1 && lane_taps) {
-    int rmin = 0x7fffffff, rmax = -1;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int yy = row0 * S + s;
-      if (rl_i(tyl.ok ? 1 : 0, yy)) { rmin = min(rmin, rl_i(tyl.lo, yy)); rmax = max(rmax, rl_i(tyl.hi, yy)); }
-    }
-    // in-bounds sample columns: coordinates are monotone in the sample index
-    int cmin = 0x7fffffff, cmax = -1;
-    {
-      const float first = axis_coord(ax, 0, crop), last = axis_coord(ax, crop - 1, crop);
-      const float lo = fminf(first, last), hi = fmaxf(first, last);
-      // any sample inside [0, limit] lies in [max(lo,0), min(hi,limit)]; the bounding cells of that
-      // interval contain every tapped column (a superset is fine: it only stages a few more cells)
-      const float a = fmaxf(lo, 0.0f), b = fminf(hi, ax.limit);
-      if (a <= b) { cmin = (int)floorf(a); cmax = (int)ceilf(b); }
-    }
-    if (rmax >= 0 && cmax >= 0) {
-      trows = rmax - rmin + 1;
-      ncols = cmax - cmin + 1;
-      r0 = rmin; c0 = cmin;
-      staged = (size_t)trows * ncols * C * 4 <= ROI_LDS_BYTES && trows * ncols < 2 * crop * S;
-    }
+  // every sample of the row inside the map (boxes clipped to the image: nearly always)?
+  const bool x_inside = __builtin_amdgcn_ballot_w64(lane < P && xok_l != 3) == 0;
+  if (yok != 3 || !x_inside) {
+    roi_row_guarded<POOL, FT>(rc, out, P, C, cabs_l, xok_l, xw0_l, xw1_l, yok);
+    return;
   }
-  if (STAGE && staged) {
-    // one coalesced pass: cell = wave-strided, channels = lanes x float4
-    const int cells = trows * ncols;
-    for (int cell = w; cell < cells; cell += 4) {
-      const int rr = cell / ncols, cc = cell - rr * ncols;
-      const float* src = feat + ((size_t)(r0 + rr) * W + (c0 + cc)) * C;
-      float* dst = tile + (size_t)cell * C;
-      for (int c = lane * 4; c < C; c += 256)
-        *reinterpret_cast<float4*>(dst + c) = *reinterpret_cast<const float4*>(src + c);
-    }
-    __syncthreads();
-    roi_bins<POOL, PAD, true>(tile, ncols, r0, c0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
-  } else {
-    if (lane_taps) roi_bins<POOL, PAD, true>(feat, W, 0, 0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
-    else roi_bins<POOL, PAD, false>(feat, W, 0, 0, C, P, crop, Hdim, Wdim, ay, ax, tyl, txl, row0, nrows, orow);
+  const int ycls = rfl_i(PAD ? 2 : share_class(ty0, ty1));
+  const uint32_t xcls_l = PAD ? 2u : (uint32_t)share_class(tx0, tx1);
+  const uint32_t c0_l = cabs_l[0];
+  const uint32_t crel_l[4] = {0u, cabs_l[1] - c0_l, cabs_l[2] - c0_l, cabs_l[3] - c0_l};
+  if (ycls < 2) {      // sharing classes: row[i] = first row + i * row pitch
+    rc.row[1] = rc.row[0] + rowB; rc.row[2] = rc.row[1] + rowB; rc.row[3] = rc.row[2];
   }
-  }   // FT == float
+  if ((C & 255) == 0) {
+    if (ycls == 0) roi_row<POOL, 0, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else if (ycls == 1) roi_row<POOL, 1, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else roi_row<POOL, 2, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+  } else {
+    if (ycls == 0) roi_row<POOL, 0, false, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else if (ycls == 1) roi_row<POOL, 1, false, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else roi_row<POOL, 2, false, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+  }
 }
 
 // The float16 instantiations live in their own translation unit (roi_half.hip = this file with ODET_ROI_HALF_TU):
 // roi.hip is compiled with -fno-slp-vectorize (hipcc's SLP pass packs the float32 lerps into v_pk_*_f32, which
-// issue slower than the scalar forms: +1.2 % for the float32 kernel), but the same flag costs the float16 kernel
-// its packed conversions (357 instead of 237 us for the 8-image launch), so that one is built with SLP.
+// issue slower than the scalar forms), but the same flag costs the float16 kernel its packed conversions, so
+// that one is built with SLP.
 #define ODET_ROI_HALF_KERNELS(X)                                                                               \
   X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_STRIDE) X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_IMAGE)                       \
   X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_TP_ALIGN) X(ODET_ROI_POOL_NONE, ODET_ROI_NORM_TP_ALIGN_NOPAD)            \
@@ -581,67 +481,48 @@ __global__ void __launch_bounds__(512) k_roi_pool(RoiParams p) {
   X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_STRIDE) X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_IMAGE)                       \
   X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_TP_ALIGN) X(ODET_ROI_POOL_AVG2, ODET_ROI_NORM_TP_ALIGN_NOPAD)
 #ifdef ODET_ROI_HALF_TU
-#define ODET_ROI_X(POOL, NORM) template __global__ void k_roi_pool<POOL, NORM, false, __half>(RoiParams);
+#define ODET_ROI_X(POOL, NORM)                                                       \
+  template __global__ void k_roi_pool<POOL, NORM, __half, 0>(RoiParams);            \
+  template __global__ void k_roi_pool<POOL, NORM, __half, 1>(RoiParams);
 ODET_ROI_HALF_KERNELS(ODET_ROI_X)
 #undef ODET_ROI_X
 #else
-#define ODET_ROI_X(POOL, NORM) extern template __global__ void k_roi_pool<POOL, NORM, false, __half>(RoiParams);
+#define ODET_ROI_X(POOL, NORM)                                                       \
+  extern template __global__ void k_roi_pool<POOL, NORM, __half, 0>(RoiParams);     \
+  extern template __global__ void k_roi_pool<POOL, NORM, __half, 1>(RoiParams);
 ODET_ROI_HALF_KERNELS(ODET_ROI_X)
 #undef ODET_ROI_X
 
-// A/B switches for profiling, read once (function-local static: thread-safe initialisation).
-//   ODET_ROI_STAGE=1   the LDS-staged tile path.  OFF by default: every bilinear tap still has to be read
-//                      once from LDS (128 B/clk/CU, only 2x the vector L1's 64 B/clk/CU) behind a
-//                      load -> ds_write -> barrier chain, and it measured 25-30 % slower than deduplicating
-//                      the shared cells in registers (RoI kernel)
-//   ODET_ROI_DESC=0    per-row / per-bin tap computation instead of the lane-parallel bin descriptors
-//   ODET_ROI_ROWS=k    output rows per workgroup of the non-descriptor form
-//   ODET_ROI_THREADS   256 | 512 threads per workgroup of the descriptor form
-struct RoiEnv {
-  int stage, desc, rows, threads, xcd_images;
-  RoiEnv() {
-    const char* e = getenv("ODET_ROI_STAGE");
-    stage = (e && e[0] == '1') ? 1 : 0;
-    e = getenv("ODET_ROI_DESC");
-    desc = e ? atoi(e) : 1;
-    e = getenv("ODET_ROI_ROWS");
-    rows = e ? atoi(e) : 0;
-    e = getenv("ODET_ROI_THREADS");
-    threads = e ? atoi(e) : 512;
-    e = getenv("ODET_ROI_XCD_IMAGES");
-    xcd_images = e ? atoi(e) : 1;
-  }
-};
-static const RoiEnv& roi_env() {
-  static const RoiEnv env;
-  return env;
-}
-static bool roi_stage_enabled() { return roi_env().stage != 0; }
-
 template <int POOL, int NORM>
-static void roi_launch(dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev) {
-  if (p.f16)
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false, __half>), grid, dim3(threads), 0, st, ev.start,
-                          ev.stop, 0, p);
-  else if (NORM != ODET_ROI_NORM_TP_ALIGN && roi_stage_enabled())
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, true, float>), grid, dim3(threads), ROI_LDS_BYTES, st,
-                          ev.start, ev.stop, 0, p);
-  else
-    hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, false, float>), grid, dim3(threads), 0, st, ev.start,
-                          ev.stop, 0, p);
+static void roi_launch(dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev, int f16) {
+  const bool timed = ev.start != nullptr || ev.stop != nullptr;
+  if (f16) {
+    if (timed)
+      hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, __half, 1>), grid, dim3(threads), 0, st, ev.start,
+                            ev.stop, 0, p);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, __half, 0>), grid, dim3(threads), 0, st, p);
+  } else {
+    if (timed)
+      hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, float, 1>), grid, dim3(threads), 0, st, ev.start,
+                            ev.stop, 0, p);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_roi_pool<POOL, NORM, float, 0>), grid, dim3(threads), 0, st, p);
+  }
 }
 
 template <int POOL>
-static void roi_launch_norm(int norm_mode, dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev) {
+static void roi_launch_norm(int norm_mode, dim3 grid, int threads, hipStream_t st, const RoiParams& p, RoiEvents ev,
+                            int f16) {
   switch (norm_mode) {
-    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, threads, st, p, ev); break;
-    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, threads, st, p, ev); break;
-    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, threads, st, p, ev); break;
-    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, threads, st, p, ev); break;
+    case ODET_ROI_NORM_STRIDE: roi_launch<POOL, ODET_ROI_NORM_STRIDE>(grid, threads, st, p, ev, f16); break;
+    case ODET_ROI_NORM_IMAGE: roi_launch<POOL, ODET_ROI_NORM_IMAGE>(grid, threads, st, p, ev, f16); break;
+    case ODET_ROI_NORM_TP_ALIGN: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN>(grid, threads, st, p, ev, f16); break;
+    default: roi_launch<POOL, ODET_ROI_NORM_TP_ALIGN_NOPAD>(grid, threads, st, p, ev, f16); break;
   }
 }
 
-// B images in one launch (blockIdx.y = image); all images share shapes and parameters
+// B images in one launch; all images share shapes and parameters
 int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int n, int norm_mode, int image_h,
                         int image_w, int pool_size, int pool_mode, hipStream_t st, RoiEvents ev, int f16) {
   ODET_REQUIRE(n >= 0, "odet_roi_pool: negative n");
@@ -649,10 +530,12 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   ODET_REQUIRE(io && B >= 1 && B <= ODET_MAX_BATCH, "odet_roi_pool: bad batch");
   ODET_REQUIRE(num_levels > 0 && num_levels <= ODET_MAX_LEVELS, "odet_roi_pool: num_levels %d out of range", num_levels);
   ODET_REQUIRE(C > 0 && (C & 3) == 0, "odet_roi_pool: C must be a positive multiple of 4 (got %d)", C);
-  ODET_REQUIRE(pool_size > 0 && pool_size <= 64, "odet_roi_pool: pool_size out of range");
   ODET_REQUIRE(norm_mode >= 0 && norm_mode <= 3, "odet_roi_pool: unknown norm_mode %d", norm_mode);
   ODET_REQUIRE(pool_mode >= 0 && pool_mode <= 2, "odet_roi_pool: unknown pool_mode %d", pool_mode);
+  // a lane holds one bin column of the row
+  ODET_REQUIRE(pool_size > 0 && pool_size <= 64, "odet_roi_pool: pool_size %d out of range (1..64)", pool_size);
   if (norm_mode == ODET_ROI_NORM_IMAGE) ODET_REQUIRE(image_h > 0 && image_w > 0, "odet_roi_pool: bad image shape");
+  const size_t esz = f16 ? 2 : 4;
   RoiParams p;
   for (int i = 0; i < ODET_MAX_BATCH; ++i) {
     const RoiImageIO& a = io[i < B ? i : 0];
@@ -661,6 +544,9 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
     for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
       const odet_level_t* L = &a.levels[l < num_levels ? l : 0];
       ODET_REQUIRE(L->data && L->H > 0 && L->W > 0, "odet_roi_pool: bad level %d", l);
+      // cells are addressed with 32-bit byte offsets from the level's base
+      ODET_REQUIRE((size_t)L->H * (size_t)L->W * (size_t)C * esz < (1ull << 31),
+                   "odet_roi_pool: level %d is larger than 2 GiB", l);
       if (norm_mode != ODET_ROI_NORM_IMAGE) ODET_REQUIRE(L->stride > 0.0f, "odet_roi_pool: bad stride on level %d", l);
       if (i > 0 && i < B)
         ODET_REQUIRE(L->H == p.H[l] && L->W == p.W[l] && L->stride == p.stride[l],
@@ -672,35 +558,24 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
     p.order.v[i] = a.order;
     p.out.v[i] = a.out;
   }
+  ODET_REQUIRE((size_t)pool_size * (size_t)C * esz < (1ull << 31), "odet_roi_pool: output row larger than 2 GiB");
   p.num_levels = num_levels;
-  p.C = C; p.n = n; p.norm_mode = norm_mode; p.P = pool_size; p.pool_mode = pool_mode;
+  p.C = C; p.n = n; p.P = pool_size;
   p.image_h = (float)image_h; p.image_w = (float)image_w;
-  const int rows_env = roi_env().rows;
-  // the row form (un-pooled 7x7 crops, tensorpack modes, LDS staging) works best with one output row
-  // per workgroup (measured: 39 us vs 45 us for whole-RoI workgroups); the descriptor form below takes
-  // the whole RoI
-  p.rows_per_wg = rows_env > 0 ? std::min(rows_env, pool_size) : 1;
-  const int desc_env = roi_env().desc, threads_env = roi_env().threads;
-  const bool desc_ok = pool_mode != ODET_ROI_POOL_NONE && norm_mode != ODET_ROI_NORM_TP_ALIGN &&
-                       pool_size * pool_size <= 64;
-  p.f16 = f16 ? 1 : 0;
-  if (f16 && !desc_ok)
-    return odet_set_error(ODET_E_INVALID, "odet_roi_pool_f16: float16 maps need a pooled (max / avg), un-padded mode "
-                          "with pool_size <= 8");
-  p.use_desc = (desc_ok && (f16 || (desc_env && !roi_stage_enabled()))) ? 1 : 0;
-  if (p.use_desc) p.rows_per_wg = pool_size;
-  p.groups_per_roi = (pool_size + p.rows_per_wg - 1) / p.rows_per_wg;
-  const int threads = p.use_desc ? ((threads_env == 256 || threads_env == 512) ? threads_env : 512) : 256;
-  int64_t rows = (int64_t)n * p.groups_per_roi;
-  ODET_REQUIRE(rows < (1ll << 30), "odet_roi_pool: too many workgroups");
-  p.nblocks = (int)rows;
-  p.xcd_images = ((B == 2 || B == 4 || B == 8) && roi_env().xcd_images) ? 1 : 0;
+  // one wave per output row; a workgroup = the P rows of one RoI (8 rows of whatever RoIs when P > 16)
+  p.waves = pool_size <= 16 ? pool_size : 8;
+  const int64_t rows = (int64_t)n * pool_size;
+  const int64_t blocks = (rows + p.waves - 1) / p.waves;
+  ODET_REQUIRE(blocks < (1ll << 30), "odet_roi_pool: too many workgroups");
+  p.nblocks = (int)blocks;
+  p.xcd_images = (B == 2 || B == 4 || B == 8) ? 1 : 0;
   p.xcds_per_img = p.xcd_images ? 8 / B : 8;
   p.blocks_per_xcd = (p.nblocks + p.xcds_per_img - 1) / p.xcds_per_img;   // per XCD of an image
   dim3 grid(p.blocks_per_xcd * 8, p.xcd_images ? 1 : B);
-  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, threads, st, p, ev);
-  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, threads, st, p, ev);
-  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, threads, st, p, ev);
+  const int threads = p.waves * 64;
+  if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, threads, st, p, ev, f16);
+  else if (pool_mode == ODET_ROI_POOL_MAX2) roi_launch_norm<ODET_ROI_POOL_MAX2>(norm_mode, grid, threads, st, p, ev, f16);
+  else roi_launch_norm<ODET_ROI_POOL_AVG2>(norm_mode, grid, threads, st, p, ev, f16);
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }

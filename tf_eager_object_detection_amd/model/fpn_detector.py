@@ -25,6 +25,11 @@ from ..pipeline import FpnHotPath, FpnStepBatch
 
 __all__ = ['ResNetFpnDetector', 'tf_legacy_resize_bilinear']
 
+# sync-free NMS chunks of the assembled detectors unless the caller says otherwise: the first two from the ranked
+# selection (shared launches), the third on the full order -- enough for clustered (trained-like) and massively tied
+# (random-init float16) score distributions; an image that still does not complete is reported empty and flagged
+DEFAULT_BLIND_CHUNKS = 4
+
 _BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 _BN_EPS = 1.001e-5
 
@@ -254,7 +259,37 @@ def rpn_pair_weights(m):
     return cached[1], cached[2]
 
 
-class ResNetFpnDetector(nn.Module):
+class _NmsCompleteness:
+    """The detectors run the proposal stage sync-free (no host check between kernels; graph-capturable) with a fixed
+    number of NMS chunks.  If an image needs more than those, the hot path reports it EMPTY and flags it
+    (nms_done = 0, include/odet.h): `forward()` checks the flags after the last launch of the pass whenever it is not
+    being captured into a HIP graph and `check_nms` is on (default), and raises.  Throughput loops that do not want a
+    host sync per pass set `model.check_nms = False` and call `check_complete()` themselves (after a graph replay too)."""
+
+    check_nms = True
+    _last_batch = 0
+
+    def nms_done(self, batch=None):
+        """device int32 flags (1 = complete) of the images of the last pass"""
+        n = self._last_batch if batch is None else batch
+        return [h.nms_done for h in self._hot[:n]]
+
+    def check_complete(self, batch=None):
+        bad = [b for b, t in enumerate(self.nms_done(batch)) if int(t.item()) != 1]
+        if bad:
+            raise RuntimeError('the RPN NMS of image(s) %s did not complete inside blind_chunks = %d sync-free chunks: their '
+                               'results are reported EMPTY.  Build the detector with more chunks (blind_chunks=...) or a '
+                               'wider first chunk (nms_first_chunk=4096)' % (bad, self._hot[0].blind_chunks))
+
+    def _after_pass(self, batch, check):
+        self._last_batch = batch
+        if check is None:
+            check = self.check_nms and not torch.cuda.is_current_stream_capturing()
+        if check:
+            self.check_complete(batch)
+
+
+class ResNetFpnDetector(_NmsCompleteness, nn.Module):
     """Inference-only ResNet-{50,101,152}-FPN detector.  `forward(images)` takes NHWC float images
     [B,H,W,3] (already mean-subtracted, as the reference's input pipeline delivers them) and returns,
     per image, the padded detections of post_ops_prediction plus their count on the device."""
@@ -290,7 +325,8 @@ class ResNetFpnDetector(nn.Module):
             nn.init.normal_(m.weight, 0.0, std)
             nn.init.zeros_(m.bias)
         self._hot_args = (self.image_shape, num_classes, num_proposals, 256)
-        self._hot_kwargs = hot_kwargs
+        self._hot_kwargs = dict(blind_chunks=DEFAULT_BLIND_CHUNKS)
+        self._hot_kwargs.update(hot_kwargs)
         self._hot = []
         self._rpn_pair = None
         self._max_batch = max_batch
@@ -421,46 +457,93 @@ class ResNetFpnDetector(nn.Module):
         return run
 
     # ---- the model ----------------------------------------------------------------------------------
-    @torch.no_grad()
-    def forward(self, images_nhwc):
-        B = images_nhwc.shape[0]
-        if B > len(self._hot):
-            raise ValueError('batch %d exceeds max_batch %d' % (B, len(self._hot)))
+    def _dense(self, images_nhwc):
+        """extractor -> neck -> RPN head: (rpn scores [B,N,2], rpn deltas [B,N,4], NHWC views of P2..P5)"""
         p_list = self.features(images_nhwc)
         rpn_scores, rpn_deltas = self.rpn(p_list)
         rpn_scores, rpn_deltas = rpn_scores.float().contiguous(), rpn_deltas.float().contiguous()
-        # NHWC views of P2..P5: float16 maps go to the RoI kernel as they are, anything else as float32
+        # float16 maps go to the RoI kernel as they are, anything else as float32
         if self.dtype == torch.float16:
             maps = [p.permute(0, 2, 3, 1) for p in p_list[:4]]
         else:
             maps = [p.permute(0, 2, 3, 1).float() for p in p_list[:4]]
+        return rpn_scores, rpn_deltas, maps
+
+    def _hot_to_head(self, B, rpn_scores, rpn_deltas, maps):
+        """proposals -> level assignment -> RoI features -> RoI head.  Per image (class softmax [K,Ccls], raw deltas
+        [K,4*Ccls]) for the level-sorted RoIs of its hot-path slot; rows >= the image's proposal count are padding."""
         if self._steps is not None:
-            return self._forward_batched(B, rpn_scores, rpn_deltas, maps)
-        outs = []
+            # B images in the same hot-path launches, the RoI head on all B x K crops at once
+            sb = self._steps
+            maps = [m if m.is_contiguous() else m.contiguous() for m in maps]
+            bind = sb.rebind if self._bound else sb.bind
+            for b in range(B):
+                bind(b, rpn_scores[b], rpn_deltas[b], [m[b:b + 1] for m in maps], self._cls[b], self._dlt[b])
+            if B == self._max_batch:
+                self._bound = True                      # every descriptor has been filled once
+            sb.enqueue(sb.STAGE_PROPOSALS | sb.STAGE_ROI, B)
+            K = self._cls.shape[1]
+            feats = sb.roi_features[:B].reshape((B * K,) + tuple(sb.roi_features.shape[2:]))
+            logits, bbox = self.roi_head(feats)
+            torch.softmax(logits.float(), dim=-1, out=self._cls[:B].view(B * K, -1))
+            self._dlt[:B].view(B * K, -1).copy_(bbox)
+            return [(self._cls[b], self._dlt[b]) for b in range(B)]
+        heads = []
         for b in range(B):
             hot = self._hot[b]
             hot.stage_proposals(rpn_scores[b], rpn_deltas[b])
             feats = hot.stage_roi([m[b:b + 1].contiguous() for m in maps])
             logits, bbox = self.roi_head(feats)
-            cls = torch.softmax(logits.float(), dim=-1).contiguous()
-            boxes, labels, scores, count = hot.stage_detect(cls, bbox.float().contiguous())
-            outs.append((boxes, labels, scores, count))
-        return outs
+            heads.append((torch.softmax(logits.float(), dim=-1).contiguous(), bbox.float().contiguous()))
+        return heads
+
+    def _run_to_head(self, images_nhwc):
+        """base_fpn_model.py:208-265 / :372-382: everything of the inference pass before post_ops_prediction"""
+        B = images_nhwc.shape[0]
+        if B > len(self._hot):
+            raise ValueError('batch %d exceeds max_batch %d' % (B, len(self._hot)))
+        return self._hot_to_head(B, *self._dense(images_nhwc))
+
+    def _detect(self, heads):
+        B = len(heads)
+        if self._steps is not None:
+            sb = self._steps
+            sb.enqueue(sb.STAGE_DETECT, B)
+            return [(h.det_boxes, h.det_labels, h.det_scores, h.det_count) for h in sb.slots[:B]]
+        return [self._hot[b].stage_detect(cls, dlt) for b, (cls, dlt) in enumerate(heads)]
 
     def _forward_batched(self, B, rpn_scores, rpn_deltas, maps):
-        """B images in the same hot-path launches, the RoI head on all B x K crops at once."""
-        sb = self._steps
-        maps = [m if m.is_contiguous() else m.contiguous() for m in maps]
-        bind = sb.rebind if self._bound else sb.bind
-        for b in range(B):
-            bind(b, rpn_scores[b], rpn_deltas[b], [m[b:b + 1] for m in maps], self._cls[b], self._dlt[b])
-        if B == self._max_batch:
-            self._bound = True                      # every descriptor has been filled once
-        sb.enqueue(sb.STAGE_PROPOSALS | sb.STAGE_ROI, B)
-        K = self._cls.shape[1]
-        feats = sb.roi_features[:B].reshape((B * K,) + tuple(sb.roi_features.shape[2:]))
-        logits, bbox = self.roi_head(feats)
-        torch.softmax(logits.float(), dim=-1, out=self._cls[:B].view(B * K, -1))
-        self._dlt[:B].view(B * K, -1).copy_(bbox)
-        sb.enqueue(sb.STAGE_DETECT, B)
-        return [(h.det_boxes, h.det_labels, h.det_scores, h.det_count) for h in sb.slots[:B]]
+        """the hot path + RoI head + post-ops of B images given the dense parts' outputs"""
+        return self._detect(self._hot_to_head(B, rpn_scores, rpn_deltas, maps))
+
+    @torch.no_grad()
+    def forward(self, images_nhwc, check=None):
+        """-> per image (boxes [M,4], labels [M], scores [M], count) padded to max_per_image, count on the device
+        (post_ops_prediction, base_fpn_model.py:267-275).  check: see _NmsCompleteness."""
+        heads = self._run_to_head(images_nhwc)
+        B = len(heads)
+        outs = self._detect(heads)
+        self._after_pass(B, check)
+        return outs
+
+    @torch.no_grad()
+    def im_detect(self, images_nhwc, img_scale):
+        """The evaluation entry of the reference models (base_fpn_model.py:364-390): per image
+        (softmax scores [R,Ccls], raw deltas [R,4*Ccls], rois / img_scale [R,4]) for the R proposals the image kept,
+        in level-sorted order with empty levels dropped (:384-388) -- what evaluation.pascal_eval.detect_image
+        (pascal_eval_files_utils.py:76-106) consumes with img_scale = 1.  img_scale: one number or one per image.
+        Host-syncs once (R is data dependent, as in the reference)."""
+        heads = self._run_to_head(images_nhwc)
+        B = len(heads)
+        self._last_batch = B
+        self.check_complete(B)
+        out = []
+        for b, (cls, dlt) in enumerate(heads):
+            hot = self._hot[b]
+            k = int(hot.roi_count.item())
+            sc = img_scale[b] if isinstance(img_scale, (list, tuple)) or (hasattr(img_scale, 'ndim') and img_scale.ndim > 0) else img_scale
+            # tensor / tensor: a true float32 division per element (tensor / python-number multiplies by the reciprocal
+            # on the GPU, which is not what tf.to_float(img_scale) division gives)
+            div = torch.full((1,), float(sc), dtype=torch.float32, device=hot.sorted_rois.device)
+            out.append((cls[:k].clone(), dlt[:k].clone(), hot.sorted_rois[:k] / div))
+        return out

@@ -15,13 +15,13 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pipeline import FrcnnHotPath
-from .fpn_detector import _BLOCKS, ResNetFpnDetector, _conv, _conv_epi, _conv_relu_pool, _fold_frozen_bn, _stack, \
-    rpn_pair_weights
+from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _conv, _conv_epi, \
+    _conv_relu_pool, _fold_frozen_bn, _stack, rpn_pair_weights
 
 __all__ = ['ResNetC4Detector', 'Vgg16Detector']
 
 
-class ResNetC4Detector(nn.Module):
+class ResNetC4Detector(_NmsCompleteness, nn.Module):
     """Inference-only ResNet-{50,101,152} C4 Faster R-CNN.  `forward(images)` takes NHWC float images [B,H,W,3]
     (mean-subtracted) and returns, per image, the padded detections of post_ops_prediction + their count."""
 
@@ -52,7 +52,7 @@ class ResNetC4Detector(nn.Module):
         self._hot_args = (self.image_shape, num_classes, num_proposals, 1024)
         # config/faster_rcnn_config.py: 'resnet_roi_pooling_max_pooling_flag': False (7x7 crop, no pool) -- what
         # model_factory.py:117 passes, overriding the class default
-        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=False)
+        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=False, blind_chunks=DEFAULT_BLIND_CHUNKS)
         self._hot_kwargs.update(hot_kwargs)
         self._hot = []
         self._max_batch = max_batch
@@ -60,9 +60,8 @@ class ResNetC4Detector(nn.Module):
 
     def prepare(self, device='cuda'):
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
-        # float16 maps go straight into the pooled RoI mode (14x14 + max); the un-pooled 7x7 crop takes float32
-        pooled = bool(self._hot_kwargs.get('max_pooling_flag', False))
-        fd = torch.float16 if (self.dtype == torch.float16 and pooled) else torch.float32
+        # float16 maps go straight into the RoI kernel (pooled 14x14 + max and un-pooled 7x7 crop alike)
+        fd = torch.float16 if self.dtype == torch.float16 else torch.float32
         self._feature_dtype = fd
         self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs) for _ in range(self._max_batch)]
         # the images' RoI features are consecutive blocks of one buffer: the RoI head takes the whole batch at once
@@ -132,8 +131,9 @@ class ResNetC4Detector(nn.Module):
     capture = ResNetFpnDetector.capture          # whole forward pass as one HIP graph (generic over self.forward)
 
     # ---- the model ----------------------------------------------------------------------------------
-    @torch.no_grad()
-    def forward(self, images_nhwc):
+    def _run_to_head(self, images_nhwc):
+        """extractor -> RPN head -> proposals -> RoI features -> RoI head (base_faster_rcnn_model.py:132-187 /
+        :279-304): per image (class softmax [K,Ccls], raw deltas [K,4*Ccls]); rows >= the proposal count are padding."""
         B = images_nhwc.shape[0]
         if B > len(self._hot):
             raise ValueError('batch %d exceeds max_batch %d' % (B, len(self._hot)))
@@ -152,10 +152,35 @@ class ResNetC4Detector(nn.Module):
         K = self._roi_feat_all.shape[1]
         feats = self._roi_feat_all[:B].reshape((B * K,) + tuple(self._roi_feat_all.shape[2:]))
         logits, bbox = self.roi_head(feats)                                      # one head pass for the whole batch
-        cls = torch.softmax(logits.float(), dim=-1).reshape(B, K, -1)
+        cls = torch.softmax(logits.float(), dim=-1).reshape(B, K, -1).contiguous()
         bbox = bbox.float().reshape(B, K, -1).contiguous()
-        cls = cls.contiguous()
-        return self._per_image(B, lambda b: self._hot[b].stage_detect(cls[b], bbox[b]))
+        return [(cls[b], bbox[b]) for b in range(B)]
+
+    @torch.no_grad()
+    def forward(self, images_nhwc, check=None):
+        heads = self._run_to_head(images_nhwc)
+        B = len(heads)
+        outs = self._per_image(B, lambda b: self._hot[b].stage_detect(heads[b][0], heads[b][1]))
+        self._after_pass(B, check)
+        return outs
+
+    @torch.no_grad()
+    def im_detect(self, images_nhwc, img_scale):
+        """The evaluation entry of the reference models (base_faster_rcnn_model.py:279-306): per image
+        (softmax scores [R,Ccls], raw deltas [R,4*Ccls], rois / img_scale [R,4]) for the R proposals the image kept
+        (NMS order); consumed by evaluation.pascal_eval.detect_image with img_scale = 1.  Host-syncs once."""
+        heads = self._run_to_head(images_nhwc)
+        B = len(heads)
+        self._last_batch = B
+        self.check_complete(B)
+        out = []
+        for b, (cls, dlt) in enumerate(heads):
+            hot = self._hot[b]
+            k = int(hot.roi_count.item())
+            sc = img_scale[b] if isinstance(img_scale, (list, tuple)) or (hasattr(img_scale, 'ndim') and img_scale.ndim > 0) else img_scale
+            div = torch.full((1,), float(sc), dtype=torch.float32, device=hot.rois.device)   # (true division: see the FPN detector)
+            out.append((cls[:k].clone(), dlt[:k].clone(), hot.rois[:k] / div))
+        return out
 
 
 class Vgg16Detector(ResNetC4Detector):
@@ -190,7 +215,7 @@ class Vgg16Detector(ResNetC4Detector):
             nn.init.normal_(m.weight, 0.0, std)
             nn.init.zeros_(m.bias)
         self._hot_args = (self.image_shape, num_classes, num_proposals, 512)
-        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=True)
+        self._hot_kwargs = dict(pool_size=7, max_pooling_flag=True, blind_chunks=DEFAULT_BLIND_CHUNKS)
         self._hot_kwargs.update(hot_kwargs)
         self._hot = []
         self._max_batch = max_batch

@@ -61,3 +61,64 @@ def all_gather_detections(rec, group=None):
         dist.all_gather(parts, rec.contiguous(), group=group)
         out = torch.stack(parts, 0)
     return out
+
+
+class GroupExchange:
+    """The exchange of the throughput arrangement (bench.py, FpnStreamPool): every rank keeps S stream groups of B
+    images in flight; when a group's launches are enqueued, the B fixed-size records of that group of EVERY rank go
+    through ONE all-gather (concatenation form) into ``gathered[g]`` = [world, B, rec_len].
+
+    GPU tensors: the collective runs on a communication stream that waits (on the device) for the group's stream;
+    the group's stream only waits for the small staging copy, so its next images may overwrite the records while
+    the collective is still in flight.  CPU tensors (gloo tests): the same calls without streams.
+
+    A group with fewer than B valid images (ragged tail of a finite image list) passes ``valid``: the records of the
+    missing images are sent as empty records (count 0, scores -1), so every rank still contributes B records."""
+
+    def __init__(self, n_groups, batch, rec_len, device, group=None):
+        self.S, self.B, self.rec_len = int(n_groups), int(batch), int(rec_len)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = torch.device(device)
+        self.cuda = dev.type == 'cuda'
+        self.gathered = torch.zeros((self.S, self.world, self.B, self.rec_len), dtype=torch.float32, device=dev)
+        self.staging = torch.zeros((self.S, self.B, self.rec_len), dtype=torch.float32, device=dev)
+        self.comm = torch.cuda.Stream(device=dev) if self.cuda else None
+        empty = torch.zeros(self.rec_len, dtype=torch.float32)
+        empty[:self.rec_len - 1].view(-1, 6)[:, 4] = -1.0
+        self.empty = empty.to(dev)
+
+    def _stage(self, g, records, valid):
+        self.staging[g].copy_(records)
+        if valid is not None and valid < self.B:
+            self.staging[g, valid:] = self.empty
+
+    def gather(self, g, records, producer_stream=None, valid=None):
+        """records: [B, rec_len] block of group g (written on ``producer_stream``).  Returns gathered[g]
+        ([world, B, rec_len]; on the GPU it is complete once the communication stream has run)."""
+        if not self.cuda:
+            self._stage(g, records, valid)
+            if self.world == 1:
+                self.gathered[g, 0].copy_(self.staging[g])
+            else:
+                parts = [torch.empty_like(self.staging[g]) for _ in range(self.world)]
+                dist.all_gather(parts, self.staging[g].contiguous(), group=self.group)
+                self.gathered[g].copy_(torch.stack(parts, 0))
+            return self.gathered[g]
+        st = producer_stream if producer_stream is not None else torch.cuda.current_stream()
+        self.comm.wait_stream(st)
+        with torch.cuda.stream(self.comm):
+            self._stage(g, records, valid)
+            copied = torch.cuda.Event()
+            copied.record(self.comm)
+            if self.world == 1:
+                self.gathered[g, 0].copy_(self.staging[g])
+            else:
+                dist.all_gather_into_tensor(self.gathered[g].view(self.world * self.B, self.rec_len), self.staging[g],
+                                            group=self.group)
+        st.wait_event(copied)            # the group's next images may overwrite its records from here on
+        return self.gathered[g]
+
+    def synchronize(self):
+        if self.cuda:
+            self.comm.synchronize()

@@ -39,12 +39,12 @@ def frcnn_case(seed, rng):
     hot.stage_proposals(g(logits), g(deltas))
     torch.cuda.synchronize()
     done, m = int(hot.nms_done.item()), int(hot.roi_count.item())
-    ok = np.array_equal(hot.roi_idx[:m].cpu().numpy(), want_idx[:m]) and (not done or m == len(want_idx))
+    ok = np.array_equal(hot.roi_idx[:m].cpu().numpy(), want_idx[:m]) and (m == len(want_idx) if done else m == 0)
     if ok and done:
         feat = rng.standard_normal((1, fh, fw, ch), dtype=np.float32)
         got = hot.stage_roi(g(feat))[:m].cpu().numpy()
         ok = np.array_equal(got, co.roi_pool(feat[0], want_rois, stride=16, pool=7, max_pool=flag))
-    return 'frcnn shape %s K %d C %d pool %d A %d blind %d: %s' % (shape, K, ch, flag, A, hot.blind_chunks, 'done' if done else 'prefix'), ok
+    return 'frcnn shape %s K %d C %d pool %d A %d blind %d: %s' % (shape, K, ch, flag, A, hot.blind_chunks, 'done' if done else 'incomplete -> empty'), ok
 
 
 def batched_case(seed, rng):
@@ -69,9 +69,9 @@ def batched_case(seed, rng):
         if int(h.nms_done.item()) == 1:
             ok = ok and torch.equal(h.record, ref.record) and torch.equal(h.roi_features, ref.roi_features) and \
                 torch.equal(h.roi_idx, ref.roi_idx)
-        else:                                   # not finished inside its chunks: the kept prefix must still be exact
-            m = int(h.roi_count.item())
-            ok = ok and m <= int(ref.roi_count.item()) and torch.equal(h.roi_idx[:m], ref.roi_idx[:m])
+        else:                                   # not finished inside its chunks: reported EMPTY (odet.h, odet_nms)
+            ok = ok and int(h.roi_count.item()) == 0 and int(h.det_count.item()) == 0 and \
+                float(h.roi_features.abs().max().item()) == 0.0
     return 'batched B %d shape %s K %d C %d %s blind %d first %d' % (B, shape, K, ch, kind, blind, first), ok
 
 
@@ -117,8 +117,8 @@ while time.time() < t_end:
     done = int(hot.nms_done.item())
     m = int(hot.roi_count.item())
     got_idx = hot.roi_idx[:m].cpu().numpy()
-    ok = np.array_equal(got_idx, want_idx[:m]) and (not done or m == len(want_idx))
-    status = 'done' if done else 'prefix(%d/%d)' % (m, len(want_idx))
+    ok = np.array_equal(got_idx, want_idx[:m]) and (m == len(want_idx) if done else m == 0)
+    status = 'done' if done else 'incomplete -> empty (%d wanted)' % len(want_idx)
     if ok and done:
         lv, perm, cnt = co.assign_levels(want_rois)
         ok = ok and np.array_equal(hot.roi_perm[:m].cpu().numpy(), perm)
