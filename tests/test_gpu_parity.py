@@ -30,12 +30,38 @@ def h(t):
     return t.detach().cpu().numpy()
 
 
-def close(a, b, tol=TOL):
+def ulp_distance(a, b):
+    """element-wise distance of two float32 arrays in units in the last place (0 = identical bits; +0 == -0)"""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, np.int64(-2 ** 31) - ia, ia)        # order-preserving map of the sign-magnitude encoding
+    ib = np.where(ib < 0, np.int64(-2 ** 31) - ib, ib)
+    return np.abs(ia - ib)
+
+
+ULP_SEEN = {}       # test-name -> histogram of the ulp distances it saw (printed by the last test of this file)
+
+
+def close(a, b, max_ulp=0, what=''):
+    """The parity bar.  max_ulp = 0: identical bits (every output whose arithmetic is IEEE +, -, *, /, sqrt, floor,
+    min / max in the reference's order: anchors, clip, IoU, bilinear crops, pools, gathered scores).  max_ulp = 1: values
+    that went through exp / log (box decode / encode, softmax): both sides round a float64 exp / log to float32, the
+    float64 libraries (glibc, ROCm's ocml) may differ in their last bit, which moves the float32 result by at most
+    one ulp (Eigen's pexp is 1-2 ulp from either).  Far inside north_star's 1e-4."""
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape, (a.shape, b.shape)
-    if a.size:
-        scale = np.maximum(1.0, np.abs(b))
-        assert np.max(np.abs(a - b) / scale) <= tol, float(np.max(np.abs(a - b)))
+    if not a.size:
+        return
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    d = ulp_distance(np.nan_to_num(a), np.nan_to_num(b))
+    hist = np.bincount(np.minimum(d, 4).reshape(-1), minlength=5)
+    key = what or 'unnamed'
+    ULP_SEEN[key] = ULP_SEEN.get(key, np.zeros(5, np.int64)) + hist
+    worst = int(d.max())
+    assert worst <= max_ulp, '%s: max distance %d ulp (allowed %d); histogram 0/1/2/3/4+ ulp: %s; max abs diff %g' % (
+        key, worst, max_ulp, hist.tolist(), float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))))
 
 
 # ------------------------------------------------------------------------------- anchors ------
@@ -70,11 +96,11 @@ def test_decode_encode_clip():
         d = syn.rpn_deltas(n, rng, sigma) if sigma < 1 else rng.normal(0, 1, (n, 4)).astype(np.float32)
         got = h(decode_bbox_with_mean_and_std(g(anchors), g(d), M0, stds))
         want = co.decode(anchors, d, M0, stds)
-        close(got, want)
+        close(got, want, 1, 'decode')
         assert np.mean(got == want) > 0.9999          # correctly rounded exp on both sides
     gt = anchors + rng.uniform(-3, 3, anchors.shape).astype(np.float32)
     gt[:, 2:] = np.maximum(gt[:, 2:], gt[:, :2] + 1)
-    close(h(encode_bbox_with_mean_and_std(g(anchors), g(gt), M0, S2)), co.encode(anchors, gt, M0, S2))
+    close(h(encode_bbox_with_mean_and_std(g(anchors), g(gt), M0, S2)), co.encode(anchors, gt, M0, S2), 1, 'encode')
     # KA5
     z = h(decode_bbox_with_mean_and_std(g(anchors[:100]), g(np.zeros((100, 4), np.float32)), M0, S1))
     np.testing.assert_allclose(z, anchors[:100] + np.float32([0, 0, 1, 1]), rtol=0, atol=1e-5)
@@ -83,7 +109,7 @@ def test_decode_encode_clip():
     d = syn.rpn_deltas(n, rng, 0.3)
     fused = h(ops.decode(g(anchors), g(d), M0, S1, clip_shape=(600, 800)))
     want, _ = co.clip_filter(co.decode(anchors, d, M0, S1), 0, 600, 800)
-    close(fused, want)
+    close(fused, want, 1, 'decode+clip')
     assert fused.min() >= 0 and fused[:, 0::2].max() <= 799 and fused[:, 1::2].max() <= 599
 
 
@@ -117,19 +143,19 @@ def test_pairwise_iou():
     a = syn.random_boxes(1000, (600, 800), rng)
     b = syn.random_boxes(37, (600, 800), rng)
     b[3] = a[5]
-    close(h(pairwise_iou(g(a), g(b))), co.pairwise_iou(a, b), 1e-6)
+    close(h(pairwise_iou(g(a), g(b))), co.pairwise_iou(a, b), 0, 'pairwise_iou')
     anchors = co.fpn_anchors((800, 1333))
     big = h(pairwise_iou(g(anchors), g(b)))
-    close(big, co.pairwise_iou(anchors, b), 1e-6)
+    close(big, co.pairwise_iou(anchors, b), 0, 'pairwise_iou 267069 x 37')
     assert pairwise_iou(g(a[:0]), g(b)).shape == (0, 37)
 
 
 def test_rpn_fg_softmax():
     rng = np.random.default_rng(14)
     lg = rng.normal(0, 3, (267069, 2)).astype(np.float32)
-    close(h(ops.rpn_fg_softmax(g(lg), 3, ops.RPN_LAYOUT_FPN)), co.rpn_fg_fpn(lg), 1e-6)
+    close(h(ops.rpn_fg_softmax(g(lg), 3, ops.RPN_LAYOUT_FPN)), co.rpn_fg_fpn(lg), 1, 'rpn fg softmax')
     lg = rng.normal(0, 3, (4200, 18)).astype(np.float32)
-    close(h(ops.rpn_fg_softmax(g(lg), 9, ops.RPN_LAYOUT_FRCNN)), co.rpn_fg_frcnn(lg, 9), 1e-6)
+    close(h(ops.rpn_fg_softmax(g(lg), 9, ops.RPN_LAYOUT_FRCNN)), co.rpn_fg_frcnn(lg, 9), 1, 'rpn fg softmax')
     # KA12
     one = np.float32([[1.0, 2.0, 3.0, 0.5, 2.0, 7.0]])
     np.testing.assert_allclose(h(ops.rpn_fg_softmax(g(one), 3, ops.RPN_LAYOUT_FRCNN)), on.rpn_fg_scores_frcnn(one, 3),
@@ -239,11 +265,11 @@ def test_fpn_proposals_fused_stage(shape, k, kind):
         m = int(cnt.item())
         assert m == len(want_idx)
         np.testing.assert_array_equal(h(idx[:m]), want_idx)
-        close(h(rois[:m]), want_rois)
+        close(h(rois[:m]), want_rois, 1, 'region proposal rois')
         np.testing.assert_array_equal(h(sperm[:m]), perm)
         np.testing.assert_array_equal(h(slv[:m]) + 2, lv[perm])
         np.testing.assert_array_equal(h(scnt), cnt_lv)
-        close(h(srois[:m]), want_rois[perm])
+        close(h(srois[:m]), want_rois[perm], 1, 'region proposal rois')
 
 
 def test_nms_sync_free_mode_reports_completion():
@@ -281,10 +307,10 @@ def test_region_proposal_full_size(shape, k, kind):
     want_rois, want_idx, stats = co.region_proposal(deltas, anchors, scores, shape, k, 0.7, return_stats=True)
     m = int(cnt.item())
     np.testing.assert_array_equal(h(idx_p[:m]), want_idx)          # kept anchor indices: bit-exact
-    close(h(rois_p[:m]), want_rois)
+    close(h(rois_p[:m]), want_rois, 1, 'RegionProposal layer')
     rois = layer(inputs, training=False)
     assert rois.shape == (len(want_idx), 4)
-    close(h(rois), want_rois)
+    close(h(rois), want_rois, 1, 'RegionProposal layer')
 
 
 # ------------------------------------------------------------------------------ RoI pooling ----
@@ -310,14 +336,15 @@ def test_roi_pooling_layers_match_oracle_bit_exact():
     got = h(RoiPoolingCropAndResize2(7)((fg, rg, [600, 800])))
     np.testing.assert_array_equal(got, co.roi_pool(feat, rois, image_shape=(600, 800), pool=7))
     got = h(RoiPoolingRoiAlign(7)((fg, rg, 16)))
-    close(got, co.roi_align(feat, rois, 16, 7), 1e-5)
+    close(got, co.roi_align(feat, rois, 16, 7), 0, 'RoiPoolingRoiAlign')
     # free functions (feature-map coordinates)
     fb = rois / np.float32(16)
-    close(h(roi_align(fg, g(fb), 7)), on.roi_align(feat, fb, 7), 1e-5)
+    close(h(roi_align(fg, g(fb), 7)), on.roi_align(feat, fb, 7), 0, 'roi_align')
     close(h(crop_and_resize(fg, g(fb[:20]), torch.zeros(20, dtype=torch.int32), 14)),
-          on.crop_and_resize_tp(feat, fb[:20], np.zeros(20, np.int32), 14), 1e-5)
+          on.crop_and_resize_tp(feat, fb[:20], np.zeros(20, np.int32), 14), 0, 'crop_and_resize (tensorpack)')
     close(h(crop_and_resize(fg, g(fb[:20]), torch.zeros(20, dtype=torch.int32), 6, pad_border=False)),
-          on.crop_and_resize_tp(feat, fb[:20], np.zeros(20, np.int32), 6, pad_border=False), 1e-5)
+          on.crop_and_resize_tp(feat, fb[:20], np.zeros(20, np.int32), 6, pad_border=False), 0,
+          'crop_and_resize (tensorpack, no pad)')
     # KA8: identity crop through the P x P (no pool) path: box = whole map
     ident = h(ops.roi_pool([g(feat[:, :7, :7])], g(np.float32([[0, 0, 6, 6]])), None, ops.ROI_NORM_STRIDE, 7,
                            ops.ROI_POOL_NONE, strides=[1.0]))
@@ -381,8 +408,8 @@ def _check_post(got, want):
         return
     assert gl.dtype == torch.int32
     np.testing.assert_array_equal(h(gl), wl)                     # labels exact (same order: score desc)
-    close(h(gs), ws, 1e-6)
-    close(h(gb), wb)
+    close(h(gs), ws, 0, 'post-ops scores')
+    close(h(gb), wb, 1, 'post-ops boxes')
 
 
 @pytest.mark.parametrize('R,ncls,mpc,mpi,sthr', [(300, 21, 50, 50, 0.0), (1000, 21, 50, 50, 0.0),
@@ -471,8 +498,8 @@ def test_predict_after_roi_matches_oracle():
     gb, gl, gs = predict_after_roi(g(S), g(D), g(rois), [600, 800], M0, S2, 5, 20, 0.3, 0.3)
     wb, wl, ws = on.predict_after_roi(S, D, rois, (600, 800), M0, S2, 5, 20, 0.3, 0.3)
     np.testing.assert_array_equal(h(gl), wl)
-    close(h(gs), ws, 1e-6)
-    close(h(gb), wb)
+    close(h(gs), ws, 0, 'post-ops scores')
+    close(h(gb), wb, 1, 'post-ops boxes')
 
 
 # ---------------------------------------------------------------------- size-independent ------
@@ -733,7 +760,7 @@ def test_frcnn_hot_path_full_size(name, shape, channels, flag, scales):
     k = int(hot.roi_count.item())
     assert k == len(want_idx)
     np.testing.assert_array_equal(h(hot.roi_idx[:k]), want_idx)
-    close(h(hot.rois[:k]), want_rois)
+    close(h(hot.rois[:k]), want_rois, 1, 'frcnn hot path rois')
     want_f = co.roi_pool(feat[0], want_rois, stride=16, pool=7, max_pool=flag)
     got_f = h(feats[:k])
     assert got_f.shape == want_f.shape
@@ -742,7 +769,7 @@ def test_frcnn_hot_path_full_size(name, shape, channels, flag, scales):
     m = int(count.item())
     assert m == len(ws)
     np.testing.assert_array_equal(h(labels[:m]), wl)
-    close(h(boxes[:m]), wb)
+    close(h(boxes[:m]), wb, 1, 'frcnn hot path boxes')
 
 
 def test_wide_first_nms_chunk_completes_clustered_scores_in_batched_launches():
@@ -868,3 +895,12 @@ def test_full_size_hashes_from_the_hip_path(name):
         got['roi_level'] = h(hot.roi_level[:k]) + 2
         got['level_perm'] = h(hot.roi_perm[:k])
     assert fs.digests(got) == {k_: v for k_, v in want.items() if k_ != 'num_anchors'}
+
+
+def test_zz_report_ulp_histograms(capsys):
+    """(last test of the file) the distances the parity assertions above actually saw, per output kind"""
+    with capsys.disabled():
+        print()
+        for k in sorted(ULP_SEEN):
+            hgram = ULP_SEEN[k]
+            print('  ulp distance %-36s 0: %-10d 1: %-8d 2: %-6d 3: %-4d 4+: %d' % ((k,) + tuple(int(v) for v in hgram)))

@@ -1,0 +1,126 @@
+"""Two ranks, one GPU: the image-parallel arrangement end to end on the HIP path -- every rank sends its shard of the
+images through the batched hot-path launches (FpnStreamPool) and the groups' records through parallel.GroupExchange
+(the exchange bench.py times), and must end with EVERY image's record, equal to the oracle's detections.  The ranks
+share cuda:0, so the backend is gloo (RCCL wants one device per rank; the driver's 8-GPU run uses "nccl"); they are
+fresh processes (spawn), never a re-exec of a process that touched the GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+SHAPE, K, NCLS, CH, B, S = (200, 320), 200, 21, 16, 2, 2
+NUM_IMAGES = 7                          # 2 ranks x (2 groups x 2 images): rank 1's last group is ragged
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from tf_eager_object_detection_amd import _lib, parallel
+        from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
+        _lib.lib()
+        mine = parallel.shard_images(NUM_IMAGES, rank, world)
+        pool = FpnStreamPool(S, SHAPE, NCLS, K, CH, batch=B, blind_chunks=3)
+        rec_len = pool.slots[0].record.numel()
+        records = torch.zeros((pool.n, rec_len), dtype=torch.float32, device='cuda')
+        keep = []
+        for k in range(pool.n):
+            pool.slots[k].record = records[k]
+            img = mine[k] if k < len(mine) else mine[0]           # (slots past the shard: any valid input, never sent)
+            _, dev = synthetic_fpn_inputs(SHAPE, NCLS, K, CH, seed=1000 + img)
+            keep.append(dev)
+            pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        ex = parallel.GroupExchange(S, B, rec_len, 'cuda')
+        got = {}
+        for g in range(S):
+            pool.submit_group(g)
+            pool.wait()
+            valid = max(0, min(B, len(mine) - g * B))
+            out = ex.gather(g, records[g * B:(g + 1) * B], producer_stream=pool._group_streams[g], valid=valid)
+            ex.synchronize()
+            for r in range(world):
+                for j in range(B):
+                    img = r + (g * B + j) * world
+                    if img < NUM_IMAGES:
+                        got[img] = out[r, j].cpu().numpy().copy()
+                    else:
+                        assert float(out[r, j, -1]) == 0.0
+        torch.cuda.synchronize()
+        done = [int(h.nms_done.item()) for h in pool.slots[:len(mine)]]
+        pool.close()
+        q.put((rank, got, done))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_hip_path_and_group_exchange_every_rank_has_every_record():
+    from oracle import c_oracle as co
+    from tf_eager_object_detection_amd import synthetic as syn
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # the oracle's detections of every image (model/fpn/base_fpn_model.py:208-276 minus the dense parts)
+    anchors = co.fpn_anchors(SHAPE)
+    want = {}
+    for img in range(NUM_IMAGES):
+        host = _host_inputs(img)
+        fg = co.rpn_fg_fpn(host['rpn_logits'])
+        rois, _ = co.region_proposal(host['rpn_deltas'], anchors, fg, SHAPE, K, 0.7)
+        lv, perm, _ = co.assign_levels(rois)
+        k = rois.shape[0]
+        want[img] = co.post_ops(host['cls_scores'][:k], host['cls_deltas'][:k], rois[perm], SHAPE, [0, 0, 0, 0],
+                                [.1, .1, .2, .2], 50, 50, 0.3, 0.0, 16, NCLS)
+    for rank, got, done in results:
+        assert all(d == 1 for d in done)
+        assert sorted(got) == list(range(NUM_IMAGES))               # every rank ends with every image's record
+        for img in range(NUM_IMAGES):
+            rec = got[img]
+            m = int(rec[-1])
+            wb, wl, ws = want[img]
+            assert m == len(ws)
+            body = rec[:-1].reshape(-1, 6)[:m]
+            order = np.lexsort((body[:, 5], -body[:, 4]))
+            worder = np.lexsort((wl, -ws))
+            np.testing.assert_array_equal(body[order, 5].astype(np.int32), wl[worder])
+            np.testing.assert_array_equal(body[order, 4], ws[worder])
+            assert np.max(np.abs(body[order, :4] - wb[worder])) <= 1e-4 * max(1.0, float(np.abs(wb).max()))
+    # both ranks hold identical copies
+    for img in range(NUM_IMAGES):
+        np.testing.assert_array_equal(results[0][1][img], results[1][1][img])
+
+
+def _host_inputs(img):
+    """the numpy side of pipeline.synthetic_fpn_inputs for image `img` without touching the GPU in the parent"""
+    from tf_eager_object_detection_amd import synthetic as syn
+    rng = np.random.default_rng(1000 + img)
+    shapes = syn.fpn_level_shapes(SHAPE)
+    n = syn.num_fpn_anchors(SHAPE)
+    syn.features(shapes[:4], CH, rng)
+    deltas = syn.rpn_deltas(n, rng, 0.1)
+    prob = syn.scores_distinct(n, rng)
+    logits = syn.logits_from_prob(prob, rng)
+    return dict(rpn_deltas=deltas, rpn_logits=logits, cls_scores=syn.class_scores(K, NCLS, rng),
+                cls_deltas=syn.class_deltas(K, NCLS, rng))

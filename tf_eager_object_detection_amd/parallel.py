@@ -113,6 +113,12 @@ class GroupExchange:
             copied.record(self.comm)
             if self.world == 1:
                 self.gathered[g, 0].copy_(self.staging[g])
+            elif dist.get_backend(self.group) == 'gloo':
+                # rehearsal of the multi-rank path on a box with fewer GPUs than ranks: gloo moves host memory
+                host = self.staging[g].cpu()                      # (synchronises the communication stream)
+                parts = [torch.empty_like(host) for _ in range(self.world)]
+                dist.all_gather(parts, host, group=self.group)
+                self.gathered[g].copy_(torch.stack(parts, 0))
             else:
                 dist.all_gather_into_tensor(self.gathered[g].view(self.world * self.B, self.rec_len), self.staging[g],
                                             group=self.group)
