@@ -164,15 +164,19 @@ size_t odet_fpn_proposals_workspace_bytes(int n, int max_output);
  * 55-81) and, when out_sorted_rois != NULL, :256 _assign_levels (:303-324) fused into the last
  * NMS launch.  rpn_logits [n,2] (bg,fg) as RpnHead emits them (:429), rpn_deltas [n,4], levels
  * concatenated in list order; fh/fw/stride/wh host arrays as in odet_anchors_fpn
- * (n = sum fh*fw*A).  Outputs as odet_region_proposal + odet_assign_levels. */
+ * (n = sum fh*fw*A).  Outputs as odet_region_proposal + odet_assign_levels.  out_order (nullable,
+ * int32 [max_output], needs out_sorted_rois and max_output <= ODET_FUSED_ORDER_MAX_ROIS): the spatial
+ * processing order of the level-sorted RoIs for odet_roi_pool_ordered (what odet_roi_order computes),
+ * produced by the tail of the NMS walk instead of a launch of its own. */
+#define ODET_FUSED_ORDER_MAX_ROIS 1024
 int odet_fpn_proposals(const float* rpn_logits, const float* rpn_deltas, int num_levels, int A,
                        const int* fh, const int* fw, const int* stride, const float* wh,
                        int image_h, int image_w, const float* means, const float* stds,
                        int max_output, float iou_threshold, int min_level, int max_level,
                        float* out_rois, int32_t* out_idx, int32_t* out_count,
                        float* out_sorted_rois, int32_t* out_level, int64_t* out_perm,
-                       int32_t* out_level_counts, int blind_chunks, int32_t* out_done,
-                       void* workspace, size_t workspace_bytes, odet_stream_t stream);
+                       int32_t* out_level_counts, int32_t* out_order, int blind_chunks,
+                       int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream);
 
 size_t odet_frcnn_proposals_workspace_bytes(int n, int max_output);
 /* The proposal stage of model/faster_rcnn/base_faster_rcnn_model.py BaseFasterRcnn.call in one entry
@@ -388,8 +392,10 @@ int odet_pack_detections(const float* boxes, const int32_t* labels, const float*
  * (model/fpn/base_fpn_model.py:208-276 minus the dense conv parts): every buffer is caller-owned
  * device memory, the struct is plain data.  odet_fpn_step_enqueue() issues the selected stages on
  * `stream` from the calling thread:
- *   ODET_STAGE_PROPOSALS = odet_fpn_proposals   (anchors, fg softmax, RegionProposal, _assign_levels)
- *   ODET_STAGE_ROI       = odet_roi_pool        (RoiPoolingCropAndResize2 over maps[0..num_maps))
+ *   ODET_STAGE_PROPOSALS = odet_fpn_proposals   (anchors, fg softmax, RegionProposal, _assign_levels; also the
+ *                          processing order into roi_order when num_proposals <= ODET_FUSED_ORDER_MAX_ROIS)
+ *   ODET_STAGE_ROI       = odet_roi_pool        (RoiPoolingCropAndResize2 over maps[0..num_maps); odet_roi_order
+ *                          first when num_proposals > ODET_FUSED_ORDER_MAX_ROIS)
  *   ODET_STAGE_DETECT    = odet_post_ops_record (post_ops_prediction + detection record) */
 #define ODET_STAGE_PROPOSALS 1
 #define ODET_STAGE_ROI 2
@@ -434,6 +440,10 @@ typedef struct {
   /* profiling (nullable): HIP events (odet_prof_event_create) attached to the RoI dispatch of this step -- in a
    * batch those of the first step bracket the one launch all its images share */
   void* roi_start_event; void* roi_stop_event;
+  /* != 0: the caller promises that ws_rpn was zero-filled once after its allocation and has only ever been handed to
+   * this library since: every call leaves its header clean again, so no launch is spent on zeroing it */
+  int32_t ws_rpn_clean;
+  int32_t reserved_flags;
 } odet_fpn_step_t;
 
 size_t odet_fpn_step_sizeof(void);

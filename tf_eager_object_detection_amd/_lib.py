@@ -52,6 +52,7 @@ class OdetFpnStep(C.Structure):
         ('ws_post', C.c_void_p), ('ws_post_bytes', C.c_size_t),
         ('stream', C.c_void_p),
         ('roi_start_event', C.c_void_p), ('roi_stop_event', C.c_void_p),
+        ('ws_rpn_clean', C.c_int32), ('reserved_flags', C.c_int32),
     ]
 
 
@@ -78,7 +79,7 @@ SIGNATURES = {
                                    _vp]),
     'odet_fpn_proposals_workspace_bytes': (_sz, [_i, _i]),
     'odet_fpn_proposals': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _f, _i, _i,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     'odet_frcnn_proposals_workspace_bytes': (_sz, [_i, _i]),
     'odet_frcnn_proposals': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp,
                                    _vp, _sz, _vp]),

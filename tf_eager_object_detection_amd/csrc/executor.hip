@@ -24,14 +24,15 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
     int fh[ODET_MAX_LEVELS], fw[ODET_MAX_LEVELS], st[ODET_MAX_LEVELS];
     for (int l = 0; l < ODET_MAX_LEVELS; ++l) { fh[l] = s->fh[l]; fw[l] = s->fw[l]; st[l] = s->stride[l]; }
     const FpnProposalIO one{s->rpn_logits, s->rpn_deltas, s->rois, s->roi_idx, s->roi_count, s->sorted_rois, s->roi_level,
-                            s->roi_perm, s->level_counts, s->nms_done, s->ws_rpn, s->ws_rpn_bytes};
+                            s->roi_perm, s->level_counts, s->nms_done, s->ws_rpn, s->ws_rpn_bytes,
+                            s->num_proposals <= ODET_FUSED_ORDER_MAX_ROIS ? s->roi_order : nullptr};
     rc = odet_fpn_proposals_batch(&one, 1, s->num_levels, s->A, fh, fw, st, s->wh, s->image_h, s->image_w, s->rpn_means,
                                   s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level, s->max_level,
-                                  s->blind_chunks, (hipStream_t)s->stream, s->nms_first_chunk);
+                                  s->blind_chunks, (hipStream_t)s->stream, s->nms_first_chunk, s->ws_rpn_clean);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_ROI) {
-    if (s->roi_order) {
+    if (s->roi_order && s->num_proposals > ODET_FUSED_ORDER_MAX_ROIS) {      // (else: written by the proposal stage)
       rc = odet_roi_order(s->sorted_rois, s->roi_level, s->num_proposals, s->roi_count, s->image_h, s->image_w,
                           s->roi_order, s->stream);
       if (rc != ODET_OK) return rc;
@@ -86,14 +87,20 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
     int fh[ODET_MAX_LEVELS], fw[ODET_MAX_LEVELS], sd[ODET_MAX_LEVELS];
     for (int l = 0; l < ODET_MAX_LEVELS; ++l) { fh[l] = s->fh[l]; fw[l] = s->fw[l]; sd[l] = s->stride[l]; }
     FpnProposalIO io[ODET_MAX_BATCH];
+    bool ordered_all = true, clean_all = true;
+    for (int i = 0; i < count; ++i) {
+      ordered_all = ordered_all && steps[i]->roi_order != nullptr;
+      clean_all = clean_all && steps[i]->ws_rpn_clean != 0;
+    }
     for (int i = 0; i < count; ++i) {
       const odet_fpn_step_t* t = steps[i];
       io[i] = FpnProposalIO{t->rpn_logits, t->rpn_deltas, t->rois, t->roi_idx, t->roi_count, t->sorted_rois,
-                            t->roi_level, t->roi_perm, t->level_counts, t->nms_done, t->ws_rpn, t->ws_rpn_bytes};
+                            t->roi_level, t->roi_perm, t->level_counts, t->nms_done, t->ws_rpn, t->ws_rpn_bytes,
+                            (ordered_all && s->num_proposals <= ODET_FUSED_ORDER_MAX_ROIS) ? t->roi_order : nullptr};
     }
     rc = odet_fpn_proposals_batch(io, count, s->num_levels, s->A, fh, fw, sd, s->wh, s->image_h, s->image_w,
                                   s->rpn_means, s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level,
-                                  s->max_level, s->blind_chunks, st, s->nms_first_chunk);
+                                  s->max_level, s->blind_chunks, st, s->nms_first_chunk, clean_all ? 1 : 0);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_ROI) {
@@ -107,7 +114,7 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
                          (float*)t->roi_features};
       oo[i] = RoiOrderIO{t->sorted_rois, t->roi_level, t->roi_count, t->roi_order};
     }
-    if (ordered) {
+    if (ordered && s->num_proposals > ODET_FUSED_ORDER_MAX_ROIS) {             // (else: written by the proposal stage)
       rc = odet_roi_order_batch(oo, count, s->num_proposals, s->image_h, s->image_w, st);
       if (rc != ODET_OK) return rc;
     }

@@ -78,8 +78,14 @@ struct NmsState {
   int32_t pad[7];
 };
 
-struct NmsHeader {   // zeroed by ONE memset per call; starts the workspace
+// Starts the workspace.  Zeroed by k_zero_headers at the start of a call -- or, for callers that promise a workspace
+// that was zero-filled once and is only ever used by this library (odet_fpn_step_t.ws_rpn_clean), left clean by the
+// call itself: hist1 is zeroed again by k_sel_hist2 (after k_sel_find1 has read it), hist2 by k_sel_rank (after
+// k_sel_compact), n_invalid_acc is moved into the state by k_sel_find1, which also resets the state.
+struct NmsHeader {
   NmsState st;
+  int32_t n_invalid_acc;               // fed by k_rp_prepare; k_sel_find1 moves it into st.n_invalid
+  int32_t pad_acc[15];
   u64 stamps[64];                      // diagnostic builds only (-DODET_STAMPS)
   uint32_t hist1[SEL_REPL][SEL_BINS];  // replica r is fed by blocks with blockIdx % SEL_REPL == r
   uint32_t hist2[SEL_BINS];
@@ -210,7 +216,7 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
     const uint32_t c = h[k];
     if (c) atomicAdd(&hdr->hist1[blockIdx.x % SEL_REPL][k], c);
   }
-  if (invalid) atomicAdd(&hdr->st.n_invalid, invalid);             // rare
+  if (invalid) atomicAdd(&hdr->n_invalid_acc, invalid);            // rare (k_sel_find1 moves it into the state)
 }
 
 // ------------------------------------------------------------------------- 2. select --------
@@ -259,7 +265,15 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_find1(PerImg<NmsHeader*> hdr_
   __shared__ uint32_t res[3];
   __shared__ int lds17[17];
   sel_find<SEL_REPL>(&hdr->hist1[0][0], target, res, lds17);
-  if (threadIdx.x == 0) { hdr->st.sel_b1 = (int32_t)res[0]; hdr->st.sel_below1 = res[1]; }
+  if (threadIdx.x == 0) {
+    // the state of a new job (a workspace kept clean between calls is not zeroed by a launch of its own)
+    NmsState z;
+    memset(&z, 0, sizeof(z));
+    z.n_invalid = hdr->n_invalid_acc;
+    z.sel_b1 = (int32_t)res[0]; z.sel_below1 = res[1];
+    hdr->st = z;
+    hdr->n_invalid_acc = 0;
+  }
 }
 
 __global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n) {
@@ -267,6 +281,12 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(PerImg<NmsHeader*> hdr_
   const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
   __shared__ uint32_t h[SEL_BINS];
   const uint32_t b1 = (uint32_t)hdr->st.sel_b1;
+  // k_sel_find1 was the last reader of the first-level histogram: leave it clean for the next call
+  {
+    uint4* z = reinterpret_cast<uint4*>(&hdr->hist1[0][0]);
+    for (int i = blockIdx.x * SEL_BLOCK + threadIdx.x; i < SEL_REPL * SEL_BINS / 4; i += gridDim.x * SEL_BLOCK)
+      z[i] = make_uint4(0, 0, 0, 0);
+  }
   uint32_t key[SEL_ITEMS];
   bool match = false;
 #pragma unroll
@@ -365,6 +385,10 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
   // sync-free chunk's (k_nms_gather with the selection as its order)
   const int cnt = min(st->sel_count, NMS_SEL_MAX);
   if (blockIdx.x == 0 && threadIdx.x == 0) st->chunk_m = min(min(cnt, cap0), n - st->n_invalid);
+  if (blockIdx.x == 0) {     // k_sel_compact was the last reader of the second-level histogram: leave it clean
+    uint4* z = reinterpret_cast<uint4*>(hdr->hist2);
+    for (int i = threadIdx.x; i < SEL_BINS / 4; i += RANK_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+  }
   if (blockIdx.x * 64 >= cnt) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
@@ -508,6 +532,7 @@ struct AssignOut {      // optional fused _assign_levels (base_fpn_model.py:303-
   int32_t* level;
   int64_t* perm;
   int32_t* counts;
+  int32_t* order;       // nullable: spatial processing order (see ScanParams::as_order)
   int min_level, max_level;
 };
 
@@ -583,6 +608,8 @@ struct ScanParams {          // pointer tables: one entry per image of the batch
   PerImg<int32_t*> as_level;
   PerImg<int64_t*> as_perm;
   PerImg<int32_t*> as_counts;
+  PerImg<int32_t*> as_order;                 // optional (K <= 1024): spatial processing order of the assigned RoIs
+  float ord_inv_h;
   int n, use_init, K, min_level, max_level;
   int fail_empty;      // last sync-free chunk of a job whose outputs feed further kernels through out_count (the fused
                        // proposal stages): an INCOMPLETE result is reported as zero proposals (+ *out_done = 0), so
@@ -883,6 +910,54 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
                                         ao.counts, lds_al);
   }
   STAMP(hdr, 5);
+  // Spatial processing order of the RoIs for the RoI kernel, in this launch instead of one of its own (odet_roi_order):
+  // the assigned RoIs were written by this workgroup just above.  A counting sort by (level, y band of 1/32 of the
+  // image) -- 256 buckets: what the order is for is that the RoIs in flight at a time tap one band of one pyramid
+  // level, and a band already holds fewer RoIs than are in flight; inside a bucket the order is whatever the LDS
+  // atomics give (results do not depend on the processing order).  ~1 us instead of the ~8 us of a full sort.
+  // Without an assignment (job not finished yet / reported empty) the order is the identity, so that the RoI kernel
+  // visits -- and zero-fills -- every row.
+  int32_t* __restrict__ order = sp.as_order.v[img];
+  if (order) {
+    __threadfence_block();
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (want_assign) {
+      int* ocnt = &lvl_cnt[0][0];                  // [256] (the level assignment is done with it)
+      int* obase = ocnt + 256;                     // [256]
+      for (int i = tid; i < 256; i += SCAN_THREADS) ocnt[i] = 0;
+      __syncthreads();
+      int bkt[2], slot[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int r = tid + e * SCAN_THREADS;
+        bkt[e] = -1;
+        if (r < nkf) {
+          const float4 bx = ao.rois[r];
+          const int l = min(max(ao.level[r], 0), 7);
+          const int qy = min(max((int)((bx.y + bx.w) * 0.5f * sp.ord_inv_h * 4096.0f), 0), 4095);
+          bkt[e] = l * 32 + (qy >> 7);
+          slot[e] = atomicAdd(&ocnt[bkt[e]], 1);
+        } else if (r < K) {
+          order[r] = r;                            // padded rows stay behind the valid ones
+        }
+      }
+      __syncthreads();
+      {
+        int total;
+        const int v = (tid < 256) ? ocnt[tid] : 0;
+        const int ex = block_excl_scan(v, keptpre, &total);
+        if (tid < 256) obase[tid] = ex;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (bkt[e] >= 0) order[obase[bkt[e]] + slot[e]] = tid + e * SCAN_THREADS;
+    } else {
+      if (tid < K) order[tid] = tid;
+      if (tid + SCAN_THREADS < K) order[tid + SCAN_THREADS] = tid + SCAN_THREADS;
+    }
+  }
 #ifdef ODET_STAMPS
   if (threadIdx.x == 0) hdr->stamps[61] = clock64();
 #endif
@@ -970,6 +1045,7 @@ struct NmsJob {
   int n, K;
   float thr;
   int blind_chunks;
+  int ws_clean;             // caller promise: the workspace header is clean (see NmsHeader): no k_zero_headers launch
   int fail_empty;           // sync-free jobs: report an incomplete result as zero proposals (ScanParams::fail_empty)
   int first_chunk;          // 0 = auto (~1.5 K candidates), else candidates of the first chunk (<= NMS_CHUNK)
   int B;                    // images in the batch (1..ODET_MAX_BATCH)
@@ -1014,8 +1090,10 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   ODET_HIP(once_rc);
   const PerImg<NmsHeader*> hdrs = per_img<NmsHeader*>(J, [&](int i) { return w[i].hdr; });
   const PerImg<const uint32_t*> keys = per_img<const uint32_t*>(J, [&](int i) { return (const uint32_t*)w[i].keys_a; });
-  hipLaunchKernelGGL(k_zero_headers, dim3((unsigned)((sizeof(NmsHeader) / 16 + 255) / 256), B), dim3(256), 0, st, hdrs);
-  ODET_LAUNCH_CHECK();
+  if (!J.ws_clean) {
+    hipLaunchKernelGGL(k_zero_headers, dim3((unsigned)((sizeof(NmsHeader) / 16 + 255) / 256), B), dim3(256), 0, st, hdrs);
+    ODET_LAUNCH_CHECK();
+  }
   // 1. prepare
   J.prep.n = n;
   J.prep.boxes_in = per_img<const float4*>(J, [&](int i) { return J.img[i].boxes_in; });
@@ -1089,6 +1167,8 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   sp.as_level = per_img<int32_t*>(J, [&](int i) { return J.img[i].assign.level; });
   sp.as_perm = per_img<int64_t*>(J, [&](int i) { return J.img[i].assign.perm; });
   sp.as_counts = per_img<int32_t*>(J, [&](int i) { return J.img[i].assign.counts; });
+  sp.as_order = per_img<int32_t*>(J, [&](int i) { return K <= ODET_FUSED_ORDER_MAX_ROIS ? J.img[i].assign.order : nullptr; });
+  sp.ord_inv_h = 1.0f / (J.prep.hmax + 1.0f);
   sp.n = n; sp.use_init = 0; sp.K = K;
   const int blind_n = J.blind_chunks < 1 ? 1 : J.blind_chunks;
   const bool fail_empty = J.fail_empty && J.img[0].out_done != nullptr;
@@ -1128,7 +1208,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     si.sboxes = shift(sp.sboxes); si.sorig = shift(sp.sorig); si.out_idx = shift(sp.out_idx);
     si.out_boxes = shift(sp.out_boxes); si.kept_boxes = shift(sp.kept_boxes); si.out_count = shift(sp.out_count);
     si.out_done = shift(sp.out_done); si.as_rois = shift(sp.as_rois); si.as_level = shift(sp.as_level);
-    si.as_perm = shift(sp.as_perm); si.as_counts = shift(sp.as_counts);
+    si.as_perm = shift(sp.as_perm); si.as_counts = shift(sp.as_counts); si.as_order = shift(sp.as_order);
     si.use_init = 1;
     si.fail_empty = 0;
     for (int k = 0; k < ODET_MAX_BATCH; ++k) si.sorted_idx.v[k] = (const uint32_t*)sorted;
@@ -1209,7 +1289,7 @@ static int nms_trivial(int32_t* out_count, int32_t* out_done, hipStream_t st) {
 }
 
 static void no_assign(AssignOut* a) {
-  a->rois = nullptr; a->level = nullptr; a->perm = nullptr; a->counts = nullptr;
+  a->rois = nullptr; a->level = nullptr; a->perm = nullptr; a->counts = nullptr; a->order = nullptr;
   a->min_level = 0; a->max_level = 0;
 }
 
@@ -1297,7 +1377,7 @@ extern "C" size_t odet_fpn_proposals_workspace_bytes(int n, int max_output) {
 int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int A, const int* fh, const int* fw,
                              const int* stride, const float* wh, int image_h, int image_w, const float* means,
                              const float* stds, int max_output, float iou_threshold, int min_level, int max_level,
-                             int blind_chunks, hipStream_t st, int first_chunk) {
+                             int blind_chunks, hipStream_t st, int first_chunk, int ws_clean) {
   ODET_REQUIRE(io && fh && fw && stride && wh && means && stds, "odet_fpn_proposals: null pointer");
   ODET_REQUIRE(first_chunk >= 0 && first_chunk <= NMS_CHUNK, "odet_fpn_proposals: nms_first_chunk %d out of range (0..%d)", first_chunk, NMS_CHUNK);
   ODET_REQUIRE(B >= 1 && B <= ODET_MAX_BATCH, "odet_fpn_proposals: batch %d out of range", B);
@@ -1308,6 +1388,7 @@ int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int
   NmsJob J;
   job_init(&J, PREP_FPN, 0, max_output, iou_threshold, blind_chunks, B);
   J.first_chunk = first_chunk;
+  J.ws_clean = ws_clean ? 1 : 0;
   FpnAnchorParams& p = J.prep.fpn;
   p.num_levels = num_levels;
   p.A = A;
@@ -1352,6 +1433,7 @@ int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int
     if (assign) {
       im.assign.rois = (float4*)a.out_sorted_rois; im.assign.level = a.out_level; im.assign.perm = a.out_perm;
       im.assign.counts = a.out_level_counts;
+      im.assign.order = a.out_order;
     }
     im.assign.min_level = min_level; im.assign.max_level = max_level;
   }
@@ -1364,10 +1446,13 @@ extern "C" int odet_fpn_proposals(const float* rpn_logits, const float* rpn_delt
                                   int image_w, const float* means, const float* stds, int max_output,
                                   float iou_threshold, int min_level, int max_level, float* out_rois,
                                   int32_t* out_idx, int32_t* out_count, float* out_sorted_rois, int32_t* out_level,
-                                  int64_t* out_perm, int32_t* out_level_counts, int blind_chunks, int32_t* out_done,
-                                  void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+                                  int64_t* out_perm, int32_t* out_level_counts, int32_t* out_order, int blind_chunks,
+                                  int32_t* out_done, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(!out_order || (out_sorted_rois && max_output <= ODET_FUSED_ORDER_MAX_ROIS),
+               "odet_fpn_proposals: out_order needs out_sorted_rois and max_output <= %d (use odet_roi_order beyond)",
+               ODET_FUSED_ORDER_MAX_ROIS);
   FpnProposalIO io{rpn_logits, rpn_deltas, out_rois, out_idx, out_count, out_sorted_rois, out_level, out_perm,
-                   out_level_counts, out_done, workspace, workspace_bytes};
+                   out_level_counts, out_done, workspace, workspace_bytes, out_order};
   return odet_fpn_proposals_batch(&io, 1, num_levels, A, fh, fw, stride, wh, image_h, image_w, means, stds,
                                   max_output, iou_threshold, min_level, max_level, blind_chunks, (hipStream_t)stream, 0);
 }

@@ -244,6 +244,20 @@ __device__ __forceinline__ unsigned long long bitonic_sort_1024_reg(unsigned lon
   return key;
 }
 
+
+// Processing-order key of RoI row r for the RoI kernel (odet_roi_order): (level, y centre, x centre) quantised to
+// 12 bits each, row index in the low word; rows >= cnt (padding of the static shape) sort last, rows >= n never.
+__device__ __forceinline__ unsigned long long d_roi_order_key(int r, int n, int cnt, const float4* rois, const int32_t* lvl,
+                                                               float inv_h, float inv_w) {
+  if (r >= n) return ~0ull;
+  if (r >= cnt) return (0xFFFFFFFEull << 32) | (unsigned)r;          // padded rows last (they are zero-filled)
+  const float4 b = rois[r];
+  const int l = lvl ? min(max(lvl[r], 0), 7) : 0;
+  const int qy = min(max((int)((b.y + b.w) * 0.5f * inv_h * 4096.0f), 0), 4095);
+  const int qx = min(max((int)((b.x + b.z) * 0.5f * inv_w * 4096.0f), 0), 4095);
+  return ((unsigned long long)((l << 24) | (qy << 12) | qx) << 32) | (unsigned)r;
+}
+
 // model/fpn/base_fpn_model.py:303-324 _assign_levels by ONE workgroup of THREADS threads: level per RoI,
 // then a stable partition by level (ascending original index inside a level) -- the order
 // tf.where + tf.gather + tf.concat produce at :316-324.  rois may have been written by this
@@ -321,11 +335,13 @@ struct FpnProposalIO {      // per-image arguments of the FPN proposal stage
   float* out_rois; int32_t* out_idx; int32_t* out_count;
   float* out_sorted_rois; int32_t* out_level; int64_t* out_perm; int32_t* out_level_counts;
   int32_t* out_done; void* workspace; size_t workspace_bytes;
+  int32_t* out_order;       // nullable: spatial processing order of the level-sorted RoIs (odet_roi_order), written by
+                            // the NMS walk's tail when max_output <= 1024
 };
 int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int A, const int* fh, const int* fw,
                              const int* stride, const float* wh, int image_h, int image_w, const float* means,
                              const float* stds, int max_output, float iou_threshold, int min_level, int max_level,
-                             int blind_chunks, hipStream_t st, int first_chunk = 0);
+                             int blind_chunks, hipStream_t st, int first_chunk = 0, int ws_clean = 0);
 
 struct RoiEvents { hipEvent_t start, stop; };   // optional: timestamps of the dispatch itself
 struct RoiImageIO {         // per-image arguments (order: nullable processing order, odet_roi_order)

@@ -602,15 +602,7 @@ __global__ void __launch_bounds__(1024) k_roi_order(RoiOrderParams p) {
   int32_t* __restrict__ order = p.order.v[img];
   const int cnt = cd ? min(*cd, p.n) : p.n;
   const int tid = threadIdx.x;
-  auto make_key = [&](int r) -> unsigned long long {
-    if (r >= p.n) return ~0ull;
-    if (r >= cnt) return (0xFFFFFFFEull << 32) | (unsigned)r;          // padded rows last (they are zero-filled)
-    const float4 b = rois[r];
-    const int l = lvl ? min(max(lvl[r], 0), 7) : 0;
-    const int qy = min(max((int)((b.y + b.w) * 0.5f * p.inv_h * 4096.0f), 0), 4095);
-    const int qx = min(max((int)((b.x + b.z) * 0.5f * p.inv_w * 4096.0f), 0), 4095);
-    return ((unsigned long long)((l << 24) | (qy << 12) | qx) << 32) | (unsigned)r;
-  };
+  auto make_key = [&](int r) -> unsigned long long { return d_roi_order_key(r, p.n, cnt, rois, lvl, p.inv_h, p.inv_w); };
   if (p.P2 <= 1024) {
     unsigned long long k = make_key(tid);
     k = bitonic_sort_1024_reg(k, okeys);

@@ -222,12 +222,17 @@ def region_proposal(deltas, anchors, scores, image_shape, num_post_nms, iou_thre
     return rois, idx, cnt
 
 
+FUSED_ORDER_MAX_ROIS = 1024          # ODET_FUSED_ORDER_MAX_ROIS
+
+
 def fpn_proposals(rpn_logits, rpn_deltas, fh_list, fw_list, stride_list, wh_table, image_shape, num_post_nms,
                   iou_threshold, means, stds, min_level=None, max_level=None, workspace=None, blind_chunks=1,
-                  done=None, out=None, out_levels=None):
+                  done=None, out=None, out_levels=None, out_order=None):
     """The whole FPN proposal stage (anchors in registers -> fg softmax -> decode+clip -> NMS over all
     anchors [-> level assignment]) as ONE C-ABI call.  -> (rois [K,4] padded, idx int32 [K], count int32[1])
-    and, when min_level is given, (sorted rois [K,4], level int32 [K], perm int64 [K], counts int32 [L])."""
+    and, when min_level is given, (sorted rois [K,4], level int32 [K], perm int64 [K], counts int32 [L]).
+    out_order (int32 [K], K <= FUSED_ORDER_MAX_ROIS, needs the level outputs): receives the spatial processing order
+    of the level-sorted RoIs (what roi_order computes) from the same launches."""
     logits = L.f32c(rpn_logits, 'rpn_score')
     deltas = L.f32c(rpn_deltas, 'rpn_bbox_txtytwth')
     nl = len(fh_list)
@@ -261,7 +266,8 @@ def fpn_proposals(rpn_logits, rpn_deltas, fh_list, fw_list, stride_list, wh_tabl
         int(image_shape[1]), L.host4(means, 'target_means'), L.host4(stds, 'target_stds'), K, float(iou_threshold),
         int(min_level or 0), int(max_level or 0), L.dptr(rois), L.dptr(idx), L.dptr(cnt),
         L.dptr(lv[0]) if lv else None, L.dptr(lv[1]) if lv else None, L.dptr(lv[2]) if lv else None,
-        L.dptr(lv[3]) if lv else None, int(blind_chunks), L.dptr(done), L.dptr(ws), ws.numel(), L.stream())
+        L.dptr(lv[3]) if lv else None, L.dptr(out_order, torch.int32, 'out_order') if out_order is not None else None,
+        int(blind_chunks), L.dptr(done), L.dptr(ws), ws.numel(), L.stream())
     return (rois, idx, cnt) + ((lv,) if lv else ())
 
 

@@ -49,7 +49,9 @@ class FpnHotPath:
         # persistent buffers (allocated once; 288 GB of HBM makes this a non-issue)
         self.fh, self.fw, self.wh = fpn_level_tables(self.image_shape, strides, base_sizes, scales, ratios)
         nb = ops.L.lib().odet_fpn_proposals_workspace_bytes(self.N, K)
-        self.ws_rpn = torch.empty(nb, dtype=torch.uint8, device=dev)
+        # zero-filled ONCE and private to this object: the library keeps its header clean between calls
+        # (odet_fpn_step_t.ws_rpn_clean), so the step-descriptor path spends no launch on zeroing it
+        self.ws_rpn = torch.zeros(nb, dtype=torch.uint8, device=dev)
         self.rois = torch.zeros((K, 4), dtype=torch.float32, device=dev)
         self.roi_idx = torch.zeros(K, dtype=torch.int32, device=dev)
         self.roi_count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -62,6 +64,8 @@ class FpnHotPath:
         self.roi_perm = torch.zeros(K, dtype=torch.int64, device=dev)
         self.level_counts = torch.zeros(nl, dtype=torch.int32, device=dev)
         self.roi_order = torch.zeros(K, dtype=torch.int32, device=dev) if spatial_order and K <= 8192 else None
+        # up to 1024 proposals the proposal stage writes the processing order itself (tail of the NMS walk)
+        self._fused_order = self.roi_order is not None and K <= ops.FUSED_ORDER_MAX_ROIS
         M = max(max_per_image, 1)
         self.det_boxes = torch.zeros((M, 4), dtype=torch.float32, device=dev)
         self.det_labels = torch.zeros(M, dtype=torch.int32, device=dev)
@@ -103,7 +107,8 @@ class FpnHotPath:
             min_level=self.min_level, max_level=self.max_level, workspace=self.ws_rpn,
             blind_chunks=self.blind_chunks, done=self.nms_done,
             out=(self.rois, self.roi_idx, self.roi_count),
-            out_levels=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts)))
+            out_levels=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts),
+            out_order=self.roi_order if self._fused_order else None))
         # base_fpn_model.py:220 (_get_anchors), :223 (fg softmax), :224 (RegionProposal), :256 / :303-324
         return self.sorted_rois, self.roi_level, self.roi_count
 
@@ -114,7 +119,7 @@ class FpnHotPath:
         nl = self.max_level - self.min_level + 1
         maps = list(p_list[:nl])
         def go(ev=None):
-            if self.roi_order is not None:
+            if self.roi_order is not None and not self._fused_order:
                 ops.roi_order(self.sorted_rois, self.roi_level, self.image_shape, count_dev=self.roi_count,
                               out=self.roi_order)
             return ops.roi_pool(maps, self.sorted_rois, self.roi_level, ops.ROI_NORM_IMAGE, self.P,
@@ -279,6 +284,7 @@ def _fill_step(st, h, stream_handle, rpn_logits, rpn_deltas, p_list, cls_softmax
     st.det_boxes, st.det_labels = h.det_boxes.data_ptr(), h.det_labels.data_ptr()
     st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
     st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
+    st.ws_rpn_clean = 1                              # (FpnHotPath zero-filled it at allocation and never exposes it)
     st.ws_post, st.ws_post_bytes = h.ws_post.data_ptr(), h.ws_post.numel()
     st.stream = stream_handle
     return tensors
