@@ -443,6 +443,13 @@ typedef struct {
   /* != 0: the caller promises that ws_rpn was zero-filled once after its allocation and has only ever been handed to
    * this library since: every call leaves its header clean again, so no launch is spent on zeroing it */
   int32_t ws_rpn_clean;
+  /* != 0: a single-level Faster R-CNN step (model/faster_rcnn/base_faster_rcnn_model.py:126-198 minus the dense
+   * parts) instead of an FPN step: num_levels = num_maps = 1; fh[0] x fw[0] cells of stride[0] with A anchors each,
+   * wh[0 .. 4A) = the anchor base (generate_anchor_base as float32 rows x1,y1,x2,y2); rpn_logits [fh*fw, 2A] in the
+   * [A bg | A fg] layout; no level assignment (sorted_rois must alias rois; roi_level, roi_perm, level_counts NULL);
+   * RoI crops normalised by maps[0].stride (ODET_ROI_NORM_STRIDE) with roi_pool_mode; min_edge = the stride. */
+  int32_t single_level;
+  int32_t roi_pool_mode;     /* single_level: ODET_ROI_POOL_MAX2 (VGG16) | ODET_ROI_POOL_NONE (ResNet C4); FPN: MAX2 */
   int32_t reserved_flags;
 } odet_fpn_step_t;
 

@@ -897,6 +897,53 @@ def test_full_size_hashes_from_the_hip_path(name):
     assert fs.digests(got) == {k_: v for k_, v in want.items() if k_ != 'num_anchors'}
 
 
+@pytest.mark.parametrize('flag,ch,K', [(True, 64, 300), (False, 128, 100)])
+def test_frcnn_step_batch_and_stream_pool_match_single_path(flag, ch, K):
+    """Configs 1-2 through the throughput arrangement: B single-level images in the SAME launches
+    (odet_fpn_step_t.single_level: FrcnnStepBatch, FrcnnStreamPool) == each image through FrcnnHotPath, bit for bit,
+    and == the oracle (base_faster_rcnn_model.py:126-198 minus the dense parts)."""
+    from tf_eager_object_detection_amd.pipeline import FrcnnHotPath, FrcnnStepBatch, FrcnnStreamPool, synthetic_frcnn_inputs
+    shape, ncls, B = (300, 420), 21, 3
+    sets = [synthetic_frcnn_inputs(shape, ncls, K, ch, seed=900 + i) for i in range(B)]
+    sb = FrcnnStepBatch(B, shape, ncls, K, ch, max_pooling_flag=flag, blind_chunks=3)
+    for b, (_, d) in enumerate(sets):
+        sb.bind(b, d['rpn_logits'], d['rpn_deltas'], d['feat'], d['cls_scores'], d['cls_deltas'])
+    sb.enqueue(7, B)
+    torch.cuda.synchronize()
+    ref = FrcnnHotPath(shape, ncls, K, ch, max_pooling_flag=flag, blind_chunks=4)
+    from tf_eager_object_detection_amd.utils.anchor_generator import generate_anchor_base
+    base = generate_anchor_base(16, [0.5, 1, 2], np.array([8, 16, 32])).astype(np.float32)
+    anchors = on.generate_by_anchor_base_tf(base, 16, ref.fh, ref.fw)
+    for b, (host, d) in enumerate(sets):
+        ref.step(d['rpn_logits'], d['rpn_deltas'], d['feat'], d['cls_scores'], d['cls_deltas'])
+        torch.cuda.synchronize()
+        s = sb.slots[b]
+        assert int(s.nms_done.item()) == 1 and int(ref.nms_done.item()) == 1
+        k = int(ref.roi_count.item())
+        assert int(s.roi_count.item()) == k and k > 0
+        assert torch.equal(s.roi_idx[:k], ref.roi_idx[:k]) and torch.equal(s.rois[:k], ref.rois[:k])
+        assert torch.equal(s.roi_features, ref.roi_features)
+        assert torch.equal(s.record, ref.record)
+        order = h(s.roi_order)
+        assert sorted(order.tolist()) == list(range(K))                  # the fused processing order is a permutation
+        fg = co.rpn_fg_frcnn(host['rpn_logits'], 9)
+        want_rois, want_idx = co.region_proposal(host['rpn_deltas'], anchors, fg, shape, K, 0.7)
+        np.testing.assert_array_equal(h(s.roi_idx[:k]), want_idx)
+        np.testing.assert_array_equal(h(s.roi_features[:k]), co.roi_pool(host['feat'][0], want_rois, stride=16, pool=7, max_pool=flag))
+    pool = FrcnnStreamPool(1, shape, ncls, K, ch, batch=B, max_pooling_flag=flag, blind_chunks=3)
+    try:
+        for b, (_, d) in enumerate(sets):
+            pool.bind(b, d['rpn_logits'], d['rpn_deltas'], d['feat'], d['cls_scores'], d['cls_deltas'])
+        pool.submit_group(0)
+        pool.wait()
+        torch.cuda.synchronize()
+        for b in range(B):
+            assert torch.equal(pool.slots[b].record, sb.slots[b].record)
+            assert torch.equal(pool.slots[b].roi_features, sb.slots[b].roi_features)
+    finally:
+        pool.close()
+
+
 def test_zz_report_ulp_histograms(capsys):
     """(last test of the file) the distances the parity assertions above actually saw, per output kind"""
     with capsys.disabled():

@@ -52,7 +52,8 @@ class OdetFpnStep(C.Structure):
         ('ws_post', C.c_void_p), ('ws_post_bytes', C.c_size_t),
         ('stream', C.c_void_p),
         ('roi_start_event', C.c_void_p), ('roi_stop_event', C.c_void_p),
-        ('ws_rpn_clean', C.c_int32), ('reserved_flags', C.c_int32),
+        ('ws_rpn_clean', C.c_int32), ('single_level', C.c_int32), ('roi_pool_mode', C.c_int32),
+        ('reserved_flags', C.c_int32),
     ]
 
 

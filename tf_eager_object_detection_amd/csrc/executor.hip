@@ -20,15 +20,28 @@ extern "C" size_t odet_fpn_step_sizeof(void) { return sizeof(odet_fpn_step_t); }
 extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
   ODET_REQUIRE(s, "odet_fpn_step_enqueue: null step");
   int rc = ODET_OK;
+  const int norm = s->single_level ? ODET_ROI_NORM_STRIDE : ODET_ROI_NORM_IMAGE;
+  const int pool_mode = s->single_level ? s->roi_pool_mode : ODET_ROI_POOL_MAX2;
+  if (s->single_level)
+    ODET_REQUIRE(s->num_levels == 1 && s->num_maps == 1 && s->sorted_rois == s->rois && !s->roi_level,
+                 "odet_fpn_step_enqueue: a single-level step has one level / map, sorted_rois aliasing rois, no roi_level");
   if (stages & ODET_STAGE_PROPOSALS) {
     int fh[ODET_MAX_LEVELS], fw[ODET_MAX_LEVELS], st[ODET_MAX_LEVELS];
     for (int l = 0; l < ODET_MAX_LEVELS; ++l) { fh[l] = s->fh[l]; fw[l] = s->fw[l]; st[l] = s->stride[l]; }
-    const FpnProposalIO one{s->rpn_logits, s->rpn_deltas, s->rois, s->roi_idx, s->roi_count, s->sorted_rois, s->roi_level,
-                            s->roi_perm, s->level_counts, s->nms_done, s->ws_rpn, s->ws_rpn_bytes,
-                            s->num_proposals <= ODET_FUSED_ORDER_MAX_ROIS ? s->roi_order : nullptr};
-    rc = odet_fpn_proposals_batch(&one, 1, s->num_levels, s->A, fh, fw, st, s->wh, s->image_h, s->image_w, s->rpn_means,
-                                  s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level, s->max_level,
-                                  s->blind_chunks, (hipStream_t)s->stream, s->nms_first_chunk, s->ws_rpn_clean);
+    int32_t* order = s->num_proposals <= ODET_FUSED_ORDER_MAX_ROIS ? s->roi_order : nullptr;
+    if (s->single_level) {
+      const FpnProposalIO one{s->rpn_logits, s->rpn_deltas, s->rois, s->roi_idx, s->roi_count, nullptr, nullptr, nullptr,
+                              nullptr, s->nms_done, s->ws_rpn, s->ws_rpn_bytes, order};
+      rc = odet_frcnn_proposals_batch(&one, 1, s->wh, s->A, st[0], fh[0], fw[0], s->image_h, s->image_w, s->rpn_means,
+                                      s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->blind_chunks,
+                                      (hipStream_t)s->stream, s->nms_first_chunk, s->ws_rpn_clean);
+    } else {
+      const FpnProposalIO one{s->rpn_logits, s->rpn_deltas, s->rois, s->roi_idx, s->roi_count, s->sorted_rois, s->roi_level,
+                              s->roi_perm, s->level_counts, s->nms_done, s->ws_rpn, s->ws_rpn_bytes, order};
+      rc = odet_fpn_proposals_batch(&one, 1, s->num_levels, s->A, fh, fw, st, s->wh, s->image_h, s->image_w, s->rpn_means,
+                                    s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level, s->max_level,
+                                    s->blind_chunks, (hipStream_t)s->stream, s->nms_first_chunk, s->ws_rpn_clean);
+    }
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_ROI) {
@@ -38,8 +51,8 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
       if (rc != ODET_OK) return rc;
     }
     const RoiImageIO one{s->maps, s->sorted_rois, s->roi_level, s->roi_count, s->roi_order, (float*)s->roi_features};
-    rc = odet_roi_pool_batch(&one, 1, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
-                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, (hipStream_t)s->stream,
+    rc = odet_roi_pool_batch(&one, 1, s->num_maps, s->channels, s->num_proposals, norm, s->image_h,
+                             s->image_w, s->pool_size, pool_mode, (hipStream_t)s->stream,
                              RoiEvents{(hipEvent_t)s->roi_start_event, (hipEvent_t)s->roi_stop_event}, s->maps_f16 ? 1 : 0);
     if (rc != ODET_OK) return rc;
   }
@@ -60,7 +73,7 @@ static bool same_config(const odet_fpn_step_t* a, const odet_fpn_step_t* b) {
   if (a->image_h != b->image_h || a->image_w != b->image_w || a->num_levels != b->num_levels || a->A != b->A) return false;
   for (int l = 0; l < a->num_levels; ++l)
     if (a->fh[l] != b->fh[l] || a->fw[l] != b->fw[l] || a->stride[l] != b->stride[l]) return false;
-  for (int i = 0; i < a->num_levels * a->A * 2; ++i) if (a->wh[i] != b->wh[i]) return false;
+  for (int i = 0; i < (a->single_level ? a->A * 4 : a->num_levels * a->A * 2); ++i) if (a->wh[i] != b->wh[i]) return false;
   for (int k = 0; k < 4; ++k)
     if (a->rpn_means[k] != b->rpn_means[k] || a->rpn_stds[k] != b->rpn_stds[k] || a->roi_means[k] != b->roi_means[k] ||
         a->roi_stds[k] != b->roi_stds[k]) return false;
@@ -69,7 +82,9 @@ static bool same_config(const odet_fpn_step_t* a, const odet_fpn_step_t* b) {
          a->channels == b->channels && a->pool_size == b->pool_size && (a->maps_f16 != 0) == (b->maps_f16 != 0) && a->ccls == b->ccls &&
          a->num_classes == b->num_classes && a->max_per_class == b->max_per_class &&
          a->max_per_image == b->max_per_image && a->nms_iou == b->nms_iou &&
-         a->score_threshold == b->score_threshold && a->min_edge == b->min_edge && a->stream == b->stream;
+         a->score_threshold == b->score_threshold && a->min_edge == b->min_edge && a->stream == b->stream &&
+         (a->single_level != 0) == (b->single_level != 0) && a->roi_pool_mode == b->roi_pool_mode &&
+         (!a->single_level || a->maps[0].stride == b->maps[0].stride);
 }
 
 extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, int count, int stages) {
@@ -77,6 +92,11 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
   const odet_fpn_step_t* s = steps[0];
   ODET_REQUIRE(s, "odet_fpn_step_enqueue_batch: null step");
   if (count == 1) return odet_fpn_step_enqueue(s, stages);
+  if (s->single_level)
+    for (int i = 0; i < count; ++i)
+      ODET_REQUIRE(steps[i] && steps[i]->num_levels == 1 && steps[i]->num_maps == 1 && steps[i]->sorted_rois == steps[i]->rois &&
+                   !steps[i]->roi_level, "odet_fpn_step_enqueue_batch: a single-level step has one level / map, sorted_rois "
+                   "aliasing rois, no roi_level");
   for (int i = 1; i < count; ++i) {
     ODET_REQUIRE(steps[i], "odet_fpn_step_enqueue_batch: null step");
     ODET_REQUIRE(same_config(s, steps[i]), "odet_fpn_step_enqueue_batch: step %d differs in shape / parameters / stream", i);
@@ -94,13 +114,20 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
     }
     for (int i = 0; i < count; ++i) {
       const odet_fpn_step_t* t = steps[i];
-      io[i] = FpnProposalIO{t->rpn_logits, t->rpn_deltas, t->rois, t->roi_idx, t->roi_count, t->sorted_rois,
-                            t->roi_level, t->roi_perm, t->level_counts, t->nms_done, t->ws_rpn, t->ws_rpn_bytes,
+      io[i] = FpnProposalIO{t->rpn_logits, t->rpn_deltas, t->rois, t->roi_idx, t->roi_count,
+                            s->single_level ? nullptr : t->sorted_rois, s->single_level ? nullptr : t->roi_level,
+                            s->single_level ? nullptr : t->roi_perm, s->single_level ? nullptr : t->level_counts,
+                            t->nms_done, t->ws_rpn, t->ws_rpn_bytes,
                             (ordered_all && s->num_proposals <= ODET_FUSED_ORDER_MAX_ROIS) ? t->roi_order : nullptr};
     }
-    rc = odet_fpn_proposals_batch(io, count, s->num_levels, s->A, fh, fw, sd, s->wh, s->image_h, s->image_w,
-                                  s->rpn_means, s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level,
-                                  s->max_level, s->blind_chunks, st, s->nms_first_chunk, clean_all ? 1 : 0);
+    if (s->single_level)
+      rc = odet_frcnn_proposals_batch(io, count, s->wh, s->A, sd[0], fh[0], fw[0], s->image_h, s->image_w, s->rpn_means,
+                                      s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->blind_chunks, st,
+                                      s->nms_first_chunk, clean_all ? 1 : 0);
+    else
+      rc = odet_fpn_proposals_batch(io, count, s->num_levels, s->A, fh, fw, sd, s->wh, s->image_h, s->image_w,
+                                    s->rpn_means, s->rpn_stds, s->num_proposals, s->rpn_nms_iou, s->min_level,
+                                    s->max_level, s->blind_chunks, st, s->nms_first_chunk, clean_all ? 1 : 0);
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_ROI) {
@@ -118,8 +145,9 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
       rc = odet_roi_order_batch(oo, count, s->num_proposals, s->image_h, s->image_w, st);
       if (rc != ODET_OK) return rc;
     }
-    rc = odet_roi_pool_batch(io, count, s->num_maps, s->channels, s->num_proposals, ODET_ROI_NORM_IMAGE, s->image_h,
-                             s->image_w, s->pool_size, ODET_ROI_POOL_MAX2, st,
+    rc = odet_roi_pool_batch(io, count, s->num_maps, s->channels, s->num_proposals,
+                             s->single_level ? ODET_ROI_NORM_STRIDE : ODET_ROI_NORM_IMAGE, s->image_h,
+                             s->image_w, s->pool_size, s->single_level ? s->roi_pool_mode : ODET_ROI_POOL_MAX2, st,
                              RoiEvents{(hipEvent_t)s->roi_start_event, (hipEvent_t)s->roi_stop_event},
                              s->maps_f16 ? 1 : 0);
     if (rc != ODET_OK) return rc;

@@ -922,7 +922,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     __threadfence_block();
     __syncthreads();
     const int tid = threadIdx.x;
-    if (want_assign) {
+    // (single-level models: no level assignment, the order is taken over the kept RoIs themselves, level 0)
+    const float4* __restrict__ osrc = want_assign ? ao.rois : ((done && !ao.rois) ? out_boxes : nullptr);
+    const int32_t* __restrict__ olvl = want_assign ? ao.level : nullptr;
+    if (osrc) {
       int* ocnt = &lvl_cnt[0][0];                  // [256] (the level assignment is done with it)
       int* obase = ocnt + 256;                     // [256]
       for (int i = tid; i < 256; i += SCAN_THREADS) ocnt[i] = 0;
@@ -933,8 +936,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
         const int r = tid + e * SCAN_THREADS;
         bkt[e] = -1;
         if (r < nkf) {
-          const float4 bx = ao.rois[r];
-          const int l = min(max(ao.level[r], 0), 7);
+          const float4 bx = osrc[r];
+          const int l = olvl ? min(max(olvl[r], 0), 7) : 0;
           const int qy = min(max((int)((bx.y + bx.w) * 0.5f * sp.ord_inv_h * 4096.0f), 0), 4095);
           bkt[e] = l * 32 + (qy >> 7);
           slot[e] = atomicAdd(&ocnt[bkt[e]], 1);
@@ -1461,34 +1464,60 @@ extern "C" size_t odet_frcnn_proposals_workspace_bytes(int n, int max_output) {
   return rp_workspace_bytes(n, max_output);
 }
 
-extern "C" int odet_frcnn_proposals(const float* rpn_logits, const float* rpn_deltas, const float* anchor_base, int A,
-                                    int feat_stride, int fh, int fw, int image_h, int image_w, const float* means,
-                                    const float* stds, int max_output, float iou_threshold, float* out_rois,
-                                    int32_t* out_idx, int32_t* out_count, int blind_chunks, int32_t* out_done,
-                                    void* workspace, size_t workspace_bytes, odet_stream_t stream) {
-  ODET_REQUIRE(rpn_logits && rpn_deltas && anchor_base && means && stds, "odet_frcnn_proposals: null pointer");
-  ODET_REQUIRE(out_rois && out_count, "odet_frcnn_proposals: null output");
+// shared by odet_frcnn_proposals (B = 1) and the single-level step descriptors (B images in the same launches)
+int odet_frcnn_proposals_batch(const FpnProposalIO* io, int B, const float* anchor_base, int A, int feat_stride, int fh,
+                               int fw, int image_h, int image_w, const float* means, const float* stds, int max_output,
+                               float iou_threshold, int blind_chunks, hipStream_t st, int first_chunk, int ws_clean) {
+  ODET_REQUIRE(io && anchor_base && means && stds, "odet_frcnn_proposals: null pointer");
+  ODET_REQUIRE(B >= 1 && B <= ODET_MAX_BATCH, "odet_frcnn_proposals: batch %d out of range", B);
+  ODET_REQUIRE(first_chunk >= 0 && first_chunk <= NMS_CHUNK, "odet_frcnn_proposals: nms_first_chunk %d out of range (0..%d)",
+               first_chunk, NMS_CHUNK);
   ODET_REQUIRE(A > 0 && A <= ODET_MAX_ANCHORS_PER_CELL, "odet_frcnn_proposals: A %d out of range", A);
   ODET_REQUIRE(feat_stride > 0 && fh >= 0 && fw >= 0 && image_h > 0 && image_w > 0 && max_output > 0,
                "odet_frcnn_proposals: bad sizes");
   const int64_t total = (int64_t)fh * fw * A;
   ODET_REQUIRE(total < (1ll << 31), "odet_frcnn_proposals: too many anchors");
-  hipStream_t st = (hipStream_t)stream;
   const int n = (int)total;
-  if (n == 0) return nms_trivial(out_count, out_done, st);
   NmsJob J;
-  job_init(&J, PREP_FRCNN, n, max_output, iou_threshold, blind_chunks, 1);
+  job_init(&J, PREP_FRCNN, n, max_output, iou_threshold, blind_chunks, B);
+  J.first_chunk = first_chunk;
+  J.ws_clean = ws_clean ? 1 : 0;
   J.prep.fpn.A = A;
   J.prep.fpn.fw[0] = fw;
   J.prep.fpn.stride[0] = feat_stride;
   for (int i = 0; i < A * 4; ++i) J.prep.fpn.wh[i] = anchor_base[i];
-  NmsImage& im = J.img[0];
-  int rc = rp_carve(n, max_output, workspace, workspace_bytes, "odet_frcnn_proposals", &im, out_idx);
-  if (rc != ODET_OK) return rc;
-  im.logits = (const float2*)rpn_logits;
-  im.deltas = rpn_deltas;
   for (int k = 0; k < 4; ++k) { J.prep.means.v[k] = means[k]; J.prep.stds.v[k] = stds[k]; }
   J.prep.wmax = (float)(image_w - 1); J.prep.hmax = (float)(image_h - 1);
-  im.out_boxes = out_rois; im.out_count = out_count; im.out_done = out_done;
+  for (int i = 0; i < B; ++i) {
+    const FpnProposalIO& a = io[i];
+    ODET_REQUIRE(a.rpn_logits && a.rpn_deltas && a.out_rois && a.out_count, "odet_frcnn_proposals: null pointer");
+    ODET_REQUIRE(!a.out_order || max_output <= ODET_FUSED_ORDER_MAX_ROIS,
+                 "odet_frcnn_proposals: out_order needs max_output <= %d", ODET_FUSED_ORDER_MAX_ROIS);
+    if (n == 0) {
+      int rc0 = nms_trivial(a.out_count, a.out_done, st);
+      if (rc0 != ODET_OK) return rc0;
+      continue;
+    }
+    NmsImage& im = J.img[i];
+    int rc = rp_carve(n, max_output, a.workspace, a.workspace_bytes, "odet_frcnn_proposals", &im, a.out_idx);
+    if (rc != ODET_OK) return rc;
+    im.logits = (const float2*)a.rpn_logits;
+    im.deltas = a.rpn_deltas;
+    im.out_boxes = a.out_rois; im.out_count = a.out_count; im.out_done = a.out_done;
+    im.assign.order = a.out_order;             // (no level assignment: the order is taken over the kept RoIs themselves)
+  }
+  if (n == 0) return ODET_OK;
   return nms_run(J, st);
+}
+
+extern "C" int odet_frcnn_proposals(const float* rpn_logits, const float* rpn_deltas, const float* anchor_base, int A,
+                                    int feat_stride, int fh, int fw, int image_h, int image_w, const float* means,
+                                    const float* stds, int max_output, float iou_threshold, float* out_rois,
+                                    int32_t* out_idx, int32_t* out_count, int blind_chunks, int32_t* out_done,
+                                    void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(rpn_logits && rpn_deltas && out_rois && out_count, "odet_frcnn_proposals: null pointer");
+  FpnProposalIO io{rpn_logits, rpn_deltas, out_rois, out_idx, out_count, nullptr, nullptr, nullptr, nullptr, out_done,
+                   workspace, workspace_bytes, nullptr};
+  return odet_frcnn_proposals_batch(&io, 1, anchor_base, A, feat_stride, fh, fw, image_h, image_w, means, stds, max_output,
+                                    iou_threshold, blind_chunks, (hipStream_t)stream, 0, 0);
 }

@@ -343,6 +343,10 @@ int odet_fpn_proposals_batch(const FpnProposalIO* io, int B, int num_levels, int
                              const float* stds, int max_output, float iou_threshold, int min_level, int max_level,
                              int blind_chunks, hipStream_t st, int first_chunk = 0, int ws_clean = 0);
 
+int odet_frcnn_proposals_batch(const FpnProposalIO* io, int B, const float* anchor_base, int A, int feat_stride, int fh,
+                               int fw, int image_h, int image_w, const float* means, const float* stds, int max_output,
+                               float iou_threshold, int blind_chunks, hipStream_t st, int first_chunk = 0, int ws_clean = 0);
+
 struct RoiEvents { hipEvent_t start, stop; };   // optional: timestamps of the dispatch itself
 struct RoiImageIO {         // per-image arguments (order: nullable processing order, odet_roi_order)
   const odet_level_t* levels; const float* rois; const int32_t* roi_level; const int32_t* count_dev;

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..pipeline import FrcnnHotPath
+from ..pipeline import FrcnnHotPath, FrcnnStepBatch
 from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _conv, _conv_epi, \
     _conv_relu_pool, _fold_frozen_bn, _stack, rpn_pair_weights
 
@@ -59,11 +59,26 @@ class ResNetC4Detector(_NmsCompleteness, nn.Module):
         self._roi_chunk = int(roi_chunk)
 
     def prepare(self, device='cuda'):
+        """Moves the model to the GPU and allocates the hot path.  Up to 8 images go through the hot path in the SAME
+        kernel launches (FrcnnStepBatch: odet_fpn_step_t.single_level) and through the RoI head as one batch;
+        `batched=False` in the hot-path keywords selects one FrcnnHotPath per image on a stream of its own."""
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
         # float16 maps go straight into the RoI kernel (pooled 14x14 + max and un-pooled 7x7 crop alike)
         fd = torch.float16 if self.dtype == torch.float16 else torch.float32
         self._feature_dtype = fd
-        self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=fd, **self._hot_kwargs) for _ in range(self._max_batch)]
+        kw = dict(self._hot_kwargs)
+        self._steps = None
+        if self._max_batch <= 8 and kw.pop('batched', True):
+            self._steps = FrcnnStepBatch(self._max_batch, *self._hot_args, feature_dtype=fd, **kw)
+            self._hot = self._steps.slots
+            self._roi_feat_all = self._steps.roi_features
+            K = self._hot_args[2]
+            dev = self._hot[0].device
+            self._cls = torch.zeros((self._max_batch, K, self.num_classes), dtype=torch.float32, device=dev)
+            self._dlt = torch.zeros((self._max_batch, K, 4 * self.num_classes), dtype=torch.float32, device=dev)
+            self._bound = False
+            return self
+        self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=fd, **kw) for _ in range(self._max_batch)]
         # the images' RoI features are consecutive blocks of one buffer: the RoI head takes the whole batch at once
         h0 = self._hot[0]
         self._roi_feat_all = torch.zeros((self._max_batch,) + tuple(h0.roi_features.shape), dtype=fd, device=h0.device)
@@ -143,13 +158,27 @@ class ResNetC4Detector(_NmsCompleteness, nn.Module):
         maps = c4.permute(0, 2, 3, 1)                                            # NHWC view
         if maps.dtype != self._feature_dtype:
             maps = maps.to(self._feature_dtype)
+        maps = maps.contiguous()
+        K = self._roi_feat_all.shape[1]
+        if self._steps is not None:
+            # B images in the same hot-path launches, the RoI head on all B x K crops at once
+            sb = self._steps
+            bind = sb.rebind if self._bound else sb.bind
+            for b in range(B):
+                bind(b, rpn_scores[b], rpn_deltas[b], [maps[b:b + 1]], self._cls[b], self._dlt[b])
+            if B == self._max_batch:
+                self._bound = True
+            sb.enqueue(sb.STAGE_PROPOSALS | sb.STAGE_ROI, B)
+            feats = sb.roi_features[:B].reshape((B * K,) + tuple(sb.roi_features.shape[2:]))
+            logits, bbox = self.roi_head(feats)
+            torch.softmax(logits.float(), dim=-1, out=self._cls[:B].view(B * K, -1))
+            self._dlt[:B].view(B * K, -1).copy_(bbox)
+            return [(self._cls[b], self._dlt[b]) for b in range(B)]
         def proposals_and_crops(b):
             hot = self._hot[b]
             hot.stage_proposals(rpn_scores[b], rpn_deltas[b])
             hot.stage_roi(maps[b:b + 1])
-        maps = maps.contiguous()
         self._per_image(B, proposals_and_crops)
-        K = self._roi_feat_all.shape[1]
         feats = self._roi_feat_all[:B].reshape((B * K,) + tuple(self._roi_feat_all.shape[2:]))
         logits, bbox = self.roi_head(feats)                                      # one head pass for the whole batch
         cls = torch.softmax(logits.float(), dim=-1).reshape(B, K, -1).contiguous()
@@ -160,7 +189,12 @@ class ResNetC4Detector(_NmsCompleteness, nn.Module):
     def forward(self, images_nhwc, check=None):
         heads = self._run_to_head(images_nhwc)
         B = len(heads)
-        outs = self._per_image(B, lambda b: self._hot[b].stage_detect(heads[b][0], heads[b][1]))
+        if self._steps is not None:
+            sb = self._steps
+            sb.enqueue(sb.STAGE_DETECT, B)
+            outs = [(h.det_boxes, h.det_labels, h.det_scores, h.det_count) for h in sb.slots[:B]]
+        else:
+            outs = self._per_image(B, lambda b: self._hot[b].stage_detect(heads[b][0], heads[b][1]))
         self._after_pass(B, check)
         return outs
 

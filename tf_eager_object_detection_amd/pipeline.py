@@ -187,8 +187,10 @@ class FrcnnHotPath:
         self.blind_chunks = blind_chunks
         dev = self.device = device or torch.device('cuda', torch.cuda.current_device())
         K = self.K
-        self.ws_rpn = torch.empty(ops.L.lib().odet_frcnn_proposals_workspace_bytes(self.N, K), dtype=torch.uint8,
+        # zero-filled once and private to this object (odet_fpn_step_t.ws_rpn_clean)
+        self.ws_rpn = torch.zeros(ops.L.lib().odet_frcnn_proposals_workspace_bytes(self.N, K), dtype=torch.uint8,
                                   device=dev)
+        self.roi_order = torch.zeros(K, dtype=torch.int32, device=dev) if K <= ops.FUSED_ORDER_MAX_ROIS else None
         self.rois = torch.zeros((K, 4), dtype=torch.float32, device=dev)
         self.roi_idx = torch.zeros(K, dtype=torch.int32, device=dev)
         self.roi_count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -290,6 +292,61 @@ def _fill_step(st, h, stream_handle, rpn_logits, rpn_deltas, p_list, cls_softmax
     return tensors
 
 
+def _fill_frcnn_step(st, h, stream_handle, rpn_logits, rpn_deltas, feat, cls_softmax, cls_deltas):
+    """Fills the odet_fpn_step_t `st` as a SINGLE-LEVEL step (odet_fpn_step_t.single_level) of FrcnnHotPath slot `h`:
+    rpn_logits [fh*fw, 2A] ([A bg | A fg]), rpn_deltas [fh*fw*A, 4], feat NHWC [1, fh, fw, C] in the slot's feature
+    dtype.  Returns the tensors the caller must keep alive."""
+    if isinstance(feat, (list, tuple)):
+        feat = feat[0]
+    for t in (rpn_logits, rpn_deltas, cls_softmax, cls_deltas):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError('FrcnnStepBatch.bind needs float32 contiguous GPU tensors')
+    fdt = h.roi_features.dtype
+    if not (feat.is_cuda and feat.dtype == fdt and feat.is_contiguous()):
+        raise ValueError('FrcnnStepBatch.bind needs a %s contiguous GPU feature map' % fdt)
+    if feat.dim() != 4 or feat.shape[0] != 1 or feat.shape[1] != h.fh or feat.shape[2] != h.fw or feat.shape[3] != h.C:
+        raise ValueError('feature map must be NHWC [1,%d,%d,%d], got %s' % (h.fh, h.fw, h.C, tuple(feat.shape)))
+    if rpn_logits.numel() != h.N * 2 or rpn_deltas.numel() != h.N * 4:
+        raise ValueError('%d anchors expected, got rpn scores %s / deltas %s'
+                         % (h.N, tuple(rpn_logits.shape), tuple(rpn_deltas.shape)))
+    if cls_softmax.dim() != 2 or cls_softmax.shape[0] != h.K or cls_deltas.numel() != cls_softmax.numel() * 4:
+        raise ValueError('class scores must be [%d, Ccls] and deltas [%d, Ccls, 4]' % (h.K, h.K))
+    c = h.cfg
+    st.single_level = 1
+    st.roi_pool_mode = ops.ROI_POOL_MAX2 if h.max_pooling_flag else ops.ROI_POOL_NONE
+    st.image_h, st.image_w = h.image_shape
+    st.num_levels, st.A = 1, h.A
+    st.fh[0], st.fw[0], st.stride[0] = h.fh, h.fw, h.stride
+    flat = h.anchor_base.reshape(-1)
+    for i in range(flat.shape[0]):
+        st.wh[i] = float(flat[i])
+    for k in range(4):
+        st.rpn_means[k], st.rpn_stds[k] = float(c['rpn_means'][k]), float(c['rpn_stds'][k])
+        st.roi_means[k], st.roi_stds[k] = float(c['roi_means'][k]), float(c['roi_stds'][k])
+    st.num_proposals, st.rpn_nms_iou = h.K, float(c['rpn_nms_iou'])
+    st.min_level, st.max_level, st.blind_chunks = 0, 0, h.blind_chunks
+    st.nms_first_chunk = 0
+    st.num_maps, st.channels, st.pool_size = 1, h.C, h.P
+    st.maps_f16 = 1 if fdt == torch.float16 else 0
+    st.maps[0].data, st.maps[0].H, st.maps[0].W, st.maps[0].stride = feat.data_ptr(), h.fh, h.fw, float(h.stride)
+    st.ccls, st.num_classes = cls_softmax.shape[1], h.num_classes
+    st.max_per_class, st.max_per_image = c['max_per_class'], c['max_per_image']
+    st.nms_iou, st.score_threshold, st.min_edge = float(c['nms_iou']), float(c['score_threshold']), float(h.stride)
+    st.rpn_logits, st.rpn_deltas = rpn_logits.data_ptr(), rpn_deltas.data_ptr()
+    st.cls_scores, st.cls_deltas = cls_softmax.data_ptr(), cls_deltas.data_ptr()
+    st.rois, st.roi_idx, st.roi_count = h.rois.data_ptr(), h.roi_idx.data_ptr(), h.roi_count.data_ptr()
+    st.nms_done, st.sorted_rois = h.nms_done.data_ptr(), h.rois.data_ptr()       # (no level sort: the same list)
+    st.roi_level, st.roi_perm, st.level_counts = None, None, None
+    st.roi_features = h.roi_features.data_ptr()
+    st.roi_order = h.roi_order.data_ptr() if h.roi_order is not None else None
+    st.det_boxes, st.det_labels = h.det_boxes.data_ptr(), h.det_labels.data_ptr()
+    st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
+    st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
+    st.ws_rpn_clean = 1
+    st.ws_post, st.ws_post_bytes = h.ws_post.data_ptr(), h.ws_post.numel()
+    st.stream = stream_handle
+    return [rpn_logits, rpn_deltas, cls_softmax, cls_deltas, feat]
+
 
 class FpnStepBatch:
     """Up to 8 images through the FPN hot path in the SAME kernel launches (odet_fpn_step_enqueue_batch) on the
@@ -302,13 +359,14 @@ class FpnStepBatch:
         sb.enqueue(STAGE_PROPOSALS | STAGE_ROI, B);  head on sb.roi_features[:B];  sb.enqueue(STAGE_DETECT, B)"""
 
     STAGE_PROPOSALS, STAGE_ROI, STAGE_DETECT = 1, 2, 4
+    _slot_class, _fill = FpnHotPath, staticmethod(_fill_step)
 
     def __init__(self, max_batch, image_shape, num_classes=21, num_proposals=1000, channels=256, **kw):
         import ctypes as C
         if not 1 <= int(max_batch) <= 8:
             raise ValueError('max_batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
         self.n = int(max_batch)
-        self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
+        self.slots = [self._slot_class(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
         h0 = self.slots[0]
         self.roi_features = torch.zeros((self.n,) + tuple(h0.roi_features.shape), dtype=h0.roi_features.dtype,
                                         device=h0.device)
@@ -320,7 +378,7 @@ class FpnStepBatch:
         self._lib = ops.L.lib()
 
     def bind(self, b, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
-        self._keep[b] = _fill_step(self.steps[b], self.slots[b], 0, rpn_logits, rpn_deltas, p_list, cls_softmax,
+        self._keep[b] = self._fill(self.steps[b], self.slots[b], 0, rpn_logits, rpn_deltas, p_list, cls_softmax,
                                    cls_deltas)
 
     def rebind(self, b, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
@@ -329,6 +387,8 @@ class FpnStepBatch:
         st = self.steps[b]
         st.rpn_logits, st.rpn_deltas = rpn_logits.data_ptr(), rpn_deltas.data_ptr()
         st.cls_scores, st.cls_deltas = cls_softmax.data_ptr(), cls_deltas.data_ptr()
+        if not isinstance(p_list, (list, tuple)):
+            p_list = [p_list]
         for l in range(st.num_maps):
             st.maps[l].data = p_list[l].data_ptr()
         self._keep[b] = (rpn_logits, rpn_deltas, cls_softmax, cls_deltas) + tuple(p_list[:st.num_maps])
@@ -340,6 +400,18 @@ class FpnStepBatch:
         for st in self.steps[:count]:
             st.stream = handle
         ops.L.check(self._lib.odet_fpn_step_enqueue_batch(self._arr, count, int(stages)))
+
+
+class FrcnnStepBatch(FpnStepBatch):
+    """FpnStepBatch for the single-level Faster R-CNN hot path (BASELINE configs 1-2: VGG16 / ResNet-C4): up to 8
+    images through odet_frcnn_proposals -> RoI crops -> post-ops in the SAME launches (odet_fpn_step_t.single_level).
+
+        sb = FrcnnStepBatch(4, image_shape, num_classes, 300, 1024, max_pooling_flag=False)
+        sb.bind(b, rpn_logits[b], rpn_deltas[b], feat_nhwc[b:b+1], cls_softmax[b], cls_deltas[b])"""
+    _slot_class, _fill = FrcnnHotPath, staticmethod(_fill_frcnn_step)
+
+    def __init__(self, max_batch, image_shape, num_classes=21, num_proposals=300, channels=1024, **kw):
+        super().__init__(max_batch, image_shape, num_classes, num_proposals, channels, **kw)
 
 
 class FpnStreamPool:
@@ -359,6 +431,8 @@ class FpnStreamPool:
     the same stream from Python (a torch op) has to be issued after wait().  A model that runs a dense
     RoI head between the stages uses FpnHotPath directly."""
 
+    _slot_class, _fill = FpnHotPath, staticmethod(_fill_step)
+
     def __init__(self, n_streams, image_shape, num_classes=21, num_proposals=1000, channels=256, batch=1, **kw):
         import ctypes as C
         self.n_streams = int(n_streams)
@@ -366,7 +440,7 @@ class FpnStreamPool:
         if not 1 <= self.batch <= 8:
             raise ValueError('batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
         self.n = self.n_streams * self.batch            # slots; slot k belongs to group k // batch
-        self.slots = [FpnHotPath(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
+        self.slots = [self._slot_class(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
         # Batched groups need ~1.4 launches per image, far below one thread's launch rate, and ONE enqueue thread
         # issuing the groups in turn measured 3-4 % faster than one thread per stream (less contention inside the
         # HIP runtime); single-image launches (batch < 4) keep a thread per stream for the launch rate.
@@ -390,7 +464,7 @@ class FpnStreamPool:
 
     def bind(self, slot, rpn_logits, rpn_deltas, p_list, cls_softmax, cls_deltas):
         """Points slot `slot` at one image's inputs (float32 contiguous GPU tensors, kept alive here)."""
-        self._keep[slot] = _fill_step(self.steps[slot], self.slots[slot], self.streams[slot].cuda_stream, rpn_logits,
+        self._keep[slot] = self._fill(self.steps[slot], self.slots[slot], self.streams[slot].cuda_stream, rpn_logits,
                                       rpn_deltas, p_list, cls_softmax, cls_deltas)
 
     def submit(self, slot=None, stages=7):
@@ -429,6 +503,30 @@ class FpnStreamPool:
             self.close()
         except Exception:
             pass
+
+
+class FrcnnStreamPool(FpnStreamPool):
+    """FpnStreamPool for the single-level Faster R-CNN hot path: stream groups of `batch` images that share their
+    launches, fed by the native executor -- configs 1-2 shard over GPUs exactly like the FPN path (parallel.py)."""
+    _slot_class, _fill = FrcnnHotPath, staticmethod(_fill_frcnn_step)
+
+    def __init__(self, n_streams, image_shape, num_classes=21, num_proposals=300, channels=1024, batch=1, **kw):
+        super().__init__(n_streams, image_shape, num_classes, num_proposals, channels, batch=batch, **kw)
+
+
+def synthetic_frcnn_inputs(image_shape, num_classes=21, num_proposals=300, channels=1024, stride=16, A=9, seed=1234,
+                           device='cuda'):
+    """Seeded synthetic inputs of one image for the single-level hot path (SURVEY 8d recipe), numpy + GPU tensors."""
+    import math
+    rng = np.random.default_rng(seed)
+    fh, fw = int(math.ceil(image_shape[0] / stride)), int(math.ceil(image_shape[1] / stride))
+    n = fh * fw * A
+    host = dict(feat=rng.standard_normal((1, fh, fw, channels), dtype=np.float32),
+                rpn_logits=rng.normal(0, 2.0, (fh * fw, 2 * A)).astype(np.float32), rpn_deltas=syn.rpn_deltas(n, rng, 0.1),
+                cls_scores=syn.class_scores(num_proposals, num_classes, rng),
+                cls_deltas=syn.class_deltas(num_proposals, num_classes, rng))
+    dev = {k: torch.from_numpy(v).to(device) for k, v in host.items()}
+    return host, dev
 
 
 def synthetic_fpn_inputs(image_shape, num_classes=21, num_proposals=1000, channels=256, seed=1234,
