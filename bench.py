@@ -292,7 +292,7 @@ def main():
         pool.bind(k, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
     hot = pool.slots[0]
     gstreams = pool._group_streams
-    exchange = parallel.GroupExchange(S, B, rec_len, 'cuda') if use_dist else None
+    exchange = parallel.GroupExchange(S, B, rec_len, 'cuda', force_collective=True) if use_dist else None
 
     def drain():
         pool.wait()

@@ -75,9 +75,11 @@ class GroupExchange:
     A group with fewer than B valid images (ragged tail of a finite image list) passes ``valid``: the records of the
     missing images are sent as empty records (count 0, scores -1), so every rank still contributes B records."""
 
-    def __init__(self, n_groups, batch, rec_len, device, group=None):
+    def __init__(self, n_groups, batch, rec_len, device, group=None, force_collective=False):
         self.S, self.B, self.rec_len = int(n_groups), int(batch), int(rec_len)
         self.group = group
+        # (a one-rank process group still issues the collective: rehearsal of the RCCL call path on a 1-GPU box)
+        self.force_collective = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         dev = torch.device(device)
         self.cuda = dev.type == 'cuda'
@@ -111,7 +113,7 @@ class GroupExchange:
             self._stage(g, records, valid)
             copied = torch.cuda.Event()
             copied.record(self.comm)
-            if self.world == 1:
+            if self.world == 1 and not self.force_collective:
                 self.gathered[g, 0].copy_(self.staging[g])
             elif dist.get_backend(self.group) == 'gloo':
                 # rehearsal of the multi-rank path on a box with fewer GPUs than ranks: gloo moves host memory
