@@ -60,6 +60,7 @@ def _fold_frozen_bn(conv):
 #   'gemm' hipBLASLt GEMM with bias (+ ReLU) in its own epilogue (no shortcut)
 #   'mfma' ops.conv1x1_f16: the hand-written MFMA kernel with bias + shortcut + ReLU fused (float16, cin <= 256)
 _GEMM_ROUTE = {}
+_ROUTE_MODE = __import__('os').environ.get('ODET_ROUTE_1X1', 'table')
 
 
 def _gemm_1x1(conv, x, bias, relu):
@@ -95,21 +96,43 @@ def _time_route(fn, reps=5):
 
 
 def _route_1x1(conv, x, bias, relu, res):
-    """'conv', 'gemm' or 'mfma' for this layer shape; measured at the first call outside a stream capture."""
-    key = (tuple(x.shape), conv.out_channels, x.dtype, bool(relu), res is not None)
-    r = _GEMM_ROUTE.get(key)
-    if r is None:
-        if torch.cuda.is_current_stream_capturing():
-            return 'conv'
-        cand = {'conv': lambda: _conv_1x1(conv, x, bias, relu, res)}
-        if res is None:
-            cand['gemm'] = lambda: _gemm_1x1(conv, x, bias, relu)
-        if x.dtype == torch.float16 and conv.in_channels in (64, 128, 256, 512) and conv.out_channels % 64 == 0:
-            cand['mfma'] = lambda: _mfma_1x1(conv, x, bias, relu, res)
-        times = {k: _time_route(f) for k, f in cand.items()}
-        r = min(times, key=times.get)
-        _GEMM_ROUTE[key] = r
-    return r
+    """'conv', 'gemm' or 'mfma' for this layer shape.  Deterministic (the routes differ in rounding: the MFMA kernel
+    adds shortcut + W.x + bias with one rounding): the table below is what timing the three routes chose on MI355X for
+    every 1x1 layer shape of the three detectors (tools/exp/conv1x1_routes.py) -- float16 layers with a shortcut and
+    the small-K layers without one go to the hand-written MFMA kernel, layers without a shortcut otherwise to the GEMM
+    with its own epilogue, the rest to the library convolution + epilogue pass.  ODET_ROUTE_1X1=measure re-times the
+    routes at first use (per device and shape), ODET_ROUTE_1X1=conv|gemm|mfma forces one where it applies."""
+    mfma_ok = x.dtype == torch.float16 and conv.in_channels in (64, 128, 256, 512) and conv.out_channels % 64 == 0
+    mode = _ROUTE_MODE
+    if mode == 'measure':
+        key = (x.device.index, tuple(x.shape), conv.out_channels, x.dtype, bool(relu), res is not None)
+        r = _GEMM_ROUTE.get(key)
+        if r is None:
+            if torch.cuda.is_current_stream_capturing():
+                mode = 'table'
+            else:
+                cand = {'conv': lambda: _conv_1x1(conv, x, bias, relu, res)}
+                if res is None:
+                    cand['gemm'] = lambda: _gemm_1x1(conv, x, bias, relu)
+                if mfma_ok:
+                    cand['mfma'] = lambda: _mfma_1x1(conv, x, bias, relu, res)
+                times = {k: _time_route(f) for k, f in cand.items()}
+                r = min(times, key=times.get)
+                _GEMM_ROUTE[key] = r
+                return r
+        else:
+            return r
+    if mode == 'mfma' and mfma_ok:
+        return 'mfma'
+    if mode == 'gemm' and res is None:
+        return 'gemm'
+    if mode == 'conv':
+        return 'conv'
+    if mfma_ok and (res is not None or conv.in_channels <= 256 and conv.out_channels <= 64):
+        return 'mfma'
+    if res is None:
+        return 'gemm'
+    return 'conv'
 
 
 def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=None):

@@ -82,7 +82,8 @@ class FpnHotPath:
     # calls; later calls replay them (a few microseconds of host time per stage instead of ~50).
     def _run(self, stage, inputs, fn):
         ok = all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in inputs)
-        key = (stage, torch.cuda.current_stream().cuda_stream) + tuple(t.data_ptr() for t in inputs)
+        # (address AND shape: a differently shaped tensor at a recycled address must not replay stale sizes)
+        key = (stage, torch.cuda.current_stream().cuda_stream) + tuple((t.data_ptr(), tuple(t.shape)) for t in inputs)
         plan = self._plans.get(key) if ok else None
         if plan is not None:
             for f, a in plan[0]:
@@ -93,9 +94,13 @@ class FpnHotPath:
         with ops.L.recording() as calls:
             out = fn()
         if ok:
-            if len(self._plans) > 64:
-                self._plans.clear()
-            self._plans[key] = (calls, out, inputs)      # inputs kept alive with the plan
+            # a plan keeps its inputs alive (their addresses must stay theirs while it can be replayed): only a few per
+            # stage, so a caller that feeds fresh tensors every pass does not pin them all
+            mine = [k for k in self._plans if k[0] == stage]
+            if len(mine) >= 4:
+                for k in mine:
+                    del self._plans[k]
+            self._plans[key] = (calls, out, inputs)
         return out
 
     # ---- stage 1: RPN outputs -> level-sorted proposals -------------------------------------
@@ -473,8 +478,9 @@ class FpnStreamPool:
         if slot is None:
             slot = self._rr
             self._rr = (self._rr + 1) % self.n
-        ops.L.check(self._lib.odet_exec_submit(self._exec, slot // self.batch, self._C.byref(self.steps[slot]),
-                                               int(stages)))
+        # (one enqueue thread per stream group -- or the single one: a group's launches always come from one thread)
+        worker = 0 if self._single_worker else slot // self.batch
+        ops.L.check(self._lib.odet_exec_submit(self._exec, worker, self._C.byref(self.steps[slot]), int(stages)))
         return slot
 
     def submit_group(self, group=None, stages=7):
