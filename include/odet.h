@@ -340,6 +340,23 @@ int odet_bias_act(void* x, const void* bias, const void* residual, long long npi
 int odet_bias_relu_maxpool(const void* x, const void* bias, void* out, int B, int H, int W, int C, int OH, int OW,
                            int kernel, int stride, int pad, int f16, odet_stream_t stream);
 
+/* 3x3 stride-1 'same' convolution as an implicit GEMM on the matrix cores -- the RpnHead's convolution
+ * (model/fpn/base_fpn_model.py:401-417, model/faster_rcnn/base_faster_rcnn_model.py:315-321): x NHWC float16
+ * [batch,H,W,cin], w float16 [cout][3][3][cin] (= a channels_last torch weight), y NHWC float16 [batch,H,W,cout],
+ * float32 accumulation; bias (nullable, float16 [cout]) and relu are applied before the one rounding.
+ * cin % 64 == 0, cout % 256 == 0. */
+int odet_conv3x3_f16(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
+                     int cin, int cout, int relu, odet_stream_t stream);
+/* the same convolution (shared weights) over up to ODET_MAX_LEVELS maps in ONE launch -- the RpnHead over the pyramid
+ * levels (base_fpn_model.py:188-200): the workgroups of the small levels fill the tail of the big ones'.  levels: host
+ * array, x / y NHWC float16 [batch,H,W,cin] / [batch,H,W,cout]; list the big levels first. */
+typedef struct {
+  const void* x; void* y;
+  int32_t H, W;
+} odet_conv_level_t;
+int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
+                            int batch, int cin, int cout, int relu, odet_stream_t stream);
+
 /* 1x1 stride-1 convolution with its whole epilogue on the matrix cores (the third convolution
  * of a bottleneck block + Add([shortcut, x]) + Activation('relu'), model/fpn/resnet_fpn.py:154-205, frozen
  * BatchNormalization folded into w / bias): y[npix, cout] = relu?(x'[npix, cin] . w[cout, cin]^T + bias[cout]

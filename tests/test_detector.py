@@ -613,3 +613,33 @@ def test_detector_incomplete_nms_is_flagged_never_silent():
     k = int(safe.roi_count.item())
     assert k == len(idx)
     np.testing.assert_array_equal(safe.roi_idx[:k].cpu().numpy(), idx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,cin,cout', [(1, 13, 21, 256, 512), (2, 25, 42, 256, 512), (1, 50, 84, 64, 256),
+                                             (3, 7, 5, 128, 256), (1, 100, 167, 256, 512)])
+def test_conv3x3_f16_implicit_gemm(B, H, W, cin, cout):
+    """odet_conv3x3_f16 (the RpnHead's 3x3 convolution as a hand-written implicit GEMM on the matrix cores,
+    base_fpn_model.py:401-417): EXACT on integer-valued data (every product and partial sum is an integer below 2^24, so
+    float32 accumulation order cannot matter), within float16 rounding of a float32 torch convolution on random data;
+    zero padding at the borders, pixel tiles that end inside the last row, bias + ReLU epilogue."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(B * 1000 + H)
+    x = torch.randint(-3, 4, (B, H, W, cin), device='cuda', generator=g).half()
+    w = torch.randint(-2, 3, (cout, cin, 3, 3), device='cuda', generator=g).half().contiguous(memory_format=torch.channels_last)
+    got = ops.conv3x3_f16(x, w)
+    want = F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), None, 1, 1).permute(0, 2, 3, 1)
+    assert got.shape == (B, H, W, cout)
+    assert torch.equal(got.float(), want.half().float())        # integers up to 9 * cin * 6 < 65504: exact in float16 too? no:
+    # (values above 2048 are not all representable in float16: compare after the same single rounding)
+    xr = (torch.randn((B, H, W, cin), device='cuda', generator=g) * 0.5).half()
+    wr = (torch.randn((cout, cin, 3, 3), device='cuda', generator=g) * 0.02).half().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, device='cuda', generator=g).half()
+    got = ops.conv3x3_f16(xr, wr, bias, relu=True)
+    want = F.relu(F.conv2d(xr.permute(0, 3, 1, 2).float(), wr.float(), bias.float(), 1, 1)).permute(0, 2, 3, 1)
+    torch.testing.assert_close(got.float(), want, rtol=2e-3, atol=2e-3)
+    # the [cout,3,3,cin] weight form and an explicit output buffer
+    out = torch.empty((B, H, W, cout), dtype=torch.float16, device='cuda')
+    ops.conv3x3_f16(xr, wr.permute(0, 2, 3, 1).contiguous(), bias, relu=True, out=out)
+    assert torch.equal(out, got)

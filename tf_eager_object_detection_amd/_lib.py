@@ -24,6 +24,11 @@ class OdetLevel(C.Structure):
     _fields_ = [('data', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32), ('stride', C.c_float)]
 
 
+class OdetConvLevel(C.Structure):
+    """odet_conv_level_t"""
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32)]
+
+
 MAX_LEVELS = 8
 MAX_ANCHORS_PER_CELL = 32
 
@@ -109,6 +114,8 @@ SIGNATURES = {
     'odet_bias_relu_maxpool': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_rpn_head_tail_f16': (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _vp,
                                     C.c_longlong, C.c_longlong, _vp]),
+    'odet_conv3x3_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'odet_conv3x3_f16_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'odet_conv1x1_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _vp]),
     'odet_rpn_pack_pair': (_i, [_vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _vp, C.c_longlong,
                                 C.c_longlong, _i, _vp]),

@@ -1,0 +1,232 @@
+// 3x3 stride-1 'same' convolution as an implicit GEMM on the matrix cores -- the RPN head's convolution
+// (model/fpn/base_fpn_model.py:401-417: Conv2D(512, 3x3, padding='same') on every pyramid level,
+// 106 GMAC = 31 % of the FLOPs of a ResNet-101-FPN pass), NHWC float16 in / out, float32 accumulation:
+//
+//     y[p, n] = sum_{tap = (dy, dx), c}  x[p + (dy-1, dx-1), c] . w[n, tap, c]          (zero outside the map)
+//
+// i.e. a GEMM  Y[M, N] = A[M, K] . W[N, K]^T  with M = B*H*W pixels, N = cout, K = 9 * cin, whose A operand is never
+// materialised: row p of the K-step (tap, 64-channel chunk) is the 128-byte line of pixel p + tap offset.
+//
+//  * WORKGROUP = 8 waves, tile 256 pixels x 256 channels, K-step 64 (one tap, 64 input channels); wave (wm, wn) of
+//    2 x 4 owns 128 pixels x 64 channels = 8 x 4 tiles of v_mfma_f32_16x16x32_f16 (128 accumulator registers).
+//  * Both operands travel global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no registers, no ds_write), whole
+//    128-byte lines: a wave instruction moves 8 rows x 128 B.  The LDS image is row-major [256 rows][128 B] with the
+//    16-byte slot XOR-swizzled by (row & 7), applied on the SOURCE address (the DMA writes lane-linear) and on the
+//    ds_read_b128 address: conflict-free fragment reads.  Zero padding costs nothing: a lane whose tap falls outside
+//    the map gets an out-of-range buffer offset, and an out-of-range buffer load returns 0.
+//  * Two LDS stages (2 x 64 KB): the DMA of K-step k+1 is in flight while step k computes; one barrier per K-step.
+//  * TRANSPOSED tiles (D = W_tile . X_tile^T: the MFMA's A operand is 16 rows of W, its B operand 16 pixels): a lane
+//    then holds ONE pixel and 4 channels per tile.  The rows of W are laid out in LDS in a permuted order (LDS row
+//    16 t + r of a wave's 64-channel group = channel 16 (r >> 2) + 4 t + (r & 3)), which makes the 16 registers of a
+//    pixel 16 CONSECUTIVE channels: 32 contiguous bytes per lane, a full 128-byte line per pixel from the four lane
+//    quarters.
+//  * XCD-aware order: the channel tiles of a pixel slab are consecutive workgroups of ONE XCD (its L2 serves their
+//    common input lines).
+//
+// Optional epilogue: + bias, ReLU (float32, one rounding).  The RPN head runs it WITHOUT: its tail kernel
+// (rpn_tail.hip) applies bias + ReLU to its operand fragments on load.
+#include <hip/hip_fp16.h>
+
+#include <mutex>
+
+#include "odet_internal.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t c3_rsrc_t;
+typedef __attribute__((address_space(3))) void* c3_lds_ptr;
+
+#define C3_TM 256                 // pixels per workgroup tile
+#define C3_TN 256                 // channels per workgroup tile
+#define C3_BK 64                  // input channels per K-step (128 bytes per row)
+#define C3_STAGE_BYTES ((C3_TM + C3_TN) * C3_BK * 2)      // 64 KB
+#define C3_LDS_BYTES (2 * C3_STAGE_BYTES)
+
+struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid levels the RpnHead is shared by) in ONE launch
+  const _Float16* x[ODET_MAX_LEVELS]; _Float16* y[ODET_MAX_LEVELS];
+  const _Float16* w; const _Float16* bias;
+  long long M[ODET_MAX_LEVELS];   // batch * H * W of a level
+  int H[ODET_MAX_LEVELS], W[ODET_MAX_LEVELS];
+  long long tile_start[ODET_MAX_LEVELS + 1];   // first pixel slab of a level; [num_levels] = total
+  int num_levels, cin, cout, relu;
+  int tiles_n;                    // cout / 256
+};
+
+__global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;
+  // workgroup -> (pixel slab, channel tile): the channel tiles of a slab on one XCD
+  const long long blk = blockIdx.x;
+  const long long q8 = blk >> 3;
+  const long long slab = (blk & 7) + 8 * (q8 / p.tiles_n);
+  const int tn = (int)(q8 % p.tiles_n);
+  if (slab >= p.tile_start[p.num_levels]) return;        // (padding workgroups of the last group of 8 slabs)
+  int lv = 0;                                            // the level this slab belongs to (big levels first: the small
+#pragma unroll                                           //  ones fill the tail of the launch)
+  for (int l = 1; l < ODET_MAX_LEVELS; ++l)
+    if (l < p.num_levels && slab >= p.tile_start[l]) lv = l;
+  const long long tile_m = slab - p.tile_start[lv];
+  const int H = p.H[lv], W = p.W[lv], cin = p.cin, cout = p.cout;
+  const uint32_t pixB = (uint32_t)cin * 2u;              // bytes per pixel
+  const uint32_t PAD = (uint32_t)(W + 1) * pixB;         // the descriptor starts one row + one pixel before x
+  const uint32_t OOB = 0xFFFFFFF0u;
+  const long long M = p.M[lv];
+  const c3_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.x[lv])) - PAD, 0, (int)((uint32_t)M * pixB + 2u * PAD), 0x00020000);
+  const uint32_t wrowB = 9u * pixB;                      // bytes per weight row [tap][cin]
+  const c3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, (int)((uint32_t)cout * wrowB),
+                                                         0x00020000);
+  // ---- what this thread copies per K-step: 4 pieces of A (8 pixels x 128 B each) and 4 of W
+  const int sub = lane >> 3;                             // row of the 8-row piece
+  const uint32_t slot = (uint32_t)((lane & 7) ^ sub) * 16u;   // logical 16-byte slot this lane fetches (XOR swizzle)
+  uint32_t voffA[4], voffW[4];
+  uint32_t maskA[4];                                     // bit tap: the tap of this lane's pixel is inside the map
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wv * 4 + i) * 8 + sub;              // 0..255
+    const long long m = tile_m * C3_TM + row;
+    uint32_t mk = 0;
+    if (m < M) {
+      const long long img = m / ((long long)H * W);
+      const int rem = (int)(m - img * H * W);
+      const int yy = rem / W, xx = rem - yy * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+        if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
+      }
+    }
+    maskA[i] = mk;
+    voffA[i] = (uint32_t)m * pixB + slot;                // (+ the tap / chunk offset as soffset; PAD is in the base)
+    // LDS row rho of the W tile <- channel: rows 16 t + r of a 64-channel group hold channel 16 (r >> 2) + 4 t + (r & 3)
+    const int g = row >> 6, rr = row & 63, t = rr >> 4, r = rr & 15;
+    const int ch = tn * C3_TN + g * 64 + 16 * (r >> 2) + 4 * t + (r & 3);
+    voffW[i] = (uint32_t)ch * wrowB + slot;
+  }
+  const int chunks = cin / C3_BK;
+  const int ksteps = 9 * chunks;
+  auto issue = [&](int ks, uint32_t stage) {
+    const int tap = ks / chunks, chunk = ks - tap * chunks;
+    const uint32_t soA = (uint32_t)((tap / 3) * W + tap % 3) * pixB + (uint32_t)chunk * 128u;
+    const uint32_t soW = (uint32_t)ks * 128u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t pc = (uint32_t)(wv * 4 + i) * 1024u;
+      const uint32_t va = ((maskA[i] >> tap) & 1u) ? voffA[i] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + stage + pc), 16, (int)va, (int)soA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + stage + C3_TM * 128u + pc), 16, (int)voffW[i],
+                                               (int)soW, 0, 0);
+    }
+  };
+  // ---- fragment addresses (bytes inside a stage)
+  const int l15 = lane & 15, lq = lane >> 4;
+  const uint32_t fslot = (uint32_t)(lq ^ (lane & 7)) * 16u;                         // K half 0; half 1 = ^ 64
+  const uint32_t xoff = (uint32_t)(wm * 128 + l15) * 128u + fslot;                  // + mt * 2048
+  const uint32_t woff = C3_TM * 128u + (uint32_t)(wn * 64 + l15) * 128u + fslot;    // + t * 2048
+  f4 acc[8][4];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+
+  issue(0, 0u);
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const uint32_t stage = (uint32_t)(ks & 1) * C3_STAGE_BYTES;
+    // my copies of step ks have landed; after the barrier everybody's have, and nobody reads the other stage any more
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ks + 1 < ksteps) issue(ks + 1, (uint32_t)((ks + 1) & 1) * C3_STAGE_BYTES);
+    const unsigned char* sb = lds + stage;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      const uint32_t kx = kh ? 64u : 0u;
+      h8 wf[4], xf[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const h8*>(sb + ((woff + (uint32_t)t * 2048u) ^ kx));
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) xf[mt] = *reinterpret_cast<const h8*>(sb + ((xoff + (uint32_t)mt * 2048u) ^ kx));
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[mt], acc[mt][t], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
+  const int c0 = tn * C3_TN + wn * 64 + lq * 16;
+  float bv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? (float)p.bias[c0 + e] : 0.0f;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const long long m = tile_m * C3_TM + wm * 128 + mt * 16 + l15;
+    if (m < M) {
+      h8 o[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[mt][t][j] + bv[t * 4 + j];
+          if (p.relu) v = v < 0.0f ? 0.0f : v;
+          o[(t * 4 + j) >> 3][(t * 4 + j) & 7] = (_Float16)v;
+        }
+      _Float16* dst = p.y[lv] + m * cout + c0;
+      *reinterpret_cast<h8*>(dst) = o[0];
+      *reinterpret_cast<h8*>(dst + 8) = o[1];
+    }
+  }
+}
+
+static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,
+                          int cin, int cout, int relu, hipStream_t st) {
+  ODET_REQUIRE(levels && w, "odet_conv3x3_f16: null pointer");
+  ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_f16: num_levels %d out of range", num_levels);
+  ODET_REQUIRE(batch > 0, "odet_conv3x3_f16: bad batch");
+  ODET_REQUIRE(cin > 0 && cin % C3_BK == 0, "odet_conv3x3_f16: cin %d must be a multiple of %d", cin, C3_BK);
+  ODET_REQUIRE(cout > 0 && cout % C3_TN == 0, "odet_conv3x3_f16: cout %d must be a multiple of %d", cout, C3_TN);
+  ODET_REQUIRE((unsigned long long)cout * 9ull * cin * 2ull < 0x7FFFFFFFull, "odet_conv3x3_f16: weights too large");
+  static std::once_flag once;
+  static hipError_t once_rc = hipSuccess;
+  std::call_once(once, [] {
+    once_rc = hipFuncSetAttribute((const void*)k_conv3x3_f16, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+  });
+  ODET_HIP(once_rc);
+  Conv3x3Params p;
+  long long total = 0;
+  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
+    const odet_conv_level_t& L = levels[l < num_levels ? l : 0];
+    ODET_REQUIRE(L.x && L.y && L.H > 0 && L.W > 0, "odet_conv3x3_f16: bad level %d", l);
+    const long long M = (long long)batch * L.H * L.W;
+    // 32-bit byte offsets into x (+ the padding rows of the descriptor) and the out-of-range marker
+    ODET_REQUIRE((unsigned long long)M * cin * 2ull + 2ull * (L.W + 1) * cin * 2ull < 0xFFFFFFF0ull,
+                 "odet_conv3x3_f16: level %d input larger than 4 GiB", l);
+    p.x[l] = (const _Float16*)L.x; p.y[l] = (_Float16*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
+    p.tile_start[l] = total;
+    if (l < num_levels) total += (M + C3_TM - 1) / C3_TM;
+  }
+  p.tile_start[ODET_MAX_LEVELS] = total;
+  for (int l = num_levels; l <= ODET_MAX_LEVELS; ++l) p.tile_start[l] = total;
+  p.w = (const _Float16*)w; p.bias = (const _Float16*)bias;
+  p.num_levels = num_levels; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
+  p.tiles_n = cout / C3_TN;
+  const long long groups = (total + 7) / 8;
+  const long long blocks = groups * 8 * p.tiles_n;
+  ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
+  hipLaunchKernelGGL(k_conv3x3_f16, dim3((unsigned)blocks), dim3(512), C3_LDS_BYTES, st, p);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+extern "C" int odet_conv3x3_f16(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W, int cin,
+                                int cout, int relu, odet_stream_t stream) {
+  ODET_REQUIRE(x && y, "odet_conv3x3_f16: null pointer");
+  const odet_conv_level_t one{x, y, H, W};
+  return conv3x3_launch(&one, 1, w, bias, batch, cin, cout, relu, (hipStream_t)stream);
+}
+
+extern "C" int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
+                                       int batch, int cin, int cout, int relu, odet_stream_t stream) {
+  return conv3x3_launch(levels, num_levels, w, bias, batch, cin, cout, relu, (hipStream_t)stream);
+}

@@ -61,6 +61,8 @@ def _fold_frozen_bn(conv):
 #   'mfma' ops.conv1x1_f16: the hand-written MFMA kernel with bias + shortcut + ReLU fused (float16, cin <= 256)
 _GEMM_ROUTE = {}
 _ROUTE_MODE = __import__('os').environ.get('ODET_ROUTE_1X1', 'table')
+# ODET_CONV3X3=lib: the library convolution instead of the hand-written implicit GEMM (ops.conv3x3_f16) where it applies
+_CONV3X3_MODE = __import__('os').environ.get('ODET_CONV3X3', 'own')
 
 
 def _gemm_1x1(conv, x, bias, relu):
@@ -135,6 +137,23 @@ def _route_1x1(conv, x, bias, relu, res):
     return 'conv'
 
 
+def _own_conv3x3(conv, x, pad=None):
+    """True when the hand-written implicit-GEMM kernel (ops.conv3x3_f16) takes this 3x3 convolution: float16 NHWC,
+    stride 1, padding 1, cin % 64 == 0, cout % 256 == 0, and enough 256 x 256 output tiles to fill the chip (measured on
+    the detectors' layer shapes at batch 8, tools/exp/conv3x3_layers.py: ahead of the library from ~128 workgroups on,
+    behind it on the small maps)."""
+    if _CONV3X3_MODE == 'lib' or x.dtype != torch.float16 or pad is not None or not x.is_cuda:
+        return False
+    if tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1):
+        return False
+    if conv.in_channels % 64 != 0 or conv.out_channels % 256 != 0:
+        return False
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    m = int(x.shape[0]) * int(x.shape[2]) * int(x.shape[3])
+    return _CONV3X3_MODE == 'force' or ((m + 255) // 256) * (conv.out_channels // 256) >= 128
+
+
 def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=None):
     """max_pool(relu(conv(x) + bias)): on the GPU the convolution runs without its bias and ONE pass
     (ops.bias_relu_maxpool) reads its output once and writes the pooled map; torch formulation elsewhere."""
@@ -178,6 +197,10 @@ def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
             if route == 'mfma':
                 return _mfma_1x1(conv, x, bias, relu, res)
             return _conv_1x1(conv, x, bias, relu, res)
+        if residual is None and _own_conv3x3(conv, x, pad):
+            # hand-written implicit GEMM on the matrix cores with bias (+ ReLU) in its epilogue
+            b16 = bias if bias.dtype == torch.float16 else bias.half()
+            return ops.conv3x3_f16(x.permute(0, 2, 3, 1), conv.weight, b16, relu=relu).permute(0, 3, 1, 2)
         y = F.conv2d(x, conv.weight, None, conv.stride, padding)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
@@ -220,9 +243,12 @@ class _Block(nn.Module):
         if y.is_cuda and y.dtype == torch.float16 and self.c3.in_channels in (64, 128, 256, 512):
             # c2 (3x3) runs WITHOUT bias / ReLU; if c3 takes the MFMA route for this shape, c2's epilogue is applied
             # to c3's operand fragments as they are loaded (ops.conv1x1_f16(in_bias=...)) and its pass disappears
-            y2 = F.conv2d(y, self.c2.weight, None, self.c2.stride, self.c2.padding)
-            if not y2.is_contiguous(memory_format=torch.channels_last):
-                y2 = y2.contiguous(memory_format=torch.channels_last)
+            if _own_conv3x3(self.c2, y):
+                y2 = ops.conv3x3_f16(y.permute(0, 2, 3, 1), self.c2.weight).permute(0, 3, 1, 2)
+            else:
+                y2 = F.conv2d(y, self.c2.weight, None, self.c2.stride, self.c2.padding)
+                if not y2.is_contiguous(memory_format=torch.channels_last):
+                    y2 = y2.contiguous(memory_format=torch.channels_last)
             res = sc.permute(0, 2, 3, 1)
             if not res.is_contiguous():
                 res = res.contiguous()
@@ -418,10 +444,21 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
             deltas = torch.empty((B, n, 4), dtype=torch.float32, device=p_list[0].device)
             off = 0
             fused = p_list[0].dtype == torch.float16 and self.rpn_conv.out_channels == 512 and self.A <= 4
-            for p in p_list:
+            convs = None
+            if fused and _CONV3X3_MODE != 'lib' and self.rpn_conv.in_channels % 64 == 0:
+                # the 3x3 convolution of ALL levels in one launch of the hand-written implicit-GEMM kernel
+                # (ops.conv3x3_f16_levels: the small levels' workgroups fill the tail of the big ones'), without bias
+                xs = [p.permute(0, 2, 3, 1) for p in p_list]
+                xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
+                convs = ops.conv3x3_f16_levels(xs, self.rpn_conv.weight)
+            for li, p in enumerate(p_list):
                 if fused:
                     # float16: the 3x3 convolution without bias, then ONE MFMA pass does bias + ReLU + both 1x1
                     # convolutions + their biases + the float32 re-layout (ops.rpn_head_tail)
+                    if convs is not None:
+                        ops.rpn_head_tail(convs[li], self.rpn_conv.bias, w, b, self.A, scores, deltas, off)
+                        off += int(p.shape[2]) * int(p.shape[3]) * self.A
+                        continue
                     c = F.conv2d(p, self.rpn_conv.weight, None, 1, self.rpn_conv.padding)
                     if not c.is_contiguous(memory_format=torch.channels_last):
                         c = c.contiguous(memory_format=torch.channels_last)

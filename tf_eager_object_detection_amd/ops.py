@@ -424,6 +424,72 @@ def rpn_head_tail(conv_out, conv_bias, weight, bias, num_anchors, scores, deltas
     return scores, deltas
 
 
+def conv3x3_f16(x, weight, bias=None, relu=False, out=None):
+    """3x3 stride-1 'same' convolution as ONE hand-written implicit-GEMM kernel on the matrix cores (the RpnHead's
+    convolution, base_fpn_model.py:401-417): ``x`` NHWC float16 contiguous [B,H,W,cin]; ``weight`` float16
+    [cout,cin,3,3] in channels_last memory format (= [cout][3][3][cin]: `w.contiguous(memory_format=channels_last)`)
+    or an explicit [cout,3,3,cin] tensor; ``bias`` float16 [cout] or None; -> NHWC float16 [B,H,W,cout].
+    cin % 64 == 0, cout % 256 == 0."""
+    if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError('x must be a contiguous NHWC float16 GPU tensor [B,H,W,cin]')
+    B, H, W, cin = (int(v) for v in x.shape)
+    cout = int(weight.shape[0])
+    if weight.dtype != torch.float16 or weight.dim() != 4 or weight.numel() != cout * 9 * cin:
+        raise ValueError('weight must be float16 [cout,cin,3,3] (channels_last) or [cout,3,3,cin]')
+    if tuple(weight.shape[1:]) == (cin, 3, 3):
+        w = weight.permute(0, 2, 3, 1)                    # [cout,3,3,cin] view; contiguous iff channels_last memory
+    elif tuple(weight.shape[1:]) == (3, 3, cin):
+        w = weight
+    else:
+        raise ValueError('weight shape %s does not match cin = %d' % (tuple(weight.shape), cin))
+    if not w.is_contiguous():
+        w = w.contiguous()
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('bias must be a contiguous float16 [cout] tensor')
+    shape = (B, H, W, cout)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor [B,H,W,cout]')
+    L.call('odet_conv3x3_f16', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
+           cin, cout, 1 if relu else 0, L.stream())
+    return out
+
+
+def conv3x3_f16_levels(xs, weight, bias=None, relu=False, outs=None):
+    """conv3x3_f16 with shared weights over a list of NHWC float16 maps [B,H_l,W_l,cin] (the RpnHead over the pyramid
+    levels) in ONE launch; -> list of [B,H_l,W_l,cout]."""
+    if not 1 <= len(xs) <= MAX_LEVELS:
+        raise ValueError('between 1 and %d maps expected' % MAX_LEVELS)
+    B, cin = int(xs[0].shape[0]), int(xs[0].shape[3])
+    cout = int(weight.shape[0])
+    if tuple(weight.shape[1:]) == (cin, 3, 3):
+        w = weight.permute(0, 2, 3, 1)
+    elif tuple(weight.shape[1:]) == (3, 3, cin):
+        w = weight
+    else:
+        raise ValueError('weight shape %s does not match cin = %d' % (tuple(weight.shape), cin))
+    if weight.dtype != torch.float16:
+        raise ValueError('weight must be float16')
+    if not w.is_contiguous():
+        w = w.contiguous()
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('bias must be a contiguous float16 [cout] tensor')
+    lv = (L.OdetConvLevel * len(xs))()
+    if outs is None:
+        outs = [torch.empty(tuple(x.shape[:3]) + (cout,), dtype=torch.float16, device=x.device) for x in xs]
+    for i, (x, y) in enumerate(zip(xs, outs)):
+        if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or int(x.shape[0]) != B \
+                or int(x.shape[3]) != cin:
+            raise ValueError('maps must be contiguous NHWC float16 GPU tensors [B,H,W,cin] of one batch size')
+        if y.dtype != torch.float16 or tuple(y.shape) != tuple(x.shape[:3]) + (cout,) or not y.is_contiguous():
+            raise ValueError('outs must be contiguous float16 tensors [B,H,W,cout]')
+        lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), y.data_ptr(), int(x.shape[1]), int(x.shape[2])
+    L.call('odet_conv3x3_f16_levels', lv, len(xs), L.dptr(w), L.dptr(bias) if bias is not None else None, B, cin, cout,
+           1 if relu else 0, L.stream())
+    return outs
+
+
 def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None, in_bias=None):
     """1x1 stride-1 convolution + bias (+ residual) (+ ReLU) in ONE kernel on the matrix cores: ``x`` [..., cin]
     NHWC float16 contiguous (any leading dims), ``weight`` [cout, cin(, 1, 1)], ``bias`` [cout], ``residual`` /
