@@ -132,27 +132,40 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mt][t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
 
+  // K loop, software-pipelined by half a K-step: the fragments of (ks, half 1) are read and the MFMAs of (ks, half 0)
+  // issued BEFORE the barrier that publishes stage ks + 1, so the matrix pipe has half a step of work queued while the
+  // waves meet, the next DMA is issued and the first fragments of step ks + 1 come out of LDS -- the burst of LDS reads
+  // right after a barrier no longer leaves the MFMAs waiting.
+  auto read_frags = [&](const unsigned char* sb, uint32_t kx, h8 (&wf)[4], h8 (&xf)[8]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const h8*>(sb + ((woff + (uint32_t)t * 2048u) ^ kx));
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) xf[mt] = *reinterpret_cast<const h8*>(sb + ((xoff + (uint32_t)mt * 2048u) ^ kx));
+  };
+  auto mfmas = [&](const h8 (&wf)[4], const h8 (&xf)[8]) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[mt], acc[mt][t], 0, 0, 0);
+  };
+  h8 wf0[4], xf0[8], wf1[4], xf1[8];
   issue(0, 0u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (ksteps > 1) issue(1, C3_STAGE_BYTES);
+  read_frags(lds, 0u, wf0, xf0);
   for (int ks = 0; ks < ksteps; ++ks) {
-    const uint32_t stage = (uint32_t)(ks & 1) * C3_STAGE_BYTES;
-    // my copies of step ks have landed; after the barrier everybody's have, and nobody reads the other stage any more
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (ks + 1 < ksteps) issue(ks + 1, (uint32_t)((ks + 1) & 1) * C3_STAGE_BYTES);
-    const unsigned char* sb = lds + stage;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      const uint32_t kx = kh ? 64u : 0u;
-      h8 wf[4], xf[8];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const h8*>(sb + ((woff + (uint32_t)t * 2048u) ^ kx));
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) xf[mt] = *reinterpret_cast<const h8*>(sb + ((xoff + (uint32_t)mt * 2048u) ^ kx));
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[mt], acc[mt][t], 0, 0, 0);
+    const unsigned char* sb = lds + (uint32_t)(ks & 1) * C3_STAGE_BYTES;
+    read_frags(sb, 64u, wf1, xf1);
+    mfmas(wf0, xf0);
+    if (ks + 1 < ksteps) {
+      // my copies of step ks + 1 have landed and my reads of stage ks are done; after the barrier everybody's
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (ks + 2 < ksteps) issue(ks + 2, (uint32_t)(ks & 1) * C3_STAGE_BYTES);
+      read_frags(lds + (uint32_t)((ks + 1) & 1) * C3_STAGE_BYTES, 0u, wf0, xf0);
     }
+    mfmas(wf1, xf1);
   }
   // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
   const int c0 = tn * C3_TN + wn * 64 + lq * 16;
