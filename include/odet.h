@@ -356,6 +356,12 @@ typedef struct {
 } odet_conv_level_t;
 int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
                             int batch, int cin, int cout, int relu, odet_stream_t stream);
+/* the float32 forms (the detectors' parity mode computes in the reference's precision): float32 x / w / bias / y,
+ * exact-float32 MFMA (v_mfma_f32_16x16x4_f32), cin % 32 == 0, cout % 256 == 0 */
+int odet_conv3x3_f32(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
+                     int cin, int cout, int relu, odet_stream_t stream);
+int odet_conv3x3_f32_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
+                            int batch, int cin, int cout, int relu, odet_stream_t stream);
 
 /* 1x1 stride-1 convolution with its whole epilogue on the matrix cores (the third convolution
  * of a bottleneck block + Add([shortcut, x]) + Activation('relu'), model/fpn/resnet_fpn.py:154-205, frozen

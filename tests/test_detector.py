@@ -643,3 +643,63 @@ def test_conv3x3_f16_implicit_gemm(B, H, W, cin, cout):
     out = torch.empty((B, H, W, cout), dtype=torch.float16, device='cuda')
     ops.conv3x3_f16(xr, wr.permute(0, 2, 3, 1).contiguous(), bias, relu=True, out=out)
     assert torch.equal(out, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,cin,cout', [(1, 13, 21, 256, 512), (2, 25, 42, 96, 256), (3, 7, 5, 32, 256),
+                                             (1, 100, 167, 256, 512)])
+def test_conv3x3_f32_implicit_gemm(B, H, W, cin, cout):
+    """odet_conv3x3_f32 (the same implicit GEMM on exact-float32 matrix instructions, for the detectors' parity mode):
+    EXACT on integer-valued data, within float32 accumulation-order noise of torch's float32 convolution on random
+    data (max |difference| <= 2e-5 of the result scale for K = 9 * cin <= 2304 terms); several levels in one launch."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(B * 1000 + H)
+    x = torch.randint(-3, 4, (B, H, W, cin), device='cuda', generator=g).float()
+    w = torch.randint(-2, 3, (cout, cin, 3, 3), device='cuda', generator=g).float().contiguous(memory_format=torch.channels_last)
+    prev = torch.backends.cudnn.allow_tf32
+    torch.backends.cudnn.allow_tf32 = False
+    try:
+        got = ops.conv3x3_f32(x, w)
+        want = F.conv2d(x.permute(0, 3, 1, 2), w, None, 1, 1).permute(0, 2, 3, 1)
+        assert got.shape == (B, H, W, cout)
+        assert torch.equal(got, want)
+        xr = torch.randn((B, H, W, cin), device='cuda', generator=g) * 0.5
+        wr = (torch.randn((cout, cin, 3, 3), device='cuda', generator=g) * 0.02).contiguous(memory_format=torch.channels_last)
+        bias = torch.randn(cout, device='cuda', generator=g)
+        got = ops.conv3x3_f32(xr, wr, bias, relu=True)
+        want64 = F.relu(F.conv2d(xr.permute(0, 3, 1, 2).double(), wr.double(), bias.double(), 1, 1)).permute(0, 2, 3, 1)
+        assert float((got.double() - want64).abs().max().item()) <= 2e-5 * max(1.0, float(want64.abs().max().item()))
+        out = torch.empty((B, H, W, cout), dtype=torch.float32, device='cuda')
+        ops.conv3x3_f32(xr, wr.permute(0, 2, 3, 1).contiguous(), bias, relu=True, out=out)
+        assert torch.equal(out, got)
+        # two maps in one launch = the two single launches, bit for bit
+        x2 = torch.randn((B, max(1, H // 2), W + 3, cin), device='cuda', generator=g)
+        ys = ops.conv3x3_f32_levels([xr, x2], wr, bias, relu=True)
+        assert torch.equal(ys[0], got) and torch.equal(ys[1], ops.conv3x3_f32(x2, wr, bias, relu=True))
+    finally:
+        torch.backends.cudnn.allow_tf32 = prev
+
+
+
+@pytest.mark.gpu
+def test_fp32_rpn_head_own_conv_matches_library_route(monkeypatch):
+    """The float32 detector's RpnHead through the grouped hand-written convolution (ops.conv3x3_f32_levels) against the
+    same head through the library convolution: float32 accumulation-order noise only, and the same proposals."""
+    from tf_eager_object_detection_amd.model import fpn_detector as fd
+    torch.manual_seed(5)
+    shape = (256, 352)
+    m = fd.ResNetFpnDetector(50, 21, shape, 100, dtype=torch.float32, blind_chunks=3).prepare()
+    rng = np.random.default_rng(5)
+    img = torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    with torch.no_grad():
+        ps = m.features(img)
+        monkeypatch.setattr(fd, '_CONV3X3_MODE', 'own')
+        s_own, d_own = m.rpn(ps)
+        s_own2, d_own2 = m.rpn(ps)
+        monkeypatch.setattr(fd, '_CONV3X3_MODE', 'lib')
+        s_lib, d_lib = m.rpn(ps)
+    assert torch.equal(s_own, s_own2) and torch.equal(d_own, d_own2)        # deterministic
+    scale = max(1.0, float(s_lib.abs().max().item()), float(d_lib.abs().max().item()))
+    assert float((s_own - s_lib).abs().max().item()) <= 1e-4 * scale
+    assert float((d_own - d_lib).abs().max().item()) <= 1e-4 * scale

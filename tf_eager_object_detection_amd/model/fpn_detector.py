@@ -451,6 +451,15 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
                 xs = [p.permute(0, 2, 3, 1) for p in p_list]
                 xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
                 convs = ops.conv3x3_f16_levels(xs, self.rpn_conv.weight)
+            heads = None
+            if not fused and p_list[0].dtype == torch.float32 and _CONV3X3_MODE != 'lib' \
+                    and self.rpn_conv.in_channels % 32 == 0 and self.rpn_conv.out_channels % 256 == 0:
+                # float32 (the parity mode): the same grouped launch on exact-float32 matrix instructions, bias + ReLU
+                # in its epilogue (ops.conv3x3_f32_levels; on a par with the library on P2 alone, ahead of its five
+                # separate launches because the small levels fill the tail: tools/exp/conv3x3_layers.py 8 f32)
+                xs = [p.permute(0, 2, 3, 1) for p in p_list]
+                xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
+                heads = ops.conv3x3_f32_levels(xs, self.rpn_conv.weight, self.rpn_conv.bias, relu=True)
             for li, p in enumerate(p_list):
                 if fused:
                     # float16: the 3x3 convolution without bias, then ONE MFMA pass does bias + ReLU + both 1x1
@@ -464,7 +473,7 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
                         c = c.contiguous(memory_format=torch.channels_last)
                     ops.rpn_head_tail(c.permute(0, 2, 3, 1), self.rpn_conv.bias, w, b, self.A, scores, deltas, off)
                 else:
-                    x = _conv_epi(self.rpn_conv, p, relu=True)
+                    x = heads[li].permute(0, 3, 1, 2) if heads is not None else _conv_epi(self.rpn_conv, p, relu=True)
                     sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
                     ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, off)
                 off += int(p.shape[2]) * int(p.shape[3]) * self.A

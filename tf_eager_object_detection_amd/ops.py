@@ -424,70 +424,88 @@ def rpn_head_tail(conv_out, conv_bias, weight, bias, num_anchors, scores, deltas
     return scores, deltas
 
 
-def conv3x3_f16(x, weight, bias=None, relu=False, out=None):
-    """3x3 stride-1 'same' convolution as ONE hand-written implicit-GEMM kernel on the matrix cores (the RpnHead's
-    convolution, base_fpn_model.py:401-417): ``x`` NHWC float16 contiguous [B,H,W,cin]; ``weight`` float16
-    [cout,cin,3,3] in channels_last memory format (= [cout][3][3][cin]: `w.contiguous(memory_format=channels_last)`)
-    or an explicit [cout,3,3,cin] tensor; ``bias`` float16 [cout] or None; -> NHWC float16 [B,H,W,cout].
-    cin % 64 == 0, cout % 256 == 0."""
-    if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4 or not x.is_contiguous():
-        raise ValueError('x must be a contiguous NHWC float16 GPU tensor [B,H,W,cin]')
-    B, H, W, cin = (int(v) for v in x.shape)
-    cout = int(weight.shape[0])
-    if weight.dtype != torch.float16 or weight.dim() != 4 or weight.numel() != cout * 9 * cin:
-        raise ValueError('weight must be float16 [cout,cin,3,3] (channels_last) or [cout,3,3,cin]')
+_CONV3X3_FORMS = {torch.float16: ('odet_conv3x3_f16', 'float16', 64), torch.float32: ('odet_conv3x3_f32', 'float32', 32)}
+
+
+def _conv3x3_weight(weight, cin, cout, dtype, name):
+    if weight.dtype != dtype or weight.dim() != 4 or weight.numel() != cout * 9 * cin:
+        raise ValueError('weight must be %s [cout,cin,3,3] (channels_last) or [cout,3,3,cin]' % name)
     if tuple(weight.shape[1:]) == (cin, 3, 3):
         w = weight.permute(0, 2, 3, 1)                    # [cout,3,3,cin] view; contiguous iff channels_last memory
     elif tuple(weight.shape[1:]) == (3, 3, cin):
         w = weight
     else:
         raise ValueError('weight shape %s does not match cin = %d' % (tuple(weight.shape), cin))
-    if not w.is_contiguous():
-        w = w.contiguous()
-    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
-        raise ValueError('bias must be a contiguous float16 [cout] tensor')
+    return w if w.is_contiguous() else w.contiguous()
+
+
+def _conv3x3(dtype, x, weight, bias, relu, out):
+    sym, name, _ = _CONV3X3_FORMS[dtype]
+    if x.dtype != dtype or not x.is_cuda or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError('x must be a contiguous NHWC %s GPU tensor [B,H,W,cin]' % name)
+    B, H, W, cin = (int(v) for v in x.shape)
+    cout = int(weight.shape[0])
+    w = _conv3x3_weight(weight, cin, cout, dtype, name)
+    if bias is not None and (bias.dtype != dtype or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('bias must be a contiguous %s [cout] tensor' % name)
     shape = (B, H, W, cout)
     if out is None:
-        out = torch.empty(shape, dtype=torch.float16, device=x.device)
-    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
-        raise ValueError('out must be a contiguous float16 tensor [B,H,W,cout]')
-    L.call('odet_conv3x3_f16', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
+        out = torch.empty(shape, dtype=dtype, device=x.device)
+    elif out.dtype != dtype or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous %s tensor [B,H,W,cout]' % name)
+    L.call(sym, L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
            cin, cout, 1 if relu else 0, L.stream())
     return out
+
+
+def _conv3x3_levels(dtype, xs, weight, bias, relu, outs):
+    sym, name, _ = _CONV3X3_FORMS[dtype]
+    if not 1 <= len(xs) <= MAX_LEVELS:
+        raise ValueError('between 1 and %d maps expected' % MAX_LEVELS)
+    B, cin = int(xs[0].shape[0]), int(xs[0].shape[3])
+    cout = int(weight.shape[0])
+    w = _conv3x3_weight(weight, cin, cout, dtype, name)
+    if bias is not None and (bias.dtype != dtype or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('bias must be a contiguous %s [cout] tensor' % name)
+    lv = (L.OdetConvLevel * len(xs))()
+    if outs is None:
+        outs = [torch.empty(tuple(x.shape[:3]) + (cout,), dtype=dtype, device=x.device) for x in xs]
+    for i, (x, y) in enumerate(zip(xs, outs)):
+        if x.dtype != dtype or not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or int(x.shape[0]) != B \
+                or int(x.shape[3]) != cin:
+            raise ValueError('maps must be contiguous NHWC %s GPU tensors [B,H,W,cin] of one batch size' % name)
+        if y.dtype != dtype or tuple(y.shape) != tuple(x.shape[:3]) + (cout,) or not y.is_contiguous():
+            raise ValueError('outs must be contiguous %s tensors [B,H,W,cout]' % name)
+        lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), y.data_ptr(), int(x.shape[1]), int(x.shape[2])
+    L.call(sym + '_levels', lv, len(xs), L.dptr(w), L.dptr(bias) if bias is not None else None, B, cin, cout,
+           1 if relu else 0, L.stream())
+    return outs
+
+
+def conv3x3_f16(x, weight, bias=None, relu=False, out=None):
+    """3x3 stride-1 'same' convolution as ONE hand-written implicit-GEMM kernel on the matrix cores (the RpnHead's
+    convolution, base_fpn_model.py:401-417): ``x`` NHWC float16 contiguous [B,H,W,cin]; ``weight`` float16
+    [cout,cin,3,3] in channels_last memory format (= [cout][3][3][cin]: `w.contiguous(memory_format=channels_last)`)
+    or an explicit [cout,3,3,cin] tensor; ``bias`` float16 [cout] or None; -> NHWC float16 [B,H,W,cout].
+    cin % 64 == 0, cout % 256 == 0."""
+    return _conv3x3(torch.float16, x, weight, bias, relu, out)
 
 
 def conv3x3_f16_levels(xs, weight, bias=None, relu=False, outs=None):
     """conv3x3_f16 with shared weights over a list of NHWC float16 maps [B,H_l,W_l,cin] (the RpnHead over the pyramid
     levels) in ONE launch; -> list of [B,H_l,W_l,cout]."""
-    if not 1 <= len(xs) <= MAX_LEVELS:
-        raise ValueError('between 1 and %d maps expected' % MAX_LEVELS)
-    B, cin = int(xs[0].shape[0]), int(xs[0].shape[3])
-    cout = int(weight.shape[0])
-    if tuple(weight.shape[1:]) == (cin, 3, 3):
-        w = weight.permute(0, 2, 3, 1)
-    elif tuple(weight.shape[1:]) == (3, 3, cin):
-        w = weight
-    else:
-        raise ValueError('weight shape %s does not match cin = %d' % (tuple(weight.shape), cin))
-    if weight.dtype != torch.float16:
-        raise ValueError('weight must be float16')
-    if not w.is_contiguous():
-        w = w.contiguous()
-    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
-        raise ValueError('bias must be a contiguous float16 [cout] tensor')
-    lv = (L.OdetConvLevel * len(xs))()
-    if outs is None:
-        outs = [torch.empty(tuple(x.shape[:3]) + (cout,), dtype=torch.float16, device=x.device) for x in xs]
-    for i, (x, y) in enumerate(zip(xs, outs)):
-        if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or int(x.shape[0]) != B \
-                or int(x.shape[3]) != cin:
-            raise ValueError('maps must be contiguous NHWC float16 GPU tensors [B,H,W,cin] of one batch size')
-        if y.dtype != torch.float16 or tuple(y.shape) != tuple(x.shape[:3]) + (cout,) or not y.is_contiguous():
-            raise ValueError('outs must be contiguous float16 tensors [B,H,W,cout]')
-        lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), y.data_ptr(), int(x.shape[1]), int(x.shape[2])
-    L.call('odet_conv3x3_f16_levels', lv, len(xs), L.dptr(w), L.dptr(bias) if bias is not None else None, B, cin, cout,
-           1 if relu else 0, L.stream())
-    return outs
+    return _conv3x3_levels(torch.float16, xs, weight, bias, relu, outs)
+
+
+def conv3x3_f32(x, weight, bias=None, relu=False, out=None):
+    """conv3x3_f16 in the reference's precision: float32 operands and result, exact-float32 matrix instructions
+    (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 256 == 0."""
+    return _conv3x3(torch.float32, x, weight, bias, relu, out)
+
+
+def conv3x3_f32_levels(xs, weight, bias=None, relu=False, outs=None):
+    """conv3x3_f32 with shared weights over a list of NHWC float32 maps in ONE launch."""
+    return _conv3x3_levels(torch.float32, xs, weight, bias, relu, outs)
 
 
 def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None, in_bias=None):
