@@ -360,6 +360,34 @@ def main():
         times = [a.elapsed_ms(b) for a, b in ev_roi][2:]      # (the first two settle clocks / caches)
         roi_ms = float(np.mean(times))
 
+        def calibrate(read_bytes, write_bytes, samples=8):
+            """odet_calib_stream_mix (csrc/calib.hip: a kernel that only moves these bytes with the RoI kernel's
+            instructions, cache policy and image -> XCD pinning) under the SAME protocol as the RoI samples above: what
+            this box's memory system needs for the launch's read : write mix."""
+            rb, wb = (int(read_bytes) // 8192) * 8192, (int(write_bytes) // 8192) * 8192
+            src = torch.zeros(rb // 4, dtype=torch.float32, device='cuda')
+            dst = torch.empty(wb // 4, dtype=torch.float32, device='cuda')
+            evs = []
+            for _ in range(samples):
+                if S > 1:
+                    for g in range(1, S):
+                        pool.submit_group(g)
+                    pool.wait()
+                else:
+                    with torch.cuda.stream(gstreams[0]):
+                        flush.fill_(1.0)
+                mine = gstreams[0]
+                for st in gstreams[1:]:
+                    mine.wait_stream(st)
+                ev = (ops.ProfEvent(), ops.ProfEvent())
+                _lib.call('odet_calib_stream_mix', src.data_ptr(), rb, dst.data_ptr(), wb, mine.cuda_stream,
+                          ev[0].handle, ev[1].handle)
+                torch.cuda.synchronize()
+                evs.append(ev)
+            ts = [a.elapsed_ms(b) for a, b in evs][2:]
+            del src, dst
+            return rb, wb, float(np.mean(ts)), len(ts)
+
         k = int(hot.roi_count.item())
         # algorithmic bytes of the timed launch = the sum over its images (the slots of stream group 0; SURVEY 8d per image)
         per_slot = []
@@ -405,6 +433,15 @@ def main():
         rf['measured_traffic_GBps'] = (traffic / (roi_ms * 1e-3) / 1e9) if (traffic and roi_ms) else None
         rf['hbm_frac_measured'] = (rf['measured_traffic_GBps'] / HBM_PEAK_GBS) if rf['measured_traffic_GBps'] else None
         rf['frac_on_B_min'] = algo['B_min'] / (roi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # what the memory system of this box does with the same bytes and nothing else: B_min = every distinct map
+        # cell once + the output once, moved by a kernel without arithmetic, gathers or reuse (see calibrate())
+        rb, wb, cal_ms, cal_n = calibrate(algo['B_min'] - algo['out'], algo['out'])
+        rf['calibration'] = {'kernel': 'k_calib_stream_mix: reads B_min - output bytes once in 1 KB rows and writes the '
+                                       'output bytes (nontemporal), interleaved, XCD-pinned like the RoI launch; same '
+                                       'cold protocol',
+                             'bytes_read': rb, 'bytes_written': wb, 'ms': cal_ms, 'samples': cal_n,
+                             'GBps': (rb + wb) / (cal_ms * 1e-3) / 1e9,
+                             'roi_kernel_vs_calibration': cal_ms / roi_ms}
         pool.close()
         del pool
         if not args.no_cpu_baseline and world == 1:

@@ -235,6 +235,12 @@ int odet_roi_pool_timed(const odet_level_t* levels, int num_levels, int C, const
                         int image_h, int image_w, int pool_size, int pool_mode, float* out,
                         odet_stream_t stream, void* start_event, void* stop_event);
 int odet_prof_event_create(void** ev);
+/* Measurement infrastructure for bench.py's roofline object (no stage of the reference; csrc/calib.hip): a kernel
+ * that only moves bytes -- reads read_bytes of src once (1 KB rows, XCD x reads the x-th eighth) and writes write_bytes
+ * of dst with the RoI kernel's store instruction, interleaved at that byte ratio.  Timed with the optional events
+ * (nullable), it is the time this box's memory system needs for the RoI launch's read : write mix. */
+int odet_calib_stream_mix(const void* src, unsigned long long read_bytes, void* dst, unsigned long long write_bytes,
+                          odet_stream_t stream, void* start_event, void* stop_event);
 int odet_prof_event_destroy(void* ev);
 int odet_prof_event_elapsed_ms(void* start, void* stop, float* ms);
 

@@ -33,6 +33,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     if r['traffic'] is not None:
         assert abs(r['hbm_frac_measured'] - r['traffic'] / (r['kernel_ms'] * 1e-3) / 8e12) < 1e-9
     assert 'k_roi_pool' in r['rocprof_kernel_name']
+    cal = r['calibration']            # the same bytes moved by a kernel that does nothing else, same protocol
+    assert cal['samples'] >= 5 and cal['ms'] > 0 and cal['bytes_written'] <= r['bytes_output']
+    assert abs(cal['roi_kernel_vs_calibration'] - cal['ms'] / r['kernel_ms']) < 1e-9
+    assert 0.3 < cal['roi_kernel_vs_calibration'] < 1.5
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'img/s' and c['value'] > 0 and c['cores'] >= 1 and 'sample' in c
     assert abs(c['map_delta']['delta']) <= 0.002

@@ -38,6 +38,9 @@ typedef __attribute__((address_space(3))) void* c3_lds_ptr;
 
 #define C3_TM 256                 // pixels per workgroup tile
 #define C3_TN 256                 // channels per workgroup tile
+#ifndef C3_EARLY_WAVES
+#define C3_EARLY_WAVES 4      // waves below this issue their copies right after the barrier, the others half a step later
+#endif
 #define C3_BK 64                  // input channels per K-step (128 bytes per row)
 #define C3_STAGE_BYTES ((C3_TM + C3_TN) * C3_BK * 2)      // 64 KB
 #define C3_LDS_BYTES (2 * C3_STAGE_BYTES)
@@ -108,18 +111,27 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   }
   const int chunks = cin / C3_BK;
   const int ksteps = 9 * chunks;
+  struct IssueAt { int tap; uint32_t soA, soW, stage; };
+  auto issue_at = [&](int ks, uint32_t stage) {
+    IssueAt a;
+    a.tap = ks / chunks;
+    const int chunk = ks - a.tap * chunks;
+    a.soA = (uint32_t)((a.tap / 3) * W + a.tap % 3) * pixB + (uint32_t)chunk * 128u;
+    a.soW = (uint32_t)ks * 128u;
+    a.stage = stage;
+    return a;
+  };
+  auto issue_piece = [&](const IssueAt& a, int i) {       // pieces i = 0..3: 1 KB of pixels + 1 KB of weights each
+    const uint32_t pc = (uint32_t)(wv * 4 + i) * 1024u;
+    const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + pc), 16, (int)va, (int)a.soA, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + pc), 16, (int)voffW[i],
+                                             (int)a.soW, 0, 0);
+  };
   auto issue = [&](int ks, uint32_t stage) {
-    const int tap = ks / chunks, chunk = ks - tap * chunks;
-    const uint32_t soA = (uint32_t)((tap / 3) * W + tap % 3) * pixB + (uint32_t)chunk * 128u;
-    const uint32_t soW = (uint32_t)ks * 128u;
+    const IssueAt a = issue_at(ks, stage);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t pc = (uint32_t)(wv * 4 + i) * 1024u;
-      const uint32_t va = ((maskA[i] >> tap) & 1u) ? voffA[i] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + stage + pc), 16, (int)va, (int)soA, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + stage + C3_TM * 128u + pc), 16, (int)voffW[i],
-                                               (int)soW, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) issue_piece(a, i);
   };
   // ---- fragment addresses (bytes inside a stage)
   const int l15 = lane & 15, lq = lane >> 4;
@@ -154,10 +166,16 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   __syncthreads();
   issue(1, C3_STAGE_BYTES);                              // (ksteps >= 9)
   read_frags(lds, 0u, wf0, xf0);
-  // steady state: no conditionals inside (a branch around the barrier would make hipcc wait for the NEW fragment reads
-  // before the queued MFMAs of the old ones -- the bubble the half-step pipelining is there to remove); the last two
-  // K-steps are peeled
+  // steady state: no conditionals around MFMAs or the barrier (hipcc would wait for the NEW fragment reads before the
+  // queued MFMAs of the old ones -- the bubble the half-step pipelining is there to remove); the last two K-steps are
+  // peeled.  STAGGER: the two waves of a SIMD (w and w + 4) run the same program between the same barriers, so they
+  // would reach their copy-issue phase (8 LDS-DMA pieces, ~100 cycles of issue each, no MFMA of that wave meanwhile)
+  // together and leave the matrix pipe idle; waves 0-3 issue right after the barrier, waves 4-7 after the half step's
+  // MFMAs (wave-uniform branches around the copies only): -4.3 % on the grouped RPN-head launch.  Measured and
+  // rejected placements: tools/exp/conv3x3_issue_placement.patch (all late -2 %, pieces spread between the MFMAs +8 %,
+  // early after the fragment reads or in mid-half +5 %).
   int ks = 0;
+  const bool early = wv < C3_EARLY_WAVES;
   for (; ks + 2 < ksteps; ++ks) {
     const uint32_t cur = (uint32_t)(ks & 1) * C3_STAGE_BYTES, nxt = C3_STAGE_BYTES - cur;
     read_frags(lds + cur, 64u, wf1, xf1);
@@ -165,9 +183,10 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     // my copies of step ks + 1 have landed and my reads of stage ks are done; after the barrier everybody's
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    issue(ks + 2, cur);
+    if (early) issue(ks + 2, cur);
     read_frags(lds + nxt, 0u, wf0, xf0);
     mfmas(wf1, xf1);
+    if (!early) issue(ks + 2, cur);
   }
   {   // step ksteps - 2: nothing left to issue
     const uint32_t cur = (uint32_t)(ks & 1) * C3_STAGE_BYTES, nxt = C3_STAGE_BYTES - cur;
@@ -276,18 +295,27 @@ __global__ void __launch_bounds__(512) k_conv3x3_f32(Conv3x3F32Params p) {
   }
   const int chunks = cin / 32;
   const int ksteps = 9 * chunks;
+  struct IssueAt { int tap; uint32_t soA, soW, stage; };
+  auto issue_at = [&](int ks, uint32_t stage) {
+    IssueAt a;
+    a.tap = ks / chunks;
+    const int chunk = ks - a.tap * chunks;
+    a.soA = (uint32_t)((a.tap / 3) * W + a.tap % 3) * pixB + (uint32_t)chunk * 128u;
+    a.soW = (uint32_t)ks * 128u;
+    a.stage = stage;
+    return a;
+  };
+  auto issue_piece = [&](const IssueAt& a, int i) {       // pieces i = 0..3: 1 KB of pixels + 1 KB of weights each
+    const uint32_t pc = (uint32_t)(wv * 4 + i) * 1024u;
+    const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + pc), 16, (int)va, (int)a.soA, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + pc), 16, (int)voffW[i],
+                                             (int)a.soW, 0, 0);
+  };
   auto issue = [&](int ks, uint32_t stage) {
-    const int tap = ks / chunks, chunk = ks - tap * chunks;
-    const uint32_t soA = (uint32_t)((tap / 3) * W + tap % 3) * pixB + (uint32_t)chunk * 128u;
-    const uint32_t soW = (uint32_t)ks * 128u;
+    const IssueAt a = issue_at(ks, stage);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t pc = (uint32_t)(wv * 4 + i) * 1024u;
-      const uint32_t va = ((maskA[i] >> tap) & 1u) ? voffA[i] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + stage + pc), 16, (int)va, (int)soA, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + stage + C3_TM * 128u + pc), 16, (int)voffW[i],
-                                               (int)soW, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) issue_piece(a, i);
   };
   const int l15 = lane & 15, lq = lane >> 4;
   const uint32_t fslot = (uint32_t)(lq ^ (lane & 7)) * 16u;                         // slot q; slot 4 + q = ^ 64

@@ -27,6 +27,9 @@ def main():
     ap.add_argument('--maps', choices=['f32', 'f16'], default='f32')
     ap.add_argument('--shape', default='800x1333')
     ap.add_argument('--tag', default='')
+    ap.add_argument('--flush', choices=['write', 'read'], default='write',
+                    help="what goes through the caches before a 'cold' launch: a 1 GiB write (leaves DIRTY lines that the "
+                         "launch has to evict) or a 1 GiB read (clean lines)")
     args = ap.parse_args()
     from tf_eager_object_detection_amd import _lib, ops
     from tf_eager_object_detection_amd.pipeline import FpnStepBatch, synthetic_fpn_inputs
@@ -58,7 +61,10 @@ def main():
         ts = []
         for _ in range(args.reps):
             if cold:
-                flush.fill_(1.0)
+                if args.flush == 'write':
+                    flush.fill_(1.0)
+                else:
+                    flush.sum()
             a, b_ = ops.ProfEvent(), ops.ProfEvent()
             sb.steps[0].roi_start_event, sb.steps[0].roi_stop_event = a.handle, b_.handle
             sb.enqueue(sb.STAGE_ROI, count)
@@ -68,7 +74,7 @@ def main():
         ts = np.array(ts[2:])
         return dict(median_us=float(np.median(ts)), min_us=float(ts.min()), mean_us=float(ts.mean()))
 
-    res = dict(tag=args.tag, lib=os.environ.get('ODET_LIB_PATH', 'in-tree'), batch=B, maps=args.maps)
+    res = dict(tag=args.tag, flush=args.flush, lib=os.environ.get('ODET_LIB_PATH', 'in-tree'), batch=B, maps=args.maps)
     res['batch_cold'] = timed(B, True)
     res['batch_warm'] = timed(B, False)
     res['one_cold'] = timed(1, True)
