@@ -699,7 +699,13 @@ def test_fp32_rpn_head_own_conv_matches_library_route(monkeypatch):
         s_own2, d_own2 = m.rpn(ps)
         monkeypatch.setattr(fd, '_CONV3X3_MODE', 'lib')
         s_lib, d_lib = m.rpn(ps)
-    assert torch.equal(s_own, s_own2) and torch.equal(d_own, d_own2)        # deterministic
+    from tf_eager_object_detection_amd import ops
+    xs = [p.permute(0, 2, 3, 1).contiguous() for p in ps]
+    h1 = ops.conv3x3_f32_levels(xs, m.rpn_conv.weight, m.rpn_conv.bias, relu=True)
+    h2 = ops.conv3x3_f32_levels(xs, m.rpn_conv.weight, m.rpn_conv.bias, relu=True)
+    assert all(torch.equal(a, b) for a, b in zip(h1, h2))                  # the hand-written kernel is deterministic
+    # (the library's 1x1 convolution behind it may split K with atomics: the head's outputs repeat to rounding only)
+    assert float((s_own - s_own2).abs().max().item()) <= 1e-4 and float((d_own - d_own2).abs().max().item()) <= 1e-4
     scale = max(1.0, float(s_lib.abs().max().item()), float(d_lib.abs().max().item()))
     assert float((s_own - s_lib).abs().max().item()) <= 1e-4 * scale
     assert float((d_own - d_lib).abs().max().item()) <= 1e-4 * scale

@@ -235,6 +235,82 @@ __device__ __forceinline__ float4 roi_bin(const RowCtx& rc, uint32_t c0, const u
   return pool4<POOL>(v);
 }
 
+// The same bin (column classes 0 / 1: NC = 2 + DX consecutive columns from c0) with its first M columns taken from the
+// registers of the previous bin of the row instead of memory.  Neighbouring bins of an output row overlap whenever
+// the samples are less than a cell apart (the usual case: median spacing 0.69 cells on the bench workload): the
+// previous bin's last column is this bin's first (M = 1), or its last two are this bin's first two (M = 2; with
+// NC = 2 the bin then loads nothing).  car[i][0..1]: the previous bin's last two columns (row i); on return this
+// bin's.  The values and the lerps are the ones roi_bin computes: results are bit-identical.
+template <int POOL, int DY, int DX, int M, typename FT>
+__device__ __forceinline__ float4 roi_bin_carry(const RowCtx& rc, uint32_t c0, const float (&xw)[2],
+                                                float4 (&car)[(DY == 2) ? 4 : 2 + DY][2]) {
+  static_assert(DX == 0 || DX == 1, "consecutive columns only");
+  constexpr int NR = (DY == 2) ? 4 : 2 + DY, NC = 2 + DX;
+  uint32_t soff[NR], voff[NC];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) soff[i] = rc.row[i] + c0;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) voff[j] = rc.vlane + (uint32_t)j * rc.cellB;
+  float4 blk[NR][NC];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (j < M) blk[i][j] = car[i][2 - M + j];
+      else blk[i][j] = Cell<FT>::load(rc.feat, voff[j], soff[i]);
+    }
+  }
+  float4 v[2][2];
+#pragma unroll
+  for (int sy = 0; sy < 2; ++sy) {
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int rt = (DY == 2) ? 2 * sy : sy * DY, rb = rt + 1;
+      const int cl = sx * DX, cr = cl + 1;
+      v[sy][sx] = lerp_tap(blk[rt][cl], blk[rt][cr], blk[rb][cl], blk[rb][cr], xw[sx], rc.yw[sy]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) { car[i][0] = blk[i][NC - 2]; car[i][1] = blk[i][NC - 1]; }
+  return pool4<POOL>(v);
+}
+
+// roi_row for a map of exactly 256 channels (one pass over the channels: a lane keeps ITS 4 channels of the carried
+// columns): the bins of the row from left to right, each taking the columns it shares with its left neighbour from
+// registers (roi_bin_carry).  7.9 -> ~5 cell loads per bin on the bench workload.
+template <int POOL, int DY, typename FT>
+__device__ __forceinline__ void roi_row_carry(const RowCtx& rc, rsrc_t out, int P, uint32_t xcls_l, uint32_t c0_l,
+                                              const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
+  constexpr int NR = (DY == 2) ? 4 : 2 + DY;
+  float4 car[NR][2];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) car[i][0] = car[i][1] = make_float4(0, 0, 0, 0);
+  uint32_t last = 0xFFFFFFFFu;        // byte offset (inside a cell row) of the carried last column; none yet
+  for (int px = 0; px < P; ++px) {
+    const int xc = rl_i((int)xcls_l, px);
+    const uint32_t c0 = rl_u(c0_l, px);
+    const float xw[2] = {rl_f(xw0_l, px), rl_f(xw1_l, px)};
+    float4 o;
+    if (xc == 2) {
+      const uint32_t crel[4] = {0u, rl_u(crel_l[1], px), rl_u(crel_l[2], px), rl_u(crel_l[3], px)};
+      o = roi_bin<POOL, DY, 2, FT>(rc, c0, crel, xw);
+      last = 0xFFFFFFFFu;
+    } else {
+      const int m = (last == 0xFFFFFFFFu) ? 0 : (c0 == last ? 1 : (c0 + rc.cellB == last ? 2 : 0));
+      switch (xc * 3 + m) {
+        case 0: o = roi_bin_carry<POOL, DY, 0, 0, FT>(rc, c0, xw, car); break;
+        case 1: o = roi_bin_carry<POOL, DY, 0, 1, FT>(rc, c0, xw, car); break;
+        case 2: o = roi_bin_carry<POOL, DY, 0, 2, FT>(rc, c0, xw, car); break;
+        case 3: o = roi_bin_carry<POOL, DY, 1, 0, FT>(rc, c0, xw, car); break;
+        case 4: o = roi_bin_carry<POOL, DY, 1, 1, FT>(rc, c0, xw, car); break;
+        default: o = roi_bin_carry<POOL, DY, 1, 2, FT>(rc, c0, xw, car); break;
+      }
+      last = c0 + (uint32_t)(1 + xc) * rc.cellB;
+    }
+    Cell<FT>::store(out, rc.vlane, (uint32_t)px * rc.cellB, o);
+  }
+}
+
 // The bins of one output row whose row class is DY, every sample of the row inside the map.  FULL: C is a
 // multiple of 256 (no lane is ever idle).
 template <int POOL, int DY, bool FULL, typename FT>
@@ -458,7 +534,12 @@ __global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
   if (ycls < 2) {      // sharing classes: row[i] = first row + i * row pitch
     rc.row[1] = rc.row[0] + rowB; rc.row[2] = rc.row[1] + rowB; rc.row[3] = rc.row[2];
   }
-  if ((C & 255) == 0) {
+  // (float32 maps only: the float16 kernel is bound by its conversion arithmetic, the carried registers cost it 20 %)
+  if (C == 256 && std::is_same<FT, float>::value) {
+    if (ycls == 0) roi_row_carry<POOL, 0, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else if (ycls == 1) roi_row_carry<POOL, 1, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else roi_row_carry<POOL, 2, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+  } else if ((C & 255) == 0) {
     if (ycls == 0) roi_row<POOL, 0, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
     else if (ycls == 1) roi_row<POOL, 1, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
     else roi_row<POOL, 2, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
