@@ -11,9 +11,9 @@ at the ResNet-101-FPN shapes: 267 069 anchors, 1000 proposals, P2..P5 x 256 chan
 dense conv parts of the model (backbone, neck, RPN head, RoI head) are NOT part of this path (SURVEY.md
 section 8): their outputs are the synthetic inputs, resident in HBM before the timed region.
 
-A STEP = `--rounds-per-step` (32) rounds over the `streams` x `batch` (3 x 8 = 24) in-flight image slots of a
-GPU = 768 images per GPU (`config.images_per_step_per_gpu`), so the driver's `--steps 20 --warmup 5` times
-15 360 images (~0.5 s), not 20.
+A STEP = `--rounds-per-step` (48) rounds over the `streams` x `batch` (3 x 8 = 24) in-flight image slots of a
+GPU = 1152 images per GPU (`config.images_per_step_per_gpu`), so the driver's `--steps 20 --warmup 5` times
+23 040 images (~0.75 s), not 20.
 
 Serving arrangement: images are independent, so `--streams` HIP streams (each fed by a native enqueue
 thread of the library) carry `--batch` images each whose kernels share their launches (one grid dimension
@@ -208,11 +208,14 @@ def e2e_record(dtype_name, batch, budget_s=8.0):
 def main():
     # (before anything initialises HSA: dmabuf IPC is the only kind the host driver supports)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # (the end-to-end record's find-mode warm-up: MIOpen's naive reference convolutions are never the fastest solver
+    # and cost the search a minute at 800x1333)
+    os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--rounds-per-step', type=int, default=32,
+    ap.add_argument('--rounds-per-step', type=int, default=48,
                     help='a step = this many rounds over the streams x batch in-flight image slots')
     ap.add_argument('--scores', choices=['distinct', 'clustered'], default='distinct',
                     help='RPN score distribution (SURVEY 8d: distinct; clustered = trained-like)')

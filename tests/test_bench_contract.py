@@ -42,6 +42,6 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(c['map_delta']['delta']) <= 0.002
     # a step = images_per_step_per_gpu images on every GPU; the driver's 20 steps time at least half a second
     ips = d['config']['images_per_step_per_gpu']
-    assert ips == 32 * d['config']['streams_per_gpu'] * d['config']['images_per_launch']
+    assert ips == 48 * d['config']['streams_per_gpu'] * d['config']['images_per_launch']
     assert d['value'] > 0 and abs(d['ms_per_step'] * d['value'] / (1000.0 * ips * d['n_gpus']) - 1.0) < 1e-6
     assert d['config']['timed_region_s'] >= 0.3 and d['config']['timed_images'] == 20 * ips

@@ -4,7 +4,7 @@
 # The product source has ONE code path; the switches live in tools/exp/roi_diag_switches.patch, applied here to a
 # temporary copy of csrc/:  -DODET_ROI_ABLATE=1 (no stores) | 2 (loads, no lerps) | 3 (only the first 2 x 2 cells of a
 # bin are loaded) | 4 (no loads);  -DODET_ROI_LOAD_AUX=<cache policy bits of the cell loads: 1 sc0, 2 nt, 16 sc1>, -DODET_ROI_STORE_AUX=<the same
-# for the float32 feature stores, product: 2>;
+# for the float32 feature stores, product: 2>, -DODET_ROI_CARRY_COLS=<0, 1: columns a bin may take from its left neighbour, product 2>;
 # at run time ODET_ROI_DEV_LDS=<bytes> (dynamic LDS to limit workgroups per CU), ODET_ROI_DEV_NOPIN=1 (no image ->
 # XCD pinning in batched launches).  Same ABI: select with ODET_LIB_PATH (tools/roi_bench.py, tools/pmc_roi.sh).
 set -e
