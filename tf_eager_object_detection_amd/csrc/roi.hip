@@ -60,6 +60,7 @@ struct RoiParams {
   int waves;          // waves (= output rows) per workgroup; == P: a workgroup is one RoI
   int xcd_images;     // 1: the image is derived from the XCD slot (batch of 2 / 4 / 8), 0: blockIdx.y
   int xcds_per_img;   // XCDs that serve one image (8 / batch)
+  int slices;         // > 1: C / 256 workgroups per RoI, one 256-channel slice each (launches that would not fill the chip)
 };
 
 struct Axis {
@@ -275,12 +276,12 @@ __device__ __forceinline__ float4 roi_bin_carry(const RowCtx& rc, uint32_t c0, c
   return pool4<POOL>(v);
 }
 
-// roi_row for a map of exactly 256 channels (one pass over the channels: a lane keeps ITS 4 channels of the carried
-// columns): the bins of the row from left to right, each taking the columns it shares with its left neighbour from
+// One 256-channel slice of an output row (a lane keeps ITS 4 channels of the carried columns): the bins of the row
+// from left to right, each taking the columns it shares with its left neighbour from
 // registers (roi_bin_carry).  7.9 -> ~5 cell loads per bin on the bench workload.
 template <int POOL, int DY, typename FT>
-__device__ __forceinline__ void roi_row_carry(const RowCtx& rc, rsrc_t out, int P, uint32_t xcls_l, uint32_t c0_l,
-                                              const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
+__device__ __forceinline__ void roi_row_carry_pass(const RowCtx& rc, rsrc_t out, int P, uint32_t xcls_l, uint32_t c0_l,
+                                                   const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
   constexpr int NR = (DY == 2) ? 4 : 2 + DY;
   float4 car[NR][2];
 #pragma unroll
@@ -311,10 +312,22 @@ __device__ __forceinline__ void roi_row_carry(const RowCtx& rc, rsrc_t out, int 
   }
 }
 
+// Maps of 256, 512, 1024, ... channels: one carrying pass per 256-channel slice (a lane's carried registers hold its 4
+// channels of ONE slice), the slice in the per-lane byte offset of the loads and of the store.
+template <int POOL, int DY, typename FT>
+__device__ __forceinline__ void roi_row_carry(const RowCtx& rc0, rsrc_t out, int P, int C, int ch0, int ch1, uint32_t xcls_l, uint32_t c0_l,
+                                              const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
+  RowCtx rc = rc0;
+  for (int ch = ch0; ch < ch1; ch += 256) {
+    rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
+    roi_row_carry_pass<POOL, DY, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+  }
+}
+
 // The bins of one output row whose row class is DY, every sample of the row inside the map.  FULL: C is a
 // multiple of 256 (no lane is ever idle).
 template <int POOL, int DY, bool FULL, typename FT>
-__device__ __forceinline__ void roi_row(const RowCtx& rc0, rsrc_t out, int P, int C, uint32_t xcls_l, uint32_t c0_l,
+__device__ __forceinline__ void roi_row(const RowCtx& rc0, rsrc_t out, int P, int C, int ch0, int ch1, uint32_t xcls_l, uint32_t c0_l,
                                         const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
   RowCtx rc = rc0;
   const int lane = threadIdx.x & 63;
@@ -328,7 +341,7 @@ __device__ __forceinline__ void roi_row(const RowCtx& rc0, rsrc_t out, int P, in
       for (int k = 1; k < 4; ++k) crel[k] = rl_u(crel_l[k], px);
     }
     const uint32_t so_out = (uint32_t)px * rc.cellB;
-    for (int ch = 0; ch < C; ch += 256) {
+    for (int ch = ch0; ch < ch1; ch += 256) {
       rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
       if (FULL || lane * 4 + ch < C) {
         float4 o;
@@ -344,7 +357,7 @@ __device__ __forceinline__ void roi_row(const RowCtx& rc0, rsrc_t out, int P, in
 // An output row with extrapolated samples (TF: such a sample is 0): every sample guarded, 4 taps each; rc.row
 // holds the four tapped rows (lo0, hi0, lo1, hi1) as they are.  Rare (boxes are clipped to the image).
 template <int POOL, typename FT>
-__device__ __forceinline__ void roi_row_guarded(const RowCtx& rc0, rsrc_t out, int P, int C, const uint32_t (&cabs_l)[4],
+__device__ __forceinline__ void roi_row_guarded(const RowCtx& rc0, rsrc_t out, int P, int C, int ch0, int ch1, const uint32_t (&cabs_l)[4],
                                              uint32_t xok_l, float xw0_l, float xw1_l, uint32_t yok) {
   RowCtx rc = rc0;
   const int lane = threadIdx.x & 63;
@@ -355,7 +368,7 @@ __device__ __forceinline__ void roi_row_guarded(const RowCtx& rc0, rsrc_t out, i
     const uint32_t xok = rl_u(xok_l, px);
     const float xw[2] = {rl_f(xw0_l, px), rl_f(xw1_l, px)};
     const uint32_t so_out = (uint32_t)px * rc.cellB;
-    for (int ch = 0; ch < C; ch += 256) {
+    for (int ch = ch0; ch < ch1; ch += 256) {
       rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
       if (lane * 4 + ch < C) {
         float4 v[2][2];
@@ -382,7 +395,7 @@ __device__ __forceinline__ void roi_row_guarded(const RowCtx& rc0, rsrc_t out, i
 
 // The un-pooled form (one sample per bin): 4 taps, guarded.
 template <typename FT>
-__device__ __forceinline__ void roi_row_single(const RowCtx& rc0, rsrc_t out, int P, int C, const uint32_t (&cabs_l)[4],
+__device__ __forceinline__ void roi_row_single(const RowCtx& rc0, rsrc_t out, int P, int C, int ch0, int ch1, const uint32_t (&cabs_l)[4],
                                                uint32_t xok_l, float xw0_l, uint32_t yok) {
   RowCtx rc = rc0;
   const int lane = threadIdx.x & 63;
@@ -392,7 +405,7 @@ __device__ __forceinline__ void roi_row_single(const RowCtx& rc0, rsrc_t out, in
     const float xw = rl_f(xw0_l, px);
     const uint32_t so_out = (uint32_t)px * rc.cellB;
     const bool ok = (yok & 1) && (xok & 1);
-    for (int ch = 0; ch < C; ch += 256) {
+    for (int ch = ch0; ch < ch1; ch += 256) {
       rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
       if (lane * 4 + ch < C) {
         float4 o = make_float4(0, 0, 0, 0);
@@ -429,7 +442,11 @@ __global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
   const int w = rfl_i(threadIdx.x >> 6);
   const int P = p.P, C = p.C;
   int ri, py;       // this wave: output row py of the ri-th RoI of the processing order
-  if (p.waves == P) {
+  int ch0 = 0, ch1 = C;     // ... and its channels
+  if (p.slices > 1) {       // few RoIs with many channels: a workgroup = one 256-channel slice of a RoI
+    ri = lb / p.slices; py = w;
+    ch0 = (lb - ri * p.slices) * 256; ch1 = ch0 + 256;
+  } else if (p.waves == P) {
     ri = lb; py = w;
   } else {
     const int u = lb * p.waves + w;
@@ -453,7 +470,7 @@ __global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
   const uint32_t vlane0 = (uint32_t)lane * Cell<FT>::LANE_BYTES;
   if (r >= cnt) {      // padded rows of the static-shape output are zero
     for (int px = 0; px < P; ++px)
-      for (int c = lane * 4, ch = 0; ch < C; c += 256, ch += 256)
+      for (int c = lane * 4 + ch0, ch = ch0; ch < ch1; c += 256, ch += 256)
         if (c < C)
           Cell<FT>::store(out, vlane0 + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4), (uint32_t)px * cellB,
                           make_float4(0, 0, 0, 0));
@@ -518,13 +535,13 @@ __global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
   rc.row[2] = rfl_u((uint32_t)ty1.lo * rowB); rc.row[3] = rfl_u((uint32_t)ty1.hi * rowB);
 
   if (S == 1) {
-    roi_row_single<FT>(rc, out, P, C, cabs_l, xok_l, xw0_l, yok);
+    roi_row_single<FT>(rc, out, P, C, ch0, ch1, cabs_l, xok_l, xw0_l, yok);
     return;
   }
   // every sample of the row inside the map (boxes clipped to the image: nearly always)?
   const bool x_inside = __builtin_amdgcn_ballot_w64(lane < P && xok_l != 3) == 0;
   if (yok != 3 || !x_inside) {
-    roi_row_guarded<POOL, FT>(rc, out, P, C, cabs_l, xok_l, xw0_l, xw1_l, yok);
+    roi_row_guarded<POOL, FT>(rc, out, P, C, ch0, ch1, cabs_l, xok_l, xw0_l, xw1_l, yok);
     return;
   }
   const int ycls = rfl_i(PAD ? 2 : share_class(ty0, ty1));
@@ -534,19 +551,20 @@ __global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
   if (ycls < 2) {      // sharing classes: row[i] = first row + i * row pitch
     rc.row[1] = rc.row[0] + rowB; rc.row[2] = rc.row[1] + rowB; rc.row[3] = rc.row[2];
   }
-  // (float32 maps only: the float16 kernel is bound by its conversion arithmetic, the carried registers cost it 20 %)
-  if (C == 256 && std::is_same<FT, float>::value) {
-    if (ycls == 0) roi_row_carry<POOL, 0, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
-    else if (ycls == 1) roi_row_carry<POOL, 1, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
-    else roi_row_carry<POOL, 2, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+  // (float32 maps of a multiple of 256 channels; the float16 kernel is bound by its conversion arithmetic, the
+  // carried registers cost it 20 %)
+  if ((C & 255) == 0 && std::is_same<FT, float>::value) {
+    if (ycls == 0) roi_row_carry<POOL, 0, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else if (ycls == 1) roi_row_carry<POOL, 1, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else roi_row_carry<POOL, 2, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
   } else if ((C & 255) == 0) {
-    if (ycls == 0) roi_row<POOL, 0, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
-    else if (ycls == 1) roi_row<POOL, 1, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
-    else roi_row<POOL, 2, true, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    if (ycls == 0) roi_row<POOL, 0, true, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else if (ycls == 1) roi_row<POOL, 1, true, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else roi_row<POOL, 2, true, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
   } else {
-    if (ycls == 0) roi_row<POOL, 0, false, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
-    else if (ycls == 1) roi_row<POOL, 1, false, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
-    else roi_row<POOL, 2, false, FT>(rc, out, P, C, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    if (ycls == 0) roi_row<POOL, 0, false, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else if (ycls == 1) roi_row<POOL, 1, false, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    else roi_row<POOL, 2, false, FT>(rc, out, P, C, ch0, ch1, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
   }
 }
 
@@ -646,7 +664,10 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   // one wave per output row; a workgroup = the P rows of one RoI (8 rows of whatever RoIs when P > 16)
   p.waves = pool_size <= 16 ? pool_size : 8;
   const int64_t rows = (int64_t)n * pool_size;
-  const int64_t blocks = (rows + p.waves - 1) / p.waves;
+  // a launch of a few hundred RoIs over 512 / 1024-channel maps (the C4 and VGG16 detectors: 300 RoIs) would leave
+  // most CUs with one workgroup: split every RoI's channels over C / 256 workgroups
+  p.slices = (p.waves == pool_size && (C & 255) == 0 && C > 256 && (int64_t)n * B < 2048) ? C / 256 : 1;
+  const int64_t blocks = p.slices > 1 ? (int64_t)n * p.slices : (rows + p.waves - 1) / p.waves;
   ODET_REQUIRE(blocks < (1ll << 30), "odet_roi_pool: too many workgroups");
   p.nblocks = (int)blocks;
   p.xcd_images = (B == 2 || B == 4 || B == 8) ? 1 : 0;
