@@ -1272,10 +1272,34 @@ static int nms_run(NmsJob& J, hipStream_t st) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, B), dim3(SCAN_THREADS), 0, st, s1);
       ODET_LAUNCH_CHECK();
     }
-    // chunks 2.. (rarely asked for): per image, on the full order
-    for (int i = 0; i < B && blind > 2; ++i) {
-      const int rc = fallback(i, false, blind - 2);
+    // chunks 2..: the full order of every image (radix sort of all n keys) and further chunks of NMS_CHUNK candidates,
+    // all in launches shared by the batch (blockIdx.y = image; an image that is done skips every one of them): with
+    // heavily overlapping proposals (a random-init or a real RPN: 5-6 candidates per kept box) every image of a batch
+    // comes here, and one image after the other this was 13 launches = 140 us PER IMAGE.
+    if (blind > 2) {
+      OdetSortImage si_[ODET_MAX_BATCH];
+      for (int i = 0; i < B; ++i)
+        si_[i] = OdetSortImage{w[i].keys_a, w[i].vals_a, w[i].keys_b, w[i].vals_b, w[i].hist, &w[i].hdr->st.done};
+      const int rc = odet_sort_keys_desc_batch(n, B, si_, st);
       if (rc != ODET_OK) return rc;
+      ScanParams s2 = sp;
+      s2.use_init = 1;
+      s2.sorted_idx = per_img<const uint32_t*>(J, [&](int i) { return (const uint32_t*)w[i].vals_a; });
+      const PerImg<const float4*> kept = per_img<const float4*>(J, [&](int i) { return (const float4*)w[i].kept_boxes; });
+      const PerImg<u64*> rinit = per_img<u64*>(J, [&](int i) { return w[i].removed_init; });
+      const int cap = std::min(NMS_CHUNK, (n + 63) / 64 * 64);
+      for (int c = 2; c < blind; ++c) {
+        hipLaunchKernelGGL(k_nms_gather, dim3((cap + 255) / 256, B), dim3(256), 0, st, sp.st, n, cap, 0, J.prep, J.mode,
+                           s2.sorted_idx, sboxes, sorig);
+        ODET_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_nms_cross, dim3((cap + 255) / 256, B), dim3(256), 0, st, cstates, csboxes, kept, J.thr, rinit);
+        ODET_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_nms_mask, dim3(tri_tiles(cap), B), dim3(256), 0, st, cstates, csboxes, J.thr, Lts, diags, 0);
+        ODET_LAUNCH_CHECK();
+        s2.fail_empty = (fail_empty && c == blind - 1) ? 1 : 0;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_nms_scan<false>), dim3(1, B), dim3(SCAN_THREADS), 0, st, s2);
+        ODET_LAUNCH_CHECK();
+      }
     }
     return ODET_OK;
   }

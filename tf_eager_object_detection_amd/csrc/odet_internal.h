@@ -368,6 +368,10 @@ int odet_post_ops_batch(const PostOpsImageIO* io, int B, int R, int Ccls, int nu
                         float nms_iou_threshold, float score_threshold, float min_edge, hipStream_t st);
 
 // shared between translation units
+struct OdetSortImage {     // one image of odet_sort_keys_desc_batch
+  uint32_t* keys_a; uint32_t* vals_a; uint32_t* keys_b; uint32_t* vals_b; uint32_t* hist; const int32_t* skip;
+};
+int odet_sort_keys_desc_batch(int n, int B, const OdetSortImage* imgs, hipStream_t st);
 int odet_sort_keys_desc(int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
                         uint32_t* hist, const int32_t* skip, uint32_t** sorted_vals, hipStream_t stream);
 size_t odet_sort_hist_entries(int n);

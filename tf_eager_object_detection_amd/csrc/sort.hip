@@ -39,11 +39,19 @@ __device__ __forceinline__ int rs_elem(int item) {
   return blockIdx.x * RS_TILE + (w * RS_ITEMS + item) * 64 + lane;
 }
 
+// One image of a batched sort (blockIdx.y): its two key / payload buffers, its histogram table and its `skip` word.
+// `flip` = 0: pass reads (ka, va) and writes (kb, vb); 1: the other way round.
+struct RsImg { uint32_t* ka; uint32_t* va; uint32_t* kb; uint32_t* vb; uint32_t* hist; const int32_t* skip; };
+struct RsBatch { RsImg v[ODET_MAX_BATCH]; };
+
 // payload (iota) + pass-0 histogram from precomputed keys
-__global__ void __launch_bounds__(RS_BLOCK) k_rs_init(const uint32_t* __restrict__ keys, int n,
-                                                      uint32_t* __restrict__ vals, uint32_t* __restrict__ hist,
-                                                      const int32_t* __restrict__ skip) {
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_init(RsBatch bt, int n) {
+  const RsImg& im = bt.v[blockIdx.y];
+  const int32_t* __restrict__ skip = im.skip;
   if (skip && *skip) return;
+  const uint32_t* __restrict__ keys = im.ka;
+  uint32_t* __restrict__ vals = im.va;
+  uint32_t* __restrict__ hist = im.hist;
   __shared__ uint32_t h[RS_RADIX];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -59,9 +67,12 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_init(const uint32_t* __restrict
   hist[(size_t)blockIdx.x * RS_RADIX + threadIdx.x] = h[threadIdx.x];   // block-major
 }
 
-__global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift,
-                                                      uint32_t* __restrict__ hist, const int32_t* __restrict__ skip) {
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_hist(RsBatch bt, int n, int shift, int flip) {
+  const RsImg& im = bt.v[blockIdx.y];
+  const int32_t* __restrict__ skip = im.skip;
   if (skip && *skip) return;
+  const uint32_t* __restrict__ keys = flip ? im.kb : im.ka;
+  uint32_t* __restrict__ hist = im.hist;
   __shared__ uint32_t h[RS_RADIX];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -84,13 +95,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   return v;
 }
 
-__global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restrict__ keys_in,
-                                                         const uint32_t* __restrict__ vals_in, int n, int shift,
-                                                         const uint32_t* __restrict__ hist, int nblocks,
-                                                         uint32_t* __restrict__ keys_out,
-                                                         uint32_t* __restrict__ vals_out,
-                                                         const int32_t* __restrict__ skip) {
+__global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(RsBatch bt, int n, int shift, int nblocks, int flip) {
+  const RsImg& im = bt.v[blockIdx.y];
+  const int32_t* __restrict__ skip = im.skip;
   if (skip && *skip) return;
+  const uint32_t* __restrict__ keys_in = flip ? im.kb : im.ka;
+  const uint32_t* __restrict__ vals_in = flip ? im.vb : im.va;
+  uint32_t* __restrict__ keys_out = flip ? im.ka : im.kb;
+  uint32_t* __restrict__ vals_out = flip ? im.va : im.vb;
+  const uint32_t* __restrict__ hist = im.hist;
   __shared__ uint32_t cnt[RS_WAVES][RS_RADIX];
   __shared__ uint32_t gbase[RS_RADIX];
   __shared__ uint32_t wsum[RS_WAVES];
@@ -180,28 +193,39 @@ __global__ void __launch_bounds__(RS_BLOCK) k_rs_scatter(const uint32_t* __restr
   }
 }
 
-// Sorts indices 0..n-1 by (key asc, index asc) = (score desc, index asc).  keys_a holds the keys on
-// entry; keys_a/vals_a/keys_b/vals_b: n uint32 each; hist: odet_sort_hist_entries(n) uint32.
-// *sorted_vals points at the buffer holding the result (vals_a after an even number of passes).
-int odet_sort_keys_desc(int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
-                        uint32_t* hist, const int32_t* skip, uint32_t** sorted_vals, hipStream_t st) {
-  int nblocks = (n + RS_TILE - 1) / RS_TILE;
-  hipLaunchKernelGGL(k_rs_init, dim3(nblocks), dim3(RS_BLOCK), 0, st, keys_a, n, vals_a, hist, skip);
+// Sorts indices 0..n-1 by (key asc, index asc) = (score desc, index asc), B images in the same launches
+// (blockIdx.y = image).  Per image: keys_a holds the keys on entry; keys_a/vals_a/keys_b/vals_b: n uint32 each; hist:
+// odet_sort_hist_entries(n) uint32; skip: the image's "done" word (nullable).  After the 4 passes the result is in
+// vals_a (and keys_a is sorted too).
+int odet_sort_keys_desc_batch(int n, int B, const OdetSortImage* imgs, hipStream_t st) {
+  if (B < 1 || B > ODET_MAX_BATCH) return odet_set_error(ODET_E_INVALID, "odet_sort_keys_desc_batch: batch %d out of range", B);
+  RsBatch bt;
+  for (int i = 0; i < ODET_MAX_BATCH; ++i) {
+    const OdetSortImage& a = imgs[i < B ? i : 0];
+    bt.v[i].ka = a.keys_a; bt.v[i].va = a.vals_a; bt.v[i].kb = a.keys_b; bt.v[i].vb = a.vals_b;
+    bt.v[i].hist = a.hist; bt.v[i].skip = a.skip;
+  }
+  const int nblocks = (n + RS_TILE - 1) / RS_TILE;
+  const dim3 grid(nblocks, B);
+  hipLaunchKernelGGL(k_rs_init, grid, dim3(RS_BLOCK), 0, st, bt, n);
   ODET_LAUNCH_CHECK();
-  uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
   for (int pass = 0; pass < 4; ++pass) {
-    int shift = pass * 8;
+    const int shift = pass * 8, flip = pass & 1;
     if (pass > 0) {
-      hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, n, shift, hist, skip);
+      hipLaunchKernelGGL(k_rs_hist, grid, dim3(RS_BLOCK), 0, st, bt, n, shift, flip);
       ODET_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_BLOCK), 0, st, kin, vin, n, shift, hist, nblocks, kout,
-                       vout, skip);
+    hipLaunchKernelGGL(k_rs_scatter, grid, dim3(RS_BLOCK), 0, st, bt, n, shift, nblocks, flip);
     ODET_LAUNCH_CHECK();
-    uint32_t* t;
-    t = kin; kin = kout; kout = t;
-    t = vin; vin = vout; vout = t;
   }
-  *sorted_vals = vin;   // == vals_a after 4 passes (keys_a is sorted too)
   return ODET_OK;
+}
+
+// one image; *sorted_vals points at the buffer holding the result (vals_a after an even number of passes)
+int odet_sort_keys_desc(int n, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b,
+                        uint32_t* hist, const int32_t* skip, uint32_t** sorted_vals, hipStream_t st) {
+  const OdetSortImage one{keys_a, vals_a, keys_b, vals_b, hist, skip};
+  const int rc = odet_sort_keys_desc_batch(n, 1, &one, st);
+  *sorted_vals = vals_a;
+  return rc;
 }

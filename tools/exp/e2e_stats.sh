@@ -3,11 +3,11 @@
 # run in the warm-up; the summary splits the time by kernel family.  Run on the GPU box.
 set -u
 cd "$(dirname "$0")/../.."
-out=gpurun_out/e2e_fp32_stats
+out=gpurun_out/e2e_${DT:-fp32}_stats
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 export MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD=0
-timeout -s KILL 900 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 tools/e2e_bench.py --dtype fp32 --batch 4 --steps 40 --warmup 5 --miopen-find > $out/run.log 2>&1
+timeout -s KILL 900 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 tools/e2e_bench.py --dtype ${DT:-fp32} --batch ${BATCH:-4} --steps ${STEPS:-40} --warmup 5 --miopen-find > $out/run.log 2>&1
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*_agent_info.csv" -delete
 tail -3 $out/run.log | cut -c1-600
 f=$(find $out -name "*_kernel_stats.csv" | head -1)
@@ -15,7 +15,7 @@ python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-for r in rows[:28]:
+for r in rows[:40]:
     print('%8.1f ms %6d calls %9.1f us  %5.2f%%  %s' % (float(r['TotalDurationNs']) / 1e6, int(r['Calls']), float(r['AverageNs']) / 1e3,
           100 * float(r['TotalDurationNs']) / tot, r['Name'][:110]))
 print('total %.1f ms' % (tot / 1e6))
