@@ -819,6 +819,62 @@ def test_wide_first_nms_chunk_completes_clustered_scores_in_batched_launches():
             bad.close()
 
 
+def test_batched_full_order_chunks_match_oracle():
+    """Chunks 2.. of a sync-free BATCH (the full radix sort of every image's keys and further 4096-candidate chunks in
+    launches shared by the images, odet_sort_keys_desc_batch): proposals = the anchors grown e-fold with scores that fall
+    along the grid (the best candidates are neighbours and suppress each other ~16 to 1), so chunk 0 + the selection's chunk 1 (~5.6 K
+    candidates) cannot keep K boxes (the oracle's pop count says how many chunks it takes); with 2 sync-free chunks the
+    heavy images report nms_done = 0 and are empty, with enough chunks every image gives the oracle's proposals.  One
+    image has far fewer competitive scores: it finishes EARLY and skips the shared launches."""
+    from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
+    shape, K, ncls, ch, B = (608, 800), 1000, 21, 8, 3
+    sets = []
+    for i in range(B):
+        host, dev = synthetic_fpn_inputs(shape, ncls, K, channels=ch, seed=900 + i)
+        host = dict(host); dev = dict(dev)
+        d = np.zeros_like(host['rpn_deltas'])
+        if i != 1:
+            # boxes e times the anchors, scores falling with the anchor index (+ a little noise): the best candidates
+            # are neighbours on the P2 grid and suppress each other ~16 to 1
+            d[:, 2:] = 1.0
+            lg = np.zeros_like(host['rpn_logits'])
+            lg[:, 1] = -2e-4 * np.arange(lg.shape[0], dtype=np.float32) + np.random.default_rng(i).normal(0, 1e-3, lg.shape[0]).astype(np.float32)
+            host['rpn_logits'] = lg
+            dev['rpn_logits'] = g(lg)
+        host['rpn_deltas'] = d
+        dev['rpn_deltas'] = g(d)
+        sets.append((host, dev))
+    anchors = co.fpn_anchors(shape)
+    wants, popped = [], []
+    for host, _ in sets:
+        fg = co.rpn_fg_fpn(host['rpn_logits'])
+        _, idx, stats = co.region_proposal(host['rpn_deltas'], anchors, fg, shape, K, 0.7, return_stats=True)
+        wants.append(idx)
+        popped.append(int(stats[0]))
+    assert popped[0] > 1536 + 4096 and popped[2] > 1536 + 4096 and popped[1] < 1536 + 4096, popped
+    enough = 2 + (max(popped) - 1536 - 4096 + 4095) // 4096 + 1
+    for blind in (2, enough):
+        pool = FpnStreamPool(1, shape, ncls, K, ch, batch=B, blind_chunks=blind)
+        try:
+            for k, (_, dev) in enumerate(sets):
+                pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+            pool.submit_group(0)
+            pool.wait()
+            torch.cuda.synchronize()
+            dones = [int(pool.slots[k].nms_done.item()) == 1 for k in range(B)]
+            assert dones == ([False, True, False] if blind == 2 else [True, True, True]), (blind, dones, popped)
+            for k in range(B):
+                slot = pool.slots[k]
+                m = int(slot.roi_count.item())
+                if dones[k]:
+                    assert m == len(wants[k])
+                    np.testing.assert_array_equal(h(slot.roi_idx[:m]), wants[k])
+                else:
+                    assert m == 0
+        finally:
+            pool.close()
+
+
 def test_nms_sync_free_chunks_from_selection_then_full_order():
     """Sync-free jobs: chunk 1 comes from the ranked radix selection (no sort), chunks 2.. from the full order per
     image; exhausted selections (massive ties: the boundary bin cannot be split) and dense suppression included."""
