@@ -645,6 +645,35 @@ def test_conv3x3_f16_implicit_gemm(B, H, W, cin, cout):
     assert torch.equal(out, got)
 
 
+def _conv3x3_tile_height(Ms, tiles_n):
+    """mirror of conv3x3_launch's choice of the pixel-tile height (csrc/conv3x3.hip): 16-pixel tiles per wave"""
+    best, mt_best = 1e300, 8
+    for mt in range(8, 3, -1):
+        slabs = sum((M + 32 * mt - 1) // (32 * mt) for M in Ms)
+        blocks = (slabs + 7) // 8 * 8 * tiles_n
+        cost = ((blocks + 255) // 256) * (mt + 2)
+        if cost < best * 0.97:
+            best, mt_best = cost, mt
+    return mt_best
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,mt', [(20, 84, 4), (328, 100, 5), (209, 200, 6), (300, 167, 7), (349, 167, 8)])
+def test_conv3x3_f16_every_tile_height(H, W, mt):
+    """the five instantiations of k_conv3x3_f16 (128 / 160 / 192 / 224 / 256-pixel workgroup tiles, picked per launch
+    so that the slabs fill whole rounds of the 256 CUs): exact on integer-valued data, the last slab ending inside a
+    tile, zero padding at the borders"""
+    from tf_eager_object_detection_amd import ops
+    assert _conv3x3_tile_height([H * W], 1) == mt
+    g = torch.Generator(device='cuda')
+    g.manual_seed(H)
+    x = torch.randint(-3, 4, (1, H, W, 64), device='cuda', generator=g).half()
+    w = torch.randint(-2, 3, (256, 64, 3, 3), device='cuda', generator=g).half().contiguous(memory_format=torch.channels_last)
+    got = ops.conv3x3_f16(x, w)
+    want = F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), None, 1, 1).permute(0, 2, 3, 1)
+    assert torch.equal(got.float(), want.half().float())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,H,W,cin,cout', [(1, 13, 21, 256, 512), (2, 25, 42, 96, 256), (3, 7, 5, 32, 256),
                                              (1, 100, 167, 256, 512)])

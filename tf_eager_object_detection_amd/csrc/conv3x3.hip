@@ -55,7 +55,12 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   int tiles_n;                    // cout / 256
 };
 
+// MT = 16-pixel tiles per wave: the workgroup tile is TM = 32 * MT pixels (MT = 8: 256; smaller tiles for launches
+// whose 256-pixel slabs would fill a fraction of a round of the 256 CUs -- chosen on the host, conv3x3_pick_mt).
+template <int MT>
 __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
+  constexpr int TM = 32 * MT;                            // pixels of the workgroup tile
+  constexpr int XP = (MT + 1) / 2;                       // pixel pieces (8 rows x 128 B) per wave: TM / 8 over 8 waves
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -82,15 +87,15 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   const uint32_t wrowB = 9u * pixB;                      // bytes per weight row [tap][cin]
   const c3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, (int)((uint32_t)cout * wrowB),
                                                          0x00020000);
-  // ---- what this thread copies per K-step: 4 pieces of A (8 pixels x 128 B each) and 4 of W
+  // ---- what this thread copies per K-step: its pieces of A (8 pixels x 128 B each; piece wv + 8 i) and 4 of W
   const int sub = lane >> 3;                             // row of the 8-row piece
   const uint32_t slot = (uint32_t)((lane & 7) ^ sub) * 16u;   // logical 16-byte slot this lane fetches (XOR swizzle)
-  uint32_t voffA[4], voffW[4];
-  uint32_t maskA[4];                                     // bit tap: the tap of this lane's pixel is inside the map
+  uint32_t voffA[XP], voffW[4];
+  uint32_t maskA[XP];                                    // bit tap: the tap of this lane's pixel is inside the map
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wv * 4 + i) * 8 + sub;              // 0..255
-    const long long m = tile_m * C3_TM + row;
+  for (int i = 0; i < XP; ++i) {
+    const int row = (wv + 8 * i) * 8 + sub;              // 0..TM-1 (pieces beyond the tile are never issued)
+    const long long m = tile_m * TM + row;
     uint32_t mk = 0;
     if (m < M) {
       const long long img = m / ((long long)H * W);
@@ -104,6 +109,10 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     }
     maskA[i] = mk;
     voffA[i] = (uint32_t)m * pixB + slot;                // (+ the tap / chunk offset as soffset; PAD is in the base)
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wv * 4 + i) * 8 + sub;              // 0..255
     // LDS row rho of the W tile <- channel: rows 16 t + r of a 64-channel group hold channel 16 (r >> 2) + 4 t + (r & 3)
     const int g = row >> 6, rr = row & 63, t = rr >> 4, r = rr & 15;
     const int ch = tn * C3_TN + g * 64 + 16 * (r >> 2) + 4 * t + (r & 3);
@@ -121,26 +130,29 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     a.stage = stage;
     return a;
   };
-  auto issue_piece = [&](const IssueAt& a, int i) {       // pieces i = 0..3: 1 KB of pixels + 1 KB of weights each
-    const uint32_t pc = (uint32_t)(wv * 4 + i) * 1024u;
-    const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + pc), 16, (int)va, (int)a.soA, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + pc), 16, (int)voffW[i],
-                                             (int)a.soW, 0, 0);
-  };
-  auto issue = [&](int ks, uint32_t stage) {
+  auto issue = [&](int ks, uint32_t stage) {              // 1 KB pieces: this wave's share of the pixel rows + 4 of weights
     const IssueAt a = issue_at(ks, stage);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(a, i);
+    for (int i = 0; i < XP; ++i) {
+      if ((MT & 1) == 0 || i + 1 < XP || wv < 4) {         // (odd MT: the last piece exists for waves 0-3 only)
+        const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + 8 * i) * 1024u), 16, (int)va,
+                                                 (int)a.soA, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + (uint32_t)(wv * 4 + i) * 1024u), 16,
+                                               (int)voffW[i], (int)a.soW, 0, 0);
   };
   // ---- fragment addresses (bytes inside a stage)
   const int l15 = lane & 15, lq = lane >> 4;
   const uint32_t fslot = (uint32_t)(lq ^ (lane & 7)) * 16u;                         // K half 0; half 1 = ^ 64
-  const uint32_t xoff = (uint32_t)(wm * 128 + l15) * 128u + fslot;                  // + mt * 2048
+  const uint32_t xoff = (uint32_t)(wm * 16 * MT + l15) * 128u + fslot;              // + mt * 2048
   const uint32_t woff = C3_TM * 128u + (uint32_t)(wn * 64 + l15) * 128u + fslot;    // + t * 2048
-  f4 acc[8][4];
+  f4 acc[MT][4];
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mt][t] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -148,19 +160,19 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   // issued BEFORE the barrier that publishes stage ks + 1, so the matrix pipe has half a step of work queued while the
   // waves meet, the next DMA is issued and the first fragments of step ks + 1 come out of LDS -- the burst of LDS reads
   // right after a barrier no longer leaves the MFMAs waiting.
-  auto read_frags = [&](const unsigned char* sb, uint32_t kx, h8 (&wf)[4], h8 (&xf)[8]) {
+  auto read_frags = [&](const unsigned char* sb, uint32_t kx, h8 (&wf)[4], h8 (&xf)[MT]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const h8*>(sb + ((woff + (uint32_t)t * 2048u) ^ kx));
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) xf[mt] = *reinterpret_cast<const h8*>(sb + ((xoff + (uint32_t)mt * 2048u) ^ kx));
+    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const h8*>(sb + ((xoff + (uint32_t)mt * 2048u) ^ kx));
   };
-  auto mfmas = [&](const h8 (&wf)[4], const h8 (&xf)[8]) {
+  auto mfmas = [&](const h8 (&wf)[4], const h8 (&xf)[MT]) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[mt], acc[mt][t], 0, 0, 0);
   };
-  h8 wf0[4], xf0[8], wf1[4], xf1[8];
+  h8 wf0[4], xf0[MT], wf1[4], xf1[MT];
   issue(0, 0u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -207,8 +219,8 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) bv[e] = p.bias ? (float)p.bias[c0 + e] : 0.0f;
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const long long m = tile_m * C3_TM + wm * 128 + mt * 16 + l15;
+  for (int mt = 0; mt < MT; ++mt) {
+    const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
     if (m < M) {
       h8 o[2];
 #pragma unroll
@@ -385,7 +397,12 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   static std::once_flag once;
   static hipError_t once_rc = hipSuccess;
   std::call_once(once, [] {
-    once_rc = hipFuncSetAttribute((const void*)k_conv3x3_f16, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+    const void* ks_[5] = {(const void*)k_conv3x3_f16<4>, (const void*)k_conv3x3_f16<5>, (const void*)k_conv3x3_f16<6>,
+                          (const void*)k_conv3x3_f16<7>, (const void*)k_conv3x3_f16<8>};
+    for (const void* k_ : ks_) {
+      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+      if (e_ != hipSuccess) once_rc = e_;
+    }
   });
   ODET_HIP(once_rc);
   Conv3x3Params p;
@@ -398,18 +415,42 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
     ODET_REQUIRE((unsigned long long)M * cin * 2ull + 2ull * (L.W + 1) * cin * 2ull < 0xFFFFFFF0ull,
                  "odet_conv3x3_f16: level %d input larger than 4 GiB", l);
     p.x[l] = (const _Float16*)L.x; p.y[l] = (_Float16*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
+  }
+  p.tiles_n = cout / C3_TN;
+  // Pixel-tile height: the launch runs in rounds of 256 workgroups (one per CU: 128 KB of LDS each), so a layer whose
+  // 256-pixel slabs fill a round badly (ResNet's conv4 at batch 8: 132 slabs) is cut into 128 .. 224-pixel slabs
+  // instead.  Cost model: rounds x (MT + 2) (a workgroup's time is its MT pixel tiles + the weight traffic they share).
+  int mt_best = 8;
+  {
+    double best = 1e300;
+    for (int mt = 8; mt >= 4; --mt) {
+      long long slabs = 0;
+      for (int l = 0; l < num_levels; ++l) slabs += (p.M[l] + 32 * mt - 1) / (32 * mt);
+      const long long blocks_mt = (slabs + 7) / 8 * 8 * p.tiles_n;
+      const double cost = (double)((blocks_mt + 255) / 256) * (mt + 2);
+      if (cost < best * 0.97) { best = cost; mt_best = mt; }       // (smaller tiles only for a clear gain)
+    }
+  }
+  const int TMsel = 32 * mt_best;
+  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     p.tile_start[l] = total;
-    if (l < num_levels) total += (M + C3_TM - 1) / C3_TM;
+    if (l < num_levels) total += (p.M[l] + TMsel - 1) / TMsel;
   }
   p.tile_start[ODET_MAX_LEVELS] = total;
   for (int l = num_levels; l <= ODET_MAX_LEVELS; ++l) p.tile_start[l] = total;
   p.w = (const _Float16*)w; p.bias = (const _Float16*)bias;
   p.num_levels = num_levels; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
-  p.tiles_n = cout / C3_TN;
   const long long groups = (total + 7) / 8;
   const long long blocks = groups * 8 * p.tiles_n;
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
-  hipLaunchKernelGGL(k_conv3x3_f16, dim3((unsigned)blocks), dim3(512), C3_LDS_BYTES, st, p);
+  const dim3 grid((unsigned)blocks);
+  switch (mt_best) {
+    case 4: hipLaunchKernelGGL(k_conv3x3_f16<4>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
+    case 5: hipLaunchKernelGGL(k_conv3x3_f16<5>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
+    case 6: hipLaunchKernelGGL(k_conv3x3_f16<6>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
+    case 7: hipLaunchKernelGGL(k_conv3x3_f16<7>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
+    default: hipLaunchKernelGGL(k_conv3x3_f16<8>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
+  }
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }

@@ -24,3 +24,10 @@ for rep in range(2):
 fl = 2.0 * B * 200 * 334 * 512 * 2304
 res['P2_tflops'] = round(fl / min(res['P2_ms_0'], res['P2_ms_1']) / 1e9)
 print(json.dumps(res))
+# mid-size layers (where the pixel-tile height matters): ResNet conv4 c2 / neck s4, neck s3, C4 RPN, VGG
+for name, (h, wd, cin, cout) in (('conv4_c2', (50, 84, 256, 256)), ('neck_s3', (100, 167, 256, 256)), ('neck_s2', (200, 334, 256, 256)),
+                                 ('c4_rpn', (50, 84, 1024, 512)), ('vgg_conv4', (75, 100, 512, 512)), ('conv5_c2', (25, 42, 512, 512))):
+    x = torch.randn(B, h, wd, cin, device='cuda').half()
+    ww = (torch.randn(cout, cin, 3, 3, device='cuda') * 0.01).half().contiguous(memory_format=torch.channels_last)
+    t = timed(lambda: ops.conv3x3_f16(x, ww))
+    print(name, round(t * 1e3, 1), 'us', round(2.0 * B * h * wd * cout * 9 * cin / t / 1e9), 'TFLOP/s')
