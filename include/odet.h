@@ -350,7 +350,7 @@ int odet_bias_relu_maxpool(const void* x, const void* bias, void* out, int B, in
  * (model/fpn/base_fpn_model.py:401-417, model/faster_rcnn/base_faster_rcnn_model.py:315-321): x NHWC float16
  * [batch,H,W,cin], w float16 [cout][3][3][cin] (= a channels_last torch weight), y NHWC float16 [batch,H,W,cout],
  * float32 accumulation; bias (nullable, float16 [cout]) and relu are applied before the one rounding.
- * cin % 64 == 0, cout % 256 == 0. */
+ * cin % 64 == 0, cout % 64 == 0 (256-channel workgroup tiles; 128 / 64-channel tiles when cout is not a multiple of 256). */
 int odet_conv3x3_f16(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
                      int cin, int cout, int relu, odet_stream_t stream);
 /* the same convolution (shared weights) over up to ODET_MAX_LEVELS maps in ONE launch -- the RpnHead over the pyramid

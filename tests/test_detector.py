@@ -617,7 +617,9 @@ def test_detector_incomplete_nms_is_flagged_never_silent():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,H,W,cin,cout', [(1, 13, 21, 256, 512), (2, 25, 42, 256, 512), (1, 50, 84, 64, 256),
-                                             (3, 7, 5, 128, 256), (1, 100, 167, 256, 512)])
+                                             (3, 7, 5, 128, 256), (1, 100, 167, 256, 512), (2, 50, 84, 64, 64),
+                                             (1, 100, 167, 128, 128), (2, 31, 45, 64, 192), (1, 200, 334, 64, 64),
+                                             (1, 160, 167, 128, 128), (1, 113, 100, 64, 384)])
 def test_conv3x3_f16_implicit_gemm(B, H, W, cin, cout):
     """odet_conv3x3_f16 (the RpnHead's 3x3 convolution as a hand-written implicit GEMM on the matrix cores,
     base_fpn_model.py:401-417): EXACT on integer-valued data (every product and partial sum is an integer below 2^24, so

@@ -55,17 +55,22 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   int tiles_n;                    // cout / 256
 };
 
-// MT = 16-pixel tiles per wave: the workgroup tile is TM = 32 * MT pixels (MT = 8: 256; smaller tiles for launches
-// whose 256-pixel slabs would fill a fraction of a round of the 256 CUs -- chosen on the host, conv3x3_pick_mt).
-template <int MT>
+// WN = waves along the channels (4: 256-channel tile, the form described above; 2 / 1: 128 / 64-channel tiles for the
+// layers with fewer output channels, the other 8 / WN waves along the pixels); MT = 16-pixel tiles per wave: the
+// workgroup tile is TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels (WN = 4, MT = 8: 256 x 256; smaller MT for
+// launches whose slabs would fill a fraction of a round of the 256 CUs -- chosen on the host, conv3x3_launch).
+template <int MT, int WN>
 __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
-  constexpr int TM = 32 * MT;                            // pixels of the workgroup tile
-  constexpr int XP = (MT + 1) / 2;                       // pixel pieces (8 rows x 128 B) per wave: TM / 8 over 8 waves
+  constexpr int WM = 8 / WN;                             // waves along the pixels
+  constexpr int TM = WM * 16 * MT;                       // pixels of the workgroup tile (<= 256)
+  constexpr int TN = 64 * WN;                            // channels of the workgroup tile
+  constexpr int XP = (TM / 8 + 7) / 8;                   // pixel pieces (8 rows x 128 B) per wave: TM / 8 over 8 waves
+  static_assert(TM <= C3_TM && TM % 8 == 0, "tile");
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 2, wn = wv & 3;
+  const int wm = wv / WN, wn = wv % WN;
   // workgroup -> (pixel slab, channel tile): the channel tiles of a slab on one XCD
   const long long blk = blockIdx.x;
   const long long q8 = blk >> 3;
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   // ---- what this thread copies per K-step: its pieces of A (8 pixels x 128 B each; piece wv + 8 i) and 4 of W
   const int sub = lane >> 3;                             // row of the 8-row piece
   const uint32_t slot = (uint32_t)((lane & 7) ^ sub) * 16u;   // logical 16-byte slot this lane fetches (XOR swizzle)
-  uint32_t voffA[XP], voffW[4];
+  uint32_t voffA[XP], voffW[WN];
   uint32_t maskA[XP];                                    // bit tap: the tap of this lane's pixel is inside the map
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
@@ -111,11 +116,11 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     voffA[i] = (uint32_t)m * pixB + slot;                // (+ the tap / chunk offset as soffset; PAD is in the base)
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wv * 4 + i) * 8 + sub;              // 0..255
+  for (int i = 0; i < WN; ++i) {
+    const int row = (wv * WN + i) * 8 + sub;             // 0..TN-1
     // LDS row rho of the W tile <- channel: rows 16 t + r of a 64-channel group hold channel 16 (r >> 2) + 4 t + (r & 3)
     const int g = row >> 6, rr = row & 63, t = rr >> 4, r = rr & 15;
-    const int ch = tn * C3_TN + g * 64 + 16 * (r >> 2) + 4 * t + (r & 3);
+    const int ch = tn * TN + g * 64 + 16 * (r >> 2) + 4 * t + (r & 3);
     voffW[i] = (uint32_t)ch * wrowB + slot;
   }
   const int chunks = cin / C3_BK;
@@ -134,15 +139,15 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     const IssueAt a = issue_at(ks, stage);
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-      if ((MT & 1) == 0 || i + 1 < XP || wv < 4) {         // (odd MT: the last piece exists for waves 0-3 only)
+      if ((wv + 8 * i) * 8 < TM) {                         // (TM / 8 not a multiple of 8: the last piece exists for the first waves only)
         const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + 8 * i) * 1024u), 16, (int)va,
                                                  (int)a.soA, 0, 0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + (uint32_t)(wv * 4 + i) * 1024u), 16,
+    for (int i = 0; i < WN; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + (uint32_t)(wv * WN + i) * 1024u), 16,
                                                (int)voffW[i], (int)a.soW, 0, 0);
   };
   // ---- fragment addresses (bytes inside a stage)
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     mfmas(wf1, xf1);
   }
   // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
-  const int c0 = tn * C3_TN + wn * 64 + lq * 16;
+  const int c0 = tn * TN + wn * 64 + lq * 16;
   float bv[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) bv[e] = p.bias ? (float)p.bias[c0 + e] : 0.0f;
@@ -392,13 +397,15 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_f16: num_levels %d out of range", num_levels);
   ODET_REQUIRE(batch > 0, "odet_conv3x3_f16: bad batch");
   ODET_REQUIRE(cin > 0 && cin % C3_BK == 0, "odet_conv3x3_f16: cin %d must be a multiple of %d", cin, C3_BK);
-  ODET_REQUIRE(cout > 0 && cout % C3_TN == 0, "odet_conv3x3_f16: cout %d must be a multiple of %d", cout, C3_TN);
+  ODET_REQUIRE(cout > 0 && cout % 64 == 0, "odet_conv3x3_f16: cout %d must be a multiple of 64", cout);
   ODET_REQUIRE((unsigned long long)cout * 9ull * cin * 2ull < 0x7FFFFFFFull, "odet_conv3x3_f16: weights too large");
   static std::once_flag once;
   static hipError_t once_rc = hipSuccess;
   std::call_once(once, [] {
-    const void* ks_[5] = {(const void*)k_conv3x3_f16<4>, (const void*)k_conv3x3_f16<5>, (const void*)k_conv3x3_f16<6>,
-                          (const void*)k_conv3x3_f16<7>, (const void*)k_conv3x3_f16<8>};
+    const void* ks_[10] = {(const void*)k_conv3x3_f16<4, 4>, (const void*)k_conv3x3_f16<5, 4>, (const void*)k_conv3x3_f16<6, 4>,
+                           (const void*)k_conv3x3_f16<7, 4>, (const void*)k_conv3x3_f16<8, 4>, (const void*)k_conv3x3_f16<2, 2>,
+                           (const void*)k_conv3x3_f16<3, 2>, (const void*)k_conv3x3_f16<4, 2>, (const void*)k_conv3x3_f16<1, 1>,
+                           (const void*)k_conv3x3_f16<2, 1>};
     for (const void* k_ : ks_) {
       const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
       if (e_ != hipSuccess) once_rc = e_;
@@ -416,22 +423,28 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
                  "odet_conv3x3_f16: level %d input larger than 4 GiB", l);
     p.x[l] = (const _Float16*)L.x; p.y[l] = (_Float16*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
   }
-  p.tiles_n = cout / C3_TN;
+  // Channel tile: 256 (four waves along the channels), or 128 / 64 for the layers with fewer output channels.
+  const int wn_sel = (cout % 256 == 0) ? 4 : (cout % 128 == 0 ? 2 : 1);
+  const int wm_sel = 8 / wn_sel;
+  p.tiles_n = cout / (64 * wn_sel);
   // Pixel-tile height: the launch runs in rounds of 256 workgroups (one per CU: 128 KB of LDS each), so a layer whose
   // 256-pixel slabs fill a round badly (ResNet's conv4 at batch 8: 132 slabs) is cut into 128 .. 224-pixel slabs
-  // instead.  Cost model: rounds x (MT + 2) (a workgroup's time is its MT pixel tiles + the weight traffic they share).
-  int mt_best = 8;
+  // instead.  Cost model: rounds x (pixel tiles + 2) (a workgroup's time is its pixel tiles + the weight traffic they
+  // share).
+  const int mt_hi = 16 / wm_sel, mt_lo = 8 / wm_sel;          // TM = wm * 16 * mt in 128 .. 256
+  int mt_best = mt_hi;
   {
     double best = 1e300;
-    for (int mt = 8; mt >= 4; --mt) {
+    for (int mt = mt_hi; mt >= mt_lo; --mt) {
+      const int tm = wm_sel * 16 * mt;
       long long slabs = 0;
-      for (int l = 0; l < num_levels; ++l) slabs += (p.M[l] + 32 * mt - 1) / (32 * mt);
+      for (int l = 0; l < num_levels; ++l) slabs += (p.M[l] + tm - 1) / tm;
       const long long blocks_mt = (slabs + 7) / 8 * 8 * p.tiles_n;
-      const double cost = (double)((blocks_mt + 255) / 256) * (mt + 2);
+      const double cost = (double)((blocks_mt + 255) / 256) * (tm / 32 + 2);
       if (cost < best * 0.97) { best = cost; mt_best = mt; }       // (smaller tiles only for a clear gain)
     }
   }
-  const int TMsel = 32 * mt_best;
+  const int TMsel = wm_sel * 16 * mt_best;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     p.tile_start[l] = total;
     if (l < num_levels) total += (p.M[l] + TMsel - 1) / TMsel;
@@ -444,13 +457,20 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   const long long blocks = groups * 8 * p.tiles_n;
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
   const dim3 grid((unsigned)blocks);
-  switch (mt_best) {
-    case 4: hipLaunchKernelGGL(k_conv3x3_f16<4>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
-    case 5: hipLaunchKernelGGL(k_conv3x3_f16<5>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
-    case 6: hipLaunchKernelGGL(k_conv3x3_f16<6>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
-    case 7: hipLaunchKernelGGL(k_conv3x3_f16<7>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
-    default: hipLaunchKernelGGL(k_conv3x3_f16<8>, grid, dim3(512), C3_LDS_BYTES, st, p); break;
+#define C3_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_>), grid, dim3(512), C3_LDS_BYTES, st, p)
+  switch (wn_sel * 16 + mt_best) {
+    case 4 * 16 + 4: C3_LAUNCH(4, 4); break;
+    case 4 * 16 + 5: C3_LAUNCH(5, 4); break;
+    case 4 * 16 + 6: C3_LAUNCH(6, 4); break;
+    case 4 * 16 + 7: C3_LAUNCH(7, 4); break;
+    case 4 * 16 + 8: C3_LAUNCH(8, 4); break;
+    case 2 * 16 + 2: C3_LAUNCH(2, 2); break;
+    case 2 * 16 + 3: C3_LAUNCH(3, 2); break;
+    case 2 * 16 + 4: C3_LAUNCH(4, 2); break;
+    case 1 * 16 + 1: C3_LAUNCH(1, 1); break;
+    default: C3_LAUNCH(2, 1); break;
   }
+#undef C3_LAUNCH
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }

@@ -139,7 +139,7 @@ def _route_1x1(conv, x, bias, relu, res):
 
 def _own_conv3x3(conv, x, pad=None):
     """True when the hand-written implicit-GEMM kernel (ops.conv3x3_f16) takes this 3x3 convolution: float16 NHWC,
-    stride 1, padding 1, cin % 64 == 0, cout % 256 == 0, and enough output tiles to fill the chip (the kernel cuts the
+    stride 1, padding 1, cin % 64 == 0, cout % 128 == 0, and enough output tiles to fill the chip (the kernel cuts the
     pixels into 128 .. 256-row slabs; measured on the detectors' layer shapes at batch 1 / 4 / 8,
     tools/exp/conv3x3_layers.py: 1.3-1.9x ahead of the library from ~100 workgroups of the smallest tile on, behind it
     on the small maps)."""
@@ -147,12 +147,15 @@ def _own_conv3x3(conv, x, pad=None):
         return False
     if tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1):
         return False
-    if conv.in_channels % 64 != 0 or conv.out_channels % 256 != 0:
+    # (64-channel tiles exist in the kernel, but ResNet's 64 -> 64 layer is faster in the library: 83 vs 121 us at batch 8)
+    if conv.in_channels % 64 != 0 or conv.out_channels % 128 != 0:
         return False
     if not x.is_contiguous(memory_format=torch.channels_last):
         return False
     m = int(x.shape[0]) * int(x.shape[2]) * int(x.shape[3])
-    return _CONV3X3_MODE == 'force' or ((m + 127) // 128) * (conv.out_channels // 256) >= 100
+    co = conv.out_channels
+    tiles_n = co // 256 if co % 256 == 0 else (co // 128 if co % 128 == 0 else co // 64)
+    return _CONV3X3_MODE == 'force' or ((m + 127) // 128) * tiles_n >= 100
 
 
 def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=None):

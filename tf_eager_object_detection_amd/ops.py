@@ -487,7 +487,7 @@ def conv3x3_f16(x, weight, bias=None, relu=False, out=None):
     convolution, base_fpn_model.py:401-417): ``x`` NHWC float16 contiguous [B,H,W,cin]; ``weight`` float16
     [cout,cin,3,3] in channels_last memory format (= [cout][3][3][cin]: `w.contiguous(memory_format=channels_last)`)
     or an explicit [cout,3,3,cin] tensor; ``bias`` float16 [cout] or None; -> NHWC float16 [B,H,W,cout].
-    cin % 64 == 0, cout % 256 == 0."""
+    cin % 64 == 0, cout % 64 == 0 (256-channel tiles; 128 / 64-channel tiles when cout is not a multiple of 256)."""
     return _conv3x3(torch.float16, x, weight, bias, relu, out)
 
 

@@ -17,7 +17,7 @@ def timed(fn, n=20):
     b.record(); b.synchronize()
     return a.elapsed_time(b) / n
 res = {}
-for name, h, wd, cin, cout in (('rpn_p2', 200, 334, 256, 512), ('rpn_p3', 100, 167, 256, 512), ('neck_s2', 200, 334, 256, 256), ('neck_s3', 100, 167, 256, 256), ('neck_s4', 50, 84, 256, 256),
+for name, h, wd, cin, cout in (('rpn_p2', 200, 334, 256, 512), ('rpn_p3', 100, 167, 256, 512), ('conv2_c2 (x3)', 200, 334, 64, 64), ('conv3_c2 (x4)', 100, 167, 128, 128), ('neck_s2', 200, 334, 256, 256), ('neck_s3', 100, 167, 256, 256), ('neck_s4', 50, 84, 256, 256),
                                ('conv4_c2 (x23)', 50, 84, 256, 256), ('conv5_c2 (x3)', 25, 42, 512, 512),
                                ('c4_rpn', 50, 84, 1024, 512), ('vgg_rpn 600x800', 38, 50, 512, 512),
                                ('vgg conv4 600x800', 75, 100, 512, 512), ('vgg conv3 600x800', 150, 200, 256, 256)):
