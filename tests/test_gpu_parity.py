@@ -352,13 +352,24 @@ def test_roi_pooling_layers_match_oracle_bit_exact():
     assert RoiPoolingCropAndResize(7)((fg, g(rois[:0]), 16)).shape == (0, 7, 7, 64)
 
 
-@pytest.mark.parametrize('C', [4, 256, 512, 1024])
-def test_roi_pool_channel_counts(C):
-    rng = np.random.default_rng(C)
+@pytest.mark.parametrize('C,n', [(4, 40), (256, 40), (512, 40), (1024, 40), (512, 2100), (768, 2050), (260, 40)])
+def test_roi_pool_channel_counts(C, n):
+    """channel counts around the kernel's 256-channel slices: one slice; several slices with one workgroup per
+    (RoI, slice) (launches of fewer than 2048 RoIs) or one workgroup per RoI looping over them (n >= 2048), both with
+    the register carry between neighbouring bins; a count that is not a multiple of 256 (the plain walk); float16 maps
+    take the same launch shapes."""
+    rng = np.random.default_rng(C + n)
     feat = _feat((20, 30), C, rng)
-    rois = syn.random_boxes(40, (320, 480), rng, 8, 300)
-    got = h(ops.roi_pool([g(feat)], g(rois), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_MAX2, strides=[16.0]))
-    np.testing.assert_array_equal(got, co.roi_pool(feat, rois, stride=16, pool=7, max_pool=True))
+    rois = syn.random_boxes(n, (320, 480), rng, 8, 300)
+    for pool in (ops.ROI_POOL_MAX2, ops.ROI_POOL_NONE):
+        got = h(ops.roi_pool([g(feat)], g(rois), None, ops.ROI_NORM_STRIDE, 7, pool, strides=[16.0]))
+        np.testing.assert_array_equal(got, co.roi_pool(feat, rois, stride=16, pool=7, max_pool=pool == ops.ROI_POOL_MAX2,
+                                                       threads=8))
+    if C % 8 == 0 and n <= 100:
+        f16 = feat.astype(np.float16)
+        got = ops.roi_pool([g(f16)], g(rois), None, ops.ROI_NORM_STRIDE, 7, ops.ROI_POOL_MAX2, strides=[16.0])
+        want = co.roi_pool(f16.astype(np.float32), rois, stride=16, pool=7, max_pool=True).astype(np.float16)
+        np.testing.assert_array_equal(h(got).view(np.uint16), want.view(np.uint16))
 
 
 def test_fpn_roi_path_full_size():
