@@ -362,6 +362,18 @@ typedef struct {
 } odet_conv_level_t;
 int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
                             int batch, int cin, int cout, int relu, odet_stream_t stream);
+/* The whole RpnHead (base_fpn_model.py:393-434, 188-200): the 3x3 convolution of every level as above, and in its
+ * epilogue relu(conv + conv_b) (one float16 rounding) . w^T + b for the 2A score and 4A delta rows (w [6A][cout] float16,
+ * b [6A] float16: rpn_score's rows, then rpn_bbox's), written as float32 into the concatenated arrays scores
+ * [batch][N][2] / deltas [batch][N][4] (image strides in VALUES; the levels follow each other in the order given, H*W*A
+ * anchors each).  levels[].y is not used: the cout-channel activation never goes to memory -- the channel tiles of a
+ * pixel slab leave 32 float32 partial sums per pixel in the workspace and a second, small launch adds them (fixed
+ * order: deterministic) with the bias.  cout = 256 or 512, 1 <= A <= 5. */
+size_t odet_rpn_head_fused_workspace_bytes(const odet_conv_level_t* levels, int num_levels, int batch, int cout);
+int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_levels, const void* conv_w, const void* conv_b,
+                            const void* w, const void* b, int A, int batch, int cin, int cout, float* scores,
+                            long long scores_image_stride, float* deltas, long long deltas_image_stride,
+                            void* workspace, size_t workspace_bytes, odet_stream_t stream);
 /* the float32 forms (the detectors' parity mode computes in the reference's precision): float32 x / w / bias / y,
  * exact-float32 MFMA (v_mfma_f32_16x16x4_f32), cin % 32 == 0, cout % 256 == 0 */
 int odet_conv3x3_f32(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,

@@ -740,3 +740,66 @@ def test_fp32_rpn_head_own_conv_matches_library_route(monkeypatch):
     scale = max(1.0, float(s_lib.abs().max().item()), float(d_lib.abs().max().item()))
     assert float((s_own - s_lib).abs().max().item()) <= 1e-4 * scale
     assert float((d_own - d_lib).abs().max().item()) <= 1e-4 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,A,cin,cout,shapes', [(2, 3, 256, 512, [(50, 84), (25, 42), (13, 21), (7, 11), (4, 6)]),
+                                               (1, 3, 64, 512, [(100, 167)]), (3, 4, 128, 256, [(20, 31), (9, 9)]),
+                                               (1, 1, 64, 512, [(37, 53)])])
+def test_rpn_head_fused_matches_the_two_pass_form(B, A, cin, cout, shapes):
+    """odet_rpn_head_fused_f16 (the RpnHead's 3x3 convolution with the two 1x1 convolutions in its epilogue, all levels
+    in one launch, the 512-channel activation never written): EXACT on integer-valued data chosen so that every
+    intermediate is an integer below 2048 (float16-exact: the fused form rounds relu(conv + bias) once, the two-pass form
+    rounds the convolution first); on random data within float16 rounding of the float32 torch formulation and of the
+    two-pass form (ops.conv3x3_f16_levels + ops.rpn_head_tail); deterministic, and every element of the pre-filled
+    output arrays is overwritten (the channel tiles' partial sums meet in a second small launch, no atomics)."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(B * 100 + A)
+    n = sum(h * w for h, w in shapes) * A
+
+    def reference(xs, w3, b3, w1, b1):
+        sc, dl = [], []
+        for x in xs:
+            t = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w3.float(), b3.float(), 1, 1)).half().float()
+            o = F.conv2d(t, w1.float().reshape(6 * A, cout, 1, 1), b1.float()).permute(0, 2, 3, 1)      # [B,h,w,6A]
+            sc.append(o[..., :2 * A].reshape(B, -1, 2))
+            dl.append(o[..., 2 * A:].reshape(B, -1, 4))
+        return torch.cat(sc, 1), torch.cat(dl, 1)
+
+    # integer data: |conv| <= 9 * cin * 1 * 1 would exceed 2048 for cin = 256 -> sparse operands keep it small
+    xs = [(torch.randint(0, 100, (B, h, w, cin), device='cuda', generator=g) < 3).half() for h, w in shapes]
+    w3 = (torch.randint(0, 100, (cout, cin, 3, 3), device='cuda', generator=g) < 4).half()
+    w3 = (w3 * torch.randint(-2, 3, w3.shape, device='cuda', generator=g).half()).contiguous(memory_format=torch.channels_last)
+    b3 = torch.randint(-3, 4, (cout,), device='cuda', generator=g).half()
+    w1 = ((torch.randint(0, 100, (6 * A, cout), device='cuda', generator=g) < 10).half()
+          * torch.randint(-2, 3, (6 * A, cout), device='cuda', generator=g).half())
+    b1 = torch.randint(-3, 4, (6 * A,), device='cuda', generator=g).half()
+    scores = torch.full((B, n, 2), 7.0, device='cuda')
+    deltas = torch.full((B, n, 4), 7.0, device='cuda')
+    ops.rpn_head_fused(xs, w3, b3, w1, b1, A, scores, deltas)
+    ws, wd = reference(xs, w3, b3, w1, b1)
+    assert float(ws.abs().max().item()) < 2048 and torch.equal(scores, ws) and torch.equal(deltas, wd)
+    # random data
+    xs = [(torch.randn((B, h, w, cin), device='cuda', generator=g) * 0.5).half() for h, w in shapes]
+    w3 = (torch.randn((cout, cin, 3, 3), device='cuda', generator=g) * 0.02).half().contiguous(memory_format=torch.channels_last)
+    b3 = (torch.randn(cout, device='cuda', generator=g) * 0.1).half()
+    w1 = (torch.randn((6 * A, cout), device='cuda', generator=g) * 0.05).half()
+    b1 = torch.randn(6 * A, device='cuda', generator=g).half()
+    ops.rpn_head_fused(xs, w3, b3, w1, b1, A, scores, deltas)
+    ws, wd = reference(xs, w3, b3, w1, b1)
+    torch.testing.assert_close(scores, ws, rtol=3e-3, atol=3e-3)
+    torch.testing.assert_close(deltas, wd, rtol=3e-3, atol=3e-3)
+    s2, d2 = torch.empty_like(scores), torch.empty_like(deltas)
+    ops.rpn_head_fused(xs, w3, b3, w1, b1, A, s2, d2)
+    assert torch.equal(s2, scores) and torch.equal(d2, deltas)
+    if cout == 512 and A <= 4:      # the two-pass form of the product (ops.rpn_head_tail takes 512 channels)
+        convs = ops.conv3x3_f16_levels(xs, w3)
+        s3, d3 = torch.empty_like(scores), torch.empty_like(deltas)
+        off = 0
+        for (h, w), c in zip(shapes, convs):
+            ops.rpn_head_tail(c, b3, w1, b1, A, s3, d3, off)
+            off += h * w * A
+        torch.testing.assert_close(scores, s3, rtol=3e-3, atol=3e-3)
+        torch.testing.assert_close(deltas, d3, rtol=3e-3, atol=3e-3)
+

@@ -53,13 +53,25 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   long long tile_start[ODET_MAX_LEVELS + 1];   // first pixel slab of a level; [num_levels] = total
   int num_levels, cin, cout, relu;
   int tiles_n;                    // cout / 256
+  // fused RpnHead tail (k_conv3x3_f16<.., true>): the 1x1 score / delta convolutions on relu(conv + bias), written
+  // straight into the concatenated float32 arrays -- the 512-channel activation never goes to memory
+  const _Float16* tail_w;         // [6A][cout]: 2A score rows, then 4A delta rows
+  const _Float16* tail_b;         // [6A]
+  float* scores; float* deltas;   // [batch][N][2] / [batch][N][4]
+  float* partial;                 // workspace [tiles_n][slab pixels of the launch][32 rows]: a channel tile's partial sums
+  long long slab_px;              // slabs * TM of the launch (pixels incl. the padding of every level's last slab)
+  int tm;                         // TM of the launch (for k_rpn_tail_finish)
+  long long s_stride, d_stride;   // values per image
+  long long px[ODET_MAX_LEVELS];  // H * W of a level
+  long long aoff[ODET_MAX_LEVELS];   // first anchor of a level inside an image
+  int A;
 };
 
 // WN = waves along the channels (4: 256-channel tile, the form described above; 2 / 1: 128 / 64-channel tiles for the
 // layers with fewer output channels, the other 8 / WN waves along the pixels); MT = 16-pixel tiles per wave: the
 // workgroup tile is TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels (WN = 4, MT = 8: 256 x 256; smaller MT for
 // launches whose slabs would fill a fraction of a round of the 256 CUs -- chosen on the host, conv3x3_launch).
-template <int MT, int WN>
+template <int MT, int WN, bool TAIL = false>
 __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   constexpr int WM = 8 / WN;                             // waves along the pixels
   constexpr int TM = WM * 16 * MT;                       // pixels of the workgroup tile (<= 256)
@@ -218,8 +230,72 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     mfmas(wf0, xf0);
     mfmas(wf1, xf1);
   }
-  // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
   const int c0 = tn * TN + wn * 64 + lq * 16;
+  if constexpr (TAIL) {
+    // ---- fused RpnHead tail (base_fpn_model.py:401-434): t = relu(conv + b1) rounded to float16 once, then the two 1x1
+    // convolutions as ONE more contraction on the matrix cores, out[o][pixel] = sum_ch W2[o][ch] . t[pixel][ch]: the MFMA's
+    // A operand = 16 rows of W2 (o = 2A score rows, then 4A delta rows, zero rows up to 32), its B operand = the 16 pixels
+    // of a tile; a lane's 16 channels are two K groups of 8 (the K order inside an MFMA is free as long as both operands
+    // agree).  A wave has 64 of the tile's 256 channels: the four waves along the channels add up through LDS (the
+    // stages are free after the K loop); the channel tiles of a slab (two for 512 channels) each leave their partial
+    // sums in the workspace and k_rpn_tail_finish adds them in a fixed order, with the bias, into the arrays (float32
+    // atomics onto the arrays instead cost as much as the separate tail pass: 26 M of them at batch 8).
+    static_assert(WN == 4, "the fused tail is for 256-channel tiles");
+    const int rows = 6 * p.A;
+    h8 w2[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int R = rt * 16 + l15;
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.0f;
+        if (R < rows) v = *reinterpret_cast<const h8*>(p.tail_w + (long long)R * cout + c0 + hh * 8);
+        w2[rt][hh] = v;
+      }
+    float b1[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) b1[e] = (float)p.bias[c0 + e];
+    __syncthreads();                                     // every wave has read its last fragments: the stages are free
+    f4* red = reinterpret_cast<f4*>(lds);                // [wm][mt][rt][wn][lane]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h8 t0, t1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[mt][t][j] + b1[t * 4 + j];
+          v = v < 0.0f ? 0.0f : v;
+          if (t < 2) t0[t * 4 + j] = (_Float16)v; else t1[(t - 2) * 4 + j] = (_Float16)v;
+        }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f4 o = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[rt][0], t0, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[rt][1], t1, o, 0, 0, 0);
+        red[(((wm * MT + mt) * 2 + rt) * 4 + wn) * 64 + lane] = o;
+      }
+    }
+    __syncthreads();
+    // wave (wm, wn) adds up the pixel tiles mt = wn, wn + 4, ... of its half (lane = rows 4 lq .. 4 lq + 3 of a row
+    // tile, pixel l15) and stores this channel tile's partial sums: 16 bytes per lane, a 128-byte line per pixel
+    for (int mt = wn; mt < MT; mt += 4) {
+      const long long gm = slab * TM + wm * 16 * MT + mt * 16 + l15;      // pixel slot of the launch
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f4* src = red + (((wm * MT + mt) * 2 + rt) * 4) * 64 + lane;
+        const f4 a0 = src[0], a1 = src[64], a2 = src[128], a3 = src[192];
+        f4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((a0[j] + a1[j]) + a2[j]) + a3[j];
+        *reinterpret_cast<f4*>(p.partial + ((long long)tn * p.slab_px + gm) * 32 + rt * 16 + 4 * lq) = v;
+      }
+    }
+    return;
+  }
+  // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
   float bv[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) bv[e] = p.bias ? (float)p.bias[c0 + e] : 0.0f;
@@ -239,6 +315,40 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
       _Float16* dst = p.y[lv] + m * cout + c0;
       *reinterpret_cast<h8*>(dst) = o[0];
       *reinterpret_cast<h8*>(dst + 8) = o[1];
+    }
+  }
+}
+
+// Second, small launch of the fused RpnHead: out = sum over the channel tiles' partial sums + bias, row R of pixel m to
+// scores (R < 2A) / deltas (R - 2A) of the level's slice.  One thread = 4 rows of a pixel slot.
+__global__ void __launch_bounds__(256) k_rpn_tail_finish(Conv3x3Params p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long gm = idx >> 3;
+  const int g = (int)(idx & 7);
+  if (gm >= p.slab_px) return;
+  const long long slab = gm / p.tm;
+  int lv = 0;
+#pragma unroll
+  for (int l = 1; l < ODET_MAX_LEVELS; ++l)
+    if (l < p.num_levels && slab >= p.tile_start[l]) lv = l;
+  const long long m = (slab - p.tile_start[lv]) * p.tm + (gm - slab * p.tm);
+  if (m >= p.M[lv]) return;
+  const int rows = 6 * p.A, nS = 2 * p.A;
+  if (4 * g >= rows) return;
+  f4 v = *reinterpret_cast<const f4*>(p.partial + gm * 32 + 4 * g);
+  for (int t = 1; t < p.tiles_n; ++t) {
+    const f4 u = *reinterpret_cast<const f4*>(p.partial + ((long long)t * p.slab_px + gm) * 32 + 4 * g);
+    v += u;
+  }
+  const long long b = m / p.px[lv], pi = m - b * p.px[lv];
+  float* so = p.scores + b * p.s_stride + (p.aoff[lv] + pi * p.A) * 2;
+  float* dO = p.deltas + b * p.d_stride + (p.aoff[lv] + pi * p.A) * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int R = 4 * g + j;
+    if (R < rows) {
+      const float o = v[j] + (float)p.tail_b[R];
+      if (R < nS) so[R] = o; else dO[R - nS] = o;
     }
   }
 }
@@ -391,8 +501,13 @@ __global__ void __launch_bounds__(512) k_conv3x3_f32(Conv3x3F32Params p) {
   }
 }
 
+struct Conv3x3Tail {             // the fused RpnHead tail (nullable in conv3x3_launch)
+  const void* w; const void* b; int A; float* scores; long long s_stride; float* deltas; long long d_stride;
+  void* ws; size_t ws_bytes;
+};
+
 static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,
-                          int cin, int cout, int relu, hipStream_t st) {
+                          int cin, int cout, int relu, hipStream_t st, const Conv3x3Tail* tail = nullptr) {
   ODET_REQUIRE(levels && w, "odet_conv3x3_f16: null pointer");
   ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_f16: num_levels %d out of range", num_levels);
   ODET_REQUIRE(batch > 0, "odet_conv3x3_f16: bad batch");
@@ -402,6 +517,13 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   static std::once_flag once;
   static hipError_t once_rc = hipSuccess;
   std::call_once(once, [] {
+    const void* kt_[5] = {(const void*)k_conv3x3_f16<4, 4, true>, (const void*)k_conv3x3_f16<5, 4, true>,
+                          (const void*)k_conv3x3_f16<6, 4, true>, (const void*)k_conv3x3_f16<7, 4, true>,
+                          (const void*)k_conv3x3_f16<8, 4, true>};
+    for (const void* k_ : kt_) {
+      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+      if (e_ != hipSuccess) once_rc = e_;
+    }
     const void* ks_[10] = {(const void*)k_conv3x3_f16<4, 4>, (const void*)k_conv3x3_f16<5, 4>, (const void*)k_conv3x3_f16<6, 4>,
                            (const void*)k_conv3x3_f16<7, 4>, (const void*)k_conv3x3_f16<8, 4>, (const void*)k_conv3x3_f16<2, 2>,
                            (const void*)k_conv3x3_f16<3, 2>, (const void*)k_conv3x3_f16<4, 2>, (const void*)k_conv3x3_f16<1, 1>,
@@ -416,12 +538,29 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   long long total = 0;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     const odet_conv_level_t& L = levels[l < num_levels ? l : 0];
-    ODET_REQUIRE(L.x && L.y && L.H > 0 && L.W > 0, "odet_conv3x3_f16: bad level %d", l);
+    ODET_REQUIRE(L.x && (L.y || tail) && L.H > 0 && L.W > 0, "odet_conv3x3_f16: bad level %d", l);
     const long long M = (long long)batch * L.H * L.W;
     // 32-bit byte offsets into x (+ the padding rows of the descriptor) and the out-of-range marker
     ODET_REQUIRE((unsigned long long)M * cin * 2ull + 2ull * (L.W + 1) * cin * 2ull < 0xFFFFFFF0ull,
                  "odet_conv3x3_f16: level %d input larger than 4 GiB", l);
     p.x[l] = (const _Float16*)L.x; p.y[l] = (_Float16*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
+    p.px[l] = (long long)L.H * L.W;
+  }
+  p.tail_w = nullptr; p.tail_b = nullptr; p.scores = nullptr; p.deltas = nullptr; p.s_stride = p.d_stride = 0; p.A = 0;
+  p.partial = nullptr; p.slab_px = 0; p.tm = 0;
+  if (tail) {
+    ODET_REQUIRE(tail->w && tail->b && tail->scores && tail->deltas && bias, "odet_rpn_head_fused_f16: null pointer");
+    ODET_REQUIRE(tail->A >= 1 && 6 * tail->A <= 32, "odet_rpn_head_fused_f16: 1 <= A <= 5");
+    // (two channel tiles at most: their two float32 partial sums commute; three or more would not add up in a fixed order)
+    ODET_REQUIRE(cout == 256 || cout == 512, "odet_rpn_head_fused_f16: cout must be 256 or 512 (got %d)", cout);
+    long long a0 = 0;
+    for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
+      p.aoff[l] = a0;
+      if (l < num_levels) a0 += p.px[l] * tail->A;
+    }
+    ODET_REQUIRE(a0 * 2 <= tail->s_stride && a0 * 4 <= tail->d_stride, "odet_rpn_head_fused_f16: the levels do not fit the arrays");
+    p.tail_w = (const _Float16*)tail->w; p.tail_b = (const _Float16*)tail->b; p.A = tail->A;
+    p.scores = tail->scores; p.deltas = tail->deltas; p.s_stride = tail->s_stride; p.d_stride = tail->d_stride;
   }
   // Channel tile: 256 (four waves along the channels), or 128 / 64 for the layers with fewer output channels.
   const int wn_sel = (cout % 256 == 0) ? 4 : (cout % 128 == 0 ? 2 : 1);
@@ -458,6 +597,27 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
   const dim3 grid((unsigned)blocks);
 #define C3_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_>), grid, dim3(512), C3_LDS_BYTES, st, p)
+#define C3_LAUNCH_TAIL(MT_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, 4, true>), grid, dim3(512), C3_LDS_BYTES, st, p)
+  if (tail) {
+    p.slab_px = total * TMsel; p.tm = TMsel;
+    const size_t need = (size_t)p.tiles_n * (size_t)p.slab_px * 32 * sizeof(float);
+    ODET_REQUIRE(tail->ws && tail->ws_bytes >= need && (uintptr_t)tail->ws % 16 == 0,
+                 "odet_rpn_head_fused_f16: workspace too small (%zu < %zu) or misaligned", tail->ws_bytes, need);
+    p.partial = (float*)tail->ws;
+    switch (mt_best) {
+      case 4: C3_LAUNCH_TAIL(4); break;
+      case 5: C3_LAUNCH_TAIL(5); break;
+      case 6: C3_LAUNCH_TAIL(6); break;
+      case 7: C3_LAUNCH_TAIL(7); break;
+      default: C3_LAUNCH_TAIL(8); break;
+    }
+    ODET_LAUNCH_CHECK();
+    const long long threads = p.slab_px * 8;
+    hipLaunchKernelGGL(k_rpn_tail_finish, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+    ODET_LAUNCH_CHECK();
+    return ODET_OK;
+  }
+#undef C3_LAUNCH_TAIL
   switch (wn_sel * 16 + mt_best) {
     case 4 * 16 + 4: C3_LAUNCH(4, 4); break;
     case 4 * 16 + 5: C3_LAUNCH(5, 4); break;
@@ -485,6 +645,23 @@ extern "C" int odet_conv3x3_f16(const void* x, const void* w, const void* bias, 
 extern "C" int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
                                        int batch, int cin, int cout, int relu, odet_stream_t stream) {
   return conv3x3_launch(levels, num_levels, w, bias, batch, cin, cout, relu, (hipStream_t)stream);
+}
+
+extern "C" int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_levels, const void* conv_w, const void* conv_b,
+                                       const void* w, const void* b, int A, int batch, int cin, int cout, float* scores,
+                                       long long scores_image_stride, float* deltas, long long deltas_image_stride,
+                                       void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(((uintptr_t)w | (uintptr_t)conv_b) % 16 == 0, "odet_rpn_head_fused_f16: pointers must be 16-byte aligned");
+  const Conv3x3Tail t{w, b, A, scores, scores_image_stride, deltas, deltas_image_stride, workspace, workspace_bytes};
+  return conv3x3_launch(levels, num_levels, conv_w, conv_b, batch, cin, cout, 1, (hipStream_t)stream, &t);
+}
+
+// upper bound of the workspace of odet_rpn_head_fused_f16: every level's pixels rounded up to a whole slab of any height
+extern "C" size_t odet_rpn_head_fused_workspace_bytes(const odet_conv_level_t* levels, int num_levels, int batch, int cout) {
+  if (!levels || num_levels < 1 || num_levels > ODET_MAX_LEVELS || batch < 1 || cout < 1) return 0;
+  size_t px = 0;
+  for (int l = 0; l < num_levels; ++l) px += (size_t)batch * levels[l].H * levels[l].W + 256;
+  return (size_t)((cout + 255) / 256) * px * 32 * sizeof(float);
 }
 
 static int conv3x3_f32_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,

@@ -61,7 +61,8 @@ def _fold_frozen_bn(conv):
 #   'mfma' ops.conv1x1_f16: the hand-written MFMA kernel with bias + shortcut + ReLU fused (float16, cin <= 256)
 _GEMM_ROUTE = {}
 _ROUTE_MODE = __import__('os').environ.get('ODET_ROUTE_1X1', 'table')
-# ODET_CONV3X3=lib: the library convolution instead of the hand-written implicit GEMM (ops.conv3x3_f16) where it applies
+# ODET_CONV3X3=lib: the library convolution instead of the hand-written implicit GEMM (ops.conv3x3_f16) where it applies;
+# twopass: the hand-written convolution, but the RpnHead as convolution launch + tail launches (not ops.rpn_head_fused)
 _CONV3X3_MODE = __import__('os').environ.get('ODET_CONV3X3', 'own')
 
 
@@ -449,6 +450,12 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
             off = 0
             fused = p_list[0].dtype == torch.float16 and self.rpn_conv.out_channels == 512 and self.A <= 4
             convs = None
+            if fused and _CONV3X3_MODE in ('own', 'force') and self.rpn_conv.in_channels % 64 == 0:
+                # the WHOLE head in one launch: the 3x3 convolution of all levels with bias + ReLU + both 1x1 convolutions
+                # in its epilogue (ops.rpn_head_fused): the 512-channel activation is never written
+                xs = [p.permute(0, 2, 3, 1) for p in p_list]
+                xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
+                return ops.rpn_head_fused(xs, self.rpn_conv.weight, self.rpn_conv.bias, w, b, self.A, scores, deltas)
             if fused and _CONV3X3_MODE != 'lib' and self.rpn_conv.in_channels % 64 == 0:
                 # the 3x3 convolution of ALL levels in one launch of the hand-written implicit-GEMM kernel
                 # (ops.conv3x3_f16_levels: the small levels' workgroups fill the tail of the big ones'), without bias

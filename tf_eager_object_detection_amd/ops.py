@@ -497,6 +497,53 @@ def conv3x3_f16_levels(xs, weight, bias=None, relu=False, outs=None):
     return _conv3x3_levels(torch.float16, xs, weight, bias, relu, outs)
 
 
+def rpn_head_fused(xs, conv_weight, conv_bias, weight, bias, num_anchors, scores, deltas):
+    """The whole RpnHead over the pyramid levels in ONE launch (odet_rpn_head_fused_f16): ``xs`` NHWC float16 maps
+    [B,H_l,W_l,cin] in concatenation order, ``conv_weight`` [cout,cin,3,3] (channels_last) / ``conv_bias`` [cout] of the
+    3x3 convolution, ``weight`` [6A,cout(,1,1)] / ``bias`` [6A] = the score rows then the delta rows of the two 1x1
+    convolutions; relu(conv + conv_bias) . weight^T + bias -> ``scores`` [B,N,2] / ``deltas`` [B,N,4] float32 (the
+    kernel's channel tiles leave partial sums in a cached workspace, a small second launch adds them).  cout in
+    {256, 512}."""
+    A = int(num_anchors)
+    if not 1 <= len(xs) <= MAX_LEVELS:
+        raise ValueError('between 1 and %d maps expected' % MAX_LEVELS)
+    B, cin = int(xs[0].shape[0]), int(xs[0].shape[3])
+    cout = int(conv_weight.shape[0])
+    w3 = _conv3x3_weight(conv_weight, cin, cout, torch.float16, 'float16')
+    if weight.dtype != torch.float16 or weight.numel() != 6 * A * cout:
+        raise ValueError('weight must be a float16 [6A, cout] tensor')
+    w1 = weight.reshape(6 * A, cout)
+    if not w1.is_contiguous():
+        w1 = w1.contiguous()
+    for t, n_ in ((conv_bias, cout), (bias, 6 * A)):
+        if t.dtype != torch.float16 or t.numel() != n_ or not t.is_contiguous():
+            raise ValueError('conv_bias [cout] / bias [6A] must be contiguous float16 tensors')
+    lv = (L.OdetConvLevel * len(xs))()
+    n = 0
+    for i, x in enumerate(xs):
+        if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4 or not x.is_contiguous() or int(x.shape[0]) != B \
+                or int(x.shape[3]) != cin:
+            raise ValueError('maps must be contiguous NHWC float16 GPU tensors [B,H,W,cin] of one batch size')
+        lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), None, int(x.shape[1]), int(x.shape[2])
+        n += int(x.shape[1]) * int(x.shape[2]) * A
+    for t, k in ((scores, 2), (deltas, 4)):
+        if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (B, n, k):
+            raise ValueError('scores / deltas must be contiguous float32 [B, N, 2] / [B, N, 4] tensors, N = sum H*W*A')
+    need = int(L.lib().odet_rpn_head_fused_workspace_bytes(lv, len(xs), B, cout))
+    key = (xs[0].device, need)
+    ws = _RPN_FUSED_WS.get(key)
+    if ws is None:
+        if len(_RPN_FUSED_WS) >= 4:
+            _RPN_FUSED_WS.clear()
+        ws = _RPN_FUSED_WS[key] = torch.empty(need, dtype=torch.uint8, device=xs[0].device)
+    L.call('odet_rpn_head_fused_f16', lv, len(xs), L.dptr(w3), L.dptr(conv_bias), L.dptr(w1), L.dptr(bias), A, B, cin, cout,
+           L.dptr(scores), n * 2, L.dptr(deltas), n * 4, C.c_void_p(ws.data_ptr()), need, L.stream())
+    return scores, deltas
+
+
+_RPN_FUSED_WS = {}      # (device, bytes) -> the partial-sum workspace of rpn_head_fused (a few shapes at most)
+
+
 def conv3x3_f32(x, weight, bias=None, relu=False, out=None):
     """conv3x3_f16 in the reference's precision: float32 operands and result, exact-float32 matrix instructions
     (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 256 == 0."""
