@@ -530,10 +530,10 @@ def rpn_head_fused(xs, conv_weight, conv_bias, weight, bias, num_anchors, scores
         if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (B, n, k):
             raise ValueError('scores / deltas must be contiguous float32 [B, N, 2] / [B, N, 4] tensors, N = sum H*W*A')
     need = int(L.lib().odet_rpn_head_fused_workspace_bytes(lv, len(xs), B, cout))
-    key = (xs[0].device, need)
+    key = (xs[0].device, need, torch.cuda.current_stream(xs[0].device).cuda_stream)     # (one per stream: calls on two streams may overlap)
     ws = _RPN_FUSED_WS.get(key)
     if ws is None:
-        if len(_RPN_FUSED_WS) >= 4:
+        if len(_RPN_FUSED_WS) >= 8:
             _RPN_FUSED_WS.clear()
         ws = _RPN_FUSED_WS[key] = torch.empty(need, dtype=torch.uint8, device=xs[0].device)
     L.call('odet_rpn_head_fused_f16', lv, len(xs), L.dptr(w3), L.dptr(conv_bias), L.dptr(w1), L.dptr(bias), A, B, cin, cout,
@@ -541,7 +541,7 @@ def rpn_head_fused(xs, conv_weight, conv_bias, weight, bias, num_anchors, scores
     return scores, deltas
 
 
-_RPN_FUSED_WS = {}      # (device, bytes) -> the partial-sum workspace of rpn_head_fused (a few shapes at most)
+_RPN_FUSED_WS = {}      # (device, bytes, stream) -> the partial-sum workspace of rpn_head_fused (a few shapes at most)
 
 
 def conv3x3_f32(x, weight, bias=None, relu=False, out=None):
