@@ -374,6 +374,14 @@ int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_levels, con
                             const void* w, const void* b, int A, int batch, int cin, int cout, float* scores,
                             long long scores_image_stride, float* deltas, long long deltas_image_stride,
                             void* workspace, size_t workspace_bytes, odet_stream_t stream);
+/* A bottleneck block's 3x3 convolution AND its last 1x1 convolution in one launch (resnet_fpn.py:154-205 with the frozen
+ * batch norms folded): y = relu( relu(conv3x3(x, w2) + b2) . w3^T + b3 + residual ), x NHWC float16 [batch,H,W,cin],
+ * w2 [256][3][3][cin], b2 [256], w3 [n3][256], b3 [n3], residual (nullable) / y NHWC float16 [batch,H,W,n3]; the
+ * 256-channel activation between the two is rounded to float16 once and never goes to memory.  cin % 64 == 0, the
+ * 3x3 convolution has exactly 256 output channels (one workgroup holds them all), n3 % 64 == 0. */
+int odet_conv3x3_conv1x1_f16(const void* x, const void* w2, const void* b2, const void* w3, const void* b3,
+                             const void* residual, void* y, int batch, int H, int W, int cin, int n3, int relu,
+                             odet_stream_t stream);
 /* the float32 forms (the detectors' parity mode computes in the reference's precision): float32 x / w / bias / y,
  * exact-float32 MFMA (v_mfma_f32_16x16x4_f32), cin % 32 == 0, cout % 256 == 0 */
 int odet_conv3x3_f32(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,

@@ -61,6 +61,9 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   float* partial;                 // workspace [tiles_n][slab pixels of the launch][32 rows]: a channel tile's partial sums
   long long slab_px;              // slabs * TM of the launch (pixels incl. the padding of every level's last slab)
   int tm;                         // TM of the launch (for k_rpn_tail_finish)
+  // fused bottleneck tail (k_conv3x3_f16<.., false, true>): y3 = relu(relu(conv + bias) . w3^T + b3 + res), cout == 256
+  const _Float16* w3; const _Float16* b3; const _Float16* res; _Float16* y3;
+  int n3, relu3;
   long long s_stride, d_stride;   // values per image
   long long px[ODET_MAX_LEVELS];  // H * W of a level
   long long aoff[ODET_MAX_LEVELS];   // first anchor of a level inside an image
@@ -71,7 +74,7 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
 // layers with fewer output channels, the other 8 / WN waves along the pixels); MT = 16-pixel tiles per wave: the
 // workgroup tile is TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels (WN = 4, MT = 8: 256 x 256; smaller MT for
 // launches whose slabs would fill a fraction of a round of the 256 CUs -- chosen on the host, conv3x3_launch).
-template <int MT, int WN, bool TAIL = false>
+template <int MT, int WN, bool TAIL = false, bool BLK = false>
 __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   constexpr int WM = 8 / WN;                             // waves along the pixels
   constexpr int TM = WM * 16 * MT;                       // pixels of the workgroup tile (<= 256)
@@ -295,6 +298,94 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     }
     return;
   }
+  if constexpr (BLK) {
+    // ---- fused bottleneck tail (resnet_fpn.py:154-205: conv 3x3 -> BN -> ReLU -> conv 1x1 -> BN -> Add -> ReLU with the
+    // frozen batch norms folded): this workgroup holds ALL 256 channels of the 3x3 convolution for its pixels, so the
+    // block's last convolution can run right here.  t = relu(acc + bias) goes to LDS once, rounded to float16 ([TM
+    // pixels][512 B], 16-byte slots XOR-swizzled by the pixel row: conflict-free as an MFMA operand), then every wave
+    // takes 64-channel groups of the n3 output channels for ALL pixels of the tile: its 4 x 8 weight fragments straight
+    // from global memory into registers (rows in the permuted order that leaves a lane with 16 consecutive channels),
+    // per pixel tile 8 fragment reads + 32 MFMAs, + bias + shortcut, ReLU, one rounding, 32 contiguous bytes per lane.
+    // The 256-channel activation of the 3x3 convolution never goes to memory.
+    static_assert(WN == 4, "needs the 256-channel tile");
+    float b2v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) b2v[e] = (float)p.bias[c0 + e];
+    __syncthreads();                                     // every wave has read its last fragments: the stages are free
+    auto taddr = [&](int prow, int slot) -> uint32_t {
+      return (uint32_t)prow * 512u + (uint32_t)((((slot & 15) ^ (prow & 15)) | (slot & 16))) * 16u;
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h8 t0, t1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[mt][t][j] + b2v[t * 4 + j];
+          v = v < 0.0f ? 0.0f : v;
+          if (t < 2) t0[t * 4 + j] = (_Float16)v; else t1[(t - 2) * 4 + j] = (_Float16)v;
+        }
+      const int prow = wm * 16 * MT + mt * 16 + l15;
+      const int slot0 = wn * 8 + lq * 2;
+      *reinterpret_cast<h8*>(lds + taddr(prow, slot0)) = t0;
+      *reinterpret_cast<h8*>(lds + taddr(prow, slot0 + 1)) = t1;
+    }
+    __syncthreads();
+    const int n3 = p.n3;
+    for (int g = wv; g * 64 < n3; g += 8) {
+      h8 a[4][8];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int ch = g * 64 + 16 * (l15 >> 2) + 4 * tt + (l15 & 3);
+        const _Float16* wr = p.w3 + (long long)ch * 256 + lq * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) a[tt][ks] = *reinterpret_cast<const h8*>(wr + ks * 32);
+      }
+      const int cg = g * 64 + lq * 16;                   // this lane's 16 output channels
+      float b3v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) b3v[e] = (float)p.b3[cg + e];
+      for (int pt = 0; pt < TM / 16; ++pt) {
+        const int prow = pt * 16 + l15;
+        const long long m = tile_m * TM + prow;
+        const bool ok = m < M;
+        h8 r0, r1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r0[e] = (_Float16)0.0f; r1[e] = (_Float16)0.0f; }
+        if (p.res && ok) {
+          r0 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg);
+          r1 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg + 8);
+        }
+        h8 bf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bf[ks] = *reinterpret_cast<const h8*>(lds + taddr(prow, 4 * ks + lq));
+        f4 o[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          o[tt] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt][ks], bf[ks], o[tt], 0, 0, 0);
+        }
+        if (ok) {
+          h8 q0, q1;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int e = tt * 4 + j;
+              float v = (o[tt][j] + b3v[e]) + (float)(e < 8 ? r0[e & 7] : r1[e & 7]);
+              if (p.relu3) v = v < 0.0f ? 0.0f : v;
+              if (e < 8) q0[e] = (_Float16)v; else q1[e - 8] = (_Float16)v;
+            }
+          _Float16* dst = p.y3 + m * n3 + cg;
+          *reinterpret_cast<h8*>(dst) = q0;
+          *reinterpret_cast<h8*>(dst + 8) = q1;
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
   float bv[16];
 #pragma unroll
@@ -505,9 +596,13 @@ struct Conv3x3Tail {             // the fused RpnHead tail (nullable in conv3x3_
   const void* w; const void* b; int A; float* scores; long long s_stride; float* deltas; long long d_stride;
   void* ws; size_t ws_bytes;
 };
+struct Conv3x3Block {            // the fused bottleneck tail (nullable in conv3x3_launch)
+  const void* w3; const void* b3; const void* res; void* y3; int n3; int relu3;
+};
 
 static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,
-                          int cin, int cout, int relu, hipStream_t st, const Conv3x3Tail* tail = nullptr) {
+                          int cin, int cout, int relu, hipStream_t st, const Conv3x3Tail* tail = nullptr,
+                          const Conv3x3Block* blk = nullptr) {
   ODET_REQUIRE(levels && w, "odet_conv3x3_f16: null pointer");
   ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_f16: num_levels %d out of range", num_levels);
   ODET_REQUIRE(batch > 0, "odet_conv3x3_f16: bad batch");
@@ -517,6 +612,13 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   static std::once_flag once;
   static hipError_t once_rc = hipSuccess;
   std::call_once(once, [] {
+    const void* kb_[5] = {(const void*)k_conv3x3_f16<4, 4, false, true>, (const void*)k_conv3x3_f16<5, 4, false, true>,
+                          (const void*)k_conv3x3_f16<6, 4, false, true>, (const void*)k_conv3x3_f16<7, 4, false, true>,
+                          (const void*)k_conv3x3_f16<8, 4, false, true>};
+    for (const void* k_ : kb_) {
+      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+      if (e_ != hipSuccess) once_rc = e_;
+    }
     const void* kt_[5] = {(const void*)k_conv3x3_f16<4, 4, true>, (const void*)k_conv3x3_f16<5, 4, true>,
                           (const void*)k_conv3x3_f16<6, 4, true>, (const void*)k_conv3x3_f16<7, 4, true>,
                           (const void*)k_conv3x3_f16<8, 4, true>};
@@ -538,7 +640,7 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   long long total = 0;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     const odet_conv_level_t& L = levels[l < num_levels ? l : 0];
-    ODET_REQUIRE(L.x && (L.y || tail) && L.H > 0 && L.W > 0, "odet_conv3x3_f16: bad level %d", l);
+    ODET_REQUIRE(L.x && (L.y || tail || blk) && L.H > 0 && L.W > 0, "odet_conv3x3_f16: bad level %d", l);
     const long long M = (long long)batch * L.H * L.W;
     // 32-bit byte offsets into x (+ the padding rows of the descriptor) and the out-of-range marker
     ODET_REQUIRE((unsigned long long)M * cin * 2ull + 2ull * (L.W + 1) * cin * 2ull < 0xFFFFFFF0ull,
@@ -548,6 +650,16 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   }
   p.tail_w = nullptr; p.tail_b = nullptr; p.scores = nullptr; p.deltas = nullptr; p.s_stride = p.d_stride = 0; p.A = 0;
   p.partial = nullptr; p.slab_px = 0; p.tm = 0;
+  p.w3 = nullptr; p.b3 = nullptr; p.res = nullptr; p.y3 = nullptr; p.n3 = 0; p.relu3 = 0;
+  if (blk) {
+    ODET_REQUIRE(blk->w3 && blk->b3 && blk->y3 && bias, "odet_conv3x3_conv1x1_f16: null pointer");
+    ODET_REQUIRE(cout == 256, "odet_conv3x3_conv1x1_f16: the 3x3 convolution must have 256 output channels (got %d)", cout);
+    ODET_REQUIRE(blk->n3 > 0 && blk->n3 % 64 == 0, "odet_conv3x3_conv1x1_f16: n3 %d must be a multiple of 64", blk->n3);
+    ODET_REQUIRE(num_levels == 1, "odet_conv3x3_conv1x1_f16: one map");
+    ODET_REQUIRE(((uintptr_t)blk->w3 | (uintptr_t)blk->res | (uintptr_t)blk->y3) % 16 == 0, "odet_conv3x3_conv1x1_f16: pointers must be 16-byte aligned");
+    p.w3 = (const _Float16*)blk->w3; p.b3 = (const _Float16*)blk->b3; p.res = (const _Float16*)blk->res;
+    p.y3 = (_Float16*)blk->y3; p.n3 = blk->n3; p.relu3 = blk->relu3 ? 1 : 0;
+  }
   if (tail) {
     ODET_REQUIRE(tail->w && tail->b && tail->scores && tail->deltas && bias, "odet_rpn_head_fused_f16: null pointer");
     ODET_REQUIRE(tail->A >= 1 && 6 * tail->A <= 32, "odet_rpn_head_fused_f16: 1 <= A <= 5");
@@ -618,6 +730,19 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
     return ODET_OK;
   }
 #undef C3_LAUNCH_TAIL
+  if (blk) {
+#define C3_LAUNCH_BLK(MT_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, 4, false, true>), grid, dim3(512), C3_LDS_BYTES, st, p)
+    switch (mt_best) {
+      case 4: C3_LAUNCH_BLK(4); break;
+      case 5: C3_LAUNCH_BLK(5); break;
+      case 6: C3_LAUNCH_BLK(6); break;
+      case 7: C3_LAUNCH_BLK(7); break;
+      default: C3_LAUNCH_BLK(8); break;
+    }
+#undef C3_LAUNCH_BLK
+    ODET_LAUNCH_CHECK();
+    return ODET_OK;
+  }
   switch (wn_sel * 16 + mt_best) {
     case 4 * 16 + 4: C3_LAUNCH(4, 4); break;
     case 4 * 16 + 5: C3_LAUNCH(5, 4); break;
@@ -654,6 +779,15 @@ extern "C" int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_
   ODET_REQUIRE(((uintptr_t)w | (uintptr_t)conv_b) % 16 == 0, "odet_rpn_head_fused_f16: pointers must be 16-byte aligned");
   const Conv3x3Tail t{w, b, A, scores, scores_image_stride, deltas, deltas_image_stride, workspace, workspace_bytes};
   return conv3x3_launch(levels, num_levels, conv_w, conv_b, batch, cin, cout, 1, (hipStream_t)stream, &t);
+}
+
+extern "C" int odet_conv3x3_conv1x1_f16(const void* x, const void* w2, const void* b2, const void* w3, const void* b3,
+                                        const void* residual, void* y, int batch, int H, int W, int cin, int n3, int relu,
+                                        odet_stream_t stream) {
+  ODET_REQUIRE(x && y, "odet_conv3x3_conv1x1_f16: null pointer");
+  const odet_conv_level_t one{x, nullptr, H, W};
+  const Conv3x3Block b{w3, b3, residual, y, n3, relu};
+  return conv3x3_launch(&one, 1, w2, b2, batch, cin, 256, 1, (hipStream_t)stream, nullptr, &b);
 }
 
 // upper bound of the workspace of odet_rpn_head_fused_f16: every level's pixels rounded up to a whole slab of any height
