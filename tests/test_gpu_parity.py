@@ -183,6 +183,16 @@ def test_nms_known_answers():
     # NaN / -inf scores are never candidates (score > lowest-float is false)
     s = np.float32([0.5, np.nan, -np.inf, 0.7])
     assert _nms_gpu(far[:4], s, 4, 0.5).tolist() == [3, 0]
+    # TensorFlow's published unit-test vectors (non_max_suppression_op_test.cc; third-party known answers, see
+    # tests/test_oracle.py::test_tf_published_nms_vectors) through the HIP path
+    tb = np.float32([[0, 0, 1, 1], [0, 0.1, 1, 1.1], [0, -0.1, 1, 0.9], [0, 10, 1, 11], [0, 10.1, 1, 11.1], [0, 100, 1, 101]])
+    ts = np.float32([0.9, 0.75, 0.6, 0.95, 0.5, 0.3])
+    assert _nms_gpu(tb, ts, 3, 0.5).tolist() == [3, 0, 5]
+    assert _nms_gpu(np.float32([[1, 1, 0, 0], [0, 0.1, 1, 1.1], [0, 0.9, 1, -0.1], [0, 10, 1, 11], [1, 10.1, 0, 11.1],
+                                [1, 101, 0, 100]]), ts, 3, 0.5).tolist() == [3, 0, 5]
+    assert _nms_gpu(tb, ts, 2, 0.5).tolist() == [3, 0]
+    assert _nms_gpu(tb, ts - np.float32(5.0), 6, 0.5).tolist() == [3, 0, 5]
+    assert _nms_gpu(np.tile(np.float32([[0, 0, 1, 1]]), (10, 1)), np.full(10, 0.9, np.float32), 3, 0.5).tolist() == [0]
 
 
 @pytest.mark.parametrize('n,k,thr,kind', [
