@@ -166,18 +166,26 @@ def load_traffic(workload_key, images_per_launch):
     return None
 
 
-def e2e_record(dtype_name, batch, budget_s=8.0):
-    """The assembled ResNet-101-FPN detector end to end on synthetic 800x1333 images (random-init weights):
-    backbone + neck + RPN head + hot path + RoI head + post-ops; not the headline metric (that one is the hot
-    path): a second, separately labelled record.  fp32 = the reference's precision (parity mode)."""
+def e2e_record(dtype_name, batch, budget_s=8.0, family='fpn'):
+    """An assembled detector end to end on synthetic images (random-init weights): backbone (+ neck) + RPN head + hot
+    path + RoI head + post-ops; not the headline metric (that one is the hot path): a second, separately labelled
+    record.  family = 'fpn': ResNet-101-FPN @ 800x1333 (BASELINE config 3); 'c4': ResNet-50 C4 Faster R-CNN @ 800x1333
+    (config 2); 'vgg16': VGG16 Faster R-CNN @ 600x800 (config 1).  fp32 = the reference's precision (parity mode)."""
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
     dt = {'fp32': torch.float32, 'fp16': torch.float16}[dtype_name]
     torch.backends.cudnn.benchmark = True                 # MIOpen find mode (its default solver is naive on some shapes)
     torch.manual_seed(0)
-    model = ResNetFpnDetector(101, NUM_CLASSES, IMAGE_SHAPE, NUM_PROPOSALS, dtype=dt, max_batch=batch,
-                              blind_chunks=3, batched=True).prepare()
+    image_shape = (600, 800) if family == 'vgg16' else IMAGE_SHAPE
+    if family == 'fpn':
+        model = ResNetFpnDetector(101, NUM_CLASSES, image_shape, NUM_PROPOSALS, dtype=dt, max_batch=batch,
+                                  blind_chunks=3, batched=True).prepare()
+    elif family == 'c4':
+        model = ResNetC4Detector(50, NUM_CLASSES, image_shape, 300, dtype=dt, max_batch=batch, blind_chunks=4).prepare()
+    else:
+        model = Vgg16Detector(NUM_CLASSES, image_shape, 300, dtype=dt, max_batch=batch, blind_chunks=4).prepare()
     rng = np.random.default_rng(0)
-    img = (rng.uniform(0, 255, (batch,) + IMAGE_SHAPE + (3,)) - np.float32([103.939, 116.779, 123.68])).astype(np.float32)
+    img = (rng.uniform(0, 255, (batch,) + image_shape + (3,)) - np.float32([103.939, 116.779, 123.68])).astype(np.float32)
     img = torch.from_numpy(img).cuda()
     t0 = time.perf_counter()
     for _ in range(3):
@@ -196,9 +204,11 @@ def e2e_record(dtype_name, batch, budget_s=8.0):
     el = time.perf_counter() - t0
     done = [int(h.nms_done.item()) for h in model._hot]
     rec = dict(value=steps * batch / el, unit='img/s', batch=batch, steps=steps, ms_per_image=el / (steps * batch) * 1e3,
-               dtype=dtype_name, model='ResNet-101-FPN', image=list(IMAGE_SHAPE), weights='random init', data='synthetic',
-               conv_path='MIOpen / hipBLASLt library convolutions (find mode) + hand-written HIP epilogues, 1x1 MFMA '
-                         'convolutions, neck merges, RPN tail (fp16) around the HIP hot path',
+               dtype=dtype_name, model={'fpn': 'ResNet-101-FPN', 'c4': 'ResNet-50 C4 Faster R-CNN', 'vgg16': 'VGG16 Faster R-CNN'}[family],
+               image=list(image_shape), weights='random init', data='synthetic',
+               conv_path='hand-written HIP convolutions (3x3 implicit GEMM incl. the fused RpnHead and bottleneck tails, 1x1 '
+                         'MFMA kernel; float16) + MIOpen / hipBLASLt for the remaining layers (find mode), fused epilogues and '
+                         'neck merges, around the HIP hot path',
                warmup_s=warm_s, nms_done=done, detections_image0=int(out[0][3].item()))
     del model
     torch.cuda.empty_cache()
@@ -455,6 +465,11 @@ def main():
                 try:
                     e2e[name] = e2e_record(name, b)
                 except Exception as ex:               # the headline record must not depend on the second one
+                    e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+            for name, fam in (('fp16_resnet50_c4', 'c4'), ('fp16_vgg16_600x800', 'vgg16')):     # BASELINE configs 2 and 1
+                try:
+                    e2e[name] = e2e_record('fp16', 8, budget_s=4.0, family=fam)
+                except Exception as ex:
                     e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
             e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
                            'mode (the reference computes in float32), fp16 = throughput mode, narrower than the reference')
