@@ -382,6 +382,17 @@ int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_levels, con
 int odet_conv3x3_conv1x1_f16(const void* x, const void* w2, const void* b2, const void* w3, const void* b3,
                              const void* residual, void* y, int batch, int H, int W, int cin, int n3, int relu,
                              odet_stream_t stream);
+/* The ResNet stem in one launch (resnet_fpn.py:262-289, resnet_faster_rcnn.py:31-60): ZeroPadding2D(3) -> Conv2D(64, 7x7,
+ * stride 2, 'valid') + folded frozen BN -> ReLU -> ZeroPadding2D(1) -> MaxPooling2D(3x3, stride 2, 'valid'), from the
+ * NHWC 3-channel image (float32: images_f16 = 0, or float16) to the NHWC float16 map [batch][PH][PW][64], PH =
+ * ((H - 1) / 2 + 1 - 1) / 2 + 1.  The convolution runs on the matrix cores in float16 with float32 accumulation; neither
+ * the padded image nor the convolution output go to memory.  packed_w: the weights repacked once by
+ * odet_stem_pack_weights_f16 (from a float16 [64][3][7][7] tensor with the given element strides) into 64 x 7 x 32
+ * float16. */
+int odet_stem_pack_weights_f16(const void* w, long long stride_o, long long stride_c, long long stride_y,
+                               long long stride_x, void* packed, odet_stream_t stream);
+int odet_stem_conv7_pool3_f16(const void* images, int images_f16, const void* packed_w, const void* bias, void* out,
+                              int batch, int H, int W, odet_stream_t stream);
 /* the float32 forms (the detectors' parity mode computes in the reference's precision): float32 x / w / bias / y,
  * exact-float32 MFMA (v_mfma_f32_16x16x4_f32), cin % 32 == 0, cout % 256 == 0 */
 int odet_conv3x3_f32(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,

@@ -848,3 +848,36 @@ def test_conv3x3_conv1x1_fused_block_tail(B, H, W, cin, n3, res):
     two = ops.conv1x1_f16(ops.conv3x3_f16(x, w2), w3, b3, residual=r, relu=True, in_bias=b2)
     torch.testing.assert_close(got.float(), two.float(), rtol=4e-3, atol=4e-3)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,dt', [(1, 64, 96, torch.float32), (2, 61, 75, torch.float16), (1, 800, 1333, torch.float32),
+                                      (3, 7, 9, torch.float32), (1, 33, 17, torch.float16)])
+def test_stem_conv7_pool3_fused(B, H, W, dt):
+    """odet_stem_conv7_pool3_f16 (the ResNet stem in one launch: pad 3 + 7x7/2 convolution + folded-BN bias + ReLU + pad 1
+    + 3x3/2 max-pooling, convolution on the matrix cores, nothing but the image read and the pooled map written): EXACT
+    on integer-valued data (products and sums are small integers), within float16 rounding of the float32 torch
+    formulation on random data; odd sizes (tiles that hang over the right / bottom edge, one-tile images)."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(H * 7 + W)
+
+    def reference(img, w, b):
+        x = F.pad(img.permute(0, 3, 1, 2).half().float(), (3, 3, 3, 3))
+        y = F.relu(F.conv2d(x, w.float(), b.float(), 2, 0)).half().float()
+        return F.max_pool2d(F.pad(y, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+
+    img = torch.randint(-3, 4, (B, H, W, 3), device='cuda', generator=g).to(dt)
+    w = torch.randint(-2, 3, (64, 3, 7, 7), device='cuda', generator=g).half()
+    b = torch.randint(-3, 4, (64,), device='cuda', generator=g).half()
+    pw = ops.stem_pack_weights(w)
+    got = ops.stem_conv7_pool3(img, pw, b)
+    want = reference(img, w, b)
+    assert got.shape == want.shape and torch.equal(got.float(), want)
+    # a channels_last weight tensor packs to the same thing
+    assert torch.equal(ops.stem_pack_weights(w.contiguous(memory_format=torch.channels_last)), pw)
+    img = (torch.randn((B, H, W, 3), device='cuda', generator=g) * 50).to(dt)
+    w = (torch.randn((64, 3, 7, 7), device='cuda', generator=g) * 0.02).half()
+    b = torch.randn(64, device='cuda', generator=g).half()
+    got = ops.stem_conv7_pool3(img, ops.stem_pack_weights(w), b)
+    torch.testing.assert_close(got.float(), reference(img, w, b), rtol=4e-3, atol=2e-2)
+

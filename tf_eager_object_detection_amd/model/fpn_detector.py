@@ -159,6 +159,22 @@ def _own_conv3x3(conv, x, pad=None):
     return _CONV3X3_MODE == 'force' or ((m + 127) // 128) * tiles_n >= 100
 
 
+def _stem(conv1, images_nhwc, dtype):
+    """conv1_pad + 7x7/2 'valid' + folded BN + ReLU + pool1_pad + 3x3/2 max-pooling (resnet_fpn.py:262-289).  float16 on the
+    GPU: ONE launch from the image (ops.stem_conv7_pool3: the 64-channel convolution output, 273 MB at batch 8, never
+    goes to memory); otherwise the library convolution + the fused bias / ReLU / pooling pass."""
+    if (_CONV3X3_MODE in ('own', 'force') and images_nhwc.is_cuda and dtype == torch.float16 and conv1.out_channels == 64
+            and images_nhwc.dtype in (torch.float32, torch.float16) and images_nhwc.is_contiguous()):
+        key = (conv1.weight.data_ptr(), conv1.weight._version)
+        packed = getattr(conv1, '_odet_packed', None)
+        if packed is None or packed[0] != key:
+            packed = (key, ops.stem_pack_weights(conv1.weight))
+            conv1._odet_packed = packed
+        return ops.stem_conv7_pool3(images_nhwc, packed[1], conv1.bias).permute(0, 3, 1, 2)
+    x = images_nhwc.to(dtype).permute(0, 3, 1, 2)                               # NHWC memory, NCHW view
+    return _conv_relu_pool(conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
+
+
 def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=None):
     """max_pool(relu(conv(x) + bias)): on the GPU the convolution runs without its bias and ONE pass
     (ops.bias_relu_maxpool) reads its output once and writes the pooled map; torch formulation elsewhere."""
@@ -422,10 +438,10 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
     # ---- dense parts ---------------------------------------------------------------------------
     def features(self, images_nhwc):
         """[B,H,W,3] -> (P2..P6), each [B,256,h,w] channels_last (= NHWC in memory)."""
-        x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)                       # NHWC memory, NCHW view
-        # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 -- the last three in one pass; x >= 0 after
-        # the ReLU, so skipping the window taps outside the map gives the same maxima as the zero padding
-        x = _conv_relu_pool(self.conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
+        # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 -- float16: one launch from the image; otherwise
+        # the last three in one pass (x >= 0 after the ReLU, so skipping the window taps outside the map gives the same
+        # maxima as the zero padding)
+        x = _stem(self.conv1, images_nhwc, self.dtype)
         c2 = self.conv2(x)
         c3 = self.conv3(c2)
         c4 = self.conv4(c3)

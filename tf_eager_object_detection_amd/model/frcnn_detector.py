@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pipeline import FrcnnHotPath, FrcnnStepBatch
-from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _conv, _conv_epi, \
+from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _conv, _conv_epi, _stem, \
     _conv_relu_pool, _fold_frozen_bn, _stack, rpn_pair_weights
 
 __all__ = ['ResNetC4Detector', 'Vgg16Detector']
@@ -111,9 +111,8 @@ class ResNetC4Detector(_NmsCompleteness, nn.Module):
     # ---- dense parts ---------------------------------------------------------------------------
     def features(self, images_nhwc):
         """[B,H,W,3] -> C4 [B,1024,ceil(H/16),ceil(W/16)] channels_last (= NHWC in memory)."""
-        x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
-        # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 (the last three in one pass on the GPU)
-        x = _conv_relu_pool(self.conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
+        # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 (float16: one launch from the image)
+        x = _stem(self.conv1, images_nhwc, self.dtype)
         return self.conv4(self.conv3(self.conv2(x)))
 
     def rpn(self, c4):

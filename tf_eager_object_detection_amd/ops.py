@@ -575,6 +575,38 @@ def conv3x3_conv1x1_f16(x, weight2, bias2, weight3, bias3, residual=None, relu=T
     return out
 
 
+def stem_pack_weights(weight):
+    """[64,3,7,7] float16 stem weights (any strides) -> the packed [64*7*32] float16 layout of stem_conv7_pool3."""
+    if weight.dtype != torch.float16 or tuple(weight.shape) != (64, 3, 7, 7) or not weight.is_cuda:
+        raise ValueError('weight must be a float16 [64,3,7,7] GPU tensor')
+    packed = torch.empty(64 * 7 * 32, dtype=torch.float16, device=weight.device)
+    so, sc, sy, sx = (int(v) for v in weight.stride())
+    L.call('odet_stem_pack_weights_f16', C.c_void_p(weight.data_ptr()), so, sc, sy, sx, L.dptr(packed), L.stream())     # (any strides)
+    return packed
+
+
+def stem_conv7_pool3(images_nhwc, packed_weight, bias, out=None):
+    """The ResNet stem in ONE launch (odet_stem_conv7_pool3_f16): pad 3 + 7x7/2 convolution + bias + ReLU + pad 1 + 3x3/2
+    max-pooling from the NHWC image [B,H,W,3] (float32 or float16) to NHWC float16 [B,PH,PW,64]."""
+    x = images_nhwc
+    if x.dtype not in (torch.float32, torch.float16) or not x.is_cuda or x.dim() != 4 or int(x.shape[3]) != 3 or not x.is_contiguous():
+        raise ValueError('images must be a contiguous NHWC float32 / float16 GPU tensor [B,H,W,3]')
+    if packed_weight.dtype != torch.float16 or packed_weight.numel() != 64 * 7 * 32 or not packed_weight.is_contiguous():
+        raise ValueError('packed_weight: the result of stem_pack_weights')
+    if bias.dtype != torch.float16 or bias.numel() != 64 or not bias.is_contiguous():
+        raise ValueError('bias must be a contiguous float16 [64] tensor')
+    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    ch, cw = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    shape = (B, (ch - 1) // 2 + 1, (cw - 1) // 2 + 1, 64)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
+    L.call('odet_stem_conv7_pool3_f16', L.dptr(x), 1 if x.dtype == torch.float16 else 0, L.dptr(packed_weight), L.dptr(bias),
+           L.dptr(out), B, H, W, L.stream())
+    return out
+
+
 def conv3x3_f32(x, weight, bias=None, relu=False, out=None):
     """conv3x3_f16 in the reference's precision: float32 operands and result, exact-float32 matrix instructions
     (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 256 == 0."""
