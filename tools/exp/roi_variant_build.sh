@@ -18,7 +18,7 @@ cp include/*.h $T/include/
 (cd $T/pkg/csrc && patch -s -p0 roi.hip < "$OLDPWD/tools/exp/roi_diag_switches.patch")
 sed -i 's#"../../include/odet.h"#"'$T'/include/odet.h"#' $T/pkg/csrc/odet_internal.h
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-variable"
-hipcc $FLAGS -fno-slp-vectorize "$@" -c $T/pkg/csrc/roi.hip -o $T/roi.o &
+hipcc $FLAGS ${ROI_SLP:--fno-slp-vectorize} "$@" -c $T/pkg/csrc/roi.hip -o $T/roi.o &
 hipcc $FLAGS "$@" -c $T/pkg/csrc/roi_half.hip -o $T/roi_half.o &
 wait
 O=tf_eager_object_detection_amd/csrc/_obj
