@@ -404,6 +404,28 @@ def test_fpn_roi_path_full_size():
     np.testing.assert_array_equal(out, want)                            # IEEE-only kernel: bit-identical
 
 
+def test_fpn_roi_path_full_size_float16_maps_config5():
+    """BASELINE config 5 at FULL size: 1333 x 1333, 1000 proposals, P2..P5 x 256 channels, FLOAT16 feature maps (float32
+    boxes and lerps, float16 in / out): the multi-level RoI kernel against the oracle's crops of the float16 values
+    widened to float32 and rounded to float16 once -- bit-identical; the same through the spatial processing order."""
+    rng = np.random.default_rng(4321)
+    shape = (1333, 1333)
+    shapes = syn.fpn_level_shapes(shape)[:4]
+    feats16 = [f.astype(np.float16) for f in syn.features(shapes, 256, rng)]
+    rois = syn.random_boxes(1000, shape, rng, 16, 1200)
+    rois[:4] = [[0, 0, 112, 112], [0, 0, 448, 448], [0, 0, 1332, 1332], [600, 10, 610, 900]]
+    lv, perm, cnt = co.assign_levels(rois)
+    srois, slv = rois[perm], (lv[perm] - 2).astype(np.int32)
+    want = np.concatenate([co.roi_pool(feats16[l].astype(np.float32), srois[slv == l], image_shape=shape, pool=7, threads=8)
+                           for l in range(4) if np.any(slv == l)], axis=0).astype(np.float16)
+    for with_order in (False, True):
+        order = ops.roi_order(g(srois), g(slv), shape) if with_order else None
+        got = ops.roi_pool([g(f) for f in feats16], g(srois), g(slv), ops.ROI_NORM_IMAGE, 7, ops.ROI_POOL_MAX2,
+                           image_shape=shape, order=order)
+        assert got.dtype == torch.float16
+        np.testing.assert_array_equal(h(got).view(np.uint16), want.view(np.uint16))
+
+
 def test_assign_levels_boundaries_and_count_dev():
     def sq(s):
         return [0, 0, s, s]
