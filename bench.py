@@ -28,12 +28,15 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
                  (k_roi_pool<..., 1>, same code), so the kernel-stats summary of a profiled run of this command
                  (profiles/) has a row whose average IS `kernel_ms`.  `frac` prices SURVEY 8(d)'s algorithmic
                  bytes B_roi (no credit for reuse between RoIs); `hbm_frac_measured` prices the HBM bytes the PMC
-                 counters saw (profiles/roi_pool_traffic.json); `B_min` / `B_taps` bracket B_roi.
+                 counters saw (profiles/roi_pool_traffic.json); `B_min` / `B_taps` bracket B_roi; `calibration` = a kernel that
+                 only moves B_min bytes with the RoI kernel's instructions (odet_calib_stream_mix), timed under the same
+                 protocol right after: what this box's memory system needs for the launch's read : write mix.
   `cpu_baseline` the C restatement of the reference path timed on this box's host cores (kind "port"); it also
                  carries the mAP delta of the evaluation loop.
-  `e2e`          (N = 1) a second, separately labelled record: the assembled ResNet-101-FPN detector end to end
-                 (library convolutions + hand-written kernels around the hot path), fp32 = the reference's
-                 precision, fp16 = throughput mode (narrower than the reference).
+  `e2e`          (N = 1) a second, separately labelled record: the assembled detectors end to end (hand-written
+                 convolutions + library layers around the hot path): ResNet-101-FPN fp32 = the reference's precision,
+                 fp16 = throughput mode (narrower than the reference; eager and as one HIP graph), ResNet-50 C4 and
+                 VGG16 (BASELINE configs 2 and 1) in fp16.
 """
 import argparse
 import ctypes
