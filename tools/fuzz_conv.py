@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Seeded sweep of the hand-written convolutions against torch on integer-valued data (exact comparison): random map
+sizes (incl. one-pixel rows / columns), batches, channel counts, so that every workgroup-tile choice of conv3x3_launch
+and the edge handling of the fused forms (RpnHead, bottleneck tail, stem) are exercised.
+
+    python tools/fuzz_conv.py [--cases N] [--seed S]"""
+import argparse, os, sys
+import torch, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tf_eager_object_detection_amd import ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', type=int, default=120)
+    ap.add_argument('--seed', type=int, default=0)
+    a = ap.parse_args()
+    g = torch.Generator(device='cuda'); g.manual_seed(a.seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), device='cuda', generator=g).item())
+    sparse = lambda shape, pct, lo, hi: ((torch.randint(0, 100, shape, device='cuda', generator=g) < pct).half()
+                                         * torch.randint(lo, hi + 1, shape, device='cuda', generator=g).half())
+    for case in range(a.cases):
+        kind = case % 4
+        B, H, W = ri(1, 3), ri(1, 70), ri(1, 90)
+        if kind == 0:      # plain 3x3, any cout % 64
+            cin, cout = 64 * ri(1, 4), 64 * ri(1, 10)
+            x = torch.randint(-2, 3, (B, H, W, cin), device='cuda', generator=g).half()
+            w = sparse((cout, cin, 3, 3), 8, -2, 2).contiguous(memory_format=torch.channels_last)
+            b = torch.randint(-3, 4, (cout,), device='cuda', generator=g).half()
+            got = ops.conv3x3_f16(x, w, b, relu=bool(case & 4))
+            want = F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b.float(), 1, 1)
+            want = (F.relu(want) if case & 4 else want).permute(0, 2, 3, 1)
+            assert float(want.abs().max()) < 2048 and torch.equal(got.float(), want), ('conv3x3', B, H, W, cin, cout)
+        elif kind == 1:    # fused RpnHead over 1..4 maps
+            A, cin, cout = ri(1, 5), 64 * ri(1, 3), 256 * ri(1, 2)
+            shapes = [(max(1, H >> l), max(1, W >> l)) for l in range(ri(1, 4))]
+            xs = [sparse((B, h, w, cin), 4, 1, 1) for h, w in shapes]
+            w3 = sparse((cout, cin, 3, 3), 4, -2, 2).contiguous(memory_format=torch.channels_last)
+            b3 = torch.randint(-3, 4, (cout,), device='cuda', generator=g).half()
+            w1 = sparse((6 * A, cout), 10, -2, 2)
+            b1 = torch.randint(-3, 4, (6 * A,), device='cuda', generator=g).half()
+            n = sum(h * w for h, w in shapes) * A
+            sc = torch.full((B, n, 2), 9.0, device='cuda'); dl = torch.full((B, n, 4), 9.0, device='cuda')
+            ops.rpn_head_fused(xs, w3, b3, w1, b1, A, sc, dl)
+            ws, wd = [], []
+            for x in xs:
+                t = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w3.float(), b3.float(), 1, 1))
+                o = F.conv2d(t, w1.float().reshape(6 * A, cout, 1, 1), b1.float()).permute(0, 2, 3, 1)
+                ws.append(o[..., :2 * A].reshape(B, -1, 2)); wd.append(o[..., 2 * A:].reshape(B, -1, 4))
+            ws, wd = torch.cat(ws, 1), torch.cat(wd, 1)
+            assert float(ws.abs().max()) < 2048 and torch.equal(sc, ws) and torch.equal(dl, wd), ('rpn_head_fused', B, shapes, cin, cout, A)
+        elif kind == 2:    # fused bottleneck tail
+            cin, n3 = 64 * ri(1, 4), 64 * ri(1, 16)
+            x = sparse((B, H, W, cin), 4, 1, 1)
+            w2 = sparse((256, cin, 3, 3), 4, -2, 2).contiguous(memory_format=torch.channels_last)
+            b2 = torch.randint(-3, 4, (256,), device='cuda', generator=g).half()
+            w3 = sparse((n3, 256), 10, -2, 2)
+            b3 = torch.randint(-3, 4, (n3,), device='cuda', generator=g).half()
+            r = torch.randint(-4, 5, (B, H, W, n3), device='cuda', generator=g).half() if case & 4 else None
+            got = ops.conv3x3_conv1x1_f16(x, w2, b2, w3, b3, residual=r, relu=True)
+            t = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w2.float(), b2.float(), 1, 1))
+            o = F.conv2d(t, w3.float().reshape(n3, 256, 1, 1), b3.float()).permute(0, 2, 3, 1)
+            want = F.relu(o + r.float() if r is not None else o)
+            assert float(want.abs().max()) < 2048 and torch.equal(got.float(), want), ('block tail', B, H, W, cin, n3)
+        else:              # stem
+            H2, W2 = ri(7, 140), ri(7, 180)
+            img = torch.randint(-3, 4, (B, H2, W2, 3), device='cuda', generator=g).to(torch.float16 if case & 4 else torch.float32)
+            w = torch.randint(-2, 3, (64, 3, 7, 7), device='cuda', generator=g).half()
+            b = torch.randint(-3, 4, (64,), device='cuda', generator=g).half()
+            got = ops.stem_conv7_pool3(img, ops.stem_pack_weights(w), b)
+            y = F.relu(F.conv2d(F.pad(img.permute(0, 3, 1, 2).float(), (3, 3, 3, 3)), w.float(), b.float(), 2, 0))
+            want = F.max_pool2d(F.pad(y, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+            assert torch.equal(got.float(), want), ('stem', B, H2, W2)
+    torch.cuda.synchronize()
+    print('all %d cases OK' % a.cases)
+
+
+if __name__ == '__main__':
+    main()
