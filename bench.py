@@ -31,12 +31,15 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
                  counters saw (profiles/roi_pool_traffic.json); `B_min` / `B_taps` bracket B_roi; `calibration` = a kernel that
                  only moves B_min bytes with the RoI kernel's instructions (odet_calib_stream_mix), timed under the same
                  protocol right after: what this box's memory system needs for the launch's read : write mix.
-  `cpu_baseline` the C restatement of the reference path timed on this box's host cores (kind "port"); it also
-                 carries the mAP delta of the evaluation loop.
+  `cpu_baseline` the C restatement of the reference path timed on this box's host cores (kind "port"), all cores
+                 (`value`) and one thread (`value_1thread`); it also carries the mAP delta of the evaluation loop.
+  `value_clustered` the same path, same protocol, on trained-like (clustered) RPN scores: a second timed region; the
+                 sync-free NMS plan is widened once by itself when a distribution needs it (`config.replanned`).
   `e2e`          (N = 1) a second, separately labelled record: the assembled detectors end to end (hand-written
                  convolutions + library layers around the hot path): ResNet-101-FPN fp32 = the reference's precision,
-                 fp16 = throughput mode (narrower than the reference; eager and as one HIP graph), ResNet-50 C4 and
-                 VGG16 (BASELINE configs 2 and 1) in fp16.
+                 fp16 = throughput mode (narrower than the reference; eager and as one HIP graph) with its accuracy gate
+                 `map_delta_vs_fp32` (float16 vs float32 detector on identical weights and annotated synthetic scenes,
+                 the reference's evaluation loop), ResNet-50 C4 and VGG16 (BASELINE configs 2 and 1) in fp16.
 """
 import argparse
 import ctypes
@@ -92,17 +95,14 @@ def algorithmic_roi_bytes(sorted_rois, levels, level_shapes, image_shape, channe
                 B_taps=R * crop * crop * 4 * channels * elem + out_bytes, out=out_bytes, unique_cells=total_cells)
 
 
-def cpu_baseline(host, image_shape, budget_s=20.0, max_images=8):
-    """The reference path as the TF-eager CPU code runs it (C restatement, oracle/oracle.c): heap NMS
-    over all anchors, un-fused 14x14 crop -> max-pool, sequential per-class loop.  Bounded sample."""
+def _cpu_leg(host, image_shape, threads, budget_s, max_images):
+    """images of the workload through the C restatement on `threads` OpenMP threads -> per-image seconds"""
     from oracle import c_oracle as co
-    threads = max(1, min(os.cpu_count() or 1, co.max_threads()))
     K = NUM_PROPOSALS
     t_all = []
-    n_img = 0
     t_start = time.perf_counter()
     scratch = np.empty((K, 14, 14, CHANNELS), np.float32)
-    while n_img < max_images and (time.perf_counter() - t_start) < budget_s:
+    while len(t_all) < max_images and (time.perf_counter() - t_start) < budget_s:
         t0 = time.perf_counter()
         anchors = co.fpn_anchors(image_shape)
         fg = co.rpn_fg_fpn(host['rpn_logits'])
@@ -119,13 +119,27 @@ def cpu_baseline(host, image_shape, budget_s=20.0, max_images=8):
         co.post_ops(host['cls_scores'][:k], host['cls_deltas'][:k], srois, image_shape, [0, 0, 0, 0],
                     [.1, .1, .2, .2], 50, 50, 0.3, 0.0, 16, NUM_CLASSES)
         t_all.append(time.perf_counter() - t0)
-        n_img += 1
-    t = float(np.median(t_all))
+    return t_all
+
+
+def cpu_baseline(host, image_shape, budget_s=12.0, max_images=24):
+    """The reference path as the TF-eager CPU code runs it (C restatement, oracle/oracle.c): heap NMS
+    over all anchors, un-fused 14x14 crop -> max-pool, sequential per-class loop.  Bounded sample, in both thread modes
+    of BASELINE.md section 3: all host cores (`value`, what TF's intra-op pool would use) and one thread."""
+    from oracle import c_oracle as co
+    threads = max(1, min(os.cpu_count() or 1, co.max_threads()))
+    _cpu_leg(host, image_shape, threads, 5.0, 1)                               # (page-in / OpenMP pool start-up)
+    t_all = _cpu_leg(host, image_shape, threads, budget_s, max_images)
+    t_one = _cpu_leg(host, image_shape, 1, budget_s, max_images)
+    t, t1 = float(np.median(t_all)), float(np.median(t_one))
     md = map_delta_vs_port()
     return dict(map_delta=md, value=1.0 / t, unit='img/s', cores=threads, kind='port',
-                sample='%d images of the same 800x1333 FPN hot-path workload, median; C restatement of the '
-                       'reference path (heap NMS over 267069 anchors single-threaded, un-fused crop 14x14 + '
-                       'max-pool on %d OpenMP threads, sequential class loop)' % (n_img, threads),
+                value_1thread=1.0 / t1, ms_per_image_1thread=t1 * 1e3, samples=len(t_all), samples_1thread=len(t_one),
+                ms_per_image_min=float(np.min(t_all)) * 1e3, ms_per_image_max=float(np.max(t_all)) * 1e3,
+                sample='%d (all cores) + %d (one thread) images of the same 800x1333 FPN hot-path workload, medians; C '
+                       'restatement of the reference path (heap NMS over 267069 anchors single-threaded, un-fused crop '
+                       '14x14 + max-pool on %d OpenMP threads / 1 thread, sequential class loop)'
+                       % (len(t_all), len(t_one), threads),
                 ms_per_image=t * 1e3)
 
 
@@ -256,6 +270,9 @@ def main():
                     help='RPN score distribution (SURVEY 8d: distinct; clustered = trained-like)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end detector record')
+    ap.add_argument('--no-second-distribution', action='store_true',
+                    help='skip the second timed region (the other RPN score distribution: value_clustered)')
+    ap.add_argument('--gate-images', type=int, default=1024, help='held-out scenes of the float16-vs-float32 mAP gate (e2e)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams (stream groups) per GPU')
     ap.add_argument('--batch', type=int, default=8, help='images that share the kernel launches of a stream (1..8)')
     ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
@@ -297,76 +314,132 @@ def main():
     from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
     _lib.lib()     # fail loudly without the HIP library
 
-    host, dev = synthetic_fpn_inputs(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, seed=1234 + rank,
-                                     score_kind=args.scores)
     # images in flight per GPU: `streams` stream groups x `batch` images that share every kernel launch of their
     # stream (one grid dimension = image)
     S, B = max(1, args.streams), max(1, min(8, args.batch))
     R = max(1, args.rounds_per_step)
     fdt = torch.float16 if args.maps == 'f16' else torch.float32
-    pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B,
-                         blind_chunks=args.blind_chunks, feature_dtype=fdt, nms_first_chunk=args.nms_first_chunk)
-    if fdt != torch.float32:
-        dev['feats'] = [f.to(fdt) for f in dev['feats']]
-    nslots = pool.n
-    rec_len = pool.slots[0].record.numel()
-    records = torch.zeros((nslots, rec_len), dtype=torch.float32, device='cuda')
-    # every in-flight image has its OWN inputs in HBM (slot 0 = the seeded numpy set the CPU baseline also
-    # uses; the others: fresh normal feature maps, the RPN / RoI-head outputs of slot 0 row-permuted), so
-    # that no image is served from lines another image pulled into L2 / Infinity Cache
-    gen = torch.Generator(device='cuda')
-    gen.manual_seed(4321 + rank)
-    slot_inputs = [dev]
-    for k in range(1, nslots):
-        pa = torch.randperm(dev['rpn_logits'].shape[0], device='cuda', generator=gen)
-        pr = torch.randperm(dev['cls_scores'].shape[0], device='cuda', generator=gen)
-        slot_inputs.append(dict(
-            rpn_logits=dev['rpn_logits'][pa].contiguous(), rpn_deltas=dev['rpn_deltas'][pa].contiguous(),
-            feats=[torch.randn(f.shape, device='cuda', dtype=torch.float32, generator=gen).to(fdt) for f in dev['feats']],
-            cls_scores=dev['cls_scores'][pr].contiguous(), cls_deltas=dev['cls_deltas'][pr].contiguous()))
-    for k in range(nslots):
-        pool.slots[k].record = records[k]                     # one contiguous block per group: ONE all-gather per group
-        d = slot_inputs[k]
-        pool.bind(k, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
+    images_per_step = R * S * B
+
+    class Workload:
+        """One score distribution's inputs (resident in HBM) + the stream pool that runs them."""
+
+        def __init__(self, score_kind, nms_first_chunk, blind_chunks):
+            self.score_kind, self.nms_first_chunk, self.blind_chunks = score_kind, nms_first_chunk, blind_chunks
+            self.host, dev = synthetic_fpn_inputs(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, seed=1234 + rank,
+                                                  score_kind=score_kind)
+            if fdt != torch.float32:
+                dev['feats'] = [f.to(fdt) for f in dev['feats']]
+            # every in-flight image has its OWN inputs in HBM (slot 0 = the seeded numpy set the CPU baseline also
+            # uses; the others: fresh normal feature maps, the RPN / RoI-head outputs of slot 0 row-permuted), so
+            # that no image is served from lines another image pulled into L2 / Infinity Cache
+            gen = torch.Generator(device='cuda')
+            gen.manual_seed(4321 + rank)
+            self.slot_inputs = [dev]
+            for k in range(1, S * B):
+                pa = torch.randperm(dev['rpn_logits'].shape[0], device='cuda', generator=gen)
+                pr = torch.randperm(dev['cls_scores'].shape[0], device='cuda', generator=gen)
+                self.slot_inputs.append(dict(
+                    rpn_logits=dev['rpn_logits'][pa].contiguous(), rpn_deltas=dev['rpn_deltas'][pa].contiguous(),
+                    feats=[torch.randn(f.shape, device='cuda', dtype=torch.float32, generator=gen).to(fdt) for f in dev['feats']],
+                    cls_scores=dev['cls_scores'][pr].contiguous(), cls_deltas=dev['cls_deltas'][pr].contiguous()))
+            self.pool = None
+            self.plan(nms_first_chunk, blind_chunks)
+
+        def plan(self, nms_first_chunk, blind_chunks):
+            if self.pool is not None:
+                self.pool.close()
+            self.nms_first_chunk, self.blind_chunks = nms_first_chunk, blind_chunks
+            pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B, blind_chunks=blind_chunks,
+                                 feature_dtype=fdt, nms_first_chunk=nms_first_chunk)
+            rec_len = pool.slots[0].record.numel()
+            self.records = torch.zeros((pool.n, rec_len), dtype=torch.float32, device='cuda')
+            for k in range(pool.n):
+                pool.slots[k].record = self.records[k]            # one contiguous block per group: ONE all-gather per group
+                d = self.slot_inputs[k]
+                pool.bind(k, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
+            self.pool, self.rec_len = pool, rec_len
+            self.exchange = parallel.GroupExchange(S, B, rec_len, 'cuda', force_collective=True) if use_dist else None
+
+        def run_steps(self, nsteps):
+            """nsteps steps of R rounds: in every round each of the S stream groups sends its B images through their
+            shared launches; with N > 1 ranks each group's records then go through one all-gather
+            (parallel.GroupExchange) -- the group's launches and its exchange are enqueued by THIS thread, in stream
+            order, so the multi-rank loop has no host wait between groups either."""
+            pool = self.pool
+            if not use_dist:
+                for _ in range(nsteps * R):
+                    for g in range(S):
+                        pool.submit_group(g)
+                return
+            gstreams = pool._group_streams
+            for _ in range(nsteps * R):
+                for g in range(S):
+                    pool.enqueue_group(g)
+                    self.exchange.gather(g, self.records[g * B:(g + 1) * B], producer_stream=gstreams[g])
+
+        def fence(self):
+            self.pool.wait()
+            torch.cuda.synchronize()
+            if use_dist:
+                self.exchange.synchronize()
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        def complete(self):
+            ok = 1 if all(int(h.nms_done.item()) == 1 for h in self.pool.slots) else 0
+            if use_dist:                                          # (every rank re-plans or none does)
+                t = torch.tensor([ok], dtype=torch.int32, device='cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+            return ok == 1
+
+        def measure(self, steps, warmup):
+            """warm-up (re-planning the sync-free NMS once or twice if the score distribution needs more candidates than
+            the plan's first chunk holds: 4096-candidate first chunk, then a second chunk from the ranked selection),
+            then exactly `steps` timed steps between fences; max over ranks."""
+            replans = []
+            for first, blind in ((self.nms_first_chunk, self.blind_chunks), (4096, self.blind_chunks),
+                                 (4096, max(2, self.blind_chunks))):
+                if (first, blind) != (self.nms_first_chunk, self.blind_chunks):
+                    self.plan(first, blind)
+                    replans.append({'nms_first_chunk': first, 'blind_chunks': blind})
+                self.run_steps(max(warmup, 1))                    # (at least one pass over every slot)
+                self.fence()
+                if self.complete():
+                    break
+            else:
+                raise SystemExit('NMS did not complete inside the sync-free chunks of any plan -- result would be invalid')
+            t0 = time.perf_counter()
+            self.run_steps(steps)
+            self.fence()
+            elapsed = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            if not self.complete():
+                raise SystemExit('NMS did not complete inside the sync-free chunks -- result would be invalid')
+            return elapsed, replans
+
+    # ---- the headline: SURVEY 8(d)'s distribution (or --scores), then the OTHER distribution beside it
+    wl = Workload(args.scores, args.nms_first_chunk, args.blind_chunks)
+    elapsed, replans = wl.measure(args.steps, args.warmup)
+    other_kind = 'clustered' if args.scores == 'distinct' else 'distinct'
+    other = None
+    if not args.no_second_distribution:
+        wl2 = Workload(other_kind, args.nms_first_chunk, args.blind_chunks)
+        el2, rp2 = wl2.measure(args.steps, args.warmup)
+        other = {'value': args.steps * images_per_step * world / el2, 'unit': 'img/s', 'ms_per_step': el2 / args.steps * 1e3,
+                 'rpn_scores': other_kind, 'timed_region_s': el2, 'nms_first_chunk': wl2.nms_first_chunk,
+                 'blind_chunks': wl2.blind_chunks, 'replanned': rp2,
+                 'proposals_kept': int(wl2.pool.slots[0].roi_count.item())}
+        wl2.pool.close()
+        del wl2
+        torch.cuda.empty_cache()
+    host, pool, records = wl.host, wl.pool, wl.records
     hot = pool.slots[0]
     gstreams = pool._group_streams
-    exchange = parallel.GroupExchange(S, B, rec_len, 'cuda', force_collective=True) if use_dist else None
-
-    def drain():
-        pool.wait()
-        torch.cuda.synchronize()
-
-    def run_steps(nsteps):
-        """nsteps steps of R rounds: in every round each of the S stream groups sends its B images through their
-        shared launches; with N > 1 ranks each group's records then go through one all-gather (parallel.GroupExchange)."""
-        for _ in range(nsteps * R):
-            for g in range(S):
-                pool.submit_group(g)
-                if use_dist:
-                    pool.wait()                               # host: the group's launches are enqueued
-                    exchange.gather(g, records[g * B:(g + 1) * B], producer_stream=gstreams[g])
-
-    def fence():
-        drain()
-        if use_dist:
-            exchange.synchronize()
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_steps(max(args.warmup, 1))                            # (at least one pass over every slot)
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if any(int(h.nms_done.item()) != 1 for h in pool.slots):
-        raise SystemExit('NMS did not complete inside the blind chunks -- result would be invalid '
-                         '(use --nms-first-chunk 4096, or --blind-chunks 2, for score distributions with heavy suppression)')
-    images_per_step = R * S * B
 
     if rank == 0:
         # ---- roofline phase (untimed): the B-image RoI launch of stream group 0, ALONE on the GPU, cold maps.  Before
@@ -437,6 +510,7 @@ def main():
         algo = {q: sum(a_[q] for a_ in per_slot) for q in per_slot[0]}
         achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
         workload = 'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps')
+        images_per_step = R * S * B
         traffic = load_traffic(workload, B)
         ft = 'float' if args.maps == 'f32' else '__half'
         result = {
@@ -452,7 +526,8 @@ def main():
                        'step': '%d rounds over the %d x %d in-flight image slots of a GPU' % (R, S, B),
                        'images_per_step_per_gpu': images_per_step, 'global_batch': images_per_step * world,
                        'timed_images': args.steps * images_per_step * world, 'timed_region_s': elapsed,
-                       'rpn_scores': args.scores, 'feature_maps': args.maps, 'nms_first_chunk': args.nms_first_chunk,
+                       'rpn_scores': args.scores, 'feature_maps': args.maps, 'nms_first_chunk': wl.nms_first_chunk,
+                       'blind_chunks': wl.blind_chunks, 'replanned': replans,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2, NORM_IMAGE> (fused crop_and_resize 14x14 + 2x2 max), the '
@@ -465,6 +540,12 @@ def main():
                          'kernel_ms_max': float(np.max(times)), 'algorithmic_bytes': algo['B_roi'],
                          'B_min': algo['B_min'], 'B_taps': algo['B_taps'], 'bytes_output': algo['out']},
         }
+        if other is not None:
+            # the same path on the other RPN score distribution, its own timed region of the same length (a trained RPN
+            # clusters its best anchors: greedy NMS suppresses most of the first candidates and needs a wider chunk)
+            result['value_%s' % other_kind] = other['value']
+            result['ms_per_step_%s' % other_kind] = other['ms_per_step']
+            result['config']['second_distribution'] = other
         # the same launch priced on the HBM bytes the PMC counters saw (reuse between RoIs served from L2 / Infinity
         # Cache is not in them; SURVEY 8d's algorithmic bytes count every RoI's cells): the plain bandwidth figure
         rf = result['roofline']
@@ -496,8 +577,28 @@ def main():
                     e2e[name] = e2e_record('fp16', 8, budget_s=4.0, family=fam)
                 except Exception as ex:
                     e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+            # the accuracy side of the throughput mode: float16 vs float32 detector, same weights, same annotated scenes,
+            # the reference's evaluation loop (evaluation/precision_gate.py)
+            try:
+                from tf_eager_object_detection_amd.evaluation import precision_gate
+                gate = precision_gate.fp16_vs_fp32(num_images=args.gate_images)
+                if isinstance(e2e.get('fp16'), dict):
+                    e2e['fp16']['map_delta_vs_fp32'] = gate
+                    if 'value' in e2e['fp16']:
+                        ok_rate = e2e['fp16']['value'] >= 200.0
+                        e2e['fp16']['target'] = ('%s the north star\'s >= 200 img/s on one MI355X (%.0f img/s); mAP delta vs the '
+                                                 'float32 mode on identical weights and images = %+.4f (paired bootstrap std %.4f, '
+                                                 '%d held-out scenes; bar +-0.002)'
+                                                 % ('meets' if ok_rate else 'misses', e2e['fp16']['value'], gate['map_delta'],
+                                                    gate['map_delta_bootstrap_std'], gate['images']))
+                else:
+                    e2e['fp16_map_delta_vs_fp32'] = gate
+            except Exception as ex:
+                e2e['fp16_map_delta_vs_fp32'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
             e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
-                           'mode (the reference computes in float32), fp16 = throughput mode, narrower than the reference')
+                           'mode (the reference computes in float32; ~69 % of the chip\'s 157 TFLOP/s float32 matrix peak, so '
+                           '>= 200 img/s is out of reach of exact float32 arithmetic: 684 GFLOP per image), fp16 = throughput '
+                           'mode, narrower than the reference, gated by map_delta_vs_fp32')
             result['e2e'] = e2e
         print(json.dumps(result))
     else:

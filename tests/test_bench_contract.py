@@ -40,6 +40,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'img/s' and c['value'] > 0 and c['cores'] >= 1 and 'sample' in c
     assert abs(c['map_delta']['delta']) <= 0.002
+    # both thread modes of BASELINE.md section 3, a bounded sample of each
+    assert c['value_1thread'] > 0 and c['samples'] >= 16 and c['samples_1thread'] >= 4
+    # the other RPN score distribution (trained-like clusters) in the same line, its own timed region; the bench widens
+    # its sync-free NMS plan by itself instead of aborting
+    assert d['value_clustered'] > 0 and d['ms_per_step_clustered'] > 0
+    sd = d['config']['second_distribution']
+    assert sd['rpn_scores'] == 'clustered' and sd['proposals_kept'] == 1000
+    assert abs(sd['ms_per_step'] * sd['value'] / (1000.0 * d['config']['images_per_step_per_gpu']) - 1.0) < 1e-6
     # a step = images_per_step_per_gpu images on every GPU; the driver's 20 steps time at least half a second
     ips = d['config']['images_per_step_per_gpu']
     assert ips == 48 * d['config']['streams_per_gpu'] * d['config']['images_per_launch']

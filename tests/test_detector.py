@@ -881,3 +881,54 @@ def test_stem_conv7_pool3_fused(B, H, W, dt):
     got = ops.stem_conv7_pool3(img, ops.stem_pack_weights(w), b)
     torch.testing.assert_close(got.float(), reference(img, w, b), rtol=4e-3, atol=2e-2)
 
+
+
+# ---- accuracy gate of the float16 throughput mode (evaluation/precision_gate.py) ------------------------------------------
+
+def test_paired_map_delta_matcher_equals_the_reference_routine_cpu():
+    """the per-image matcher the bootstrap re-uses gives the same mAP as evaluate_detections (the restated voc_eval,
+    pinned by the reference's own routine in tests/test_evaluation.py) on imperfect detections"""
+    from tf_eager_object_detection_amd.evaluation import precision_gate as pg, pascal_eval as pe
+    from tf_eager_object_detection_amd import synthetic as syn
+    from oracle import oracle_np as on
+    rng = np.random.default_rng(5)
+    dets, dets2, gb, gl = [], [], [], []
+    for i in range(10):
+        im = syn.eval_image(rng, num_rois=100)
+        kw = dict(score_threshold=0.05, iou_threshold=0.3, max_objects_per_class=50, max_objects_per_image=50, min_size=10)
+        sc = im['scores'] * rng.uniform(0.3, 1.0, im['scores'].shape).astype(np.float32)       # degrade: misses, re-ranking
+        dets.append(on.eval_detect_image(sc, im['deltas'] + rng.normal(0, 1.5, im['deltas'].shape).astype(np.float32),
+                                         im['rois'], im['img_scale'], im['raw_h'], im['raw_w'], **kw))
+        dets2.append(on.eval_detect_image(im['scores'], im['deltas'], im['rois'], im['img_scale'], im['raw_h'], im['raw_w'], **kw))
+        gb.append(im['gt_boxes'])
+        gl.append(im['gt_labels'])
+    present = sorted(set(int(l) for g in gl for l in g))
+    for d in (dets, dets2):
+        aps = pe.evaluate_detections(d, gb, gl)[1]
+        want = float(np.mean([aps[j - 1] for j in present]))
+        got = pg._map_from_matches(pg._image_matches(d, gb, gl, 21), np.arange(10))
+        assert abs(got - want) < 1e-12
+    pair = pg.paired_map_delta(dets, dets2, gb, gl, resamples=50)
+    assert 0.0 < pair['map_a'] < pair['map_b'] <= 1.0 + 1e-12 and pair['delta'] > 0
+    assert pair['delta_ci95'][0] <= pair['delta_boot_mean'] <= pair['delta_ci95'][1]
+
+
+@pytest.mark.gpu
+def test_fp16_detector_map_delta_vs_fp32_on_identical_weights_and_images():
+    """BASELINE metric's second half for the mode that meets the throughput target: ResNet-101-FPN @ 800x1333, float16
+    against float32 on the same seeded weights (last linear layers fitted on annotated scenes: a genuine detector,
+    mAP ~0.5) and the same 256 held-out scenes, through im_detect -> detect_image -> VOC07 mAP against the annotations.
+    Bar: |mAP(fp16) - mAP(fp32)| <= 0.002 (north star), at the resolution this sample has (paired bootstrap)."""
+    from tf_eager_object_detection_amd.evaluation import precision_gate as pg
+    rec = pg.fp16_vs_fp32(num_images=256, resamples=200)
+    print('\n  fp16 vs fp32: mAP %.4f -> %.4f, delta %+.4f (bootstrap std %.4f, CI95 [%+.4f, %+.4f]); reproduction: %.1f %% of '
+          'the fp32 detections matched, RPN kept-index agreement %.3f, median |dscore| %.1e'
+          % (rec['map_fp32'], rec['map_fp16'], rec['map_delta'], rec['map_delta_bootstrap_std'],
+             rec['map_delta_ci95_paired_bootstrap'][0], rec['map_delta_ci95_paired_bootstrap'][1],
+             100 * rec['reproduction']['matched_fraction'], rec['rpn_kept_index_agreement_mean'], rec['median_abs_dscore']))
+    assert rec['classes_scored'] == 20 and rec['map_fp32'] >= 0.3            # the fitted detector has real signal
+    assert abs(rec['map_delta']) <= 0.002 + 3.0 * rec['map_delta_bootstrap_std']
+    lo, hi = rec['map_delta_ci95_paired_bootstrap']
+    assert lo - 0.002 <= 0.0 <= hi + 0.002                                    # +-0.002 is inside what the sample allows
+    assert rec['reproduction']['matched_fraction'] >= 0.95 and rec['rpn_kept_index_agreement_mean'] >= 0.96
+    assert rec['median_abs_dscore'] <= 2e-3 and rec['median_abs_dbox_px'] <= 0.5

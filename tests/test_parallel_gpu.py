@@ -47,12 +47,24 @@ def _rank(rank, world, port, q):
             pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
         ex = parallel.GroupExchange(S, B, rec_len, 'cuda')
         got = {}
+        # the loop bench.py runs with N > 1: a group's launches and its exchange are enqueued by this thread in stream
+        # order -- no host wait between groups (pool.wait / stream or device synchronisation would show up here)
+        host_syncs = []
+        real_wait, real_sync = pool.wait, torch.cuda.synchronize
+        pool.wait = lambda: host_syncs.append('pool.wait') or real_wait()
+        torch.cuda.synchronize = lambda *a, **k: host_syncs.append('synchronize') or real_sync(*a, **k)
+        outs = []
         for g in range(S):
-            pool.submit_group(g)
-            pool.wait()
+            pool.enqueue_group(g)
             valid = max(0, min(B, len(mine) - g * B))
-            out = ex.gather(g, records[g * B:(g + 1) * B], producer_stream=pool._group_streams[g], valid=valid)
-            ex.synchronize()
+            outs.append(ex.gather(g, records[g * B:(g + 1) * B], producer_stream=pool._group_streams[g], valid=valid))
+        pool.wait, torch.cuda.synchronize = real_wait, real_sync
+        # (the gloo rehearsal backend moves host memory: its staging .cpu() copy synchronises the communication stream,
+        # which RCCL's device-side collective does not; neither pool.wait nor a device synchronisation may appear)
+        assert 'pool.wait' not in host_syncs and 'synchronize' not in host_syncs, host_syncs
+        ex.synchronize()
+        for g in range(S):
+            out = outs[g]
             for r in range(world):
                 for j in range(B):
                     img = r + (g * B + j) * world

@@ -141,19 +141,11 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
         if (q < 2) acc0[idx] = v; else acc1[idx] = v;
       }
     }
-#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 2      /* diagnostic: the weight group is loaded once */
-    if (more && n0 == n_begin) {
-#else
     if (more) {
-#endif
 #pragma unroll
       for (int i = 0; i < CHUNKS; ++i) wreg[i] = ldg16(p.w + (long long)(n0 + 64) * K + goff[i]);
     }
-#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 3      /* diagnostic: the shortcut is loaded once */
-    if (p.res && n0 + 128 < n_end && n0 == n_begin) {
-#else
     if (p.res && n0 + 128 < n_end) {
-#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) pre[q] = ldg16(p.res + row_off + n0 + 128 + 8 * q);
     }
@@ -164,23 +156,15 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
     h8 f0[3], f1[3];
     f0[0] = *reinterpret_cast<const h8*>(l0); f1[0] = *reinterpret_cast<const h8*>(l1);
     f0[1] = *reinterpret_cast<const h8*>(l0 + 16); f1[1] = *reinterpret_cast<const h8*>(l1 + 16);
-#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 5      /* diagnostic: no k-loop (no LDS reads, no MFMAs) */
-    for (int s = 0; s < (p.relu == 77 ? KSTEPS : 0); ++s) {
-#else
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-#endif
       if (s + 2 < KSTEPS) {
         f0[(s + 2) % 3] = *reinterpret_cast<const h8*>(l0 + 16 * (s + 2));
         f1[(s + 2) % 3] = *reinterpret_cast<const h8*>(l1 + 16 * (s + 2));
       }
       __builtin_amdgcn_sched_barrier(0);
-#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 4      /* diagnostic: LDS reads but no MFMAs */
-      acc0[s & 15] += (float)f0[s % 3][0]; acc1[s & 15] += (float)f1[s % 3][1];
-#else
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[s % 3], xa[s], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[s % 3], xa[s], acc1, 0, 0, 0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     // lane (pixel r, half h): channels n0 + 32 h + [0, 32): acc0 -> +0..15, acc1 -> +16..31
@@ -197,11 +181,7 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
         if (p.relu) v = (v < 0.0f) ? 0.0f : v;
         ov[e] = (_Float16)v;
       }
-#if defined(ODET_C1_ABLATE) && ODET_C1_ABLATE == 1      /* diagnostic: no output stores */
-      if (store && ov[0] == (_Float16)12345.0f) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
-#else
       if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
-#endif
     }
     if (more) {
 #pragma unroll

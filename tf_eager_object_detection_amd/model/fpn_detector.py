@@ -532,7 +532,26 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)
         x = F.relu(self.fc1(x))
         x = F.relu(self.fc2(x))
+        if x.dtype == torch.float16:
+            # the class logits and box regressions leave the network in float32 (float32 accumulation AND float32
+            # outputs: a float16 logit near 10 is 0.008 coarse, 1 % of a softmax score): one small contraction of the
+            # 1024-d activation with the concatenated [Ccls + 4 Ccls, 1024] weights
+            w, b = self._final_f32()
+            y = torch.addmm(b, x.float(), w)
+            return y[:, :self.num_classes], y[:, self.num_classes:]
         return self.score(x), self.bbox(x)
+
+    def _final_f32(self):
+        ps = (self.score.weight, self.score.bias, self.bbox.weight, self.bbox.bias)
+        key = tuple((t._version, t.data_ptr()) for t in ps)
+        c = getattr(self, '_final_cache', None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                w = torch.cat([ps[0], ps[2]], 0).float().t().contiguous()
+                b = torch.cat([ps[1], ps[3]], 0).float().contiguous()
+            c = (key, w, b)
+            self._final_cache = c
+        return c[1], c[2]
 
     # ---- HIP-graph replay ---------------------------------------------------------------------------
     def capture(self, batch, warmup=3):
