@@ -382,6 +382,28 @@ int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_levels, con
 int odet_conv3x3_conv1x1_f16(const void* x, const void* w2, const void* b2, const void* w3, const void* b3,
                              const void* residual, void* y, int batch, int H, int W, int cin, int n3, int relu,
                              odet_stream_t stream);
+/* 1x1 convolutions and dense layers as the same LDS-staged GEMM on the matrix cores (the implicit-GEMM kernel with one
+ * tap): y = relu?( x(:, ::stride, ::stride, :) . w^T + bias + residual ).  x NHWC float16 [batch,H,W,cin], w [cout][cin]
+ * (a Conv2D 1x1 kernel, or a Dense kernel transposed), bias [cout] (nullable), residual (nullable) / y NHWC float16
+ * [batch, ceil(H/stride), ceil(W/stride), cout].  Replaces, in the reference's ResNet-FPN (model/fpn/resnet_fpn.py): the
+ * bottlenecks' first 1x1 convolution and their strided shortcut / first convolutions (:154-205; Conv2D(1x1, strides=2,
+ * 'valid') reads every second pixel), the neck's P5 convolution (:339-384) and the RoI head's Dense layers (:292-336;
+ * batch = 1, H = 1, W = rows).  cin % 64 == 0 and >= 128, cout % 64 == 0, stride 1 or 2.  The workgroup tile (256 / 128 /
+ * 64 channels x 128..256 pixels) is picked per launch so that the workgroups fill whole rounds of the CUs. */
+int odet_pointwise_f16(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                       int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream);
+/* The network's LAST dense layer on the same kernel with float32 results: y[rows][cout] (float32) = relu?( x . w^T + bias ),
+ * x [rows][cin] / w [cout][cin] float16, bias [cout] float32 (nullable) -- float32 accumulation and no rounding of the
+ * result: the class logits and box regressions of the RoI head (resnet_fpn.py:327-336; a float16 logit near 10 is 0.008
+ * coarse).  cout % 64 == 0: the caller pads the weight rows (Ccls + 4 Ccls -> 128) with zeros. */
+int odet_dense_f16_out_f32(const void* x, const void* w, const float* bias, float* y, long long rows, int cin, int cout,
+                           int relu, odet_stream_t stream);
+/* A lateral 1x1 convolution of the FPN neck WITH the top-down merge in its epilogue (resnet_fpn.py:385-398):
+ * y = 0.5 * resize_bilinear(top, (H, W)) + 0.5 * (x . w^T + bias), TF 1.x legacy resize (align_corners = False) in
+ * float32 as odet_fpn_topdown_merge computes it, one rounding; top NHWC float16 [batch,th,tw,cout].  The lateral map
+ * never goes to memory. */
+int odet_lateral_merge_f16(const void* x, const void* w, const void* bias, const void* top, int th, int tw, void* y,
+                           int batch, int H, int W, int cin, int cout, odet_stream_t stream);
 /* The ResNet stem in one launch (resnet_fpn.py:262-289, resnet_faster_rcnn.py:31-60): ZeroPadding2D(3) -> Conv2D(64, 7x7,
  * stride 2, 'valid') + folded frozen BN -> ReLU -> ZeroPadding2D(1) -> MaxPooling2D(3x3, stride 2, 'valid'), from the
  * NHWC 3-channel image (float32: images_f16 = 0, or float16) to the NHWC float16 map [batch][PH][PW][64], PH =

@@ -932,3 +932,104 @@ def test_fp16_detector_map_delta_vs_fp32_on_identical_weights_and_images():
     assert lo - 0.002 <= 0.0 <= hi + 0.002                                    # +-0.002 is inside what the sample allows
     assert rec['reproduction']['matched_fraction'] >= 0.95 and rec['rpn_kept_index_agreement_mean'] >= 0.96
     assert rec['median_abs_dscore'] <= 2e-3 and rec['median_abs_dbox_px'] <= 0.5
+
+
+# ---- pointwise form of the implicit-GEMM kernel (odet_pointwise_f16 / odet_lateral_merge_f16) -----------------------------
+
+def _int_operands(g, M, K, N):
+    """small-integer float16 operands whose contraction stays exactly representable: sparse x for long K"""
+    ri = lambda lo, hi, *sh: torch.randint(lo, hi, sh, device='cuda', generator=g).to(torch.float16)
+    x, w = ri(-2, 3, M, K), ri(-1, 2, N, K)
+    if K > 512:
+        keep = torch.rand((M, K), device='cuda', generator=g) < 256.0 / K
+        x = x * keep.to(torch.float16)
+    w[:, 0] += torch.arange(N, device='cuda').remainder(5).to(torch.float16)
+    x[:, 1] += torch.arange(M, device='cuda').remainder(7).to(torch.float16)
+    return x, w
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,K,N,stride', [(2, 25, 42, 1024, 256, 1), (1, 50, 84, 512, 128, 1), (2, 50, 84, 256, 512, 2),
+                                             (1, 33, 47, 512, 1024, 2), (3, 13, 21, 2048, 512, 1), (1, 1, 1000, 12544, 1024, 1),
+                                             (1, 100, 167, 256, 128, 2), (2, 31, 17, 128, 64, 1), (1, 9, 11, 1024, 2048, 2)])
+def test_pointwise_f16_exact_on_integer_data_and_close_on_random(B, H, W, K, N, stride):
+    """odet_pointwise_f16: the bottlenecks' first / strided shortcut 1x1 convolutions, the neck's P5 convolution and the
+    RoI head's dense layers (resnet_fpn.py:154-205, 292-336, 339-384) on the LDS-staged GEMM.  EXACT on small-integer
+    data (any fragment / permutation / stride slip shows), within float16 rounding of a float32 torch formulation on
+    random data; every epilogue combination; maps whose pixel count does not fill a tile."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(B * 7 + H + K + N + stride)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    x2, w = _int_operands(g, B * H * W, K, N)
+    x = x2.view(B, H, W, K)
+    b = torch.randint(-8, 9, (N,), device='cuda', generator=g).to(torch.float16)
+    r = torch.randint(-16, 17, (B, Ho, Wo, N), device='cuda', generator=g).to(torch.float16)
+    xs = x[:, ::stride, ::stride].float()
+    for res, relu, bias in ((r, True, b), (None, True, b), (r, False, b), (None, False, None)):
+        want = xs @ w.float().t()
+        if bias is not None:
+            want = want + bias.float()
+        if res is not None:
+            want = want + res.float()
+        if relu:
+            want = torch.relu(want)
+        assert float(want.abs().max()) < 2048
+        got = ops.pointwise_f16(x, w.view(N, K, 1, 1), bias, res, relu, stride)
+        assert got.shape == (B, Ho, Wo, N) and torch.equal(got.float(), want)
+    x = torch.randn((B, H, W, K), device='cuda', generator=g).to(torch.float16)
+    w = (torch.randn((N, K), device='cuda', generator=g) / K ** 0.5).to(torch.float16)
+    want = torch.relu(x[:, ::stride, ::stride].float() @ w.float().t() + b.float() + r.float())
+    got = ops.pointwise_f16(x, w, b, r, True, stride)
+    torch.testing.assert_close(got.float(), want, rtol=2e-3, atol=4e-3)
+    if H == 1 and B == 1 and stride == 1:                               # the dense-layer view
+        assert torch.equal(ops.dense_f16(x.view(W, K), w, b, True), ops.pointwise_f16(x, w, b, None, True).view(W, N))
+    with pytest.raises(Exception):
+        ops.pointwise_f16(x[..., :64].contiguous(), w[:, :64].contiguous(), b)       # K = 64: one K-step, not served
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,h,w_,K', [(2, 50, 84, 25, 42, 1024), (1, 100, 167, 50, 84, 512), (1, 37, 53, 19, 27, 256),
+                                          (2, 20, 20, 10, 10, 128)])
+def test_lateral_merge_f16_equals_lateral_then_merge(B, H, W, h, w_, K):
+    """odet_lateral_merge_f16 (resnet_fpn.py:385-398 fused into the lateral convolution's epilogue): identical to
+    odet_fpn_topdown_merge applied to the un-rounded lateral convolution on integer data (where the lateral map is exact
+    in float16), within float16 rounding of the float32 formulation on random data."""
+    from tf_eager_object_detection_amd import ops
+    from tf_eager_object_detection_amd.model.fpn_detector import tf_legacy_resize_bilinear
+    g = torch.Generator(device='cuda'); g.manual_seed(H * W + K)
+    N = 256
+    x2, w = _int_operands(g, B * H * W, K, N)
+    x = x2.view(B, H, W, K)
+    b = torch.randint(-8, 9, (N,), device='cuda', generator=g).to(torch.float16)
+    top = torch.randint(-64, 65, (B, h, w_, N), device='cuda', generator=g).to(torch.float16)
+    lat = (x.float() @ w.float().t() + b.float())
+    assert float(lat.abs().max()) < 2048
+    want = ops.fpn_topdown_merge(top, lat.to(torch.float16))            # the two-launch form on the exact lateral map
+    got = ops.lateral_merge_f16(x, w, b, top)
+    assert torch.equal(got, want)
+    x = torch.randn((B, H, W, K), device='cuda', generator=g).to(torch.float16)
+    w = (torch.randn((N, K), device='cuda', generator=g) / K ** 0.5).to(torch.float16)
+    top = torch.randn((B, h, w_, N), device='cuda', generator=g).to(torch.float16)
+    lat = x.float() @ w.float().t() + b.float()
+    up = tf_legacy_resize_bilinear(top.float().permute(0, 3, 1, 2), (H, W)).permute(0, 2, 3, 1)
+    want = up * 0.5 + lat * 0.5
+    torch.testing.assert_close(ops.lateral_merge_f16(x, w, b, top).float(), want, rtol=2e-3, atol=4e-3)
+
+
+@pytest.mark.gpu
+def test_dense_f16_out_f32_last_layer():
+    """odet_dense_f16_out_f32: the RoI head's score / bbox layer with float32 results -- exact on integer data, equal to
+    the float32 contraction of the float16 operands on random data up to accumulation order"""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    M, K, N = 1037, 1024, 128
+    x, w = _int_operands(g, M, K, N)
+    w[105:] = 0
+    b = torch.randint(-50, 51, (N,), device='cuda', generator=g).float() * 0.25
+    got = ops.dense_f16_out_f32(x, w, b)
+    assert got.dtype == torch.float32 and torch.equal(got, x.float() @ w.float().t() + b)
+    x = torch.randn((M, K), device='cuda', generator=g).to(torch.float16)
+    w = (torch.randn((N, K), device='cuda', generator=g) / K ** 0.5).to(torch.float16)
+    want = x.double() @ w.double().t() + b.double()
+    torch.testing.assert_close(ops.dense_f16_out_f32(x, w, b).double(), want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(ops.dense_f16_out_f32(x, w, b, relu=True), torch.relu(ops.dense_f16_out_f32(x, w, b)))

@@ -27,6 +27,8 @@
 // (rpn_tail.hip) applies bias + ReLU to its operand fragments on load.
 #include <hip/hip_fp16.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 #include "odet_internal.h"
@@ -68,19 +70,33 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   long long px[ODET_MAX_LEVELS];  // H * W of a level
   long long aoff[ODET_MAX_LEVELS];   // first anchor of a level inside an image
   int A;
+  // pointwise form (k_pointwise_f16: TAPS == 1, one map): a 1x1 convolution / dense layer, optionally strided --
+  // output row m = (image, yo, xo) of a Ho x Wo map reads input pixel (yo * stride, xo * stride) of the H x W map
+  int stride, Ho, Wo;
+  long long Min;                  // input rows (batch * H * W)
+  // its epilogues: + shortcut `res` [M][cout] (shared with the fused tail's member), or the FPN top-down merge
+  // (resnet_fpn.py:385-398): out = 0.5 * resize_bilinear(top) + 0.5 * (conv + bias), top [batch][th][tw][cout]
+  const _Float16* top; int th, tw; float tys, txs;
+  // or float32 results (the network's last layer: class logits / box regressions leave in float32): y32 [M][cout], bias32
+  float* y32; const float* bias32;
 };
 
 // WN = waves along the channels (4: 256-channel tile, the form described above; 2 / 1: 128 / 64-channel tiles for the
 // layers with fewer output channels, the other 8 / WN waves along the pixels); MT = 16-pixel tiles per wave: the
 // workgroup tile is TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels (WN = 4, MT = 8: 256 x 256; smaller MT for
 // launches whose slabs would fill a fraction of a round of the 256 CUs -- chosen on the host, conv3x3_launch).
-template <int MT, int WN, bool TAIL = false, bool BLK = false>
-__global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
+template <int MT, int WN, bool TAIL, bool BLK, int TAPS>
+__device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
+  static_assert(TAPS == 9 || (TAPS == 1 && !TAIL && !BLK), "taps");
   constexpr int WM = 8 / WN;                             // waves along the pixels
   constexpr int TM = WM * 16 * MT;                       // pixels of the workgroup tile (<= 256)
   constexpr int TN = 64 * WN;                            // channels of the workgroup tile
   constexpr int XP = (TM / 8 + 7) / 8;                   // pixel pieces (8 rows x 128 B) per wave: TM / 8 over 8 waves
   static_assert(TM <= C3_TM && TM % 8 == 0, "tile");
+  // a stage = the pixel rows, then the weight rows, 128 bytes each: (TM + TN) * 128 bytes (64 KB for the 256 x 256 tile;
+  // small tiles leave room for a second workgroup on the CU -- the launch asks for 2 stages of its own tile)
+  constexpr uint32_t STAGE = (uint32_t)(TM + TN) * 128u;
+  constexpr uint32_t WBASE = (uint32_t)TM * 128u;
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,12 +115,13 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   const long long tile_m = slab - p.tile_start[lv];
   const int H = p.H[lv], W = p.W[lv], cin = p.cin, cout = p.cout;
   const uint32_t pixB = (uint32_t)cin * 2u;              // bytes per pixel
-  const uint32_t PAD = (uint32_t)(W + 1) * pixB;         // the descriptor starts one row + one pixel before x
+  const uint32_t PAD = TAPS == 9 ? (uint32_t)(W + 1) * pixB : 0u;   // the descriptor starts one row + one pixel before x
   const uint32_t OOB = 0xFFFFFFF0u;
   const long long M = p.M[lv];
+  const long long Min = TAPS == 9 ? M : p.Min;           // input rows (a strided pointwise layer reads more than it writes)
   const c3_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.x[lv])) - PAD, 0, (int)((uint32_t)M * pixB + 2u * PAD), 0x00020000);
-  const uint32_t wrowB = 9u * pixB;                      // bytes per weight row [tap][cin]
+      const_cast<char*>(reinterpret_cast<const char*>(p.x[lv])) - PAD, 0, (int)((uint32_t)Min * pixB + 2u * PAD), 0x00020000);
+  const uint32_t wrowB = (uint32_t)TAPS * pixB;          // bytes per weight row [tap][cin]
   const c3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, (int)((uint32_t)cout * wrowB),
                                                          0x00020000);
   // ---- what this thread copies per K-step: its pieces of A (8 pixels x 128 B each; piece wv + 8 i) and 4 of W
@@ -117,18 +134,31 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     const int row = (wv + 8 * i) * 8 + sub;              // 0..TM-1 (pieces beyond the tile are never issued)
     const long long m = tile_m * TM + row;
     uint32_t mk = 0;
-    if (m < M) {
-      const long long img = m / ((long long)H * W);
-      const int rem = (int)(m - img * H * W);
-      const int yy = rem / W, xx = rem - yy * W;
+    if constexpr (TAPS == 9) {
+      if (m < M) {
+        const long long img = m / ((long long)H * W);
+        const int rem = (int)(m - img * H * W);
+        const int yy = rem / W, xx = rem - yy * W;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-        if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
+        for (int t = 0; t < 9; ++t) {
+          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
+        }
       }
+      voffA[i] = (uint32_t)m * pixB + slot;              // (+ the tap / chunk offset as soffset; PAD is in the base)
+    } else {
+      long long src = m;
+      if (p.stride != 1 && m < M) {
+        const long long opx = (long long)p.Ho * p.Wo;
+        const long long img = m / opx;
+        const int rem = (int)(m - img * opx);
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        src = (img * H + (long long)yo * p.stride) * W + (long long)xo * p.stride;
+      }
+      mk = m < M ? 1u : 0u;
+      voffA[i] = (uint32_t)src * pixB + slot;
     }
     maskA[i] = mk;
-    voffA[i] = (uint32_t)m * pixB + slot;                // (+ the tap / chunk offset as soffset; PAD is in the base)
   }
 #pragma unroll
   for (int i = 0; i < WN; ++i) {
@@ -139,13 +169,18 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     voffW[i] = (uint32_t)ch * wrowB + slot;
   }
   const int chunks = cin / C3_BK;
-  const int ksteps = 9 * chunks;
+  const int ksteps = TAPS * chunks;
   struct IssueAt { int tap; uint32_t soA, soW, stage; };
   auto issue_at = [&](int ks, uint32_t stage) {
     IssueAt a;
-    a.tap = ks / chunks;
-    const int chunk = ks - a.tap * chunks;
-    a.soA = (uint32_t)((a.tap / 3) * W + a.tap % 3) * pixB + (uint32_t)chunk * 128u;
+    if constexpr (TAPS == 9) {
+      a.tap = ks / chunks;
+      const int chunk = ks - a.tap * chunks;
+      a.soA = (uint32_t)((a.tap / 3) * W + a.tap % 3) * pixB + (uint32_t)chunk * 128u;
+    } else {
+      a.tap = 0;
+      a.soA = (uint32_t)ks * 128u;
+    }
     a.soW = (uint32_t)ks * 128u;
     a.stage = stage;
     return a;
@@ -162,14 +197,14 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     }
 #pragma unroll
     for (int i = 0; i < WN; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + (uint32_t)(wv * WN + i) * 1024u), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + WBASE + (uint32_t)(wv * WN + i) * 1024u), 16,
                                                (int)voffW[i], (int)a.soW, 0, 0);
   };
   // ---- fragment addresses (bytes inside a stage)
   const int l15 = lane & 15, lq = lane >> 4;
   const uint32_t fslot = (uint32_t)(lq ^ (lane & 7)) * 16u;                         // K half 0; half 1 = ^ 64
   const uint32_t xoff = (uint32_t)(wm * 16 * MT + l15) * 128u + fslot;              // + mt * 2048
-  const uint32_t woff = C3_TM * 128u + (uint32_t)(wn * 64 + l15) * 128u + fslot;    // + t * 2048
+  const uint32_t woff = WBASE + (uint32_t)(wn * 64 + l15) * 128u + fslot;    // + t * 2048
   f4 acc[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -196,7 +231,7 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   issue(0, 0u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  issue(1, C3_STAGE_BYTES);                              // (ksteps >= 9)
+  issue(1, STAGE);                              // (ksteps >= 2: nine taps, or cin >= 128 in the pointwise form)
   read_frags(lds, 0u, wf0, xf0);
   // steady state: no conditionals around MFMAs or the barrier (hipcc would wait for the NEW fragment reads before the
   // queued MFMAs of the old ones -- the bubble the half-step pipelining is there to remove); the last two K-steps are
@@ -209,7 +244,7 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
   int ks = 0;
   const bool early = wv < C3_EARLY_WAVES;
   for (; ks + 2 < ksteps; ++ks) {
-    const uint32_t cur = (uint32_t)(ks & 1) * C3_STAGE_BYTES, nxt = C3_STAGE_BYTES - cur;
+    const uint32_t cur = (uint32_t)(ks & 1) * STAGE, nxt = STAGE - cur;
     read_frags(lds + cur, 64u, wf1, xf1);
     mfmas(wf0, xf0);
     // my copies of step ks + 1 have landed and my reads of stage ks are done; after the barrier everybody's
@@ -221,7 +256,7 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     if (!early) issue(ks + 2, cur);
   }
   {   // step ksteps - 2: nothing left to issue
-    const uint32_t cur = (uint32_t)(ks & 1) * C3_STAGE_BYTES, nxt = C3_STAGE_BYTES - cur;
+    const uint32_t cur = (uint32_t)(ks & 1) * STAGE, nxt = STAGE - cur;
     read_frags(lds + cur, 64u, wf1, xf1);
     mfmas(wf0, xf0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -395,11 +430,73 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
     const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
     if (m < M) {
       h8 o[2];
+      if constexpr (TAPS == 1) {
+        if (p.y32) {                                       // float32 out: the accumulators as they are, + float32 bias
+          float* dst = p.y32 + m * cout + c0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            f4 v = acc[mt][t];
+            if (p.bias32) v += *reinterpret_cast<const f4*>(p.bias32 + c0 + 4 * t);
+            if (p.relu) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.0f ? 0.0f : v[j];
+            }
+            *reinterpret_cast<f4*>(dst + 4 * t) = v;
+          }
+          continue;
+        }
+        if (p.top) {
+          // FPN top-down merge in the lateral convolution's epilogue (neck.hip's arithmetic: TF1 legacy resize, float32,
+          // up * 0.5 + lateral * 0.5, one rounding) -- the lateral map never goes to memory
+          const long long opx = (long long)p.Ho * p.Wo;
+          const long long img = m / opx;
+          const int rem = (int)(m - img * opx);
+          const int yy = rem / p.Wo, xx = rem - yy * p.Wo;
+          const float fy = (float)yy * p.tys, fx = (float)xx * p.txs;
+          const float y0f = floorf(fy), x0f = floorf(fx);
+          const int y0 = (int)y0f, x0 = (int)x0f;
+          const int y1 = min(y0 + 1, p.th - 1), x1 = min(x0 + 1, p.tw - 1);
+          const float yl = fy - y0f, xl = fx - x0f;
+          const _Float16* tb = p.top + (img * p.th * p.tw) * cout + c0;
+          h8 tl[2], tr[2], bl[2], br[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            tl[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y0 * p.tw + x0) * cout + 8 * hh);
+            tr[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y0 * p.tw + x1) * cout + 8 * hh);
+            bl[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y1 * p.tw + x0) * cout + 8 * hh);
+            br[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y1 * p.tw + x1) * cout + 8 * hh);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int e = t * 4 + j;
+              const float lat = acc[mt][t][j] + bv[e];
+              const float a = (float)tl[e >> 3][e & 7], b = (float)tr[e >> 3][e & 7];
+              const float c = (float)bl[e >> 3][e & 7], d = (float)br[e >> 3][e & 7];
+              const float tp = a + (b - a) * xl;
+              const float bt = c + (d - c) * xl;
+              const float up = tp + (bt - tp) * yl;
+              o[e >> 3][e & 7] = (_Float16)(up * 0.5f + lat * 0.5f);
+            }
+          _Float16* dst = p.y[lv] + m * cout + c0;
+          *reinterpret_cast<h8*>(dst) = o[0];
+          *reinterpret_cast<h8*>(dst + 8) = o[1];
+          continue;
+        }
+      }
+      h8 rs[2];
+      const bool has_res = TAPS == 1 && p.res != nullptr;
+      if (has_res) {
+        rs[0] = *reinterpret_cast<const h8*>(p.res + m * cout + c0);
+        rs[1] = *reinterpret_cast<const h8*>(p.res + m * cout + c0 + 8);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = acc[mt][t][j] + bv[t * 4 + j];
+          if (has_res) v += (float)rs[(t * 4 + j) >> 3][(t * 4 + j) & 7];
           if (p.relu) v = v < 0.0f ? 0.0f : v;
           o[(t * 4 + j) >> 3][(t * 4 + j) & 7] = (_Float16)v;
         }
@@ -408,6 +505,19 @@ __global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
       *reinterpret_cast<h8*>(dst + 8) = o[1];
     }
   }
+}
+
+template <int MT, int WN, bool TAIL = false, bool BLK = false>
+__global__ void __launch_bounds__(512) k_conv3x3_f16(Conv3x3Params p) {
+  conv_tile_f16<MT, WN, TAIL, BLK, 9>(p);
+}
+
+// The pointwise form: 1x1 convolutions (optionally strided) and dense layers with K >= 128 as the same LDS-staged GEMM --
+// the bottlenecks' first and shortcut convolutions (resnet_fpn.py:154-205), the neck's laterals with the top-down merge
+// in the epilogue (resnet_fpn.py:339-398), the RoI head's dense layers (resnet_fpn.py:292-336).
+template <int MT, int WN>
+__global__ void __launch_bounds__(512) k_pointwise_f16(Conv3x3Params p) {
+  conv_tile_f16<MT, WN, false, false, 1>(p);
 }
 
 // Second, small launch of the fused RpnHead: out = sum over the channel tiles' partial sums + bias, row R of pixel m to
@@ -651,6 +761,8 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   p.tail_w = nullptr; p.tail_b = nullptr; p.scores = nullptr; p.deltas = nullptr; p.s_stride = p.d_stride = 0; p.A = 0;
   p.partial = nullptr; p.slab_px = 0; p.tm = 0;
   p.w3 = nullptr; p.b3 = nullptr; p.res = nullptr; p.y3 = nullptr; p.n3 = 0; p.relu3 = 0;
+  p.stride = 1; p.Ho = p.Wo = 0; p.Min = 0; p.top = nullptr; p.th = p.tw = 0; p.tys = p.txs = 0.0f;
+  p.y32 = nullptr; p.bias32 = nullptr;
   if (blk) {
     ODET_REQUIRE(blk->w3 && blk->b3 && blk->y3 && bias, "odet_conv3x3_conv1x1_f16: null pointer");
     ODET_REQUIRE(cout == 256, "odet_conv3x3_conv1x1_f16: the 3x3 convolution must have 256 output channels (got %d)", cout);
@@ -708,7 +820,9 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   const long long blocks = groups * 8 * p.tiles_n;
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
   const dim3 grid((unsigned)blocks);
-#define C3_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_>), grid, dim3(512), C3_LDS_BYTES, st, p)
+  // (plain form: two stages of the launch's own tile; the fused tails re-use the whole 128 KB after the K loop)
+  const unsigned lds_plain = 2u * (unsigned)(TMsel + 64 * wn_sel) * 128u;
+#define C3_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_>), grid, dim3(512), lds_plain, st, p)
 #define C3_LAUNCH_TAIL(MT_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, 4, true>), grid, dim3(512), C3_LDS_BYTES, st, p)
   if (tail) {
     p.slab_px = total * TMsel; p.tm = TMsel;
@@ -788,6 +902,125 @@ extern "C" int odet_conv3x3_conv1x1_f16(const void* x, const void* w2, const voi
   const odet_conv_level_t one{x, nullptr, H, W};
   const Conv3x3Block b{w3, b3, residual, y, n3, relu};
   return conv3x3_launch(&one, 1, w2, b2, batch, cin, 256, 1, (hipStream_t)stream, nullptr, &b);
+}
+
+// ---- pointwise form: host side ------------------------------------------------------------------------------------------
+struct PwEpilogue { const void* res; const void* top; int th, tw; float* y32; const float* bias32; };
+
+static int pointwise_launch(const char* who, const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
+                            int stride, int cin, int cout, int relu, const PwEpilogue& epi, hipStream_t st) {
+  ODET_REQUIRE(x && w && (y || epi.y32), "%s: null pointer", who);
+  ODET_REQUIRE(batch > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", who);
+  ODET_REQUIRE(!epi.y32 || (!epi.res && !epi.top && !bias && ((uintptr_t)epi.y32 | (uintptr_t)epi.bias32) % 16 == 0),
+               "%s: bad float32-output arguments", who);
+  ODET_REQUIRE(cin >= 2 * C3_BK && cin % C3_BK == 0, "%s: cin %d must be a multiple of %d, at least %d", who, cin, C3_BK, 2 * C3_BK);
+  ODET_REQUIRE(cout > 0 && cout % 64 == 0, "%s: cout %d must be a multiple of 64", who, cout);
+  ODET_REQUIRE((unsigned long long)cout * cin * 2ull < 0x7FFFFFFFull, "%s: weights too large", who);
+  ODET_REQUIRE(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)epi.res | (uintptr_t)epi.top) % 16 == 0,
+               "%s: pointers must be 16-byte aligned", who);
+  ODET_REQUIRE(!(epi.res && epi.top), "%s: shortcut and top-down merge exclude each other", who);
+  ODET_REQUIRE(!epi.top || (stride == 1 && epi.th > 0 && epi.tw > 0 && !relu), "%s: bad merge arguments", who);
+  static std::once_flag once;
+  static hipError_t once_rc = hipSuccess;
+  std::call_once(once, [] {
+    const void* ks_[10] = {(const void*)k_pointwise_f16<4, 4>, (const void*)k_pointwise_f16<5, 4>, (const void*)k_pointwise_f16<6, 4>,
+                           (const void*)k_pointwise_f16<7, 4>, (const void*)k_pointwise_f16<8, 4>, (const void*)k_pointwise_f16<2, 2>,
+                           (const void*)k_pointwise_f16<3, 2>, (const void*)k_pointwise_f16<4, 2>, (const void*)k_pointwise_f16<1, 1>,
+                           (const void*)k_pointwise_f16<2, 1>};
+    for (const void* k_ : ks_) {
+      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
+      if (e_ != hipSuccess) once_rc = e_;
+    }
+  });
+  ODET_HIP(once_rc);
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const long long M = (long long)batch * Ho * Wo, Min = (long long)batch * H * W;
+  ODET_REQUIRE((unsigned long long)Min * cin * 2ull < 0xFFFFFFF0ull, "%s: input larger than 4 GiB", who);
+  Conv3x3Params p;
+  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
+    p.x[l] = (const _Float16*)x; p.y[l] = (_Float16*)y; p.M[l] = M; p.H[l] = H; p.W[l] = W; p.px[l] = (long long)Ho * Wo;
+    p.aoff[l] = 0;
+  }
+  p.tail_w = nullptr; p.tail_b = nullptr; p.scores = nullptr; p.deltas = nullptr; p.s_stride = p.d_stride = 0; p.A = 0;
+  p.partial = nullptr; p.slab_px = 0; p.tm = 0;
+  p.w3 = nullptr; p.b3 = nullptr; p.y3 = nullptr; p.n3 = 0; p.relu3 = 0;
+  p.res = (const _Float16*)epi.res;
+  p.top = (const _Float16*)epi.top; p.th = epi.th; p.tw = epi.tw;
+  p.tys = epi.top ? (float)epi.th / (float)Ho : 0.0f;
+  p.txs = epi.top ? (float)epi.tw / (float)Wo : 0.0f;
+  p.stride = stride; p.Ho = Ho; p.Wo = Wo; p.Min = Min;
+  p.y32 = epi.y32; p.bias32 = epi.bias32;
+  // Tile: channels 256 / 128 / 64 (WN = 4 / 2 / 1 waves along the channels) x pixels (8 / WN) * 16 * MT.  One workgroup
+  // per CU (128 KB of LDS), so the launch runs in rounds of 256 workgroups; per K-step a workgroup needs about
+  // max(matrix cycles TM * TN / 32, staging cycles 2 * (TM + TN)).  Pick the pair with the least rounds x that.
+  int wn_best = 0, mt_best = 0;
+  double best = 1e300;
+  for (int wn = 4; wn >= 1; wn >>= 1) {
+    if (cout % (64 * wn)) continue;
+    const int wm = 8 / wn, tn = 64 * wn, tiles_n = cout / tn;
+    for (int mt = 16 / wm; mt >= 8 / wm; --mt) {
+      const int tm = wm * 16 * mt;
+      const long long slabs = (M + tm - 1) / tm;
+      const long long blocks = (slabs + 7) / 8 * 8 * tiles_n;
+      const double per = std::max((double)tm * tn / 32.0, 2.0 * (tm + tn)) + 150.0;
+      const double cost = (double)((blocks + 255) / 256) * per;
+      if (cost < best * 0.97) { best = cost; wn_best = wn; mt_best = mt; }
+    }
+  }
+  if (const char* ov = getenv("ODET_PW_TILE")) {          // experiments (tools/exp/pointwise_tiles.py): "wn,mt[,cin]"
+    int a_ = 0, b_ = 0, c_ = 0;
+    const int n_ = sscanf(ov, "%d,%d,%d", &a_, &b_, &c_);
+    if (n_ >= 2 && (n_ == 2 || c_ == cin) && (a_ == 4 || a_ == 2 || a_ == 1) && cout % (64 * a_) == 0 &&
+        b_ * (8 / a_) >= 8 && b_ * (8 / a_) <= 16) { wn_best = a_; mt_best = b_; }
+  }
+  const int wm_sel = 8 / wn_best, TMsel = wm_sel * 16 * mt_best;
+  p.tiles_n = cout / (64 * wn_best);
+  const long long total = (M + TMsel - 1) / TMsel;
+  p.tile_start[0] = 0;
+  for (int l = 1; l <= ODET_MAX_LEVELS; ++l) p.tile_start[l] = total;
+  p.w = (const _Float16*)w; p.bias = (const _Float16*)bias;
+  p.num_levels = 1; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
+  const long long blocks = (total + 7) / 8 * 8 * p.tiles_n;
+  ODET_REQUIRE(blocks < (1ll << 31), "%s: too many workgroups", who);
+  const dim3 grid((unsigned)blocks);
+  const unsigned lds_bytes = 2u * (unsigned)(TMsel + 64 * wn_best) * 128u;
+#define PW_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_pointwise_f16<MT_, WN_>), grid, dim3(512), lds_bytes, st, p)
+  switch (wn_best * 16 + mt_best) {
+    case 4 * 16 + 4: PW_LAUNCH(4, 4); break;
+    case 4 * 16 + 5: PW_LAUNCH(5, 4); break;
+    case 4 * 16 + 6: PW_LAUNCH(6, 4); break;
+    case 4 * 16 + 7: PW_LAUNCH(7, 4); break;
+    case 4 * 16 + 8: PW_LAUNCH(8, 4); break;
+    case 2 * 16 + 2: PW_LAUNCH(2, 2); break;
+    case 2 * 16 + 3: PW_LAUNCH(3, 2); break;
+    case 2 * 16 + 4: PW_LAUNCH(4, 2); break;
+    case 1 * 16 + 1: PW_LAUNCH(1, 1); break;
+    default: PW_LAUNCH(2, 1); break;
+  }
+#undef PW_LAUNCH
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+extern "C" int odet_pointwise_f16(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                                  int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream) {
+  const PwEpilogue e{residual, nullptr, 0, 0, nullptr, nullptr};
+  return pointwise_launch("odet_pointwise_f16", x, w, bias, y, batch, H, W, stride, cin, cout, relu, e, (hipStream_t)stream);
+}
+
+extern "C" int odet_lateral_merge_f16(const void* x, const void* w, const void* bias, const void* top, int th, int tw, void* y,
+                                      int batch, int H, int W, int cin, int cout, odet_stream_t stream) {
+  ODET_REQUIRE(top, "odet_lateral_merge_f16: null pointer");
+  const PwEpilogue e{nullptr, top, th, tw, nullptr, nullptr};
+  return pointwise_launch("odet_lateral_merge_f16", x, w, bias, y, batch, H, W, 1, cin, cout, 0, e, (hipStream_t)stream);
+}
+
+extern "C" int odet_dense_f16_out_f32(const void* x, const void* w, const float* bias, float* y, long long rows, int cin,
+                                      int cout, int relu, odet_stream_t stream) {
+  ODET_REQUIRE(y && rows > 0 && rows < (1ll << 31), "odet_dense_f16_out_f32: bad arguments");
+  const PwEpilogue e{nullptr, nullptr, 0, 0, y, bias};
+  return pointwise_launch("odet_dense_f16_out_f32", x, w, nullptr, nullptr, 1, 1, (int)rows, 1, cin, cout, relu, e,
+                          (hipStream_t)stream);
 }
 
 // upper bound of the workspace of odet_rpn_head_fused_f16: every level's pixels rounded up to a whole slab of any height

@@ -59,6 +59,7 @@ def _fold_frozen_bn(conv):
 #   'conv' library convolution without bias + the fused epilogue pass (ops.bias_act_)
 #   'gemm' hipBLASLt GEMM with bias (+ ReLU) in its own epilogue (no shortcut)
 #   'mfma' ops.conv1x1_f16: the hand-written MFMA kernel with bias + shortcut + ReLU fused (float16, cin <= 256)
+#   'pw'   ops.pointwise_f16: the LDS-staged GEMM form of the implicit-GEMM kernel (float16, cin >= 128; any stride)
 _GEMM_ROUTE = {}
 _ROUTE_MODE = __import__('os').environ.get('ODET_ROUTE_1X1', 'table')
 # ODET_CONV3X3=lib: the library convolution instead of the hand-written implicit GEMM (ops.conv3x3_f16) where it applies;
@@ -84,6 +85,24 @@ def _conv_1x1(conv, x, bias, relu, res):
 
 def _mfma_1x1(conv, x, bias, relu, res, in_bias=None):
     return ops.conv1x1_f16(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu, in_bias=in_bias).permute(0, 3, 1, 2)
+
+
+# ODET_PW=0: the layers of the pointwise GEMM kernel back on their round-2 routes (library GEMM / convolution); a comma list of
+# names from {c1, s2, short, lateral, fc, final} switches single classes of layers off (same-box A/B runs)
+_PW_OFF = set(filter(None, __import__('os').environ.get('ODET_PW_OFF', '').split(',')))
+if __import__('os').environ.get('ODET_PW', '1') == '0':
+    _PW_OFF = {'c1', 's2', 'short', 'lateral', 'fc', 'final'}
+
+
+def _pw_ok(conv, x):
+    """the pointwise GEMM kernel takes this 1x1 convolution (stride 1 or 2, no padding)"""
+    return (x.is_cuda and x.dtype == torch.float16 and tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0)
+            and tuple(conv.stride) in ((1, 1), (2, 2)) and conv.in_channels % 64 == 0 and conv.in_channels >= 128
+            and conv.out_channels % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _pw_1x1(conv, x, bias, relu, res):
+    return ops.pointwise_f16(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu, conv.stride[0]).permute(0, 3, 1, 2)
 
 
 def _time_route(fn, reps=5):
@@ -119,6 +138,8 @@ def _route_1x1(conv, x, bias, relu, res):
                     cand['gemm'] = lambda: _gemm_1x1(conv, x, bias, relu)
                 if mfma_ok:
                     cand['mfma'] = lambda: _mfma_1x1(conv, x, bias, relu, res)
+                if _pw_ok(conv, x):
+                    cand['pw'] = lambda: _pw_1x1(conv, x, bias, relu, res)
                 times = {k: _time_route(f) for k, f in cand.items()}
                 r = min(times, key=times.get)
                 _GEMM_ROUTE[key] = r
@@ -131,7 +152,15 @@ def _route_1x1(conv, x, bias, relu, res):
         return 'gemm'
     if mode == 'conv':
         return 'conv'
-    if mfma_ok and (res is not None or conv.in_channels <= 256 and conv.out_channels <= 64):
+    pw_ok = _pw_ok(conv, x) and 'c1' not in _PW_OFF
+    # (tools/exp/pointwise_layers.py, pointwise_tiles.py: the register-resident kernel keeps the layers with a shortcut up
+    # to 256 input channels and the 64-channel outputs; everything else -- every first 1x1 of a bottleneck, K = 512 with a
+    # shortcut (38 vs 49 us), the neck's P5 -- is ahead or level on the LDS-staged GEMM)
+    if mfma_ok and conv.in_channels <= 256 and (res is not None or conv.out_channels <= 64 or not pw_ok):
+        return 'mfma'
+    if pw_ok:
+        return 'pw'
+    if mfma_ok:
         return 'mfma'
     if res is None:
         return 'gemm'
@@ -213,11 +242,21 @@ def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
                 if not res.is_contiguous():
                     res = res.contiguous()
             route = _route_1x1(conv, x, bias, relu, res)
+            if route == 'pw':
+                return _pw_1x1(conv, x, bias, relu, res)
             if route == 'gemm':
                 return _gemm_1x1(conv, x, bias, relu)
             if route == 'mfma':
                 return _mfma_1x1(conv, x, bias, relu, res)
             return _conv_1x1(conv, x, bias, relu, res)
+        if pad is None and _ROUTE_MODE == 'table' and 's2' not in _PW_OFF and tuple(conv.stride) == (2, 2) and _pw_ok(conv, x):
+            # Conv2D(1x1, strides 2, 'valid') = the same GEMM over every second pixel (the first block of a stage)
+            res = None
+            if residual is not None:
+                res = residual.permute(0, 2, 3, 1)
+                if not res.is_contiguous():
+                    res = res.contiguous()
+            return _pw_1x1(conv, x, bias, relu, res)
         if residual is None and _own_conv3x3(conv, x, pad):
             # hand-written implicit GEMM on the matrix cores with bias (+ ReLU) in its epilogue
             b16 = bias if bias.dtype == torch.float16 else bias.half()
@@ -258,6 +297,12 @@ class _Block(nn.Module):
         # which is added to c3's instead
         if self.short is None:
             sc, sb = x, None
+        elif x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'short' not in _PW_OFF and (
+                _pw_ok(self.short, x) or (tuple(self.short.stride) == (1, 1) and self.short.in_channels == 64
+                                          and x.is_contiguous(memory_format=torch.channels_last))):
+            # float16: the shortcut convolution WITH its bias on the own kernels (strided or long K: the pointwise GEMM;
+            # ResNet conv2's 64 -> 256: the register-resident kernel) -- no library convolution, no separate bias add
+            sc, sb = _conv_epi(self.short, x, relu=False), None
         else:
             sc, sb = F.conv2d(x, self.short.weight, None, self.short.stride, self.short.padding), self.short.bias
         y = _conv_epi(self.c1, x, relu=True)
@@ -276,20 +321,18 @@ class _Block(nn.Module):
                 out = ops.conv3x3_conv1x1_f16(y.permute(0, 2, 3, 1), self.c2.weight, self.c2.bias, self.c3.weight, b3,
                                               residual=res, relu=True)
                 return out.permute(0, 3, 1, 2)
-            if _own_conv3x3(self.c2, y):
-                y2 = ops.conv3x3_f16(y.permute(0, 2, 3, 1), self.c2.weight).permute(0, 3, 1, 2)
-            else:
-                y2 = F.conv2d(y, self.c2.weight, None, self.c2.stride, self.c2.padding)
-                if not y2.is_contiguous(memory_format=torch.channels_last):
-                    y2 = y2.contiguous(memory_format=torch.channels_last)
             res = sc.permute(0, 2, 3, 1)
             if not res.is_contiguous():
                 res = res.contiguous()
             b3 = self.c3.bias if sb is None else self.c3.bias + sb
-            if _route_1x1(self.c3, y2, b3, True, res) == 'mfma':
+            if _route_1x1(self.c3, y, b3, True, res) == 'mfma':           # (c2's output has y's shape)
+                if _own_conv3x3(self.c2, y):
+                    y2 = ops.conv3x3_f16(y.permute(0, 2, 3, 1), self.c2.weight).permute(0, 3, 1, 2)
+                else:
+                    y2 = F.conv2d(y, self.c2.weight, None, self.c2.stride, self.c2.padding)
+                    if not y2.is_contiguous(memory_format=torch.channels_last):
+                        y2 = y2.contiguous(memory_format=torch.channels_last)
                 return _mfma_1x1(self.c3, y2, b3, True, res, in_bias=self.c2.bias)
-            ops.bias_act_(y2.permute(0, 2, 3, 1), self.c2.bias, None, True)
-            return _conv_epi(self.c3, y2, relu=True, residual=sc, extra_bias=sb)
         y = _conv_epi(self.c2, y, relu=True)
         return _conv_epi(self.c3, y, relu=True, residual=sc, extra_bias=sb)
 
@@ -422,7 +465,7 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
         fd = torch.float16 if self.dtype == torch.float16 else torch.float32
         self._rpn_pair = None
         self._steps = None
-        if self._max_batch <= 8 and self._hot_kwargs.pop('batched', True):
+        if self._max_batch <= 64 and self._hot_kwargs.pop('batched', True):
             self._steps = FpnStepBatch(self._max_batch, *self._hot_args, feature_dtype=fd, **self._hot_kwargs)
             self._hot = self._steps.slots
             K = self._hot_args[2]
@@ -448,10 +491,21 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
         c5 = self.conv5(c4)
         p5 = _conv_epi(self.p5, c5)
         p6 = p5[:, :, ::2, ::2]                                                  # MaxPooling2D(1x1, stride 2)
-        p4 = self._merge(p5, _conv_epi(self.l4, c4))
-        p3 = self._merge(p4, _conv_epi(self.l3, c3))
-        p2 = self._merge(p3, _conv_epi(self.l2, c2))
+        p4 = self._lateral_merge(p5, self.l4, c4)
+        p3 = self._lateral_merge(p4, self.l3, c3)
+        p2 = self._lateral_merge(p3, self.l2, c2)
         return _conv_epi(self.s2, p2), _conv_epi(self.s3, p3), _conv_epi(self.s4, p4), p5, p6
+
+    def _lateral_merge(self, top, conv, c):
+        """P_k = 0.5 * resize_bilinear(P_{k+1}) + 0.5 * lateral(C_k) (resnet_fpn.py:385-398).  float16: ONE launch -- the
+        merge rides in the epilogue of the lateral 1x1 convolution (ops.lateral_merge_f16: the lateral map is never
+        written; 226 vs 301 us for P2 at batch 8); otherwise the convolution, then the merge launch."""
+        if _ROUTE_MODE == 'table' and 'lateral' not in _PW_OFF and _pw_ok(conv, c) and tuple(conv.stride) == (1, 1) \
+                and top.dtype == torch.float16:
+            t = top.permute(0, 2, 3, 1)
+            t = t if t.is_contiguous() else t.contiguous()
+            return ops.lateral_merge_f16(c.permute(0, 2, 3, 1), conv.weight, conv.bias, t).permute(0, 3, 1, 2)
+        return self._merge(top, _conv_epi(conv, c))
 
     @staticmethod
     def _merge(top, lateral):
@@ -530,28 +584,45 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
 
     def roi_head(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)
-        x = F.relu(self.fc1(x))
-        x = F.relu(self.fc2(x))
+        if x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'fc' not in _PW_OFF and x.is_contiguous():
+            # the Dense layers on the pointwise GEMM kernel with bias + ReLU in its epilogue (resnet_fpn.py:292-336)
+            x = ops.dense_f16(x, self.fc1.weight, self.fc1.bias, relu=True)
+            x = ops.dense_f16(x, self.fc2.weight, self.fc2.bias, relu=True)
+        else:
+            x = F.relu(self.fc1(x))
+            x = F.relu(self.fc2(x))
         if x.dtype == torch.float16:
             # the class logits and box regressions leave the network in float32 (float32 accumulation AND float32
             # outputs: a float16 logit near 10 is 0.008 coarse, 1 % of a softmax score): one small contraction of the
             # 1024-d activation with the concatenated [Ccls + 4 Ccls, 1024] weights
-            w, b = self._final_f32()
-            y = torch.addmm(b, x.float(), w)
-            return y[:, :self.num_classes], y[:, self.num_classes:]
+            w, b, w16 = self._final_f32()
+            n5 = 5 * self.num_classes
+            if x.is_cuda and _ROUTE_MODE == 'table' and 'final' not in _PW_OFF and x.is_contiguous() and w16 is not None:
+                y = ops.dense_f16_out_f32(x, w16, b)         # (weight rows zero-padded to a multiple of 64)
+            else:
+                y = torch.addmm(b[:n5], x.float(), w)
+            return y[:, :self.num_classes], y[:, self.num_classes:n5]
         return self.score(x), self.bbox(x)
 
     def _final_f32(self):
+        """the concatenated score / bbox layer: (float32 [1024, 5 Ccls] weight, float32 bias padded to the float16 form's
+        rows, float16 [rows, 1024] weight zero-padded to a multiple of 64 rows)"""
         ps = (self.score.weight, self.score.bias, self.bbox.weight, self.bbox.bias)
         key = tuple((t._version, t.data_ptr()) for t in ps)
         c = getattr(self, '_final_cache', None)
         if c is None or c[0] != key:
             with torch.no_grad():
-                w = torch.cat([ps[0], ps[2]], 0).float().t().contiguous()
-                b = torch.cat([ps[1], ps[3]], 0).float().contiguous()
-            c = (key, w, b)
+                wc = torch.cat([ps[0], ps[2]], 0)
+                bc = torch.cat([ps[1], ps[3]], 0).float()
+                rows = (wc.shape[0] + 63) // 64 * 64
+                w16 = torch.zeros((rows, wc.shape[1]), dtype=torch.float16, device=wc.device)
+                w16[:wc.shape[0]] = wc
+                b = torch.zeros(rows, dtype=torch.float32, device=wc.device)
+                b[:bc.shape[0]] = bc
+                w = wc.float().t().contiguous()
+            c = (key, w, b.contiguous(), w16 if wc.shape[1] % 64 == 0 and wc.shape[1] >= 128 else None)
             self._final_cache = c
-        return c[1], c[2]
+        return c[1], c[2], c[3]
 
     # ---- HIP-graph replay ---------------------------------------------------------------------------
     def capture(self, batch, warmup=3):

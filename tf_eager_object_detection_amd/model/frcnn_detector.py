@@ -68,7 +68,7 @@ class ResNetC4Detector(_NmsCompleteness, nn.Module):
         self._feature_dtype = fd
         kw = dict(self._hot_kwargs)
         self._steps = None
-        if self._max_batch <= 8 and kw.pop('batched', True):
+        if self._max_batch <= 64 and kw.pop('batched', True):
             self._steps = FrcnnStepBatch(self._max_batch, *self._hot_args, feature_dtype=fd, **kw)
             self._hot = self._steps.slots
             self._roi_feat_all = self._steps.roi_features

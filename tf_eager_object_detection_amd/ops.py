@@ -652,6 +652,88 @@ def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None, in_bias=Non
     return out
 
 
+def _pw_args(x, weight, bias, who):
+    if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError('%s: x must be a contiguous float16 GPU tensor [batch, H, W, cin]' % who)
+    cin, cout = int(x.shape[-1]), int(weight.shape[0])
+    if weight.dtype != torch.float16 or weight.numel() != cout * cin:
+        raise ValueError('%s: weight must be a float16 [cout, cin(, 1, 1)] tensor' % who)
+    w = weight.reshape(cout, cin)
+    if not w.is_contiguous():
+        w = w.contiguous()
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('%s: bias must be a contiguous float16 [cout] tensor' % who)
+    if cin % 64 or cin < 128 or cout % 64:
+        raise ValueError('%s: cin %d must be a multiple of 64 (>= 128), cout %d a multiple of 64' % (who, cin, cout))
+    return w, cin, cout
+
+
+def pointwise_f16(x, weight, bias=None, residual=None, relu=False, stride=1, out=None):
+    """A 1x1 convolution (stride 1 or 2, 'valid') or dense layer as the LDS-staged GEMM on the matrix cores
+    (odet_pointwise_f16): ``x`` [B,H,W,cin] NHWC float16 contiguous, ``weight`` [cout, cin(, 1, 1)], ``residual`` / ``out``
+    [B, ceil(H/stride), ceil(W/stride), cout]; relu?(x[:, ::stride, ::stride] . w^T + bias + residual)."""
+    w, cin, cout = _pw_args(x, weight, bias, 'pointwise_f16')
+    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    stride = int(stride)
+    shape = (B, (H + stride - 1) // stride, (W + stride - 1) // stride, cout)
+    if residual is not None and (residual.dtype != torch.float16 or tuple(residual.shape) != shape or not residual.is_contiguous()):
+        raise ValueError('residual must be a contiguous float16 tensor shaped like the output %s' % (shape,))
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
+    L.call('odet_pointwise_f16', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None,
+           L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, stride, cin, cout, 1 if relu else 0,
+           L.stream())
+    return out
+
+
+def dense_f16(x, weight, bias=None, relu=False, out=None):
+    """keras Dense on the same kernel: ``x`` [rows, cin] float16 contiguous, ``weight`` [cout, cin] -> [rows, cout]."""
+    if x.dim() != 2:
+        raise ValueError('dense_f16: x must be [rows, cin]')
+    y = pointwise_f16(x.view(1, 1, x.shape[0], x.shape[1]), weight, bias, None, relu, 1,
+                      None if out is None else out.view(1, 1, out.shape[0], out.shape[1]))
+    return y.view(x.shape[0], -1)
+
+
+def dense_f16_out_f32(x, weight, bias=None, relu=False, out=None):
+    """The last dense layer with float32 results (odet_dense_f16_out_f32): ``x`` [rows, cin] / ``weight`` [cout, cin]
+    float16 contiguous, ``bias`` [cout] float32 -> float32 [rows, cout]; cout % 64 == 0 (pad the weight rows with zeros)."""
+    if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 2:
+        raise ValueError('dense_f16_out_f32: x must be a contiguous float16 GPU tensor [rows, cin]')
+    w, cin, cout = _pw_args(x.view(1, 1, x.shape[0], x.shape[1]), weight, None, 'dense_f16_out_f32')
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('dense_f16_out_f32: bias must be a contiguous float32 [cout] tensor')
+    rows = int(x.shape[0])
+    if out is None:
+        out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (rows, cout) or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float32 tensor [rows, cout]')
+    L.call('odet_dense_f16_out_f32', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(out), rows,
+           cin, cout, 1 if relu else 0, L.stream())
+    return out
+
+
+def lateral_merge_f16(x, weight, bias, top, out=None):
+    """The FPN neck's lateral 1x1 convolution with the top-down merge in its epilogue (odet_lateral_merge_f16;
+    resnet_fpn.py:385-398): 0.5 * resize_bilinear(top) + 0.5 * (x . w^T + bias); ``x`` [B,H,W,cin], ``top`` [B,h,w,cout]
+    NHWC float16 contiguous."""
+    w, cin, cout = _pw_args(x, weight, bias, 'lateral_merge_f16')
+    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    if top.dtype != torch.float16 or not top.is_cuda or not top.is_contiguous() or top.dim() != 4 \
+            or top.shape[0] != B or top.shape[3] != cout:
+        raise ValueError('top must be a contiguous float16 GPU tensor [batch, h, w, cout]')
+    shape = (B, H, W, cout)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
+    L.call('odet_lateral_merge_f16', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(top),
+           int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, L.stream())
+    return out
+
+
 def rpn_pack_pair(level_out, bias, num_anchors, scores, deltas, anchor_offset):
     """rpn_pack for the RpnHead's two 1x1 convolutions run as one contraction: ``level_out`` [B,h,w,6A] (2A score
     channels then 4A delta channels, no bias), ``bias`` [6A]; writes the level's slices of ``scores`` [B,N,2] and

@@ -354,7 +354,7 @@ def _fill_frcnn_step(st, h, stream_handle, rpn_logits, rpn_deltas, feat, cls_sof
 
 
 class FpnStepBatch:
-    """Up to 8 images through the FPN hot path in the SAME kernel launches (odet_fpn_step_enqueue_batch) on the
+    """Images through the FPN hot path in the SAME kernel launches, 8 per launch sequence (odet_fpn_step_enqueue_batch), on the
     CURRENT stream, stage by stage -- for a model that runs its dense RoI head between the stages (the
     assembled detectors): no enqueue thread, capturable into a HIP graph.  The RoI features of the images are
     consecutive blocks of one buffer, so the head can take them as one [B*K, ...] batch.
@@ -368,8 +368,8 @@ class FpnStepBatch:
 
     def __init__(self, max_batch, image_shape, num_classes=21, num_proposals=1000, channels=256, **kw):
         import ctypes as C
-        if not 1 <= int(max_batch) <= 8:
-            raise ValueError('max_batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
+        if not 1 <= int(max_batch) <= 64:
+            raise ValueError('max_batch must be in 1..64')
         self.n = int(max_batch)
         self.slots = [self._slot_class(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
         h0 = self.slots[0]
@@ -378,7 +378,12 @@ class FpnStepBatch:
         for b, h in enumerate(self.slots):
             h.roi_features = self.roi_features[b]
         self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
-        self._arr = (C.c_void_p * self.n)(*[C.addressof(st) for st in self.steps])
+        # a launch sequence carries up to 8 images (ODET_MAX_STEP_BATCH: the kernels' per-image pointer tables); a larger
+        # batch goes out as consecutive sequences of 8
+        self._chunks = []
+        for s0 in range(0, self.n, 8):
+            m = min(8, self.n - s0)
+            self._chunks.append((s0, (C.c_void_p * m)(*[C.addressof(st) for st in self.steps[s0:s0 + m]])))
         self._keep = [None] * self.n
         self._lib = ops.L.lib()
 
@@ -404,7 +409,9 @@ class FpnStepBatch:
         handle = torch.cuda.current_stream().cuda_stream
         for st in self.steps[:count]:
             st.stream = handle
-        ops.L.check(self._lib.odet_fpn_step_enqueue_batch(self._arr, count, int(stages)))
+        for s0, arr in self._chunks:
+            if s0 < count:
+                ops.L.check(self._lib.odet_fpn_step_enqueue_batch(arr, min(8, count - s0), int(stages)))
 
 
 class FrcnnStepBatch(FpnStepBatch):
