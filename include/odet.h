@@ -392,6 +392,13 @@ int odet_conv3x3_conv1x1_f16(const void* x, const void* w2, const void* b2, cons
  * 64 channels x 128..256 pixels) is picked per launch so that the workgroups fill whole rounds of the CUs. */
 int odet_pointwise_f16(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                        int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream);
+/* The end of a stage's FIRST bottleneck (resnet_fpn.py:154-205 with conv_shortcut: last 1x1 convolution + BN, convolutional
+ * shortcut + BN on the block's input, Add, ReLU) as ONE contraction along the concatenated K:
+ *   y = relu?( [x1 | x2(:, ::stride2, ::stride2, :)] . w^T + bias ),  w [cout][cin1 + cin2] = [w3 | w_shortcut], bias = b3 + b_sc.
+ * x1 NHWC float16 [batch, ceil(H2/stride2), ceil(W2/stride2), cin1] (the block's 3x3 convolution output), x2 NHWC float16
+ * [batch,H2,W2,cin2] (the block's input).  The shortcut map is never written or re-read.  cin1, cin2 % 64 == 0. */
+int odet_pointwise_dual_f16(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
+                            const void* w, const void* bias, void* y, int batch, int cout, int relu, odet_stream_t stream);
 /* The network's LAST dense layer on the same kernel with float32 results: y[rows][cout] (float32) = relu?( x . w^T + bias ),
  * x [rows][cin] / w [cout][cin] float16, bias [cout] float32 (nullable) -- float32 accumulation and no rounding of the
  * result: the class logits and box regressions of the RoI head (resnet_fpn.py:327-336; a float16 logit near 10 is 0.008

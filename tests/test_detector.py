@@ -1033,3 +1033,32 @@ def test_dense_f16_out_f32_last_layer():
     want = x.double() @ w.double().t() + b.double()
     torch.testing.assert_close(ops.dense_f16_out_f32(x, w, b).double(), want, rtol=1e-5, atol=1e-5)
     assert torch.equal(ops.dense_f16_out_f32(x, w, b, relu=True), torch.relu(ops.dense_f16_out_f32(x, w, b)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,K1,K2,N,stride', [(2, 20, 33, 64, 64, 256, 1), (1, 50, 84, 128, 256, 512, 2),
+                                                  (2, 25, 41, 256, 512, 1024, 2), (1, 13, 21, 512, 1024, 2048, 2)])
+def test_pointwise_dual_f16_last_conv_and_shortcut_in_one_contraction(B, H, W, K1, K2, N, stride):
+    """odet_pointwise_dual_f16 (a stage's first bottleneck, resnet_fpn.py:154-205): relu(w3 . y2 + b3 + w_sc . x(::s) + b_sc)
+    as ONE contraction over the concatenated K.  EXACT on integer data, within float16 rounding of float32 torch."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(K1 + K2 + N)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    a, wa = _int_operands(g, B * Ho * Wo, K1, N)
+    c, wc = _int_operands(g, B * H * W, K2, N)
+    if K1 + K2 > 512:
+        keep = torch.rand((B * H * W, K2), device='cuda', generator=g) < 128.0 / K2
+        c = c * keep.to(torch.float16)
+        a = a * (torch.rand((B * Ho * Wo, K1), device='cuda', generator=g) < 128.0 / K1).to(torch.float16)
+    a, c = a.view(B, Ho, Wo, K1), c.view(B, H, W, K2)
+    b = torch.randint(-8, 9, (N,), device='cuda', generator=g).to(torch.float16)
+    w = torch.cat([wa, wc], 1).contiguous()
+    want = a.float() @ wa.float().t() + c[:, ::stride, ::stride].float() @ wc.float().t() + b.float()
+    assert float(want.abs().max()) < 2048
+    assert torch.equal(ops.pointwise_dual_f16(a, c, w, b, stride, relu=True).float(), torch.relu(want))
+    assert torch.equal(ops.pointwise_dual_f16(a, c, w, None, stride, relu=False).float(), want - b.float())
+    a = torch.randn((B, Ho, Wo, K1), device='cuda', generator=g).to(torch.float16)
+    c = torch.randn((B, H, W, K2), device='cuda', generator=g).to(torch.float16)
+    w = (torch.randn((N, K1 + K2), device='cuda', generator=g) / (K1 + K2) ** 0.5).to(torch.float16)
+    want = torch.relu(a.float() @ w[:, :K1].float().t() + c[:, ::stride, ::stride].float() @ w[:, K1:].float().t() + b.float())
+    torch.testing.assert_close(ops.pointwise_dual_f16(a, c, w, b, stride).float(), want, rtol=2e-3, atol=4e-3)

@@ -79,6 +79,10 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   const _Float16* top; int th, tw; float tys, txs;
   // or float32 results (the network's last layer: class logits / box regressions leave in float32): y32 [M][cout], bias32
   float* y32; const float* bias32;
+  // or TWO sources along K (a stage's first bottleneck, resnet_fpn.py:154-205: last 1x1 convolution + convolutional
+  // shortcut + Add + ReLU as ONE contraction over [y2 | x(::stride)] with the weights concatenated): K-steps below k1steps
+  // read x (rows m, cin channels), the others x2 (rows of the strided H x W map, cin2 channels)
+  const _Float16* x2; int cin2, k1steps; long long Min2;
 };
 
 // WN = waves along the channels (4: 256-channel tile, the form described above; 2 / 1: 128 / 64-channel tiles for the
@@ -121,13 +125,18 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   const long long Min = TAPS == 9 ? M : p.Min;           // input rows (a strided pointwise layer reads more than it writes)
   const c3_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.x[lv])) - PAD, 0, (int)((uint32_t)Min * pixB + 2u * PAD), 0x00020000);
-  const uint32_t wrowB = (uint32_t)TAPS * pixB;          // bytes per weight row [tap][cin]
+  const bool dual = TAPS == 1 && p.x2 != nullptr;
+  const uint32_t pixB2 = dual ? (uint32_t)p.cin2 * 2u : 0u;
+  const c3_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(dual ? p.x2 : p.x[lv])), 0, (int)((uint32_t)(dual ? p.Min2 : 0) * pixB2), 0x00020000);
+  const uint32_t wrowB = (uint32_t)TAPS * pixB + pixB2;  // bytes per weight row [tap][cin] (+ [cin2] of the second source)
   const c3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.w), 0, (int)((uint32_t)cout * wrowB),
                                                          0x00020000);
   // ---- what this thread copies per K-step: its pieces of A (8 pixels x 128 B each; piece wv + 8 i) and 4 of W
   const int sub = lane >> 3;                             // row of the 8-row piece
   const uint32_t slot = (uint32_t)((lane & 7) ^ sub) * 16u;   // logical 16-byte slot this lane fetches (XOR swizzle)
   uint32_t voffA[XP], voffW[WN];
+  uint32_t voffA2[TAPS == 1 ? XP : 1];                   // the second source's rows (pointwise form with two sources)
   uint32_t maskA[XP];                                    // bit tap: the tap of this lane's pixel is inside the map
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
@@ -156,7 +165,8 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
         src = (img * H + (long long)yo * p.stride) * W + (long long)xo * p.stride;
       }
       mk = m < M ? 1u : 0u;
-      voffA[i] = (uint32_t)src * pixB + slot;
+      voffA[i] = (uint32_t)(dual ? m : src) * pixB + slot;
+      voffA2[i] = (uint32_t)src * pixB2 + slot;
     }
     maskA[i] = mk;
   }
@@ -169,7 +179,8 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     voffW[i] = (uint32_t)ch * wrowB + slot;
   }
   const int chunks = cin / C3_BK;
-  const int ksteps = TAPS * chunks;
+  const int ksteps = TAPS * chunks + (dual ? p.cin2 / C3_BK : 0);
+  const int k1steps = dual ? p.k1steps : ksteps;
   struct IssueAt { int tap; uint32_t soA, soW, stage; };
   auto issue_at = [&](int ks, uint32_t stage) {
     IssueAt a;
@@ -187,12 +198,23 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   };
   auto issue = [&](int ks, uint32_t stage) {              // 1 KB pieces: this wave's share of the pixel rows + 4 of weights
     const IssueAt a = issue_at(ks, stage);
+    if (TAPS == 1 && ks >= k1steps) {                      // (wave-uniform) the second source's K-steps
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      if ((wv + 8 * i) * 8 < TM) {                         // (TM / 8 not a multiple of 8: the last piece exists for the first waves only)
-        const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + 8 * i) * 1024u), 16, (int)va,
-                                                 (int)a.soA, 0, 0);
+      for (int i = 0; i < XP; ++i) {
+        if ((wv + 8 * i) * 8 < TM) {
+          const uint32_t va = (maskA[i] & 1u) ? voffA2[i] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + 8 * i) * 1024u), 16, (int)va,
+                                                   (int)((uint32_t)(ks - k1steps) * 128u), 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        if ((wv + 8 * i) * 8 < TM) {                       // (TM / 8 not a multiple of 8: the last piece exists for the first waves only)
+          const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + 8 * i) * 1024u), 16, (int)va,
+                                                   (int)a.soA, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -762,7 +784,7 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   p.partial = nullptr; p.slab_px = 0; p.tm = 0;
   p.w3 = nullptr; p.b3 = nullptr; p.res = nullptr; p.y3 = nullptr; p.n3 = 0; p.relu3 = 0;
   p.stride = 1; p.Ho = p.Wo = 0; p.Min = 0; p.top = nullptr; p.th = p.tw = 0; p.tys = p.txs = 0.0f;
-  p.y32 = nullptr; p.bias32 = nullptr;
+  p.y32 = nullptr; p.bias32 = nullptr; p.x2 = nullptr; p.cin2 = 0; p.k1steps = 0; p.Min2 = 0;
   if (blk) {
     ODET_REQUIRE(blk->w3 && blk->b3 && blk->y3 && bias, "odet_conv3x3_conv1x1_f16: null pointer");
     ODET_REQUIRE(cout == 256, "odet_conv3x3_conv1x1_f16: the 3x3 convolution must have 256 output channels (got %d)", cout);
@@ -803,11 +825,20 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
       long long slabs = 0;
       for (int l = 0; l < num_levels; ++l) slabs += (p.M[l] + tm - 1) / tm;
       const long long blocks_mt = (slabs + 7) / 8 * 8 * p.tiles_n;
-      const double cost = (double)((blocks_mt + 255) / 256) * (tm / 32 + 2);
+      // plain launches ask for two stages of their own tile: tiles of <= 80 KB run two workgroups per CU (each at ~1 / 1.7
+      // of the speed it has alone: they overlap each other's staging, barriers and epilogues)
+      const int occ = (!tail && !blk && 2 * (tm + 64 * wn_sel) * 128 <= 80 * 1024) ? 2 : 1;
+      const double cost = (double)((blocks_mt + 256 * occ - 1) / (256 * occ)) * (tm / 32 + 2) * (occ == 2 ? 1.7 : 1.0);
       if (cost < best * 0.97) { best = cost; mt_best = mt; }       // (smaller tiles only for a clear gain)
     }
   }
-  const int TMsel = wm_sel * 16 * mt_best;
+  int wn_use = wn_sel, wm_use = wm_sel;
+  if (const char* ov = getenv("ODET_C3_TILE")) {          // experiments (tools/exp/conv3x3_small.py): "wn,mt" of the plain form
+    int a_ = 0, b_ = 0;
+    if (!tail && !blk && sscanf(ov, "%d,%d", &a_, &b_) == 2 && (a_ == 4 || a_ == 2 || a_ == 1) && cout % (64 * a_) == 0 &&
+        b_ * (8 / a_) >= 8 && b_ * (8 / a_) <= 16) { wn_use = a_; wm_use = 8 / a_; mt_best = b_; p.tiles_n = cout / (64 * a_); }
+  }
+  const int TMsel = wm_use * 16 * mt_best;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     p.tile_start[l] = total;
     if (l < num_levels) total += (p.M[l] + TMsel - 1) / TMsel;
@@ -821,7 +852,7 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
   const dim3 grid((unsigned)blocks);
   // (plain form: two stages of the launch's own tile; the fused tails re-use the whole 128 KB after the K loop)
-  const unsigned lds_plain = 2u * (unsigned)(TMsel + 64 * wn_sel) * 128u;
+  const unsigned lds_plain = 2u * (unsigned)(TMsel + 64 * wn_use) * 128u;
 #define C3_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_>), grid, dim3(512), lds_plain, st, p)
 #define C3_LAUNCH_TAIL(MT_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, 4, true>), grid, dim3(512), C3_LDS_BYTES, st, p)
   if (tail) {
@@ -857,7 +888,7 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
     ODET_LAUNCH_CHECK();
     return ODET_OK;
   }
-  switch (wn_sel * 16 + mt_best) {
+  switch (wn_use * 16 + mt_best) {
     case 4 * 16 + 4: C3_LAUNCH(4, 4); break;
     case 4 * 16 + 5: C3_LAUNCH(5, 4); break;
     case 4 * 16 + 6: C3_LAUNCH(6, 4); break;
@@ -905,7 +936,8 @@ extern "C" int odet_conv3x3_conv1x1_f16(const void* x, const void* w2, const voi
 }
 
 // ---- pointwise form: host side ------------------------------------------------------------------------------------------
-struct PwEpilogue { const void* res; const void* top; int th, tw; float* y32; const float* bias32; };
+struct PwEpilogue { const void* res; const void* top; int th, tw; float* y32; const float* bias32;
+                    const void* x2; int cin2; };     // x2: second source along K ([batch][H][W][cin2], strided; x is then [M][cin])
 
 static int pointwise_launch(const char* who, const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
                             int stride, int cin, int cout, int relu, const PwEpilogue& epi, hipStream_t st) {
@@ -913,7 +945,8 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
   ODET_REQUIRE(batch > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", who);
   ODET_REQUIRE(!epi.y32 || (!epi.res && !epi.top && !bias && ((uintptr_t)epi.y32 | (uintptr_t)epi.bias32) % 16 == 0),
                "%s: bad float32-output arguments", who);
-  ODET_REQUIRE(cin >= 2 * C3_BK && cin % C3_BK == 0, "%s: cin %d must be a multiple of %d, at least %d", who, cin, C3_BK, 2 * C3_BK);
+  ODET_REQUIRE(cin % C3_BK == 0 && cin + (epi.x2 ? epi.cin2 : 0) >= 2 * C3_BK,
+               "%s: cin %d must be a multiple of %d, at least %d along K", who, cin, C3_BK, 2 * C3_BK);
   ODET_REQUIRE(cout > 0 && cout % 64 == 0, "%s: cout %d must be a multiple of 64", who, cout);
   ODET_REQUIRE((unsigned long long)cout * cin * 2ull < 0x7FFFFFFFull, "%s: weights too large", who);
   ODET_REQUIRE(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)epi.res | (uintptr_t)epi.top) % 16 == 0,
@@ -934,8 +967,12 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
   });
   ODET_HIP(once_rc);
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
-  const long long M = (long long)batch * Ho * Wo, Min = (long long)batch * H * W;
+  const long long M = (long long)batch * Ho * Wo;
+  const long long Min = epi.x2 ? M : (long long)batch * H * W;       // (two sources: x has the OUTPUT's rows)
   ODET_REQUIRE((unsigned long long)Min * cin * 2ull < 0xFFFFFFF0ull, "%s: input larger than 4 GiB", who);
+  ODET_REQUIRE(!epi.x2 || (epi.cin2 > 0 && epi.cin2 % C3_BK == 0 && (uintptr_t)epi.x2 % 16 == 0 &&
+                           (unsigned long long)batch * H * W * epi.cin2 * 2ull < 0xFFFFFFF0ull &&
+                           (unsigned long long)cout * (cin + epi.cin2) * 2ull < 0x7FFFFFFFull), "%s: bad second source", who);
   Conv3x3Params p;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     p.x[l] = (const _Float16*)x; p.y[l] = (_Float16*)y; p.M[l] = M; p.H[l] = H; p.W[l] = W; p.px[l] = (long long)Ho * Wo;
@@ -950,6 +987,7 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
   p.txs = epi.top ? (float)epi.tw / (float)Wo : 0.0f;
   p.stride = stride; p.Ho = Ho; p.Wo = Wo; p.Min = Min;
   p.y32 = epi.y32; p.bias32 = epi.bias32;
+  p.x2 = (const _Float16*)epi.x2; p.cin2 = epi.x2 ? epi.cin2 : 0; p.k1steps = cin / C3_BK; p.Min2 = (long long)batch * H * W;
   // Tile: channels 256 / 128 / 64 (WN = 4 / 2 / 1 waves along the channels) x pixels (8 / WN) * 16 * MT.  One workgroup
   // per CU (128 KB of LDS), so the launch runs in rounds of 256 workgroups; per K-step a workgroup needs about
   // max(matrix cycles TM * TN / 32, staging cycles 2 * (TM + TN)).  Pick the pair with the least rounds x that.
@@ -1004,21 +1042,30 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
 
 extern "C" int odet_pointwise_f16(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
                                   int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream) {
-  const PwEpilogue e{residual, nullptr, 0, 0, nullptr, nullptr};
+  const PwEpilogue e{residual, nullptr, 0, 0, nullptr, nullptr, nullptr, 0};
   return pointwise_launch("odet_pointwise_f16", x, w, bias, y, batch, H, W, stride, cin, cout, relu, e, (hipStream_t)stream);
 }
 
 extern "C" int odet_lateral_merge_f16(const void* x, const void* w, const void* bias, const void* top, int th, int tw, void* y,
                                       int batch, int H, int W, int cin, int cout, odet_stream_t stream) {
   ODET_REQUIRE(top, "odet_lateral_merge_f16: null pointer");
-  const PwEpilogue e{nullptr, top, th, tw, nullptr, nullptr};
+  const PwEpilogue e{nullptr, top, th, tw, nullptr, nullptr, nullptr, 0};
   return pointwise_launch("odet_lateral_merge_f16", x, w, bias, y, batch, H, W, 1, cin, cout, 0, e, (hipStream_t)stream);
+}
+
+extern "C" int odet_pointwise_dual_f16(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
+                                       const void* w, const void* bias, void* y, int batch, int cout, int relu,
+                                       odet_stream_t stream) {
+  ODET_REQUIRE(x2, "odet_pointwise_dual_f16: null pointer");
+  const PwEpilogue e{nullptr, nullptr, 0, 0, nullptr, nullptr, x2, cin2};
+  return pointwise_launch("odet_pointwise_dual_f16", x1, w, bias, y, batch, H2, W2, stride2, cin1, cout, relu, e,
+                          (hipStream_t)stream);
 }
 
 extern "C" int odet_dense_f16_out_f32(const void* x, const void* w, const float* bias, float* y, long long rows, int cin,
                                       int cout, int relu, odet_stream_t stream) {
   ODET_REQUIRE(y && rows > 0 && rows < (1ll << 31), "odet_dense_f16_out_f32: bad arguments");
-  const PwEpilogue e{nullptr, nullptr, 0, 0, y, bias};
+  const PwEpilogue e{nullptr, nullptr, 0, 0, y, bias, nullptr, 0};
   return pointwise_launch("odet_dense_f16_out_f32", x, w, nullptr, nullptr, 1, 1, (int)rows, 1, cin, cout, relu, e,
                           (hipStream_t)stream);
 }

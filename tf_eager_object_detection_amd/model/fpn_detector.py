@@ -177,14 +177,17 @@ def _own_conv3x3(conv, x, pad=None):
         return False
     if tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1):
         return False
-    # (64-channel tiles exist in the kernel, but ResNet's 64 -> 64 layer is faster in the library: 83 vs 121 us at batch 8)
-    if conv.in_channels % 64 != 0 or conv.out_channels % 128 != 0:
+    # (ResNet conv2's 64 -> 64 layer on 64-channel tiles: 82 vs 87 us at batch 8, 138 vs 160 at 15, since the LDS stages are
+    # sized by the tile and several of the small workgroups share a CU)
+    if conv.in_channels % 64 != 0 or conv.out_channels % 64 != 0:
         return False
     if not x.is_contiguous(memory_format=torch.channels_last):
         return False
     m = int(x.shape[0]) * int(x.shape[2]) * int(x.shape[3])
     co = conv.out_channels
     tiles_n = co // 256 if co % 256 == 0 else (co // 128 if co % 128 == 0 else co // 64)
+    if 'c3x3_64' in _PW_OFF and co % 128 != 0:
+        return False
     return _CONV3X3_MODE == 'force' or ((m + 127) // 128) * tiles_n >= 100
 
 
@@ -292,9 +295,33 @@ class _Block(nn.Module):
         with torch.no_grad():
             self.c3.weight.mul_(0.2)
 
+    def _dual_weights(self):
+        """[w3 | w_shortcut] along K and b3 + b_shortcut (ops.pointwise_dual_f16), cached until a parameter changes"""
+        ps = (self.c3.weight, self.c3.bias, self.short.weight, self.short.bias)
+        key = tuple((t._version, t.data_ptr(), t.dtype) for t in ps)
+        c = getattr(self, '_dual_cache', None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                n = self.c3.out_channels
+                w = torch.cat([ps[0].reshape(n, -1), ps[2].reshape(n, -1)], 1).contiguous()
+                b = (ps[1].float() + ps[3].float()).to(ps[1].dtype).contiguous()
+            c = (key, w, b)
+            self._dual_cache = c
+        return c[1], c[2]
+
     def forward(self, x):
         # Add([shortcut, x]) + ReLU ride on c3's epilogue; a convolutional shortcut runs without its bias,
         # which is added to c3's instead
+        if (self.short is not None and x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'dual' not in _PW_OFF
+                and self.c3.in_channels % 64 == 0 and self.short.in_channels % 64 == 0 and self.c3.out_channels % 64 == 0
+                and tuple(self.short.stride) in ((1, 1), (2, 2)) and x.is_contiguous(memory_format=torch.channels_last)):
+            # a stage's first block, float16: the last 1x1 convolution AND the convolutional shortcut as ONE contraction
+            # over [c2's output | the block's (strided) input] with the weights concatenated along K
+            # (ops.pointwise_dual_f16) -- the shortcut map is never written or re-read, one launch instead of two
+            y = _conv_epi(self.c2, _conv_epi(self.c1, x, relu=True), relu=True)
+            w, b = self._dual_weights()
+            return ops.pointwise_dual_f16(y.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), w, b, self.short.stride[0],
+                                          relu=True).permute(0, 3, 1, 2)
         if self.short is None:
             sc, sb = x, None
         elif x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'short' not in _PW_OFF and (
@@ -400,7 +427,13 @@ class _NmsCompleteness:
         return [h.nms_done for h in self._hot[:n]]
 
     def check_complete(self, batch=None):
-        bad = [b for b, t in enumerate(self.nms_done(batch)) if int(t.item()) != 1]
+        steps = getattr(self, '_steps', None)
+        if steps is not None and hasattr(steps, 'nms_done_all'):
+            n = self._last_batch if batch is None else batch
+            flags = steps.nms_done_all[:n].tolist()                       # one device -> host copy for the whole pass
+        else:
+            flags = [int(t.item()) for t in self.nms_done(batch)]
+        bad = [b for b, f in enumerate(flags) if f != 1]
         if bad:
             raise RuntimeError('the RPN NMS of image(s) %s did not complete inside blind_chunks = %d sync-free chunks: their '
                                'results are reported EMPTY.  Build the detector with more chunks (blind_chunks=...) or a '

@@ -697,6 +697,36 @@ def dense_f16(x, weight, bias=None, relu=False, out=None):
     return y.view(x.shape[0], -1)
 
 
+def pointwise_dual_f16(x1, x2, weight, bias=None, stride=1, relu=True, out=None):
+    """relu?([x1 | x2[:, ::stride, ::stride]] . weight^T + bias) in one contraction (odet_pointwise_dual_f16): the last 1x1
+    convolution of a stage's first bottleneck together with its convolutional shortcut.  ``x1`` [B,Ho,Wo,cin1], ``x2``
+    [B,H,W,cin2] NHWC float16 contiguous, ``weight`` [cout, cin1 + cin2] float16 contiguous."""
+    for t, nm in ((x1, 'x1'), (x2, 'x2')):
+        if t.dtype != torch.float16 or not t.is_cuda or not t.is_contiguous() or t.dim() != 4:
+            raise ValueError('pointwise_dual_f16: %s must be a contiguous float16 GPU tensor [batch, H, W, C]' % nm)
+    B, H, W, c2 = (int(v) for v in x2.shape)
+    stride = int(stride)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    c1 = int(x1.shape[3])
+    if tuple(x1.shape[:3]) != (B, Ho, Wo):
+        raise ValueError('pointwise_dual_f16: x1 %s does not match the strided x2 map (%d, %d, %d)' % (tuple(x1.shape), B, Ho, Wo))
+    cout = int(weight.shape[0])
+    if weight.dtype != torch.float16 or tuple(weight.shape) != (cout, c1 + c2) or not weight.is_contiguous():
+        raise ValueError('pointwise_dual_f16: weight must be a contiguous float16 [cout, cin1 + cin2] tensor')
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('pointwise_dual_f16: bias must be a contiguous float16 [cout] tensor')
+    if c1 % 64 or c2 % 64 or cout % 64:
+        raise ValueError('pointwise_dual_f16: channel counts must be multiples of 64')
+    shape = (B, Ho, Wo, cout)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x1.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
+    L.call('odet_pointwise_dual_f16', L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, L.dptr(weight),
+           L.dptr(bias) if bias is not None else None, L.dptr(out), B, cout, 1 if relu else 0, L.stream())
+    return out
+
+
 def dense_f16_out_f32(x, weight, bias=None, relu=False, out=None):
     """The last dense layer with float32 results (odet_dense_f16_out_f32): ``x`` [rows, cin] / ``weight`` [cout, cin]
     float16 contiguous, ``bias`` [cout] float32 -> float32 [rows, cout]; cout % 64 == 0 (pad the weight rows with zeros)."""

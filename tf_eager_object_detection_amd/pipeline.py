@@ -375,8 +375,11 @@ class FpnStepBatch:
         h0 = self.slots[0]
         self.roi_features = torch.zeros((self.n,) + tuple(h0.roi_features.shape), dtype=h0.roi_features.dtype,
                                         device=h0.device)
+        # (the images' NMS-completeness flags side by side: ONE device -> host copy checks a whole pass)
+        self.nms_done_all = torch.zeros(self.n, dtype=torch.int32, device=h0.device)
         for b, h in enumerate(self.slots):
             h.roi_features = self.roi_features[b]
+            h.nms_done = self.nms_done_all[b:b + 1]
         self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
         # a launch sequence carries up to 8 images (ODET_MAX_STEP_BATCH: the kernels' per-image pointer tables); a larger
         # batch goes out as consecutive sequences of 8
