@@ -176,8 +176,9 @@ def load_traffic(workload_key, images_per_launch):
     p = os.path.join(ROOT, 'profiles', 'roi_pool_traffic.json')
     try:
         d = json.load(open(p))
-        if d.get('workload') == workload_key:
-            return d.get('hbm_bytes_per_launch') / float(d.get('images_per_launch', 1)) * images_per_launch
+        for rec in [d] + list(d.get('also', [])):             # (one record per workload: float32 maps, float16 maps)
+            if rec.get('workload') == workload_key:
+                return rec.get('hbm_bytes_per_launch') / float(rec.get('images_per_launch', 1)) * images_per_launch
     except Exception:
         pass
     return None

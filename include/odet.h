@@ -241,6 +241,11 @@ int odet_prof_event_create(void** ev);
  * (nullable), it is the time this box's memory system needs for the RoI launch's read : write mix. */
 int odet_calib_stream_mix(const void* src, unsigned long long read_bytes, void* dst, unsigned long long write_bytes,
                           odet_stream_t stream, void* start_event, void* stop_event);
+/* Counter calibration (measurement infrastructure): reads (an odd number of) 64 * bytes_per_lane-byte rows of src, `bytes`
+ * in all, exactly once with 8 or 16 bytes per lane in a permuted row order -- a known byte count in the access shape of
+ * the float16 / float32 RoI kernels, against which FETCH_SIZE's gfx950 factor is measured in the same profiler pass
+ * (kernel names k_calib_read<8> / k_calib_read<16>).  Returns the rows read through *sink only in name (never written). */
+int odet_calib_read_rows(const void* src, unsigned long long bytes, int bytes_per_lane, void* sink, odet_stream_t stream);
 int odet_prof_event_destroy(void* ev);
 int odet_prof_event_elapsed_ms(void* start, void* stop, float* ms);
 

@@ -60,7 +60,8 @@ struct RoiParams {
   int waves;          // waves (= output rows) per workgroup; == P: a workgroup is one RoI
   int xcd_images;     // 1: the image is derived from the XCD slot (batch of 2 / 4 / 8), 0: blockIdx.y
   int xcds_per_img;   // XCDs that serve one image (8 / batch)
-  int slices;         // > 1: C / 256 workgroups per RoI, one 256-channel slice each (launches that would not fill the chip)
+  int slices;         // > 1: C / 256 workgroups per RoI, one 256-channel slice each
+  int rois_per_xcd;   // slices > 1: an XCD walks its RoIs once per slice, SLICE-MAJOR (all of slice 0, then slice 1, ...)
 };
 
 struct Axis {
@@ -443,9 +444,14 @@ __global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
   const int P = p.P, C = p.C;
   int ri, py;       // this wave: output row py of the ri-th RoI of the processing order
   int ch0 = 0, ch1 = C;     // ... and its channels
-  if (p.slices > 1) {       // few RoIs with many channels: a workgroup = one 256-channel slice of a RoI
-    ri = lb / p.slices; py = w;
-    ch0 = (lb - ri * p.slices) * 256; ch1 = ch0 + 256;
+  if (p.slices > 1) {
+    // maps of 512 / 1024 channels: a workgroup = one 256-channel slice of a RoI, and an XCD's workgroups are dealt
+    // SLICE-MAJOR -- the first rois_per_xcd slots are slice 0 of its RoIs, the next ones slice 1, ... -- so that what
+    // its L2 has to hold at a time is one 256-channel slice of the map (50 x 84 x 1 KB = 4.3 MB of the C4 map, not 17 MB):
+    // the L2-miss stream of the 8-image C4 launch fell from 750 to ~200 MB (tools/pmc_roi_forms.sh)
+    const int sl = slot / p.rois_per_xcd;
+    ri = sub * p.rois_per_xcd + (slot - sl * p.rois_per_xcd); py = w;
+    ch0 = sl * 256; ch1 = ch0 + 256;
   } else if (p.waves == P) {
     ri = lb; py = w;
   } else {
@@ -666,13 +672,19 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   const int64_t rows = (int64_t)n * pool_size;
   // a launch of a few hundred RoIs over 512 / 1024-channel maps (the C4 and VGG16 detectors: 300 RoIs) would leave
   // most CUs with one workgroup: split every RoI's channels over C / 256 workgroups
-  p.slices = (p.waves == pool_size && (C & 255) == 0 && C > 256 && (int64_t)n * B < 2048) ? C / 256 : 1;
+  p.slices = (p.waves == pool_size && (C & 255) == 0 && C > 256) ? C / 256 : 1;
   const int64_t blocks = p.slices > 1 ? (int64_t)n * p.slices : (rows + p.waves - 1) / p.waves;
   ODET_REQUIRE(blocks < (1ll << 30), "odet_roi_pool: too many workgroups");
   p.nblocks = (int)blocks;
   p.xcd_images = (B == 2 || B == 4 || B == 8) ? 1 : 0;
   p.xcds_per_img = p.xcd_images ? 8 / B : 8;
   p.blocks_per_xcd = (p.nblocks + p.xcds_per_img - 1) / p.xcds_per_img;   // per XCD of an image
+  p.rois_per_xcd = 0;
+  if (p.slices > 1) {
+    p.rois_per_xcd = (n + p.xcds_per_img - 1) / p.xcds_per_img;
+    p.blocks_per_xcd = p.rois_per_xcd * p.slices;
+    p.nblocks = p.blocks_per_xcd * p.xcds_per_img;        // (slots beyond the last RoI leave at `ri >= n`)
+  }
   dim3 grid(p.blocks_per_xcd * 8, p.xcd_images ? 1 : B);
   const int threads = p.waves * 64;
   if (pool_mode == ODET_ROI_POOL_NONE) roi_launch_norm<ODET_ROI_POOL_NONE>(norm_mode, grid, threads, st, p, ev, f16);
