@@ -75,7 +75,12 @@ struct NmsState {
   int32_t reserved0;
   int32_t sel_b1;        // threshold bin of the first 12 key bits
   uint32_t sel_below1;   // candidates in bins < sel_b1
-  int32_t pad[7];
+  // tie split (k_sel_tie_hist / k_sel_tie_take): the boundary bin (24-bit prefix sel_b1:sel_b2) did not fit the
+  // selection and was left out by k_sel_compact; sel_below = candidates strictly below it
+  int32_t sel_b2;
+  int32_t sel_overflow;
+  uint32_t sel_below;
+  int32_t pad[4];
 };
 
 // Starts the workspace.  Zeroed by k_zero_headers at the start of a call -- or, for callers that promise a workspace
@@ -89,6 +94,7 @@ struct NmsHeader {
   u64 stamps[64];                      // diagnostic builds only (-DODET_STAMPS)
   uint32_t hist1[SEL_REPL][SEL_BINS];  // replica r is fed by blocks with blockIdx % SEL_REPL == r
   uint32_t hist2[SEL_BINS];
+  uint32_t hist3[256];                 // tie split: the last 8 key bits inside the boundary bin (zeroed again by k_sel_rank)
 };
 
 #ifdef ODET_STAMPS
@@ -328,6 +334,11 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(PerImg<NmsHeader*> hd
   // chunk-0 scan), otherwise the chunk is the (smaller, still valid) set strictly below it and the
   // fallback path picks up from there.
   const bool incl = (below1 + res[1] + res[2]) <= limit;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {               // for the tie split (wide selections only)
+    hdr->st.sel_b2 = (int32_t)b2;
+    hdr->st.sel_overflow = incl ? 0 : 1;
+    hdr->st.sel_below = below1 + res[1];
+  }
   // block-local append (LDS counter, one LDS atomic per wave and item), then ONE global atomic per block
   __shared__ u64 stage[SEL_TILE];
   __shared__ int s_cnt, s_base;
@@ -365,6 +376,112 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(PerImg<NmsHeader*> hd
     if (gb + i < NMS_SEL_MAX) cand[gb + i] = stage[i];
 }
 
+// ---- tie split: a boundary bin that does not fit ------------------------------------------------------------------------
+// A saturated RPN (softmax == 1.0f for tens of thousands of anchors: the fg - bg margin is beyond float32's reach -- the
+// random-init float16 detector of the benchmark, and any confident trained one) puts thousands of EQUAL keys at the very
+// top of the order: the boundary bin of the selection holds more candidates than the selection may take, k_sel_compact
+// leaves it out whole, and the chunks from the selection come up empty.  For the wide selection of sync-free jobs with
+// more than one chunk the bin is split exactly, in (key, index) order -- the declared tie rule, SURVEY H2:
+//   k_sel_tie_hist : histogram of the LAST 8 key bits inside the boundary bin, per block (index ranges in order) and summed
+//   k_sel_tie_take : boundary value b3 = where the running count reaches the quota; everything below b3 is taken, of the
+//                    keys EQUAL to b3 the first q3 in index order: a block knows how many ties the blocks before it hold
+//                    (per-block counts) and ranks its own by ballots.
+// Both exit at once when the bin fitted (st.sel_overflow == 0).  The selection stays an exact prefix of the order.
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_tie_hist(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n,
+                                                            PerImg<unsigned short*> bh_) {
+  NmsHeader* hdr = hdr_.v[blockIdx.y];
+  if (!hdr->st.sel_overflow) return;
+  const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
+  unsigned short* __restrict__ bh = bh_.v[blockIdx.y] + (size_t)blockIdx.x * 256;
+  __shared__ uint32_t h[256];
+  const uint32_t pref = ((uint32_t)hdr->st.sel_b1 << 12) | (uint32_t)hdr->st.sel_b2;
+  h[threadIdx.x] = 0;                                       // (SEL_BLOCK == 256)
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
+    if (e < n) {
+      const uint32_t k = keys[e];
+      if ((k >> 8) == pref) atomicAdd(&h[k & 0xFFu], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t c = h[threadIdx.x];
+  bh[threadIdx.x] = (unsigned short)c;
+  if (c) atomicAdd(&hdr->hist3[threadIdx.x], c);
+}
+
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_tie_take(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n,
+                                                            uint32_t limit, PerImg<const unsigned short*> bh_,
+                                                            PerImg<u64*> cand_) {
+  NmsHeader* hdr = hdr_.v[blockIdx.y];
+  if (!hdr->st.sel_overflow) return;
+  const uint32_t below = hdr->st.sel_below;
+  if (below >= limit) return;
+  const uint32_t quota = limit - below;                    // candidates of the boundary bin the selection still takes
+  const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
+  const unsigned short* __restrict__ bh = bh_.v[blockIdx.y];
+  u64* __restrict__ cand = cand_.v[blockIdx.y];
+  __shared__ int lds17[17];
+  __shared__ uint32_t s_b3, s_q3, s_pre;
+  __shared__ int s_wave[4];
+  __shared__ u64 stage[SEL_TILE];
+  __shared__ int s_cnt, s_base;
+  const uint32_t pref = ((uint32_t)hdr->st.sel_b1 << 12) | (uint32_t)hdr->st.sel_b2;
+  // boundary value: running count over the 256 last-byte values (thread = value)
+  const uint32_t hv = hdr->hist3[threadIdx.x];
+  int total;
+  const uint32_t excl = (uint32_t)block_excl_scan((int)hv, lds17, &total);
+  if (threadIdx.x == 0) { s_b3 = 256; s_q3 = 0; s_pre = 0; s_cnt = 0; }
+  __syncthreads();
+  if (hv > 0 && excl < quota && quota <= excl + hv) { s_b3 = threadIdx.x; s_q3 = quota - excl; }
+  __syncthreads();
+  const uint32_t b3 = s_b3, q3 = s_q3;                     // (b3 == 256: the whole bin fits after all -- not reached)
+  // ties of value b3 in the blocks before this one
+  if (b3 < 256) {
+    uint32_t mine = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SEL_BLOCK) mine += bh[(size_t)b * 256 + b3];
+    int tot2;
+    block_excl_scan((int)mine, lds17, &tot2);
+    if (threadIdx.x == 0) s_pre = (uint32_t)tot2;
+  }
+  __syncthreads();
+  uint32_t run = s_pre;                                    // ties of value b3 before the current item (block-uniform)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
+    const uint32_t k = (e < n) ? keys[e] : 0xFFFFFFFFu;
+    const bool inbin = (e < n) && (k >> 8) == pref;
+    const uint32_t v = k & 0xFFu;
+    const bool tie = inbin && v == b3;
+    const u64 tb = __ballot(tie);
+    if (lane == 0) s_wave[wv] = (int)__popcll(tb);
+    __syncthreads();
+    uint32_t before = run;
+    for (int q = 0; q < wv; ++q) before += (uint32_t)s_wave[q];
+    const uint32_t my_rank = before + (uint32_t)__popcll(tb & lt_mask);
+    const uint32_t all4 = (uint32_t)(s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]);
+    const bool sel = inbin && (v < b3 || (tie && my_rank < q3));
+    const u64 bal = __ballot(sel);
+    if (bal) {
+      int base = 0;
+      if (lane == __builtin_ctzll(bal)) base = atomicAdd(&s_cnt, (int)__popcll(bal));
+      base = __shfl(base, __builtin_ctzll(bal));
+      if (sel) stage[base + (int)__popcll(bal & lt_mask)] = ((u64)k << 32) | (uint32_t)e;
+    }
+    run += all4;
+    __syncthreads();
+  }
+  const int c = s_cnt;
+  if (c == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&hdr->st.sel_count, c);
+  __syncthreads();
+  const int gb = s_base;
+  for (int i = threadIdx.x; i < c; i += SEL_BLOCK)
+    if (gb + i < NMS_SEL_MAX) cand[gb + i] = stage[i];
+}
+
 // chunk 0: order the selected candidates by counting (all (key, index) pairs are distinct, so the
 // rank of a pair = number of smaller pairs is a permutation) and gather their boxes.  Workgroup =
 // 64 candidates (lane) x 16 slices of the comparison range (wave); the pair list is staged in LDS and
@@ -388,6 +505,7 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
   if (blockIdx.x == 0) {     // k_sel_compact was the last reader of the second-level histogram: leave it clean
     uint4* z = reinterpret_cast<uint4*>(hdr->hist2);
     for (int i = threadIdx.x; i < SEL_BINS / 4; i += RANK_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < 256) hdr->hist3[threadIdx.x] = 0;      // (and the tie split's, whose last reader ran before this launch)
   }
   if (blockIdx.x * 64 >= cnt) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1142,6 +1260,16 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     const PerImg<u64*> cand = per_img<u64*>(J, [&](int i) { return w[i].cand; });
     hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, hdrs, keys, n, sel_target, sel_limit, cand);
     ODET_LAUNCH_CHECK();
+    if (wide) {
+      // a boundary bin too large for the selection (thousands of equal keys: a saturated RPN) is split exactly in
+      // (key, index) order; both launches exit at once when the bin fitted.  Scratch: the bit-matrix buffer (idle here).
+      const PerImg<unsigned short*> bh = per_img<unsigned short*>(J, [&](int i) { return (unsigned short*)w[i].Lt; });
+      hipLaunchKernelGGL(k_sel_tie_hist, grid, block, 0, st, hdrs, keys, n, bh);
+      ODET_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_sel_tie_take, grid, block, 0, st, hdrs, keys, n, sel_limit,
+                         per_img<const unsigned short*>(J, [&](int i) { return (const unsigned short*)w[i].Lt; }), cand);
+      ODET_LAUNCH_CHECK();
+    }
     const int rank_wgs = (std::min(n, (int)sel_limit) + 63) / 64;
     hipLaunchKernelGGL(k_sel_rank, dim3(rank_wgs, B), dim3(RANK_THREADS), 0, st, hdrs, n, (int)limit,
                        per_img<const u64*>(J, [&](int i) { return (const u64*)w[i].cand; }), J.prep, J.mode,

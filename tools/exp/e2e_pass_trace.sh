@@ -12,8 +12,11 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # a pass ends with k_postops_merge; take the kernels between the 3rd-last and 2nd-last merge of the timed loop
 idx = [i for i, r in enumerate(rows) if 'k_postops_merge' in r['Kernel_Name']]
-# e2e_bench runs per-part timing passes after the loop (features x5, rpn x5): use merges only
-a, b = idx[-3] + 1, idx[-2] + 1
+# e2e_bench runs per-part timing passes after the loop (features x5, rpn x5): use merges only; a pass of B images ends
+# with ceil(B / 8) merge launches (one per launch sequence of 8 images)
+import os
+m = (int(os.environ.get('BATCH', '8')) + 7) // 8
+a, b = idx[-2 * m - 1] + 1, idx[-m - 1] + 1
 t0 = int(rows[a]['Start_Timestamp'])
 tot = 0
 for r in rows[a:b]:
