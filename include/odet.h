@@ -427,12 +427,29 @@ int odet_stem_pack_weights_f16(const void* w, long long stride_o, long long stri
                                long long stride_x, void* packed, odet_stream_t stream);
 int odet_stem_conv7_pool3_f16(const void* images, int images_f16, const void* packed_w, const void* bias, void* out,
                               int batch, int H, int W, odet_stream_t stream);
-/* the float32 forms (the detectors' parity mode computes in the reference's precision): float32 x / w / bias / y,
- * exact-float32 MFMA (v_mfma_f32_16x16x4_f32), cin % 32 == 0, cout % 256 == 0 */
+/* The float32 forms (csrc/conv_f32.hip): the detectors' PARITY mode computes in the reference's precision -- float32 x / w /
+ * bias / y, exact-float32 matrix instructions (v_mfma_f32_16x16x4_f32: a chain of fmaf, no rounding the reference does
+ * not have), the same tiling / staging / epilogues as the float16 entry points of the same names.  cin % 32 == 0,
+ * cout % 64 == 0. */
 int odet_conv3x3_f32(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
                      int cin, int cout, int relu, odet_stream_t stream);
 int odet_conv3x3_f32_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
                             int batch, int cin, int cout, int relu, odet_stream_t stream);
+/* 1x1 convolutions (stride 1 or 2) / dense layers (odet_pointwise_f16's float32 twin; cin >= 64 along K), the lateral
+ * convolution with the top-down merge in its epilogue (bit-identical to odet_fpn_topdown_merge applied to the
+ * convolution's float32 result) and a stage's first bottleneck's last convolution + convolutional shortcut as one
+ * contraction (resnet_fpn.py:154-205, 292-336, 339-398). */
+int odet_pointwise_f32(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
+                       int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream);
+int odet_lateral_merge_f32(const void* x, const void* w, const void* bias, const void* top, int th, int tw, void* y,
+                           int batch, int H, int W, int cin, int cout, odet_stream_t stream);
+int odet_pointwise_dual_f32(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
+                            const void* w, const void* bias, void* y, int batch, int cout, int relu, odet_stream_t stream);
+/* The stem's patch matrix in float32 mode: row (image, yo, xo) = the zero-padded 7 x 7 x 3 window of conv1_pad +
+ * Conv2D(64, 7x7, strides 2, 'valid') (resnet_fpn.py:262-289) in (dy, dx, channel) order, padded from 147 to 160 floats;
+ * images NHWC float32 [batch,H,W,3] -> patches [batch * Ho * Wo][160], Ho = (H - 1) / 2 + 1.  The convolution is then
+ * odet_pointwise_f32 with cin = 160 on it (weights [64][160] in the same order). */
+int odet_stem_patches_f32(const float* images, float* patches, int batch, int H, int W, odet_stream_t stream);
 
 /* 1x1 stride-1 convolution with its whole epilogue on the matrix cores (the third convolution
  * of a bottleneck block + Add([shortcut, x]) + Activation('relu'), model/fpn/resnet_fpn.py:154-205, frozen

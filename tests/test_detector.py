@@ -1062,3 +1062,89 @@ def test_pointwise_dual_f16_last_conv_and_shortcut_in_one_contraction(B, H, W, K
     w = (torch.randn((N, K1 + K2), device='cuda', generator=g) / (K1 + K2) ** 0.5).to(torch.float16)
     want = torch.relu(a.float() @ w[:, :K1].float().t() + c[:, ::stride, ::stride].float() @ w[:, K1:].float().t() + b.float())
     torch.testing.assert_close(ops.pointwise_dual_f16(a, c, w, b, stride).float(), want, rtol=2e-3, atol=4e-3)
+
+
+# ---- float32 forms (csrc/conv_f32.hip): the parity mode's dense layers on exact-float32 matrix instructions --------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,K,N,stride', [(2, 25, 42, 1024, 256, 1), (1, 50, 84, 256, 512, 2), (1, 33, 47, 64, 64, 1),
+                                             (2, 13, 21, 2048, 512, 1), (1, 1, 700, 12544, 1024, 1), (1, 100, 167, 256, 128, 2),
+                                             (1, 40, 61, 160, 64, 1)])
+def test_pointwise_f32_exact_on_integer_data_and_equal_to_float64_on_random(B, H, W, K, N, stride):
+    """odet_pointwise_f32: EXACT on integer data (float32 holds every partial sum), within float32 accumulation error of a
+    float64 contraction on random data; shortcut and ReLU epilogues; strided rows."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(B + H + K + N + stride)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    ri = lambda lo, hi, *sh: torch.randint(lo, hi, sh, device='cuda', generator=g).float()
+    x, w, b, r = ri(-8, 9, B, H, W, K), ri(-4, 5, N, K), ri(-100, 101, N), ri(-1000, 1001, B, Ho, Wo, N)
+    xs = x[:, ::stride, ::stride]
+    for res, relu, bias in ((r, True, b), (None, False, b), (r, False, None)):
+        want = xs.double() @ w.double().t()
+        if bias is not None:
+            want = want + bias.double()
+        if res is not None:
+            want = want + res.double()
+        if relu:
+            want = torch.relu(want)
+        assert float(want.abs().max()) < 2 ** 24
+        got = ops.pointwise(x, w, bias, res, relu, stride)
+        assert got.dtype == torch.float32 and torch.equal(got.double(), want)
+    x = torch.randn((B, H, W, K), device='cuda', generator=g)
+    w = torch.randn((N, K), device='cuda', generator=g) / K ** 0.5
+    want = torch.relu(x[:, ::stride, ::stride].double() @ w.double().t() + b.double() + r.double())
+    got = ops.pointwise(x, w, b, r, True, stride).double()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_float32_lateral_merge_dual_and_small_tile_convolutions():
+    """the other float32 forms: lateral convolution + top-down merge in one launch is BIT-IDENTICAL to the merge launch on
+    the convolution's result; a stage's first bottleneck (last convolution + shortcut as one contraction) and the 64 /
+    128-channel 3x3 tiles exact on integer data; the stem's patch matrix + GEMM equals the library convolution."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    x = torch.randn((2, 37, 53, 512), device='cuda', generator=g)
+    w = torch.randn((256, 512), device='cuda', generator=g) / 512 ** 0.5
+    b = torch.randn(256, device='cuda', generator=g)
+    top = torch.randn((2, 19, 27, 256), device='cuda', generator=g)
+    assert torch.equal(ops.lateral_merge(x, w, b, top), ops.fpn_topdown_merge(top, ops.pointwise(x, w, b)))
+    ri = lambda lo, hi, *sh: torch.randint(lo, hi, sh, device='cuda', generator=g).float()
+    a, c = ri(-8, 9, 1, 25, 42, 128), ri(-8, 9, 1, 50, 84, 256)
+    wa, wc, bb = ri(-4, 5, 512, 128), ri(-4, 5, 512, 256), ri(-50, 51, 512)
+    want = torch.relu(a.double() @ wa.double().t() + c[:, ::2, ::2].double() @ wc.double().t() + bb.double())
+    assert torch.equal(ops.pointwise_dual(a, c, torch.cat([wa, wc], 1).contiguous(), bb, 2, relu=True).double(), want)
+    for cin, cout in ((64, 64), (128, 128), (64, 192)):
+        xi, wi, bi = ri(-4, 5, 2, 19, 23, cin), ri(-3, 4, cout, cin, 3, 3), ri(-20, 21, cout)
+        want = torch.relu(F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double(), bi.double(), 1, 1)).permute(0, 2, 3, 1)
+        got = ops.conv3x3_f32(xi, wi.contiguous(memory_format=torch.channels_last), bi, relu=True)
+        assert torch.equal(got.double(), want)
+    img = torch.randn((2, 61, 83, 3), device='cuda', generator=g)
+    w7 = torch.randn((64, 3, 7, 7), device='cuda', generator=g) * 0.1
+    w160 = torch.zeros((64, 160), device='cuda')
+    w160[:, :147] = w7.permute(0, 2, 3, 1).reshape(64, 147)
+    got = ops.pointwise(ops.stem_patches_f32(img), w160, None)
+    want = F.conv2d(img.permute(0, 3, 1, 2).double(), w7.double(), None, 2, 3).permute(0, 2, 3, 1)
+    assert got.shape == want.shape and float((got.double() - want).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_float32_detector_pass_runs_no_library_convolution_or_gemm(monkeypatch):
+    """the parity mode's dense path is this repository's kernels end to end: a float32 ResNet-50-FPN pass calls neither
+    torch's convolution nor its GEMMs (the routes would fall back to them silently otherwise)"""
+    import torch.nn.functional as Fn
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(1)
+    m = ResNetFpnDetector(50, 21, (320, 480), 300, dtype=torch.float32, max_batch=2).prepare()
+    img = torch.randn((2, 320, 480, 3), device='cuda') * 50
+    out_ref = m(img)
+    calls = []
+    for name in ('conv2d', 'linear'):
+        real = getattr(Fn, name)
+        monkeypatch.setattr(Fn, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
+    for name in ('addmm', '_addmm_activation', 'matmul', 'mm'):
+        real = getattr(torch, name)
+        monkeypatch.setattr(torch, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
+    out = m(img)
+    assert calls == [], calls
+    assert int(out[0][3].item()) == int(out_ref[0][3].item())

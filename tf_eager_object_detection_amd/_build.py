@@ -11,7 +11,7 @@ CSRC = os.path.join(PKG, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(PKG), 'include')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libodet_hip.so')
-SOURCES = ['boxes.hip', 'sort.hip', 'nms.hip', 'roi.hip', 'roi_half.hip', 'postops.hip', 'neck.hip', 'epilogue.hip', 'conv1x1.hip', 'conv3x3.hip', 'rpn_tail.hip',
+SOURCES = ['boxes.hip', 'sort.hip', 'nms.hip', 'roi.hip', 'roi_half.hip', 'postops.hip', 'neck.hip', 'epilogue.hip', 'conv1x1.hip', 'conv3x3.hip', 'conv_f32.hip', 'rpn_tail.hip',
            'calib.hip', 'stem.hip', 'executor.hip']
 HEADERS = [os.path.join(CSRC, 'odet_internal.h'), os.path.join(INCLUDE, 'odet.h')]
 

@@ -576,153 +576,7 @@ __global__ void __launch_bounds__(256) k_rpn_tail_finish(Conv3x3Params p) {
   }
 }
 
-// ---- float32 form (the parity mode of the detectors computes in the reference's precision) --------------------
-// Same tiling, staging and transposed-tile layout with 4-byte elements: a K-step is one tap x 32 input channels (the
-// same 128-byte rows and swizzle), the tiles are v_mfma_f32_16x16x4_f32 (exact float32: a chain of fmaf, 1/16 of the
-// float16 rate, so the loop is bound by the matrix pipe and needs no pipelining finesse).  A lane reads the two 16-byte
-// slots q and 4 + q of its row (q = lane >> 4) and uses float j of those eight in MFMA step j: both operands order K the
-// same way, so every k of the 32 is visited exactly once.
-struct Conv3x3F32Params {
-  const float* x[ODET_MAX_LEVELS]; float* y[ODET_MAX_LEVELS];
-  const float* w; const float* bias;
-  long long M[ODET_MAX_LEVELS];
-  int H[ODET_MAX_LEVELS], W[ODET_MAX_LEVELS];
-  long long tile_start[ODET_MAX_LEVELS + 1];
-  int num_levels, cin, cout, relu;
-  int tiles_n;
-};
-
-typedef float c3f4 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(512) k_conv3x3_f32(Conv3x3F32Params p) {
-  extern __shared__ __align__(16) unsigned char lds[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 2, wn = wv & 3;
-  const long long blk = blockIdx.x;
-  const long long q8 = blk >> 3;
-  const long long slab = (blk & 7) + 8 * (q8 / p.tiles_n);
-  const int tn = (int)(q8 % p.tiles_n);
-  if (slab >= p.tile_start[p.num_levels]) return;
-  int lv = 0;
-#pragma unroll
-  for (int l = 1; l < ODET_MAX_LEVELS; ++l)
-    if (l < p.num_levels && slab >= p.tile_start[l]) lv = l;
-  const long long tile_m = slab - p.tile_start[lv];
-  const int H = p.H[lv], W = p.W[lv], cin = p.cin, cout = p.cout;
-  const uint32_t pixB = (uint32_t)cin * 4u;
-  const uint32_t PAD = (uint32_t)(W + 1) * pixB;
-  const uint32_t OOB = 0xFFFFFFF0u;
-  const long long M = p.M[lv];
-  const c3_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(p.x[lv])) - PAD, 0, (int)((uint32_t)M * pixB + 2u * PAD), 0x00020000);
-  const uint32_t wrowB = 9u * pixB;
-  const c3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((uint32_t)cout * wrowB), 0x00020000);
-  const int sub = lane >> 3;
-  const uint32_t slot = (uint32_t)((lane & 7) ^ sub) * 16u;
-  uint32_t voffA[4], voffW[4], maskA[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wv * 4 + i) * 8 + sub;
-    const long long m = tile_m * C3_TM + row;
-    uint32_t mk = 0;
-    if (m < M) {
-      const long long img = m / ((long long)H * W);
-      const int rem = (int)(m - img * H * W);
-      const int yy = rem / W, xx = rem - yy * W;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-        if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
-      }
-    }
-    maskA[i] = mk;
-    voffA[i] = (uint32_t)m * pixB + slot;
-    const int g = row >> 6, rr = row & 63, t = rr >> 4, r = rr & 15;
-    const int ch = tn * C3_TN + g * 64 + 16 * (r >> 2) + 4 * t + (r & 3);
-    voffW[i] = (uint32_t)ch * wrowB + slot;
-  }
-  const int chunks = cin / 32;
-  const int ksteps = 9 * chunks;
-  struct IssueAt { int tap; uint32_t soA, soW, stage; };
-  auto issue_at = [&](int ks, uint32_t stage) {
-    IssueAt a;
-    a.tap = ks / chunks;
-    const int chunk = ks - a.tap * chunks;
-    a.soA = (uint32_t)((a.tap / 3) * W + a.tap % 3) * pixB + (uint32_t)chunk * 128u;
-    a.soW = (uint32_t)ks * 128u;
-    a.stage = stage;
-    return a;
-  };
-  auto issue_piece = [&](const IssueAt& a, int i) {       // pieces i = 0..3: 1 KB of pixels + 1 KB of weights each
-    const uint32_t pc = (uint32_t)(wv * 4 + i) * 1024u;
-    const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + pc), 16, (int)va, (int)a.soA, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + C3_TM * 128u + pc), 16, (int)voffW[i],
-                                             (int)a.soW, 0, 0);
-  };
-  auto issue = [&](int ks, uint32_t stage) {
-    const IssueAt a = issue_at(ks, stage);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) issue_piece(a, i);
-  };
-  const int l15 = lane & 15, lq = lane >> 4;
-  const uint32_t fslot = (uint32_t)(lq ^ (lane & 7)) * 16u;                         // slot q; slot 4 + q = ^ 64
-  const uint32_t xoff = (uint32_t)(wm * 128 + l15) * 128u + fslot;
-  const uint32_t woff = C3_TM * 128u + (uint32_t)(wn * 64 + l15) * 128u + fslot;
-  c3f4 acc[8][4];
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[mt][t] = (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
-  issue(0, 0u);
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const uint32_t stage = (uint32_t)(ks & 1) * C3_STAGE_BYTES;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (ks + 1 < ksteps) issue(ks + 1, C3_STAGE_BYTES - stage);
-    const unsigned char* sb = lds + stage;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      const uint32_t kx = kh ? 64u : 0u;
-      c3f4 wf[4], xf[8];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const c3f4*>(sb + ((woff + (uint32_t)t * 2048u) ^ kx));
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) xf[mt] = *reinterpret_cast<const c3f4*>(sb + ((xoff + (uint32_t)mt * 2048u) ^ kx));
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][j], xf[mt][j], acc[mt][t], 0, 0, 0);
-    }
-  }
-  const int c0 = tn * C3_TN + wn * 64 + lq * 16;
-  float bv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[c0 + e] : 0.0f;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const long long m = tile_m * C3_TM + wm * 128 + mt * 16 + l15;
-    if (m < M) {
-      float* dst = p.y[lv] + m * cout + c0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        c3f4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[mt][t][j] + bv[t * 4 + j];
-          if (p.relu) v = v < 0.0f ? 0.0f : v;
-          o[j] = v;
-        }
-        *reinterpret_cast<c3f4*>(dst + t * 4) = o;
-      }
-    }
-  }
-}
+// (the float32 forms -- the detectors' parity mode -- live in conv_f32.hip)
 
 struct Conv3x3Tail {             // the fused RpnHead tail (nullable in conv3x3_launch)
   const void* w; const void* b; int A; float* scores; long long s_stride; float* deltas; long long d_stride;
@@ -1078,52 +932,3 @@ extern "C" size_t odet_rpn_head_fused_workspace_bytes(const odet_conv_level_t* l
   return (size_t)((cout + 255) / 256) * px * 32 * sizeof(float);
 }
 
-static int conv3x3_f32_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,
-                              int cin, int cout, int relu, hipStream_t st) {
-  ODET_REQUIRE(levels && w, "odet_conv3x3_f32: null pointer");
-  ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_f32: num_levels %d out of range", num_levels);
-  ODET_REQUIRE(batch > 0, "odet_conv3x3_f32: bad batch");
-  ODET_REQUIRE(cin > 0 && cin % 32 == 0, "odet_conv3x3_f32: cin %d must be a multiple of 32", cin);
-  ODET_REQUIRE(cout > 0 && cout % C3_TN == 0, "odet_conv3x3_f32: cout %d must be a multiple of %d", cout, C3_TN);
-  ODET_REQUIRE((unsigned long long)cout * 9ull * cin * 4ull < 0x7FFFFFFFull, "odet_conv3x3_f32: weights too large");
-  static std::once_flag once;
-  static hipError_t once_rc = hipSuccess;
-  std::call_once(once, [] {
-    once_rc = hipFuncSetAttribute((const void*)k_conv3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
-  });
-  ODET_HIP(once_rc);
-  Conv3x3F32Params p;
-  long long total = 0;
-  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
-    const odet_conv_level_t& L = levels[l < num_levels ? l : 0];
-    ODET_REQUIRE(L.x && L.y && L.H > 0 && L.W > 0, "odet_conv3x3_f32: bad level %d", l);
-    const long long M = (long long)batch * L.H * L.W;
-    ODET_REQUIRE((unsigned long long)M * cin * 4ull + 2ull * (L.W + 1) * cin * 4ull < 0xFFFFFFF0ull,
-                 "odet_conv3x3_f32: level %d input larger than 4 GiB", l);
-    p.x[l] = (const float*)L.x; p.y[l] = (float*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
-    p.tile_start[l] = total;
-    if (l < num_levels) total += (M + C3_TM - 1) / C3_TM;
-  }
-  for (int l = num_levels; l <= ODET_MAX_LEVELS; ++l) p.tile_start[l] = total;
-  p.w = (const float*)w; p.bias = (const float*)bias;
-  p.num_levels = num_levels; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
-  p.tiles_n = cout / C3_TN;
-  const long long groups = (total + 7) / 8;
-  const long long blocks = groups * 8 * p.tiles_n;
-  ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f32: too many workgroups");
-  hipLaunchKernelGGL(k_conv3x3_f32, dim3((unsigned)blocks), dim3(512), C3_LDS_BYTES, st, p);
-  ODET_LAUNCH_CHECK();
-  return ODET_OK;
-}
-
-extern "C" int odet_conv3x3_f32(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W, int cin,
-                                int cout, int relu, odet_stream_t stream) {
-  ODET_REQUIRE(x && y, "odet_conv3x3_f32: null pointer");
-  const odet_conv_level_t one{x, y, H, W};
-  return conv3x3_f32_launch(&one, 1, w, bias, batch, cin, cout, relu, (hipStream_t)stream);
-}
-
-extern "C" int odet_conv3x3_f32_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
-                                       int batch, int cin, int cout, int relu, odet_stream_t stream) {
-  return conv3x3_f32_launch(levels, num_levels, w, bias, batch, cin, cout, relu, (hipStream_t)stream);
-}

@@ -96,13 +96,16 @@ if __import__('os').environ.get('ODET_PW', '1') == '0':
 
 def _pw_ok(conv, x):
     """the pointwise GEMM kernel takes this 1x1 convolution (stride 1 or 2, no padding)"""
-    return (x.is_cuda and x.dtype == torch.float16 and tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0)
-            and tuple(conv.stride) in ((1, 1), (2, 2)) and conv.in_channels % 64 == 0 and conv.in_channels >= 128
+    if not x.is_cuda or x.dtype not in (torch.float16, torch.float32) or ('f32' in _PW_OFF and x.dtype == torch.float32):
+        return False
+    gran = 64 if x.dtype == torch.float16 else 32          # channels per K-step
+    return (tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0)
+            and tuple(conv.stride) in ((1, 1), (2, 2)) and conv.in_channels % gran == 0 and conv.in_channels >= 2 * gran
             and conv.out_channels % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
 
 
 def _pw_1x1(conv, x, bias, relu, res):
-    return ops.pointwise_f16(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu, conv.stride[0]).permute(0, 3, 1, 2)
+    return ops.pointwise(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu, conv.stride[0]).permute(0, 3, 1, 2)
 
 
 def _time_route(fn, reps=5):
@@ -173,10 +176,15 @@ def _own_conv3x3(conv, x, pad=None):
     pixels into 128 .. 256-row slabs; measured on the detectors' layer shapes at batch 1 / 4 / 8,
     tools/exp/conv3x3_layers.py: 1.3-1.9x ahead of the library from ~100 workgroups of the smallest tile on, behind it
     on the small maps)."""
-    if _CONV3X3_MODE == 'lib' or x.dtype != torch.float16 or pad is not None or not x.is_cuda:
+    if _CONV3X3_MODE == 'lib' or x.dtype not in (torch.float16, torch.float32) or pad is not None or not x.is_cuda:
         return False
     if tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1):
         return False
+    if x.dtype == torch.float32:
+        # the parity mode: exact-float32 matrix instructions, always the own kernel (ops.conv3x3_f32; on a par with the
+        # library's float32 rate, and no solver search whose choice could change the summation order between runs)
+        return ('f32' not in _PW_OFF and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
+                and x.is_contiguous(memory_format=torch.channels_last))
     # (ResNet conv2's 64 -> 64 layer on 64-channel tiles: 82 vs 87 us at batch 8, 138 vs 160 at 15, since the LDS stages are
     # sized by the tile and several of the small workgroups share a CU)
     if conv.in_channels % 64 != 0 or conv.out_channels % 64 != 0:
@@ -203,6 +211,21 @@ def _stem(conv1, images_nhwc, dtype):
             packed = (key, ops.stem_pack_weights(conv1.weight))
             conv1._odet_packed = packed
         return ops.stem_conv7_pool3(images_nhwc, packed[1], conv1.bias).permute(0, 3, 1, 2)
+    if (images_nhwc.is_cuda and dtype == torch.float32 and images_nhwc.dtype == torch.float32 and images_nhwc.is_contiguous()
+            and conv1.out_channels == 64 and tuple(conv1.kernel_size) == (7, 7) and 'f32' not in _PW_OFF
+            and _CONV3X3_MODE in ('own', 'force')):
+        # float32 (parity mode): the 7x7 / 2 convolution as the exact-float32 GEMM on its patch matrix (ops.stem_patches_f32:
+        # 160 floats per output pixel), then bias + ReLU + the 3x3 / 2 pooling in one pass -- no library convolution
+        key = (conv1.weight.data_ptr(), conv1.weight._version)
+        packed = getattr(conv1, '_odet_packed32', None)
+        if packed is None or packed[0] != key:
+            with torch.no_grad():
+                w = torch.zeros((64, 160), dtype=torch.float32, device=conv1.weight.device)
+                w[:, :147] = conv1.weight.permute(0, 2, 3, 1).reshape(64, 147)
+            packed = (key, w)
+            conv1._odet_packed32 = packed
+        y = ops.pointwise(ops.stem_patches_f32(images_nhwc), packed[1], None)
+        return ops.bias_relu_maxpool(y, conv1.bias, 3, 2, 1, False).permute(0, 3, 1, 2)
     x = images_nhwc.to(dtype).permute(0, 3, 1, 2)                               # NHWC memory, NCHW view
     return _conv_relu_pool(conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
 
@@ -262,6 +285,8 @@ def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
             return _pw_1x1(conv, x, bias, relu, res)
         if residual is None and _own_conv3x3(conv, x, pad):
             # hand-written implicit GEMM on the matrix cores with bias (+ ReLU) in its epilogue
+            if x.dtype == torch.float32:
+                return ops.conv3x3_f32(x.permute(0, 2, 3, 1), conv.weight, bias, relu=relu).permute(0, 3, 1, 2)
             b16 = bias if bias.dtype == torch.float16 else bias.half()
             return ops.conv3x3_f16(x.permute(0, 2, 3, 1), conv.weight, b16, relu=relu).permute(0, 3, 1, 2)
         y = F.conv2d(x, conv.weight, None, conv.stride, padding)
@@ -312,7 +337,8 @@ class _Block(nn.Module):
     def forward(self, x):
         # Add([shortcut, x]) + ReLU ride on c3's epilogue; a convolutional shortcut runs without its bias,
         # which is added to c3's instead
-        if (self.short is not None and x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'dual' not in _PW_OFF
+        if (self.short is not None and x.is_cuda and x.dtype in (torch.float16, torch.float32) and _ROUTE_MODE == 'table'
+                and 'dual' not in _PW_OFF and not ('f32' in _PW_OFF and x.dtype == torch.float32)
                 and self.c3.in_channels % 64 == 0 and self.short.in_channels % 64 == 0 and self.c3.out_channels % 64 == 0
                 and tuple(self.short.stride) in ((1, 1), (2, 2)) and x.is_contiguous(memory_format=torch.channels_last)):
             # a stage's first block, float16: the last 1x1 convolution AND the convolutional shortcut as ONE contraction
@@ -320,8 +346,8 @@ class _Block(nn.Module):
             # (ops.pointwise_dual_f16) -- the shortcut map is never written or re-read, one launch instead of two
             y = _conv_epi(self.c2, _conv_epi(self.c1, x, relu=True), relu=True)
             w, b = self._dual_weights()
-            return ops.pointwise_dual_f16(y.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), w, b, self.short.stride[0],
-                                          relu=True).permute(0, 3, 1, 2)
+            return ops.pointwise_dual(y.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), w, b, self.short.stride[0],
+                                      relu=True).permute(0, 3, 1, 2)
         if self.short is None:
             sc, sb = x, None
         elif x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'short' not in _PW_OFF and (
@@ -534,10 +560,10 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
         merge rides in the epilogue of the lateral 1x1 convolution (ops.lateral_merge_f16: the lateral map is never
         written; 226 vs 301 us for P2 at batch 8); otherwise the convolution, then the merge launch."""
         if _ROUTE_MODE == 'table' and 'lateral' not in _PW_OFF and _pw_ok(conv, c) and tuple(conv.stride) == (1, 1) \
-                and top.dtype == torch.float16:
+                and top.dtype == c.dtype:
             t = top.permute(0, 2, 3, 1)
             t = t if t.is_contiguous() else t.contiguous()
-            return ops.lateral_merge_f16(c.permute(0, 2, 3, 1), conv.weight, conv.bias, t).permute(0, 3, 1, 2)
+            return ops.lateral_merge(c.permute(0, 2, 3, 1), conv.weight, conv.bias, t).permute(0, 3, 1, 2)
         return self._merge(top, _conv_epi(conv, c))
 
     @staticmethod
@@ -600,7 +626,11 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
                     ops.rpn_head_tail(c.permute(0, 2, 3, 1), self.rpn_conv.bias, w, b, self.A, scores, deltas, off)
                 else:
                     x = heads[li].permute(0, 3, 1, 2) if heads is not None else _conv_epi(self.rpn_conv, p, relu=True)
-                    sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
+                    if heads is not None and 'f32' not in _PW_OFF and self.rpn_conv.out_channels % 32 == 0:
+                        # float32: the two 1x1 convolutions as the exact-float32 GEMM (weight rows zero-padded to 64)
+                        sd = ops.pointwise(heads[li], self._rpn_pair_padded(w), None)[..., :6 * self.A]
+                    else:
+                        sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
                     ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, off)
                 off += int(p.shape[2]) * int(p.shape[3]) * self.A
             return scores, deltas
@@ -615,47 +645,62 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
     def _rpn_pair_weights(self):
         return rpn_pair_weights(self)
 
+    def _rpn_pair_padded(self, w):
+        """the concatenated [6A, 512, 1, 1] weight as [64, 512] with zero rows (the GEMM kernel's channel granule)"""
+        c = getattr(self, '_rpn_pad', None)
+        if c is None or c[0] is not w:
+            with torch.no_grad():
+                wp = torch.zeros((64, w.shape[1]), dtype=w.dtype, device=w.device)
+                wp[:w.shape[0]] = w.reshape(w.shape[0], -1)
+            c = (w, wp)
+            self._rpn_pad = c
+        return c[1]
+
     def roi_head(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)
-        if x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'fc' not in _PW_OFF and x.is_contiguous():
+        own = (x.is_cuda and x.dtype in (torch.float16, torch.float32) and _ROUTE_MODE == 'table' and x.is_contiguous()
+               and not ('f32' in _PW_OFF and x.dtype == torch.float32))
+        if own and 'fc' not in _PW_OFF:
             # the Dense layers on the pointwise GEMM kernel with bias + ReLU in its epilogue (resnet_fpn.py:292-336)
-            x = ops.dense_f16(x, self.fc1.weight, self.fc1.bias, relu=True)
-            x = ops.dense_f16(x, self.fc2.weight, self.fc2.bias, relu=True)
+            x = ops.dense(x, self.fc1.weight, self.fc1.bias, relu=True)
+            x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
         else:
             x = F.relu(self.fc1(x))
             x = F.relu(self.fc2(x))
+        n5 = 5 * self.num_classes
+        if own and 'final' not in _PW_OFF:
+            # the class logits and box regressions as ONE contraction with the concatenated [Ccls + 4 Ccls, 1024] weights
+            # (rows zero-padded to a multiple of 64), float32 results in both modes: float32 accumulation AND no rounding of
+            # the result (a float16 logit near 10 is 0.008 coarse, 1 % of a softmax score)
+            wpad, b32 = self._final_layer()
+            if wpad is not None:
+                y = ops.dense(x, wpad, b32) if x.dtype == torch.float32 else ops.dense_f16_out_f32(x, wpad, b32)
+                return y[:, :self.num_classes], y[:, self.num_classes:n5]
         if x.dtype == torch.float16:
-            # the class logits and box regressions leave the network in float32 (float32 accumulation AND float32
-            # outputs: a float16 logit near 10 is 0.008 coarse, 1 % of a softmax score): one small contraction of the
-            # 1024-d activation with the concatenated [Ccls + 4 Ccls, 1024] weights
-            w, b, w16 = self._final_f32()
-            n5 = 5 * self.num_classes
-            if x.is_cuda and _ROUTE_MODE == 'table' and 'final' not in _PW_OFF and x.is_contiguous() and w16 is not None:
-                y = ops.dense_f16_out_f32(x, w16, b)         # (weight rows zero-padded to a multiple of 64)
-            else:
-                y = torch.addmm(b[:n5], x.float(), w)
+            wpad, b32 = self._final_layer()
+            y = torch.addmm(b32[:n5], x.float(), wpad[:n5].float().t())
             return y[:, :self.num_classes], y[:, self.num_classes:n5]
         return self.score(x), self.bbox(x)
 
-    def _final_f32(self):
-        """the concatenated score / bbox layer: (float32 [1024, 5 Ccls] weight, float32 bias padded to the float16 form's
-        rows, float16 [rows, 1024] weight zero-padded to a multiple of 64 rows)"""
+    def _final_layer(self):
+        """the concatenated score / bbox layer: ([rows, 1024] weight in the model's dtype, zero-padded to a multiple of 64
+        rows -- None when the kernel does not take its K --, float32 bias padded alike)"""
         ps = (self.score.weight, self.score.bias, self.bbox.weight, self.bbox.bias)
-        key = tuple((t._version, t.data_ptr()) for t in ps)
+        key = tuple((t._version, t.data_ptr(), t.dtype) for t in ps)
         c = getattr(self, '_final_cache', None)
         if c is None or c[0] != key:
             with torch.no_grad():
                 wc = torch.cat([ps[0], ps[2]], 0)
                 bc = torch.cat([ps[1], ps[3]], 0).float()
                 rows = (wc.shape[0] + 63) // 64 * 64
-                w16 = torch.zeros((rows, wc.shape[1]), dtype=torch.float16, device=wc.device)
-                w16[:wc.shape[0]] = wc
+                wpad = torch.zeros((rows, wc.shape[1]), dtype=wc.dtype, device=wc.device)
+                wpad[:wc.shape[0]] = wc
                 b = torch.zeros(rows, dtype=torch.float32, device=wc.device)
                 b[:bc.shape[0]] = bc
-                w = wc.float().t().contiguous()
-            c = (key, w, b.contiguous(), w16 if wc.shape[1] % 64 == 0 and wc.shape[1] >= 128 else None)
+            gran = 64 if wc.dtype == torch.float16 else 32
+            c = (key, wpad if wc.shape[1] % gran == 0 and wc.shape[1] >= 2 * gran else None, b.contiguous())
             self._final_cache = c
-        return c[1], c[2], c[3]
+        return c[1], c[2]
 
     # ---- HIP-graph replay ---------------------------------------------------------------------------
     def capture(self, batch, warmup=3):

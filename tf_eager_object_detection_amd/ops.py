@@ -609,7 +609,7 @@ def stem_conv7_pool3(images_nhwc, packed_weight, bias, out=None):
 
 def conv3x3_f32(x, weight, bias=None, relu=False, out=None):
     """conv3x3_f16 in the reference's precision: float32 operands and result, exact-float32 matrix instructions
-    (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 256 == 0."""
+    (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 64 == 0."""
     return _conv3x3(torch.float32, x, weight, bias, relu, out)
 
 
@@ -652,78 +652,126 @@ def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None, in_bias=Non
     return out
 
 
-def _pw_args(x, weight, bias, who):
-    if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
-        raise ValueError('%s: x must be a contiguous float16 GPU tensor [batch, H, W, cin]' % who)
+_PW_FORMS = {torch.float16: ('f16', 'float16', 64), torch.float32: ('f32', 'float32', 32)}     # suffix, name, K granule
+
+
+def _pw_args(x, weight, bias, who, min_k=True):
+    if x.dtype not in _PW_FORMS:
+        raise ValueError('%s: x must be float16 or float32' % who)
+    sfx, name, gran = _PW_FORMS[x.dtype]
+    if not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError('%s: x must be a contiguous %s GPU tensor [batch, H, W, cin]' % (who, name))
     cin, cout = int(x.shape[-1]), int(weight.shape[0])
-    if weight.dtype != torch.float16 or weight.numel() != cout * cin:
-        raise ValueError('%s: weight must be a float16 [cout, cin(, 1, 1)] tensor' % who)
-    w = weight.reshape(cout, cin)
+    if weight.dtype != x.dtype or weight.numel() % cout or weight.numel() // cout < cin:
+        raise ValueError('%s: weight must be a %s [cout, cin(, 1, 1)] tensor' % (who, name))
+    w = weight.reshape(cout, -1)
     if not w.is_contiguous():
         w = w.contiguous()
-    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
-        raise ValueError('%s: bias must be a contiguous float16 [cout] tensor' % who)
-    if cin % 64 or cin < 128 or cout % 64:
-        raise ValueError('%s: cin %d must be a multiple of 64 (>= 128), cout %d a multiple of 64' % (who, cin, cout))
-    return w, cin, cout
+    if bias is not None and (bias.dtype != x.dtype or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('%s: bias must be a contiguous %s [cout] tensor' % (who, name))
+    if cin % gran or (min_k and cin < 2 * gran) or cout % 64:
+        raise ValueError('%s: cin %d must be a multiple of %d (>= %d), cout %d a multiple of 64' % (who, cin, gran, 2 * gran, cout))
+    return w, cin, cout, sfx
 
 
-def pointwise_f16(x, weight, bias=None, residual=None, relu=False, stride=1, out=None):
+def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=None):
     """A 1x1 convolution (stride 1 or 2, 'valid') or dense layer as the LDS-staged GEMM on the matrix cores
-    (odet_pointwise_f16): ``x`` [B,H,W,cin] NHWC float16 contiguous, ``weight`` [cout, cin(, 1, 1)], ``residual`` / ``out``
-    [B, ceil(H/stride), ceil(W/stride), cout]; relu?(x[:, ::stride, ::stride] . w^T + bias + residual)."""
-    w, cin, cout = _pw_args(x, weight, bias, 'pointwise_f16')
+    (odet_pointwise_f16 / odet_pointwise_f32 by the dtype of ``x``): ``x`` [B,H,W,cin] NHWC contiguous, ``weight``
+    [cout, cin(, 1, 1)], ``residual`` / ``out`` [B, ceil(H/stride), ceil(W/stride), cout];
+    relu?(x[:, ::stride, ::stride] . w^T + bias + residual).  float32: exact-float32 matrix instructions."""
+    w, cin, cout, sfx = _pw_args(x, weight, bias, 'pointwise')
+    if w.shape[1] != cin:
+        raise ValueError('pointwise: weight has %d input channels, x %d' % (w.shape[1], cin))
     B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
     stride = int(stride)
     shape = (B, (H + stride - 1) // stride, (W + stride - 1) // stride, cout)
-    if residual is not None and (residual.dtype != torch.float16 or tuple(residual.shape) != shape or not residual.is_contiguous()):
-        raise ValueError('residual must be a contiguous float16 tensor shaped like the output %s' % (shape,))
+    if residual is not None and (residual.dtype != x.dtype or tuple(residual.shape) != shape or not residual.is_contiguous()):
+        raise ValueError('residual must be a contiguous tensor of the output\'s dtype and shape %s' % (shape,))
     if out is None:
-        out = torch.empty(shape, dtype=torch.float16, device=x.device)
-    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
-        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
-    L.call('odet_pointwise_f16', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None,
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
+    L.call('odet_pointwise_' + sfx, L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None,
            L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, stride, cin, cout, 1 if relu else 0,
            L.stream())
     return out
 
 
-def dense_f16(x, weight, bias=None, relu=False, out=None):
-    """keras Dense on the same kernel: ``x`` [rows, cin] float16 contiguous, ``weight`` [cout, cin] -> [rows, cout]."""
+def dense(x, weight, bias=None, relu=False, out=None):
+    """keras Dense on the same kernel: ``x`` [rows, cin] contiguous, ``weight`` [cout, cin] -> [rows, cout]."""
     if x.dim() != 2:
-        raise ValueError('dense_f16: x must be [rows, cin]')
-    y = pointwise_f16(x.view(1, 1, x.shape[0], x.shape[1]), weight, bias, None, relu, 1,
-                      None if out is None else out.view(1, 1, out.shape[0], out.shape[1]))
+        raise ValueError('dense: x must be [rows, cin]')
+    y = pointwise(x.view(1, 1, x.shape[0], x.shape[1]), weight, bias, None, relu, 1,
+                  None if out is None else out.view(1, 1, out.shape[0], out.shape[1]))
     return y.view(x.shape[0], -1)
 
 
-def pointwise_dual_f16(x1, x2, weight, bias=None, stride=1, relu=True, out=None):
-    """relu?([x1 | x2[:, ::stride, ::stride]] . weight^T + bias) in one contraction (odet_pointwise_dual_f16): the last 1x1
-    convolution of a stage's first bottleneck together with its convolutional shortcut.  ``x1`` [B,Ho,Wo,cin1], ``x2``
-    [B,H,W,cin2] NHWC float16 contiguous, ``weight`` [cout, cin1 + cin2] float16 contiguous."""
+def lateral_merge(x, weight, bias, top, out=None):
+    """The FPN neck's lateral 1x1 convolution with the top-down merge in its epilogue (odet_lateral_merge_f16 / _f32;
+    resnet_fpn.py:385-398): 0.5 * resize_bilinear(top) + 0.5 * (x . w^T + bias); ``x`` [B,H,W,cin], ``top`` [B,h,w,cout]
+    NHWC contiguous, float16 or float32."""
+    w, cin, cout, sfx = _pw_args(x, weight, bias, 'lateral_merge')
+    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    if top.dtype != x.dtype or not top.is_cuda or not top.is_contiguous() or top.dim() != 4 \
+            or top.shape[0] != B or top.shape[3] != cout:
+        raise ValueError('top must be a contiguous GPU tensor [batch, h, w, cout] of x\'s dtype')
+    shape = (B, H, W, cout)
+    if out is None:
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
+    L.call('odet_lateral_merge_' + sfx, L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(top),
+           int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, L.stream())
+    return out
+
+
+def pointwise_dual(x1, x2, weight, bias=None, stride=1, relu=True, out=None):
+    """relu?([x1 | x2[:, ::stride, ::stride]] . weight^T + bias) in one contraction (odet_pointwise_dual_f16 / _f32): the
+    last 1x1 convolution of a stage's first bottleneck together with its convolutional shortcut.  ``x1`` [B,Ho,Wo,cin1],
+    ``x2`` [B,H,W,cin2] NHWC contiguous of one dtype, ``weight`` [cout, cin1 + cin2] contiguous."""
+    if x1.dtype != x2.dtype or x1.dtype not in _PW_FORMS:
+        raise ValueError('pointwise_dual: x1 and x2 must both be float16 or float32')
+    sfx, name, gran = _PW_FORMS[x1.dtype]
     for t, nm in ((x1, 'x1'), (x2, 'x2')):
-        if t.dtype != torch.float16 or not t.is_cuda or not t.is_contiguous() or t.dim() != 4:
-            raise ValueError('pointwise_dual_f16: %s must be a contiguous float16 GPU tensor [batch, H, W, C]' % nm)
+        if not t.is_cuda or not t.is_contiguous() or t.dim() != 4:
+            raise ValueError('pointwise_dual: %s must be a contiguous GPU tensor [batch, H, W, C]' % nm)
     B, H, W, c2 = (int(v) for v in x2.shape)
     stride = int(stride)
     Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
     c1 = int(x1.shape[3])
     if tuple(x1.shape[:3]) != (B, Ho, Wo):
-        raise ValueError('pointwise_dual_f16: x1 %s does not match the strided x2 map (%d, %d, %d)' % (tuple(x1.shape), B, Ho, Wo))
+        raise ValueError('pointwise_dual: x1 %s does not match the strided x2 map (%d, %d, %d)' % (tuple(x1.shape), B, Ho, Wo))
     cout = int(weight.shape[0])
-    if weight.dtype != torch.float16 or tuple(weight.shape) != (cout, c1 + c2) or not weight.is_contiguous():
-        raise ValueError('pointwise_dual_f16: weight must be a contiguous float16 [cout, cin1 + cin2] tensor')
-    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous()):
-        raise ValueError('pointwise_dual_f16: bias must be a contiguous float16 [cout] tensor')
-    if c1 % 64 or c2 % 64 or cout % 64:
-        raise ValueError('pointwise_dual_f16: channel counts must be multiples of 64')
+    if weight.dtype != x1.dtype or tuple(weight.shape) != (cout, c1 + c2) or not weight.is_contiguous():
+        raise ValueError('pointwise_dual: weight must be a contiguous %s [cout, cin1 + cin2] tensor' % name)
+    if bias is not None and (bias.dtype != x1.dtype or bias.numel() != cout or not bias.is_contiguous()):
+        raise ValueError('pointwise_dual: bias must be a contiguous %s [cout] tensor' % name)
+    if c1 % gran or c2 % gran or cout % 64:
+        raise ValueError('pointwise_dual: cin1 / cin2 must be multiples of %d, cout of 64' % gran)
     shape = (B, Ho, Wo, cout)
     if out is None:
-        out = torch.empty(shape, dtype=torch.float16, device=x1.device)
-    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
-        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
-    L.call('odet_pointwise_dual_f16', L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, L.dptr(weight),
+        out = torch.empty(shape, dtype=x1.dtype, device=x1.device)
+    elif out.dtype != x1.dtype or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous tensor %s of x1\'s dtype' % (shape,))
+    L.call('odet_pointwise_dual_' + sfx, L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, L.dptr(weight),
            L.dptr(bias) if bias is not None else None, L.dptr(out), B, cout, 1 if relu else 0, L.stream())
+    return out
+
+
+# (the float16 names the round-3 callers and tests use)
+pointwise_f16, dense_f16, lateral_merge_f16, pointwise_dual_f16 = pointwise, dense, lateral_merge, pointwise_dual
+
+
+def stem_patches_f32(images_nhwc):
+    """The stem's patch matrix for the float32 mode (odet_stem_patches_f32): NHWC float32 [B,H,W,3] -> [B, Ho, Wo, 160] with
+    row = the zero-padded 7 x 7 x 3 window of conv1_pad + the 7x7 / 2 'valid' convolution in (dy, dx, channel) order,
+    Ho = (H - 1) // 2 + 1.  The convolution is then `pointwise` on it (weights [64, 160] in the same order)."""
+    x = images_nhwc
+    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[3] != 3:
+        raise ValueError('stem_patches_f32: images must be a contiguous float32 GPU tensor [B, H, W, 3]')
+    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 160), dtype=torch.float32, device=x.device)
+    L.call('odet_stem_patches_f32', L.dptr(x), L.dptr(out), B, H, W, L.stream())
     return out
 
 
@@ -732,7 +780,7 @@ def dense_f16_out_f32(x, weight, bias=None, relu=False, out=None):
     float16 contiguous, ``bias`` [cout] float32 -> float32 [rows, cout]; cout % 64 == 0 (pad the weight rows with zeros)."""
     if x.dtype != torch.float16 or not x.is_cuda or not x.is_contiguous() or x.dim() != 2:
         raise ValueError('dense_f16_out_f32: x must be a contiguous float16 GPU tensor [rows, cin]')
-    w, cin, cout = _pw_args(x.view(1, 1, x.shape[0], x.shape[1]), weight, None, 'dense_f16_out_f32')
+    w, cin, cout, _ = _pw_args(x.view(1, 1, x.shape[0], x.shape[1]), weight, None, 'dense_f16_out_f32')
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != cout or not bias.is_contiguous()):
         raise ValueError('dense_f16_out_f32: bias must be a contiguous float32 [cout] tensor')
     rows = int(x.shape[0])
@@ -742,25 +790,6 @@ def dense_f16_out_f32(x, weight, bias=None, relu=False, out=None):
         raise ValueError('out must be a contiguous float32 tensor [rows, cout]')
     L.call('odet_dense_f16_out_f32', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(out), rows,
            cin, cout, 1 if relu else 0, L.stream())
-    return out
-
-
-def lateral_merge_f16(x, weight, bias, top, out=None):
-    """The FPN neck's lateral 1x1 convolution with the top-down merge in its epilogue (odet_lateral_merge_f16;
-    resnet_fpn.py:385-398): 0.5 * resize_bilinear(top) + 0.5 * (x . w^T + bias); ``x`` [B,H,W,cin], ``top`` [B,h,w,cout]
-    NHWC float16 contiguous."""
-    w, cin, cout = _pw_args(x, weight, bias, 'lateral_merge_f16')
-    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
-    if top.dtype != torch.float16 or not top.is_cuda or not top.is_contiguous() or top.dim() != 4 \
-            or top.shape[0] != B or top.shape[3] != cout:
-        raise ValueError('top must be a contiguous float16 GPU tensor [batch, h, w, cout]')
-    shape = (B, H, W, cout)
-    if out is None:
-        out = torch.empty(shape, dtype=torch.float16, device=x.device)
-    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
-        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
-    L.call('odet_lateral_merge_f16', L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(top),
-           int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, L.stream())
     return out
 
 

@@ -25,7 +25,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 tot = collections.defaultdict(float)
 for d in ids:
     n = names[d]
-    fam = ('odet_mfma' if any(k in n for k in ('k_conv1x1', 'k_rpn_tail', 'k_conv3x3', 'k_stem')) else
+    fam = ('odet_mfma' if any(k in n for k in ('k_conv1x1', 'k_rpn_tail', 'k_conv3x3', 'k_stem', 'k_pointwise')) else
            'mfma_conv_gemm' if any(k in n for k in ('igemm', 'ck16', 'Cijk', 'gemm', 'conv', 'Conv')) and 'naive' not in n else
            'odet_hip' if (n.startswith('k_') or 'k_roi' in n or 'k_rp_' in n or 'k_nms' in n or 'k_fpn' in n or 'k_bias' in n) else 'other')
     for c, v in per[d].items():
