@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Seeded sweep of the hand-written convolutions against torch on integer-valued data (exact comparison): random map
 sizes (incl. one-pixel rows / columns), batches, channel counts, so that every workgroup-tile choice of conv3x3_launch
-and the edge handling of the fused forms (RpnHead, bottleneck tail, stem) are exercised.
+and the edge handling of the fused forms (RpnHead, bottleneck tail, stem) and of the pointwise forms (1x1 / strided /
+shortcut, lateral + merge, two sources along K; float16 and float32) are exercised.
 
     python tools/fuzz_conv.py [--cases N] [--seed S]"""
 import argparse, os, sys
@@ -12,7 +13,7 @@ from tf_eager_object_detection_amd import ops
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--cases', type=int, default=120)
+    ap.add_argument('--cases', type=int, default=210)
     ap.add_argument('--seed', type=int, default=0)
     a = ap.parse_args()
     g = torch.Generator(device='cuda'); g.manual_seed(a.seed)
@@ -20,8 +21,51 @@ def main():
     sparse = lambda shape, pct, lo, hi: ((torch.randint(0, 100, shape, device='cuda', generator=g) < pct).half()
                                          * torch.randint(lo, hi + 1, shape, device='cuda', generator=g).half())
     for case in range(a.cases):
-        kind = case % 4
+        kind = case % 7
         B, H, W = ri(1, 3), ri(1, 70), ri(1, 90)
+        if kind >= 4:      # pointwise forms (round 3), float16 and float32: 1x1 / strided / shortcut, lateral + merge, two sources
+            f32 = bool(case & 8)
+            dt = torch.float32 if f32 else torch.float16
+            gran = 32 if f32 else 64
+            stride = ri(1, 2)
+            K, N = gran * ri(2, 12), 64 * ri(1, 9)
+            Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+            x = sparse((B, H, W, K), 30, -2, 2).to(dt)
+            w = sparse((N, K), 40, -2, 2).to(dt)
+            b = torch.randint(-3, 4, (N,), device='cuda', generator=g).to(dt)
+            xs = x[:, ::stride, ::stride].double()
+            if kind == 4:
+                r = torch.randint(-4, 5, (B, Ho, Wo, N), device='cuda', generator=g).to(dt) if case & 16 else None
+                want = xs @ w.double().t() + b.double() + (r.double() if r is not None else 0)
+                want = torch.relu(want) if case & 32 else want
+                got = ops.pointwise(x, w, b, r, bool(case & 32), stride)
+                what = ('pointwise', dt, B, H, W, K, N, stride)
+            elif kind == 5:
+                h2, w2 = max(1, (H + 1) // 2), max(1, (W + 1) // 2)
+                top = torch.randint(-8, 9, (B, h2, w2, N), device='cuda', generator=g).to(dt)
+                lat = (x.double() @ w.double().t() + b.double()).to(dt)
+                want = ops.fpn_topdown_merge(top, lat).double()
+                got = ops.lateral_merge(x, w, b, top)
+                what = ('lateral_merge', dt, B, H, W, K, N)
+            else:
+                K1 = gran * ri(1, 6)
+                a1 = sparse((B, Ho, Wo, K1), 30, -2, 2).to(dt)
+                w1 = sparse((N, K1), 40, -2, 2).to(dt)
+                want = torch.relu(a1.double() @ w1.double().t() + xs @ w.double().t() + b.double())
+                got = ops.pointwise_dual(a1, x, torch.cat([w1, w], 1).contiguous(), b, stride, relu=True)
+                what = ('pointwise_dual', dt, B, H, W, K1, K, N, stride)
+            assert float(want.abs().max()) < 2048 and torch.equal(got.double(), want), what
+            continue
+        if kind == 0 and case & 8:      # float32 3x3, any cout % 64
+            cin, cout = 32 * ri(1, 6), 64 * ri(1, 6)
+            x = torch.randint(-2, 3, (B, H, W, cin), device='cuda', generator=g).float()
+            w = sparse((cout, cin, 3, 3), 8, -2, 2).float().contiguous(memory_format=torch.channels_last)
+            b = torch.randint(-3, 4, (cout,), device='cuda', generator=g).float()
+            got = ops.conv3x3_f32(x, w, b, relu=bool(case & 4))
+            want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1)
+            want = (F.relu(want) if case & 4 else want).permute(0, 2, 3, 1)
+            assert torch.equal(got.double(), want), ('conv3x3_f32', B, H, W, cin, cout)
+            continue
         if kind == 0:      # plain 3x3, any cout % 64
             cin, cout = 64 * ri(1, 4), 64 * ri(1, 10)
             x = torch.randint(-2, 3, (B, H, W, cin), device='cuda', generator=g).half()
