@@ -197,7 +197,7 @@ def e2e_record(dtype_name, batch, budget_s=8.0, family='fpn'):
     image_shape = (600, 800) if family == 'vgg16' else IMAGE_SHAPE
     if family == 'fpn':
         model = ResNetFpnDetector(101, NUM_CLASSES, image_shape, NUM_PROPOSALS, dtype=dt, max_batch=batch,
-                                  blind_chunks=3, batched=True).prepare()
+                                  blind_chunks=2, batched=True).prepare()
     elif family == 'c4':
         model = ResNetC4Detector(50, NUM_CLASSES, image_shape, 300, dtype=dt, max_batch=batch, blind_chunks=4).prepare()
     else:

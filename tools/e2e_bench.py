@@ -23,6 +23,7 @@ ap.add_argument('--h', type=int, default=800)
 ap.add_argument('--w', type=int, default=1333)
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
 ap.add_argument('--graph', action='store_true', help='replay the whole forward pass as one HIP graph')
+ap.add_argument('--blind-chunks', type=int, default=3, help='FPN: sync-free NMS chunks (3: the third one on the full order)')
 ap.add_argument('--per-image', action='store_true', help='FPN: every image through its own hot-path launches and RoI-head call '
                 'instead of the batched launches (FpnStepBatch)')
 a = ap.parse_args()
@@ -32,7 +33,7 @@ torch.manual_seed(0)
 if a.model == 'fpn':
     # chunk 0 + chunk 1 from the ranked selection + one per-image chunk on the full order: the float16 logits of the
     # random-init RPN tie in thousands, which the selection cannot split
-    hot_kw = dict(blind_chunks=3, batched=not a.per_image)
+    hot_kw = dict(blind_chunks=a.blind_chunks, batched=not a.per_image)
     model = ResNetFpnDetector(a.depth, 21, (a.h, a.w), 1000, dtype=dt, max_batch=a.batch, **hot_kw).prepare()
 elif a.model == 'c4':
     model = ResNetC4Detector(a.depth, 21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4).prepare()
