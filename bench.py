@@ -324,6 +324,13 @@ def main():
     fdt = torch.float16 if args.maps == 'f16' else torch.float32
     images_per_step = R * S * B
 
+    trace_on = os.environ.get('ODET_BENCH_TRACE') == '1'
+
+    def mark(what):
+        if trace_on:
+            torch.cuda.synchronize()
+            print('[bench %.3f] %s' % (time.perf_counter(), what), file=sys.stderr, flush=True)
+
     class Workload:
         """One score distribution's inputs (resident in HBM) + the stream pool that runs them."""
 
@@ -363,6 +370,9 @@ def main():
                 pool.bind(k, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
             self.pool, self.rec_len = pool, rec_len
             self.exchange = parallel.GroupExchange(S, B, rec_len, 'cuda', force_collective=True) if use_dist else None
+            # the inputs (generated by torch kernels on the default stream) are resident before anything is enqueued on the
+            # group streams, which do not wait for the default stream by themselves
+            torch.cuda.synchronize()
 
         def run_steps(self, nsteps):
             """nsteps steps of R rounds: in every round each of the S stream groups sends its B images through their
@@ -407,8 +417,10 @@ def main():
                 if (first, blind) != (self.nms_first_chunk, self.blind_chunks):
                     self.plan(first, blind)
                     replans.append({'nms_first_chunk': first, 'blind_chunks': blind})
+                mark('warm-up of plan (%d, %d) on %s scores' % (first, blind, self.score_kind))
                 self.run_steps(max(warmup, 1))                    # (at least one pass over every slot)
                 self.fence()
+                mark('warm-up done')
                 if self.complete():
                     break
             else:
@@ -417,6 +429,7 @@ def main():
             self.run_steps(steps)
             self.fence()
             elapsed = time.perf_counter() - t0
+            mark('timed region done')
             if use_dist:
                 t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -471,6 +484,7 @@ def main():
                 first.roi_start_event, first.roi_stop_event = None, None
             torch.cuda.synchronize()
             ev_roi.append(ev)
+        mark('roofline samples done')
         times = [a.elapsed_ms(b) for a, b in ev_roi][2:]      # (the first two settle clocks / caches)
         roi_ms = float(np.mean(times))
 
@@ -558,6 +572,7 @@ def main():
         # what the memory system of this box does with the same bytes and nothing else: B_min = every distinct map
         # cell once + the output once, moved by a kernel without arithmetic, gathers or reuse (see calibrate())
         rb, wb, cal_ms, cal_n = calibrate(algo['B_min'] - algo['out'], algo['out'])
+        mark('calibration done')
         rf['calibration'] = {'kernel': 'k_calib_stream_mix: reads B_min - output bytes once in 1 KB rows and writes the '
                                        'output bytes (nontemporal), interleaved, XCD-pinned like the RoI launch; same '
                                        'cold protocol',
