@@ -234,6 +234,10 @@ def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=No
     """max_pool(relu(conv(x) + bias)): on the GPU the convolution runs without its bias and ONE pass
     (ops.bias_relu_maxpool) reads its output once and writes the pooled map; torch formulation elsewhere."""
     if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
+        if _own_conv3x3(conv, x, pad):
+            # the hand-written implicit GEMM without its epilogue, then the fused bias + ReLU + pooling pass
+            yn = (ops.conv3x3_f32 if x.dtype == torch.float32 else ops.conv3x3_f16)(x.permute(0, 2, 3, 1), conv.weight)
+            return ops.bias_relu_maxpool(yn, conv.bias, kernel, stride, pool_pad, ceil_mode).permute(0, 3, 1, 2)
         padding = conv.padding
         if pad is not None:
             if pad[0] == pad[1] == pad[2] == pad[3] and tuple(conv.padding) == (0, 0):
@@ -437,6 +441,62 @@ def rpn_pair_weights(m):
     return cached[1], cached[2]
 
 
+def rpn_pair_padded(m, w):
+    """the concatenated [6A, cin, 1, 1] RpnHead weight as [64 k, cin] with zero rows (the GEMM kernel's channel granule)"""
+    c = getattr(m, '_rpn_pad', None)
+    if c is None or c[0] is not w:
+        with torch.no_grad():
+            rows = (int(w.shape[0]) + 63) // 64 * 64
+            wp = torch.zeros((rows, w.shape[1]), dtype=w.dtype, device=w.device)
+            wp[:w.shape[0]] = w.reshape(w.shape[0], -1)
+        c = (w, wp)
+        m._rpn_pad = c
+    return c[1]
+
+
+class _FinalLayer:
+    """The RoI heads' last layer of the three detectors: class logits and box regressions as ONE contraction with the
+    concatenated [Ccls + 4 Ccls, K] weights (rows zero-padded to a multiple of 64) on the pointwise GEMM kernel, float32
+    results in both modes (float32 accumulation AND no rounding of the result: a float16 logit near 10 is 0.008 coarse,
+    1 % of a softmax score)."""
+
+    def _final_layer(self):
+        ps = (self.score.weight, self.score.bias, self.bbox.weight, self.bbox.bias)
+        key = tuple((t._version, t.data_ptr(), t.dtype) for t in ps)
+        c = getattr(self, '_final_cache', None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                wc = torch.cat([ps[0], ps[2]], 0)
+                bc = torch.cat([ps[1], ps[3]], 0).float()
+                rows = (wc.shape[0] + 63) // 64 * 64
+                wpad = torch.zeros((rows, wc.shape[1]), dtype=wc.dtype, device=wc.device)
+                wpad[:wc.shape[0]] = wc
+                b = torch.zeros(rows, dtype=torch.float32, device=wc.device)
+                b[:bc.shape[0]] = bc
+            gran = 64 if wc.dtype == torch.float16 else 32
+            c = (key, wpad if wc.shape[1] % gran == 0 and wc.shape[1] >= 2 * gran else None, b.contiguous())
+            self._final_cache = c
+        return c[1], c[2]
+
+    def _final_outputs(self, x):
+        """x [rows, K] (the head's last activation) -> (class logits [rows, Ccls], box regressions [rows, 4 Ccls])"""
+        n1 = self.score.out_features
+        n5 = n1 + self.bbox.out_features
+        own = (x.is_cuda and x.dtype in (torch.float16, torch.float32) and _ROUTE_MODE == 'table' and x.is_contiguous()
+               and 'final' not in _PW_OFF and not ('f32' in _PW_OFF and x.dtype == torch.float32))
+        if own:
+            wpad, b32 = self._final_layer()
+            if wpad is not None:
+                y = ops.dense(x, wpad, b32) if x.dtype == torch.float32 else ops.dense_f16_out_f32(x, wpad, b32)
+                return y[:, :n1], y[:, n1:n5]
+        if x.dtype == torch.float16:
+            wpad, b32 = self._final_layer()
+            wsrc = torch.cat([self.score.weight, self.bbox.weight], 0) if wpad is None else wpad[:n5]
+            y = torch.addmm(b32[:n5], x.float(), wsrc.float().t())
+            return y[:, :n1], y[:, n1:n5]
+        return self.score(x), self.bbox(x)
+
+
 class _NmsCompleteness:
     """The detectors run the proposal stage sync-free (no host check between kernels; graph-capturable) with a fixed
     number of NMS chunks.  If an image needs more than those, the hot path reports it EMPTY and flags it
@@ -473,7 +533,7 @@ class _NmsCompleteness:
             self.check_complete(batch)
 
 
-class ResNetFpnDetector(_NmsCompleteness, nn.Module):
+class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
     """Inference-only ResNet-{50,101,152}-FPN detector.  `forward(images)` takes NHWC float images
     [B,H,W,3] (already mean-subtracted, as the reference's input pipeline delivers them) and returns,
     per image, the padded detections of post_ops_prediction plus their count on the device."""
@@ -646,15 +706,7 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
         return rpn_pair_weights(self)
 
     def _rpn_pair_padded(self, w):
-        """the concatenated [6A, 512, 1, 1] weight as [64, 512] with zero rows (the GEMM kernel's channel granule)"""
-        c = getattr(self, '_rpn_pad', None)
-        if c is None or c[0] is not w:
-            with torch.no_grad():
-                wp = torch.zeros((64, w.shape[1]), dtype=w.dtype, device=w.device)
-                wp[:w.shape[0]] = w.reshape(w.shape[0], -1)
-            c = (w, wp)
-            self._rpn_pad = c
-        return c[1]
+        return rpn_pair_padded(self, w)
 
     def roi_head(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)
@@ -667,40 +719,7 @@ class ResNetFpnDetector(_NmsCompleteness, nn.Module):
         else:
             x = F.relu(self.fc1(x))
             x = F.relu(self.fc2(x))
-        n5 = 5 * self.num_classes
-        if own and 'final' not in _PW_OFF:
-            # the class logits and box regressions as ONE contraction with the concatenated [Ccls + 4 Ccls, 1024] weights
-            # (rows zero-padded to a multiple of 64), float32 results in both modes: float32 accumulation AND no rounding of
-            # the result (a float16 logit near 10 is 0.008 coarse, 1 % of a softmax score)
-            wpad, b32 = self._final_layer()
-            if wpad is not None:
-                y = ops.dense(x, wpad, b32) if x.dtype == torch.float32 else ops.dense_f16_out_f32(x, wpad, b32)
-                return y[:, :self.num_classes], y[:, self.num_classes:n5]
-        if x.dtype == torch.float16:
-            wpad, b32 = self._final_layer()
-            y = torch.addmm(b32[:n5], x.float(), wpad[:n5].float().t())
-            return y[:, :self.num_classes], y[:, self.num_classes:n5]
-        return self.score(x), self.bbox(x)
-
-    def _final_layer(self):
-        """the concatenated score / bbox layer: ([rows, 1024] weight in the model's dtype, zero-padded to a multiple of 64
-        rows -- None when the kernel does not take its K --, float32 bias padded alike)"""
-        ps = (self.score.weight, self.score.bias, self.bbox.weight, self.bbox.bias)
-        key = tuple((t._version, t.data_ptr(), t.dtype) for t in ps)
-        c = getattr(self, '_final_cache', None)
-        if c is None or c[0] != key:
-            with torch.no_grad():
-                wc = torch.cat([ps[0], ps[2]], 0)
-                bc = torch.cat([ps[1], ps[3]], 0).float()
-                rows = (wc.shape[0] + 63) // 64 * 64
-                wpad = torch.zeros((rows, wc.shape[1]), dtype=wc.dtype, device=wc.device)
-                wpad[:wc.shape[0]] = wc
-                b = torch.zeros(rows, dtype=torch.float32, device=wc.device)
-                b[:bc.shape[0]] = bc
-            gran = 64 if wc.dtype == torch.float16 else 32
-            c = (key, wpad if wc.shape[1] % gran == 0 and wc.shape[1] >= 2 * gran else None, b.contiguous())
-            self._final_cache = c
-        return c[1], c[2]
+        return self._final_outputs(x)
 
     # ---- HIP-graph replay ---------------------------------------------------------------------------
     def capture(self, batch, warmup=3):

@@ -15,13 +15,14 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..pipeline import FrcnnHotPath, FrcnnStepBatch
-from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _conv, _conv_epi, _stem, \
+from . import fpn_detector as fd
+from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _FinalLayer, _conv, _conv_epi, _stem, \
     _conv_relu_pool, _fold_frozen_bn, _stack, rpn_pair_weights
 
 __all__ = ['ResNetC4Detector', 'Vgg16Detector']
 
 
-class ResNetC4Detector(_NmsCompleteness, nn.Module):
+class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
     """Inference-only ResNet-{50,101,152} C4 Faster R-CNN.  `forward(images)` takes NHWC float images [B,H,W,3]
     (mean-subtracted) and returns, per image, the padded detections of post_ops_prediction + their count."""
 
@@ -123,7 +124,14 @@ class ResNetC4Detector(_NmsCompleteness, nn.Module):
             # the two 1x1 convolutions as one contraction, then ONE pass: + bias, float32, split (ops.rpn_pack_pair;
             # [fh*fw, 2A] and [fh*fw*A, 2] are the same memory)
             w, b = rpn_pair_weights(self)
-            sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
+            xn = x.permute(0, 2, 3, 1)
+            gran = 64 if x.dtype == torch.float16 else 32
+            if ('c1' not in fd._PW_OFF and not ('f32' in fd._PW_OFF and x.dtype == torch.float32) and xn.is_contiguous()
+                    and x.shape[1] % gran == 0 and x.shape[1] >= 2 * gran):
+                # the two 1x1 convolutions as ONE contraction on the pointwise GEMM kernel (weight rows zero-padded to 64)
+                sd = ops.pointwise(xn, fd.rpn_pair_padded(self, w), None)[..., :6 * self.A]
+            else:
+                sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
             n = int(sd.shape[1]) * int(sd.shape[2]) * self.A
             scores = torch.empty((B, n, 2), dtype=torch.float32, device=x.device)
             deltas = torch.empty((B, n, 4), dtype=torch.float32, device=x.device)
@@ -140,7 +148,7 @@ class ResNetC4Detector(_NmsCompleteness, nn.Module):
         step = self._roi_chunk if self._roi_chunk > 0 else R
         outs = [self.conv5(x[i:i + step]).mean(dim=(2, 3)) for i in range(0, R, step)]
         y = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
-        return self.score(y), self.bbox(y)
+        return self._final_outputs(y.contiguous())
 
     capture = ResNetFpnDetector.capture          # whole forward pass as one HIP graph (generic over self.forward)
 
@@ -270,6 +278,12 @@ class Vgg16Detector(ResNetC4Detector):
 
     def roi_head(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)        # Flatten() of NHWC crops
-        x = F.relu(self.fc1(x))                                                   # (dropout: inference)
-        x = F.relu(self.fc2(x))
-        return self.score(x), self.bbox(x)
+        if (x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.is_contiguous() and 'fc' not in fd._PW_OFF
+                and not ('f32' in fd._PW_OFF and x.dtype == torch.float32)):
+            # fc6 / fc7 on the pointwise GEMM kernel, bias + ReLU in its epilogue (dropout: inference)
+            x = ops.dense(x, self.fc1.weight, self.fc1.bias, relu=True)
+            x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
+        else:
+            x = F.relu(self.fc1(x))                                               # (dropout: inference)
+            x = F.relu(self.fc2(x))
+        return self._final_outputs(x)
