@@ -1115,3 +1115,50 @@ def test_nms_tie_split_of_an_overflowing_boundary_bin():
         assert int(hs.nms_done.item()) == 1
         k = int(hs.roi_count.item())
         np.testing.assert_array_equal(h(hs.roi_idx[:k]), widx)
+
+
+def test_step_batch_beyond_eight_images_and_direct_group_enqueue():
+    """FpnStepBatch with more than 8 images goes out as consecutive 8-image launch sequences (round 3: 15 / 30 images per
+    detector pass) -- bit-identical, image by image, to the single-image path; FpnStreamPool.enqueue_group (the multi-rank
+    loop's enqueue by the calling thread) gives the same records as submit_group through the executor thread."""
+    from tf_eager_object_detection_amd.pipeline import FpnHotPath, FpnStepBatch, FpnStreamPool, synthetic_fpn_inputs
+    shape, K, C, B = (224, 320), 200, 32, 11
+    sb = FpnStepBatch(B, shape, 21, K, C, blind_chunks=2)
+    devs = []
+    for b in range(B):
+        _, dev = synthetic_fpn_inputs(shape, 21, K, C, seed=300 + b, score_kind='clustered' if b % 3 == 0 else 'distinct')
+        devs.append(dev)
+        sb.bind(b, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+    sb.enqueue(7, B)
+    torch.cuda.synchronize()
+    assert sb.nms_done_all.tolist() == [1] * B
+    ref = FpnHotPath(shape, 21, K, C, blind_chunks=3)
+    for b in range(B):
+        d = devs[b]
+        feats, boxes, labels, scores, count = ref.step(d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
+        torch.cuda.synchronize()
+        hs = sb.slots[b]
+        k = int(ref.roi_count.item())
+        assert k == int(hs.roi_count.item())
+        assert torch.equal(ref.roi_idx[:k], hs.roi_idx[:k]) and torch.equal(feats[:k], sb.roi_features[b][:k])
+        m = int(count.item())
+        assert m == int(hs.det_count.item()) and torch.equal(boxes[:m], hs.det_boxes[:m])
+        assert torch.equal(labels[:m], hs.det_labels[:m]) and torch.equal(scores[:m], hs.det_scores[:m])
+    # the two ways of enqueuing a stream group
+    pool = FpnStreamPool(2, shape, 21, K, C, batch=4, blind_chunks=2)
+    for k_ in range(pool.n):
+        d = devs[k_]
+        pool.bind(k_, d['rpn_logits'], d['rpn_deltas'], d['feats'], d['cls_scores'], d['cls_deltas'])
+    for g_ in range(2):
+        pool.submit_group(g_)
+    pool.wait()
+    torch.cuda.synchronize()
+    want = [s.record.clone() for s in pool.slots]
+    for s in pool.slots:
+        s.record.zero_()
+    for g_ in range(2):
+        pool.enqueue_group(g_)
+    torch.cuda.synchronize()
+    for s, w in zip(pool.slots, want):
+        assert torch.equal(s.record, w) and float(w[-1]) > 0
+    pool.close()
