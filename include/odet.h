@@ -416,6 +416,11 @@ int odet_dense_f16_out_f32(const void* x, const void* w, const float* bias, floa
  * never goes to memory. */
 int odet_lateral_merge_f16(const void* x, const void* w, const void* bias, const void* top, int th, int tw, void* y,
                            int batch, int H, int W, int cin, int cout, odet_stream_t stream);
+/* The same with the 3x3 convolution's channel count as an argument: cmid = 64 (ResNet conv2), 128 (conv3) or 256 (conv4);
+ * w2 [cmid][3][3][cin], b2 [cmid], w3 [n3][cmid].  odet_conv3x3_conv1x1_f16 = cmid 256. */
+int odet_bottleneck_tail_f16(const void* x, const void* w2, const void* b2, const void* w3, const void* b3,
+                             const void* residual, void* y, int batch, int H, int W, int cin, int cmid, int n3, int relu,
+                             odet_stream_t stream);
 /* The ResNet stem in one launch (resnet_fpn.py:262-289, resnet_faster_rcnn.py:31-60): ZeroPadding2D(3) -> Conv2D(64, 7x7,
  * stride 2, 'valid') + folded frozen BN -> ReLU -> ZeroPadding2D(1) -> MaxPooling2D(3x3, stride 2, 'valid'), from the
  * NHWC 3-channel image (float32: images_f16 = 0, or float16) to the NHWC float16 map [batch][PH][PW][64], PH =

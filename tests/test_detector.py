@@ -805,11 +805,14 @@ def test_rpn_head_fused_matches_the_two_pass_form(B, A, cin, cout, shapes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,H,W,cin,n3,res', [(1, 13, 21, 256, 1024, True), (2, 25, 42, 256, 1024, True), (1, 50, 84, 64, 256, False),
-                                              (3, 7, 5, 128, 64, True), (1, 57, 100, 256, 512, True)])
-def test_conv3x3_conv1x1_fused_block_tail(B, H, W, cin, n3, res):
+@pytest.mark.parametrize('B,H,W,cin,n3,res,cmid', [(1, 13, 21, 256, 1024, True, 256), (2, 25, 42, 256, 1024, True, 256),
+                                                   (1, 50, 84, 64, 256, False, 256), (3, 7, 5, 128, 64, True, 256),
+                                                   (1, 57, 100, 256, 512, True, 256), (2, 25, 42, 128, 512, True, 128),
+                                                   (1, 33, 47, 64, 256, True, 64), (1, 9, 70, 128, 192, False, 128),
+                                                   (3, 6, 5, 64, 64, True, 64)])
+def test_conv3x3_conv1x1_fused_block_tail(B, H, W, cin, n3, res, cmid):
     """odet_conv3x3_conv1x1_f16 (a bottleneck's 3x3 convolution with the block's last 1x1 convolution, bias, shortcut and
-    ReLU in its epilogue; the 256-channel activation between them lives in LDS only): EXACT on integer-valued data whose
+    ReLU in its epilogue; the 64 / 128 / 256-channel activation between them lives in LDS only): EXACT on integer-valued data whose
     intermediates stay below 2048, within float16 rounding of the float32 formulation on random data, and of the
     two-launch form of the product (ops.conv3x3_f16 + ops.conv1x1_f16(in_bias=...))."""
     from tf_eager_object_detection_amd import ops
@@ -818,26 +821,26 @@ def test_conv3x3_conv1x1_fused_block_tail(B, H, W, cin, n3, res):
 
     def reference(x, w2, b2, w3, b3, r):
         t = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w2.float(), b2.float(), 1, 1)).half().float()
-        o = F.conv2d(t, w3.float().reshape(n3, 256, 1, 1), b3.float()).permute(0, 2, 3, 1)
+        o = F.conv2d(t, w3.float().reshape(n3, cmid, 1, 1), b3.float()).permute(0, 2, 3, 1)
         if r is not None:
             o = o + r.float()
         return F.relu(o)
 
     x = (torch.randint(0, 100, (B, H, W, cin), device='cuda', generator=g) < 3).half()
-    w2 = (torch.randint(0, 100, (256, cin, 3, 3), device='cuda', generator=g) < 4).half()
+    w2 = (torch.randint(0, 100, (cmid, cin, 3, 3), device='cuda', generator=g) < 4).half()
     w2 = (w2 * torch.randint(-2, 3, w2.shape, device='cuda', generator=g).half()).contiguous(memory_format=torch.channels_last)
-    b2 = torch.randint(-3, 4, (256,), device='cuda', generator=g).half()
-    w3 = ((torch.randint(0, 100, (n3, 256), device='cuda', generator=g) < 10).half()
-          * torch.randint(-2, 3, (n3, 256), device='cuda', generator=g).half())
+    b2 = torch.randint(-3, 4, (cmid,), device='cuda', generator=g).half()
+    w3 = ((torch.randint(0, 100, (n3, cmid), device='cuda', generator=g) < 10).half()
+          * torch.randint(-2, 3, (n3, cmid), device='cuda', generator=g).half())
     b3 = torch.randint(-3, 4, (n3,), device='cuda', generator=g).half()
     r = torch.randint(-4, 5, (B, H, W, n3), device='cuda', generator=g).half() if res else None
     got = ops.conv3x3_conv1x1_f16(x, w2, b2, w3, b3, residual=r, relu=True)
     want = reference(x, w2, b2, w3, b3, r)
     assert float(want.abs().max().item()) < 2048 and torch.equal(got.float(), want)
     x = (torch.randn((B, H, W, cin), device='cuda', generator=g) * 0.5).half()
-    w2 = (torch.randn((256, cin, 3, 3), device='cuda', generator=g) * 0.02).half().contiguous(memory_format=torch.channels_last)
-    b2 = (torch.randn(256, device='cuda', generator=g) * 0.1).half()
-    w3 = (torch.randn((n3, 256), device='cuda', generator=g) * 0.05).half()
+    w2 = (torch.randn((cmid, cin, 3, 3), device='cuda', generator=g) * 0.02).half().contiguous(memory_format=torch.channels_last)
+    b2 = (torch.randn(cmid, device='cuda', generator=g) * 0.1).half()
+    w3 = (torch.randn((n3, cmid), device='cuda', generator=g) * 0.05).half()
     b3 = torch.randn(n3, device='cuda', generator=g).half()
     r = torch.randn((B, H, W, n3), device='cuda', generator=g).half() if res else None
     got = ops.conv3x3_conv1x1_f16(x, w2, b2, w3, b3, residual=r, relu=True)

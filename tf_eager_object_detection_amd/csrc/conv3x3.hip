@@ -357,20 +357,24 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   }
   if constexpr (BLK) {
     // ---- fused bottleneck tail (resnet_fpn.py:154-205: conv 3x3 -> BN -> ReLU -> conv 1x1 -> BN -> Add -> ReLU with the
-    // frozen batch norms folded): this workgroup holds ALL 256 channels of the 3x3 convolution for its pixels, so the
-    // block's last convolution can run right here.  t = relu(acc + bias) goes to LDS once, rounded to float16 ([TM
-    // pixels][512 B], 16-byte slots XOR-swizzled by the pixel row: conflict-free as an MFMA operand), then every wave
-    // takes 64-channel groups of the n3 output channels for ALL pixels of the tile: its 4 x 8 weight fragments straight
-    // from global memory into registers (rows in the permuted order that leaves a lane with 16 consecutive channels),
-    // per pixel tile 8 fragment reads + 32 MFMAs, + bias + shortcut, ReLU, one rounding, 32 contiguous bytes per lane.
-    // The 256-channel activation of the 3x3 convolution never goes to memory.
-    static_assert(WN == 4, "needs the 256-channel tile");
+    // frozen batch norms folded): this workgroup holds ALL CMID = 64 * WN channels of the 3x3 convolution for its pixels
+    // (256: ResNet's conv4, 128: conv3, 64: conv2), so the block's last convolution can run right here.  t = relu(acc + bias)
+    // goes to LDS once, rounded to float16 ([TM pixels][2 CMID bytes], 16-byte slots XOR-swizzled by the pixel row:
+    // conflict-free as an MFMA operand), then every wave takes 64-channel groups of the n3 output channels for ALL pixels of
+    // the tile: its 4 x (CMID / 32) weight fragments straight from global memory into registers (rows in the permuted
+    // order that leaves a lane with 16 consecutive channels), per pixel tile CMID / 32 fragment reads + 4 CMID / 32 MFMAs,
+    // + bias + shortcut, ReLU, one rounding, 32 contiguous bytes per lane.  The activation of the 3x3 convolution never goes
+    // to memory.
+    constexpr int CMID = 64 * WN;                        // channels of the 3x3 convolution = K of the 1x1 convolution
+    constexpr int KS3 = CMID / 32;                       // its K-steps
+    constexpr uint32_t TROW = (uint32_t)CMID * 2u;       // bytes of a pixel's row of t
+    constexpr uint32_t SMASK = (uint32_t)(CMID / 8 - 1) < 15u ? (uint32_t)(CMID / 8 - 1) : 15u;   // slots swizzled among
     float b2v[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) b2v[e] = (float)p.bias[c0 + e];
     __syncthreads();                                     // every wave has read its last fragments: the stages are free
     auto taddr = [&](int prow, int slot) -> uint32_t {
-      return (uint32_t)prow * 512u + (uint32_t)((((slot & 15) ^ (prow & 15)) | (slot & 16))) * 16u;
+      return (uint32_t)prow * TROW + (uint32_t)((((uint32_t)slot & SMASK) ^ ((uint32_t)prow & SMASK)) | ((uint32_t)slot & ~SMASK)) * 16u;
     };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -391,13 +395,13 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     __syncthreads();
     const int n3 = p.n3;
     for (int g = wv; g * 64 < n3; g += 8) {
-      h8 a[4][8];
+      h8 a[4][KS3];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int ch = g * 64 + 16 * (l15 >> 2) + 4 * tt + (l15 & 3);
-        const _Float16* wr = p.w3 + (long long)ch * 256 + lq * 8;
+        const _Float16* wr = p.w3 + (long long)ch * CMID + lq * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) a[tt][ks] = *reinterpret_cast<const h8*>(wr + ks * 32);
+        for (int ks = 0; ks < KS3; ++ks) a[tt][ks] = *reinterpret_cast<const h8*>(wr + ks * 32);
       }
       const int cg = g * 64 + lq * 16;                   // this lane's 16 output channels
       float b3v[16];
@@ -414,15 +418,15 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
           r0 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg);
           r1 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg + 8);
         }
-        h8 bf[8];
+        h8 bf[KS3];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) bf[ks] = *reinterpret_cast<const h8*>(lds + taddr(prow, 4 * ks + lq));
+        for (int ks = 0; ks < KS3; ++ks) bf[ks] = *reinterpret_cast<const h8*>(lds + taddr(prow, 4 * ks + lq));
         f4 o[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           o[tt] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt][ks], bf[ks], o[tt], 0, 0, 0);
+          for (int ks = 0; ks < KS3; ++ks) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt][ks], bf[ks], o[tt], 0, 0, 0);
         }
         if (ok) {
           h8 q0, q1;
@@ -598,9 +602,11 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   static std::once_flag once;
   static hipError_t once_rc = hipSuccess;
   std::call_once(once, [] {
-    const void* kb_[5] = {(const void*)k_conv3x3_f16<4, 4, false, true>, (const void*)k_conv3x3_f16<5, 4, false, true>,
-                          (const void*)k_conv3x3_f16<6, 4, false, true>, (const void*)k_conv3x3_f16<7, 4, false, true>,
-                          (const void*)k_conv3x3_f16<8, 4, false, true>};
+    const void* kb_[10] = {(const void*)k_conv3x3_f16<4, 4, false, true>, (const void*)k_conv3x3_f16<5, 4, false, true>,
+                           (const void*)k_conv3x3_f16<6, 4, false, true>, (const void*)k_conv3x3_f16<7, 4, false, true>,
+                           (const void*)k_conv3x3_f16<8, 4, false, true>, (const void*)k_conv3x3_f16<2, 2, false, true>,
+                           (const void*)k_conv3x3_f16<3, 2, false, true>, (const void*)k_conv3x3_f16<4, 2, false, true>,
+                           (const void*)k_conv3x3_f16<1, 1, false, true>, (const void*)k_conv3x3_f16<2, 1, false, true>};
     for (const void* k_ : kb_) {
       const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
       if (e_ != hipSuccess) once_rc = e_;
@@ -641,7 +647,8 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   p.y32 = nullptr; p.bias32 = nullptr; p.x2 = nullptr; p.cin2 = 0; p.k1steps = 0; p.Min2 = 0;
   if (blk) {
     ODET_REQUIRE(blk->w3 && blk->b3 && blk->y3 && bias, "odet_conv3x3_conv1x1_f16: null pointer");
-    ODET_REQUIRE(cout == 256, "odet_conv3x3_conv1x1_f16: the 3x3 convolution must have 256 output channels (got %d)", cout);
+    ODET_REQUIRE(cout == 256 || cout == 128 || cout == 64,
+                 "odet_conv3x3_conv1x1_f16: the 3x3 convolution must have 64, 128 or 256 output channels (got %d)", cout);
     ODET_REQUIRE(blk->n3 > 0 && blk->n3 % 64 == 0, "odet_conv3x3_conv1x1_f16: n3 %d must be a multiple of 64", blk->n3);
     ODET_REQUIRE(num_levels == 1, "odet_conv3x3_conv1x1_f16: one map");
     ODET_REQUIRE(((uintptr_t)blk->w3 | (uintptr_t)blk->res | (uintptr_t)blk->y3) % 16 == 0, "odet_conv3x3_conv1x1_f16: pointers must be 16-byte aligned");
@@ -689,8 +696,8 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   int wn_use = wn_sel, wm_use = wm_sel;
   if (const char* ov = getenv("ODET_C3_TILE")) {          // experiments (tools/exp/conv3x3_small.py): "wn,mt" of the plain form
     int a_ = 0, b_ = 0;
-    if (!tail && !blk && sscanf(ov, "%d,%d", &a_, &b_) == 2 && (a_ == 4 || a_ == 2 || a_ == 1) && cout % (64 * a_) == 0 &&
-        b_ * (8 / a_) >= 8 && b_ * (8 / a_) <= 16) { wn_use = a_; wm_use = 8 / a_; mt_best = b_; p.tiles_n = cout / (64 * a_); }
+    if (!tail && sscanf(ov, "%d,%d", &a_, &b_) == 2 && (a_ == 4 || a_ == 2 || a_ == 1) && cout % (64 * a_) == 0 &&
+        b_ * (8 / a_) >= 8 && b_ * (8 / a_) <= 16 && (!blk || a_ == wn_sel)) { wn_use = a_; wm_use = 8 / a_; mt_best = b_; p.tiles_n = cout / (64 * a_); }
   }
   const int TMsel = wm_use * 16 * mt_best;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
@@ -730,13 +737,20 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   }
 #undef C3_LAUNCH_TAIL
   if (blk) {
-#define C3_LAUNCH_BLK(MT_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, 4, false, true>), grid, dim3(512), C3_LDS_BYTES, st, p)
-    switch (mt_best) {
-      case 4: C3_LAUNCH_BLK(4); break;
-      case 5: C3_LAUNCH_BLK(5); break;
-      case 6: C3_LAUNCH_BLK(6); break;
-      case 7: C3_LAUNCH_BLK(7); break;
-      default: C3_LAUNCH_BLK(8); break;
+    // (LDS: the K loop's two stages, re-used after it for the TM x 2 CMID-byte activation tile -- never more than the stages)
+    const unsigned lds_blk = std::max(2u * (unsigned)(TMsel + 64 * wn_use) * 128u, (unsigned)TMsel * 128u * (unsigned)wn_use);
+#define C3_LAUNCH_BLK(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_, false, true>), grid, dim3(512), lds_blk, st, p)
+    switch (wn_use * 16 + mt_best) {
+      case 4 * 16 + 4: C3_LAUNCH_BLK(4, 4); break;
+      case 4 * 16 + 5: C3_LAUNCH_BLK(5, 4); break;
+      case 4 * 16 + 6: C3_LAUNCH_BLK(6, 4); break;
+      case 4 * 16 + 7: C3_LAUNCH_BLK(7, 4); break;
+      case 4 * 16 + 8: C3_LAUNCH_BLK(8, 4); break;
+      case 2 * 16 + 2: C3_LAUNCH_BLK(2, 2); break;
+      case 2 * 16 + 3: C3_LAUNCH_BLK(3, 2); break;
+      case 2 * 16 + 4: C3_LAUNCH_BLK(4, 2); break;
+      case 1 * 16 + 1: C3_LAUNCH_BLK(1, 1); break;
+      default: C3_LAUNCH_BLK(2, 1); break;
     }
 #undef C3_LAUNCH_BLK
     ODET_LAUNCH_CHECK();
@@ -922,6 +936,15 @@ extern "C" int odet_dense_f16_out_f32(const void* x, const void* w, const float*
   const PwEpilogue e{nullptr, nullptr, 0, 0, y, bias, nullptr, 0};
   return pointwise_launch("odet_dense_f16_out_f32", x, w, nullptr, nullptr, 1, 1, (int)rows, 1, cin, cout, relu, e,
                           (hipStream_t)stream);
+}
+
+extern "C" int odet_bottleneck_tail_f16(const void* x, const void* w2, const void* b2, const void* w3, const void* b3,
+                                       const void* residual, void* y, int batch, int H, int W, int cin, int cmid, int n3,
+                                       int relu, odet_stream_t stream) {
+  ODET_REQUIRE(x && y, "odet_bottleneck_tail_f16: null pointer");
+  const odet_conv_level_t one{x, nullptr, H, W};
+  const Conv3x3Block b{w3, b3, residual, y, n3, relu};
+  return conv3x3_launch(&one, 1, w2, b2, batch, cin, cmid, 1, (hipStream_t)stream, nullptr, &b);
 }
 
 // upper bound of the workspace of odet_rpn_head_fused_f16: every level's pixels rounded up to a whole slab of any height

@@ -366,11 +366,12 @@ class _Block(nn.Module):
         if y.is_cuda and y.dtype == torch.float16 and self.c3.in_channels in (64, 128, 256, 512):
             # c2 (3x3) runs WITHOUT bias / ReLU; if c3 takes the MFMA route for this shape, c2's epilogue is applied
             # to c3's operand fragments as they are loaded (ops.conv1x1_f16(in_bias=...)) and its pass disappears
-            if self.c2.out_channels == 256 and _CONV3X3_MODE in ('own', 'force') and _own_conv3x3(self.c2, y) \
-                    and (int(y.shape[0]) * int(y.shape[2]) * int(y.shape[3]) + 127) // 128 >= 128:
-                # conv4's blocks: the 3x3 convolution AND the block's last 1x1 convolution + bias + shortcut + ReLU in one
-                # launch (ops.conv3x3_conv1x1_f16: the 256-channel activation between them stays in LDS); 83 vs 108 us at
-                # batch 8, 67 vs 73 at batch 4, behind the two launches on smaller maps (tools/exp/block_fused_quick.py)
+            if self.c2.out_channels in ((256,) if 'tail' in _PW_OFF else (64, 128, 256)) and _CONV3X3_MODE in ('own', 'force') \
+                    and _own_conv3x3(self.c2, y) and (int(y.shape[0]) * int(y.shape[2]) * int(y.shape[3]) + 127) // 128 >= 128:
+                # the 3x3 convolution AND the block's last 1x1 convolution + bias + shortcut + ReLU in one launch
+                # (ops.conv3x3_conv1x1_f16: the 64 / 128 / 256-channel activation between them stays in LDS): conv4 83 vs 108 us
+                # at batch 8 (253 vs 320 at 30), conv3 122 vs 134 (400 vs 477), conv2 198 vs 226 (640-700 vs 787); behind the
+                # two launches on smaller maps (tools/exp/block_tail_layers.py)
                 res = sc.permute(0, 2, 3, 1)
                 if not res.is_contiguous():
                     res = res.contiguous()

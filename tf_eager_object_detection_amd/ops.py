@@ -547,22 +547,24 @@ _RPN_FUSED_WS = {}      # (device, bytes, stream) -> the partial-sum workspace o
 def conv3x3_conv1x1_f16(x, weight2, bias2, weight3, bias3, residual=None, relu=True, out=None):
     """A bottleneck block's 3x3 convolution and its last 1x1 convolution in ONE launch (odet_conv3x3_conv1x1_f16):
     relu(relu(conv3x3(x, weight2) + bias2) . weight3^T + bias3 + residual).  ``x`` NHWC float16 [B,H,W,cin], ``weight2``
-    [256,cin,3,3] (channels_last), ``weight3`` [n3,256(,1,1)], ``residual`` / ``out`` NHWC float16 [B,H,W,n3]."""
+    [cmid,cin,3,3] (channels_last) with cmid = 64, 128 or 256 (ResNet conv2 / conv3 / conv4: one workgroup holds all of them),
+    ``weight3`` [n3,cmid(,1,1)], ``residual`` / ``out`` NHWC float16 [B,H,W,n3]."""
     if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4 or not x.is_contiguous():
         raise ValueError('x must be a contiguous NHWC float16 GPU tensor [B,H,W,cin]')
     B, H, W, cin = (int(v) for v in x.shape)
-    if int(weight2.shape[0]) != 256:
-        raise ValueError('the 3x3 convolution must have 256 output channels')
-    w2 = _conv3x3_weight(weight2, cin, 256, torch.float16, 'float16')
+    cmid = int(weight2.shape[0])
+    if cmid not in (64, 128, 256):
+        raise ValueError('the 3x3 convolution must have 64, 128 or 256 output channels')
+    w2 = _conv3x3_weight(weight2, cin, cmid, torch.float16, 'float16')
     n3 = int(weight3.shape[0])
-    if weight3.dtype != torch.float16 or weight3.numel() != n3 * 256:
-        raise ValueError('weight3 must be a float16 [n3, 256] tensor')
-    w3 = weight3.reshape(n3, 256)
+    if weight3.dtype != torch.float16 or weight3.numel() != n3 * cmid:
+        raise ValueError('weight3 must be a float16 [n3, cmid] tensor')
+    w3 = weight3.reshape(n3, cmid)
     if not w3.is_contiguous():
         w3 = w3.contiguous()
-    for t, n_ in ((bias2, 256), (bias3, n3)):
+    for t, n_ in ((bias2, cmid), (bias3, n3)):
         if t.dtype != torch.float16 or t.numel() != n_ or not t.is_contiguous():
-            raise ValueError('bias2 [256] / bias3 [n3] must be contiguous float16 tensors')
+            raise ValueError('bias2 [cmid] / bias3 [n3] must be contiguous float16 tensors')
     shape = (B, H, W, n3)
     if residual is not None and (residual.dtype != torch.float16 or tuple(residual.shape) != shape or not residual.is_contiguous()):
         raise ValueError('residual must be a contiguous float16 tensor [B,H,W,n3]')
@@ -570,8 +572,9 @@ def conv3x3_conv1x1_f16(x, weight2, bias2, weight3, bias3, residual=None, relu=T
         out = torch.empty(shape, dtype=torch.float16, device=x.device)
     elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous float16 tensor [B,H,W,n3]')
-    L.call('odet_conv3x3_conv1x1_f16', L.dptr(x), L.dptr(w2), L.dptr(bias2), L.dptr(w3), L.dptr(bias3),
-           L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, cin, n3, 1 if relu else 0, L.stream())
+    L.call('odet_bottleneck_tail_f16', L.dptr(x), L.dptr(w2), L.dptr(bias2), L.dptr(w3), L.dptr(bias3),
+           L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, cin, cmid, n3, 1 if relu else 0,
+           L.stream())
     return out
 
 

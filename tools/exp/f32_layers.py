@@ -47,8 +47,8 @@ for name, H, W, K, N, s in rows:
         def lib():
             y = F.conv2d(xn, w4, None, s); ops.bias_act_(y.permute(0, 2, 3, 1), b, None, True); return y
         t_lib = timed(lib)
-    gf = 2.0 * out.numel() // N * K * N / 1e9
-    print('%-22s own %s | library %.1f us | %.0f TF/s own-pick' % (name, ' '.join('%s:%.0f' % kv for kv in ts.items()), t_lib, gf / ts['pick'] * 1e3 / 1e3))
+    gf = 2.0 * (out.numel() // N) * K * N / 1e9
+    print('%-22s own %s | library %.1f us | %.0f TF/s own-pick' % (name, ' '.join('%s:%.0f' % kv for kv in ts.items()), t_lib, gf / ts['pick'] * 1e3))
 for name, H, W, C, N in (('conv2 3x3 64', 200, 334, 64, 64), ('conv3 3x3 128', 100, 167, 128, 128), ('conv4 3x3 256', 50, 84, 256, 256),
                          ('conv5 3x3 512', 25, 42, 512, 512), ('neck s2 256', 200, 334, 256, 256)):
     x = torch.randn(B, H, W, C, device='cuda')
@@ -68,4 +68,4 @@ for name, H, W, C, N in (('conv2 3x3 64', 200, 334, 64, 64), ('conv3 3x3 128', 1
     xn = x.permute(0, 3, 1, 2)
     t_lib = timed(lambda: F.conv2d(xn, w, None, 1, 1))
     gf = 2.0 * B * H * W * C * 9 * N / 1e9
-    print('%-22s own %s | library %.1f us | %.0f TF/s own-pick' % (name, ' '.join('%s:%.0f' % kv for kv in ts.items()), t_lib, gf / ts['pick'] * 1e3 / 1e3))
+    print('%-22s own %s | library %.1f us | %.0f TF/s own-pick' % (name, ' '.join('%s:%.0f' % kv for kv in ts.items()), t_lib, gf / ts['pick'] * 1e3))

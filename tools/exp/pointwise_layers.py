@@ -51,8 +51,8 @@ for name, H, W, K, N, s, relu in rows:
     err = (ops.pointwise_f16(x, w, b, res, relu, s).float() - ref.float()).abs().max().item()
     gf = 2.0 * B * Ho * Wo * K * N / 1e9
     mb = (B * Ho * Wo * (K + N * (2 if res is not None else 1))) * 2 / 1e6
-    print('%-22s M %7d K %5d N %5d  own %7.1f us (%5.0f TF/s, %4.2f TB/s)  library %7.1f us   max|diff| %.3f'
-          % (name, B * Ho * Wo, K, N, t_own, gf / t_own * 1e-3 * 1e3, mb / t_own, t_lib, err))
+    print('%-22s M %7d K %5d N %5d  own %7.1f us (%5.0f TFLOP/s, %4.2f TB/s)  library %7.1f us   max|diff| %.3f'
+          % (name, B * Ho * Wo, K, N, t_own, gf / t_own * 1e3, mb / t_own, t_lib, err))
 # laterals with the merge
 for name, H, W, K in (('l4 + merge', 50, 84, 1024), ('l3 + merge', 100, 167, 512), ('l2 + merge', 200, 334, 256)):
     N = 256
