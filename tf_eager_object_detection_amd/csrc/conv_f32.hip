@@ -127,8 +127,11 @@ __device__ __forceinline__ void conv_tile_f32(const ConvF32Params& p) {
 #pragma unroll
   for (int i = 0; i < WN; ++i) {
     const int row = (wv * WN + i) * 8 + sub;
-    const int g = row >> 6, rr = row & 63, t = rr >> 4, r = rr & 15;
-    const int ch = tn * TN + g * 64 + 16 * (r >> 2) + 4 * t + (r & 3);
+    // LDS row rho of the W tile <- channel rho (identity): an MFMA tile t of a wave's 64-channel group then leaves lane
+    // (pixel, q) with channels 16 t + 4 q .. + 3, i.e. the four lanes of a pixel hold 64 CONTIGUOUS bytes of the output row
+    // per tile -- one store instruction writes whole 64-byte segments (the float16 kernel's permuted order, 16 consecutive
+    // channels per lane, would scatter float32 results in 16-byte pieces 64 bytes apart)
+    const int ch = tn * TN + row;
     voffW[i] = (uint32_t)ch * wrowB + slot;
   }
   const int chunks = cin / F32_BK;
@@ -226,11 +229,12 @@ __device__ __forceinline__ void conv_tile_f32(const ConvF32Params& p) {
       compute(lds + stage);
     }
   }
-  // ---- epilogue: lane = pixel l15 of every pixel tile, channels c0 .. c0 + 15
-  const int c0 = tn * TN + wn * 64 + lq * 16;
-  float bv[16];
+  // ---- epilogue: lane = pixel l15 of every pixel tile; tile t of the wave's 64-channel group: channels c0 + 16 t .. + 3
+  const int c0 = tn * TN + wn * 64 + lq * 4;
+  c3f4 bv[4];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[c0 + e] : 0.0f;
+  for (int t = 0; t < 4; ++t)
+    bv[t] = p.bias ? *reinterpret_cast<const c3f4*>(p.bias + c0 + 16 * t) : (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
@@ -252,20 +256,20 @@ __device__ __forceinline__ void conv_tile_f32(const ConvF32Params& p) {
           const float* tb = p.top + (img * p.th * p.tw) * cout + c0;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const c3f4 a = *reinterpret_cast<const c3f4*>(tb + ((long long)y0 * p.tw + x0) * cout + 4 * t);
-            const c3f4 b = *reinterpret_cast<const c3f4*>(tb + ((long long)y0 * p.tw + x1) * cout + 4 * t);
-            const c3f4 c = *reinterpret_cast<const c3f4*>(tb + ((long long)y1 * p.tw + x0) * cout + 4 * t);
-            const c3f4 d = *reinterpret_cast<const c3f4*>(tb + ((long long)y1 * p.tw + x1) * cout + 4 * t);
+            const c3f4 a = *reinterpret_cast<const c3f4*>(tb + ((long long)y0 * p.tw + x0) * cout + 16 * t);
+            const c3f4 b = *reinterpret_cast<const c3f4*>(tb + ((long long)y0 * p.tw + x1) * cout + 16 * t);
+            const c3f4 c = *reinterpret_cast<const c3f4*>(tb + ((long long)y1 * p.tw + x0) * cout + 16 * t);
+            const c3f4 d = *reinterpret_cast<const c3f4*>(tb + ((long long)y1 * p.tw + x1) * cout + 16 * t);
             c3f4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float lat = acc[mt][t][j] + bv[t * 4 + j];
+              const float lat = acc[mt][t][j] + bv[t][j];
               const float tp = a[j] + (b[j] - a[j]) * xl;
               const float bt = c[j] + (d[j] - c[j]) * xl;
               const float up = tp + (bt - tp) * yl;
               o[j] = up * 0.5f + lat * 0.5f;
             }
-            *reinterpret_cast<c3f4*>(dst + t * 4) = o;
+            *reinterpret_cast<c3f4*>(dst + 16 * t) = o;
           }
           continue;
         }
@@ -274,15 +278,15 @@ __device__ __forceinline__ void conv_tile_f32(const ConvF32Params& p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         c3f4 o, r = (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (has_res) r = *reinterpret_cast<const c3f4*>(p.res + m * cout + c0 + 4 * t);
+        if (has_res) r = *reinterpret_cast<const c3f4*>(p.res + m * cout + c0 + 16 * t);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = acc[mt][t][j] + bv[t * 4 + j];
+          float v = acc[mt][t][j] + bv[t][j];
           if (has_res) v += r[j];
           if (p.relu) v = v < 0.0f ? 0.0f : v;
           o[j] = v;
         }
-        *reinterpret_cast<c3f4*>(dst + t * 4) = o;
+        *reinterpret_cast<c3f4*>(dst + 16 * t) = o;
       }
     }
   }
