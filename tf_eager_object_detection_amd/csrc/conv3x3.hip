@@ -17,9 +17,11 @@
 //  * Two LDS stages (2 x 64 KB): the DMA of K-step k+1 is in flight while step k computes; one barrier per K-step.
 //  * TRANSPOSED tiles (D = W_tile . X_tile^T: the MFMA's A operand is 16 rows of W, its B operand 16 pixels): a lane
 //    then holds ONE pixel and 4 channels per tile.  The rows of W are laid out in LDS in a permuted order (LDS row
-//    16 t + r of a wave's 64-channel group = channel 16 (r >> 2) + 4 t + (r & 3)), which makes the 16 registers of a
-//    pixel 16 CONSECUTIVE channels: 32 contiguous bytes per lane, a full 128-byte line per pixel from the four lane
-//    quarters.
+//    16 t + r of a wave's 64-channel group = channel 16 (r >> 2) + 4 t + (r & 3)) which makes the 16 registers of a
+//    pixel 16 CONSECUTIVE channels (the fused forms, whose second GEMM consumes them in K order), or -- plain and
+//    pointwise forms -- in the order that gives a lane channels 8 q .. 8 q + 7 of both 32-channel halves, so that each of
+//    its two 16-byte stores joins the other three lanes of the pixel in 64 contiguous bytes (round 3: 16-byte pieces
+//    32 bytes apart cost the output-heavy 1x1 layers 10-20 %).
 //  * XCD-aware order: the channel tiles of a pixel slab are consecutive workgroups of ONE XCD (its L2 serves their
 //    common input lines).
 //
@@ -92,6 +94,7 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
 template <int MT, int WN, bool TAIL, bool BLK, int TAPS>
 __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   static_assert(TAPS == 9 || (TAPS == 1 && !TAIL && !BLK), "taps");
+  constexpr bool LIN = !TAIL && !BLK;                    // the order of a lane's output channels, see voffW below
   constexpr int WM = 8 / WN;                             // waves along the pixels
   constexpr int TM = WM * 16 * MT;                       // pixels of the workgroup tile (<= 256)
   constexpr int TN = 64 * WN;                            // channels of the workgroup tile
@@ -173,9 +176,13 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
 #pragma unroll
   for (int i = 0; i < WN; ++i) {
     const int row = (wv * WN + i) * 8 + sub;             // 0..TN-1
-    // LDS row rho of the W tile <- channel: rows 16 t + r of a 64-channel group hold channel 16 (r >> 2) + 4 t + (r & 3)
+    // LDS row rho of the W tile <- channel.  The fused forms (their second GEMM takes a lane's 16 results as K-ordered
+    // operands): rows 16 t + r of a 64-channel group hold channel 16 (r >> 2) + 4 t + (r & 3) -- 16 consecutive channels
+    // per lane.  The plain and pointwise forms (LIN): channel 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3) -- a lane
+    // holds channels 8 q .. 8 q + 7 of each 32-channel half, so the four lanes of a pixel store 64 CONTIGUOUS bytes per
+    // instruction instead of four 16-byte pieces 32 bytes apart
     const int g = row >> 6, rr = row & 63, t = rr >> 4, r = rr & 15;
-    const int ch = tn * TN + g * 64 + 16 * (r >> 2) + 4 * t + (r & 3);
+    const int ch = tn * TN + g * 64 + (LIN ? 32 * (t >> 1) + 8 * (r >> 2) + 4 * (t & 1) + (r & 3) : 16 * (r >> 2) + 4 * t + (r & 3));
     voffW[i] = (uint32_t)ch * wrowB + slot;
   }
   const int chunks = cin / C3_BK;
@@ -290,7 +297,8 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     mfmas(wf0, xf0);
     mfmas(wf1, xf1);
   }
-  const int c0 = tn * TN + wn * 64 + lq * 16;
+  const int c0 = tn * TN + wn * 64 + lq * (LIN ? 8 : 16);
+  constexpr int HOFF = LIN ? 32 : 8;                     // channel offset of a lane's second group of 8 results
   if constexpr (TAIL) {
     // ---- fused RpnHead tail (base_fpn_model.py:401-434): t = relu(conv + b1) rounded to float16 once, then the two 1x1
     // convolutions as ONE more contraction on the matrix cores, out[o][pixel] = sum_ch W2[o][ch] . t[pixel][ch]: the MFMA's
@@ -362,8 +370,8 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     // goes to LDS once, rounded to float16 ([TM pixels][2 CMID bytes], 16-byte slots XOR-swizzled by the pixel row:
     // conflict-free as an MFMA operand), then every wave takes 64-channel groups of the n3 output channels for ALL pixels of
     // the tile: its 4 x (CMID / 32) weight fragments straight from global memory into registers (rows in the permuted
-    // order that leaves a lane with 16 consecutive channels), per pixel tile CMID / 32 fragment reads + 4 CMID / 32 MFMAs,
-    // + bias + shortcut, ReLU, one rounding, 32 contiguous bytes per lane.  The activation of the 3x3 convolution never goes
+    // order that leaves a pixel's four lanes with 64 contiguous bytes per store), per pixel tile CMID / 32 fragment reads + 4 CMID / 32 MFMAs,
+    // + bias + shortcut, ReLU, one rounding, two 16-byte stores per lane.  The activation of the 3x3 convolution never goes
     // to memory.
     constexpr int CMID = 64 * WN;                        // channels of the 3x3 convolution = K of the 1x1 convolution
     constexpr int KS3 = CMID / 32;                       // its K-steps
@@ -398,15 +406,15 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
       h8 a[4][KS3];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        const int ch = g * 64 + 16 * (l15 >> 2) + 4 * tt + (l15 & 3);
+        const int ch = g * 64 + 32 * (tt >> 1) + 8 * (l15 >> 2) + 4 * (tt & 1) + (l15 & 3);
         const _Float16* wr = p.w3 + (long long)ch * CMID + lq * 8;
 #pragma unroll
         for (int ks = 0; ks < KS3; ++ks) a[tt][ks] = *reinterpret_cast<const h8*>(wr + ks * 32);
       }
-      const int cg = g * 64 + lq * 16;                   // this lane's 16 output channels
+      const int cg = g * 64 + lq * 8;                    // this lane's output channels: cg .. cg + 7 and cg + 32 .. cg + 39
       float b3v[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) b3v[e] = (float)p.b3[cg + e];
+      for (int e = 0; e < 16; ++e) b3v[e] = (float)p.b3[cg + (e >> 3) * 32 + (e & 7)];
       for (int pt = 0; pt < TM / 16; ++pt) {
         const int prow = pt * 16 + l15;
         const long long m = tile_m * TM + prow;
@@ -416,7 +424,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
         for (int e = 0; e < 8; ++e) { r0[e] = (_Float16)0.0f; r1[e] = (_Float16)0.0f; }
         if (p.res && ok) {
           r0 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg);
-          r1 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg + 8);
+          r1 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg + 32);
         }
         h8 bf[KS3];
 #pragma unroll
@@ -441,7 +449,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
             }
           _Float16* dst = p.y3 + m * n3 + cg;
           *reinterpret_cast<h8*>(dst) = q0;
-          *reinterpret_cast<h8*>(dst + 8) = q1;
+          *reinterpret_cast<h8*>(dst + 32) = q1;
         }
       }
     }
@@ -450,7 +458,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
   float bv[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? (float)p.bias[c0 + e] : 0.0f;
+  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? (float)p.bias[c0 + (e >> 3) * HOFF + (e & 7)] : 0.0f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
@@ -462,12 +470,12 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             f4 v = acc[mt][t];
-            if (p.bias32) v += *reinterpret_cast<const f4*>(p.bias32 + c0 + 4 * t);
+            if (p.bias32) v += *reinterpret_cast<const f4*>(p.bias32 + c0 + (t >> 1) * HOFF + 4 * (t & 1));
             if (p.relu) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.0f ? 0.0f : v[j];
             }
-            *reinterpret_cast<f4*>(dst + 4 * t) = v;
+            *reinterpret_cast<f4*>(dst + (t >> 1) * HOFF + 4 * (t & 1)) = v;
           }
           continue;
         }
@@ -487,10 +495,10 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
           h8 tl[2], tr[2], bl[2], br[2];
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            tl[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y0 * p.tw + x0) * cout + 8 * hh);
-            tr[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y0 * p.tw + x1) * cout + 8 * hh);
-            bl[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y1 * p.tw + x0) * cout + 8 * hh);
-            br[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y1 * p.tw + x1) * cout + 8 * hh);
+            tl[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y0 * p.tw + x0) * cout + HOFF * hh);
+            tr[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y0 * p.tw + x1) * cout + HOFF * hh);
+            bl[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y1 * p.tw + x0) * cout + HOFF * hh);
+            br[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y1 * p.tw + x1) * cout + HOFF * hh);
           }
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -507,7 +515,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
             }
           _Float16* dst = p.y[lv] + m * cout + c0;
           *reinterpret_cast<h8*>(dst) = o[0];
-          *reinterpret_cast<h8*>(dst + 8) = o[1];
+          *reinterpret_cast<h8*>(dst + HOFF) = o[1];
           continue;
         }
       }
@@ -515,7 +523,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
       const bool has_res = TAPS == 1 && p.res != nullptr;
       if (has_res) {
         rs[0] = *reinterpret_cast<const h8*>(p.res + m * cout + c0);
-        rs[1] = *reinterpret_cast<const h8*>(p.res + m * cout + c0 + 8);
+        rs[1] = *reinterpret_cast<const h8*>(p.res + m * cout + c0 + HOFF);
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -528,7 +536,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
         }
       _Float16* dst = p.y[lv] + m * cout + c0;
       *reinterpret_cast<h8*>(dst) = o[0];
-      *reinterpret_cast<h8*>(dst + 8) = o[1];
+      *reinterpret_cast<h8*>(dst + HOFF) = o[1];
     }
   }
 }
