@@ -415,42 +415,83 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
       float b3v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) b3v[e] = (float)p.b3[cg + (e >> 3) * 32 + (e & 7)];
-      for (int pt = 0; pt < TM / 16; ++pt) {
+      // The weight fragments must have ARRIVED before the pixel loop: the compiler puts the wait for a load at its first
+      // use, which is inside the loop -- and a `s_waitcnt vmcnt(0)` there also waits, on every step, for the previous
+      // step's output stores (the counter is in order on gfx950).  These empty statements use the registers here.
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks) asm volatile("" :: "v"(a[tt][ks]));
+      // The shortcut rows of a later step are requested BEFORE this step's stores for the same reason (waiting for them
+      // then leaves the younger stores in flight).  Loads and stores go through buffer descriptors WITHOUT branches: a row
+      // past the end (or no shortcut at all: an empty descriptor) reads 0 and its store is dropped by the range check --
+      // behind a branch the compiler can no longer count the operations in flight and falls back to vmcnt(0).
+      constexpr int NPT = TM / 16;
+      static_assert(NPT % 2 == 0, "pixel tiles");
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const uint32_t rowB = (uint32_t)n3 * 2u;
+      const c3_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.res ? p.res : p.y3), 0,
+                                                               p.res ? (int)((uint32_t)M * rowB) : 0, 0x00020000);
+      const c3_rsrc_t ry3 = __builtin_amdgcn_make_buffer_rsrc(p.y3, 0, (int)((uint32_t)M * rowB), 0x00020000);
+      const uint32_t off0 = (uint32_t)(tile_m * TM + l15) * rowB + (uint32_t)cg * 2u;   // pixel tile 0 (M * rowB < 2^32: host)
+      auto fetch = [&](int pt, u4 (&d)[2]) {
+        const long long m = tile_m * TM + pt * 16 + l15;
+        const uint32_t off = (m < M && pt < NPT) ? off0 + (uint32_t)pt * 16u * rowB : OOB;   // (pt >= NPT: the last steps' "next")
+        d[0] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0);
+        d[1] = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 64, 0);
+      };
+      // TWO steps of lead (a step is ~0.5 us for the two waves of a SIMD, a loaded HBM round trip 1-2 us): four register
+      // buffers in rotation, the loop unrolled by four so that the rotation is a renaming.  The dropped stores (range check)
+      // give the loop's entry the same sequence of operations in flight as its back edge, so the compiler's count at the
+      // head of the loop is the steady-state one instead of vmcnt(0).
+      u4 r0[2], r1[2], r2[2], r3[2];
+      auto drop2 = [&]() {
+        __builtin_amdgcn_raw_buffer_store_b128((u4){0u, 0u, 0u, 0u}, ry3, (int)OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u4){0u, 0u, 0u, 0u}, ry3, (int)OOB, 64, 0);
+      };
+      fetch(0, r0); drop2();
+      fetch(1, r1); drop2();
+      auto step = [&](int pt, u4 (&cur)[2], u4 (&nxt)[2]) {
+        fetch(pt + 2, nxt);
+        __builtin_amdgcn_sched_barrier(0);
         const int prow = pt * 16 + l15;
         const long long m = tile_m * TM + prow;
-        const bool ok = m < M;
-        h8 r0, r1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { r0[e] = (_Float16)0.0f; r1[e] = (_Float16)0.0f; }
-        if (p.res && ok) {
-          r0 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg);
-          r1 = *reinterpret_cast<const h8*>(p.res + m * n3 + cg + 32);
-        }
         h8 bf[KS3];
 #pragma unroll
         for (int ks = 0; ks < KS3; ++ks) bf[ks] = *reinterpret_cast<const h8*>(lds + taddr(prow, 4 * ks + lq));
         f4 o[4];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          o[tt] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int tt = 0; tt < 4; ++tt) o[tt] = (f4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int ks = 0; ks < KS3; ++ks) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt][ks], bf[ks], o[tt], 0, 0, 0);
-        }
-        if (ok) {
-          h8 q0, q1;
+        for (int ks = 0; ks < KS3; ++ks)                 // four independent accumulation chains, interleaved
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt)
+          for (int tt = 0; tt < 4; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tt][ks], bf[ks], o[tt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);               // (the shortcut's conversions stay behind the MFMAs: so does their wait)
+        const h8 s0 = __builtin_bit_cast(h8, cur[0]), s1 = __builtin_bit_cast(h8, cur[1]);
+        h8 q0, q1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int e = tt * 4 + j;
-              float v = (o[tt][j] + b3v[e]) + (float)(e < 8 ? r0[e & 7] : r1[e & 7]);
-              if (p.relu3) v = v < 0.0f ? 0.0f : v;
-              if (e < 8) q0[e] = (_Float16)v; else q1[e - 8] = (_Float16)v;
-            }
-          _Float16* dst = p.y3 + m * n3 + cg;
-          *reinterpret_cast<h8*>(dst) = q0;
-          *reinterpret_cast<h8*>(dst + 32) = q1;
-        }
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = tt * 4 + j;
+            float v = (o[tt][j] + b3v[e]) + (float)(e < 8 ? s0[e & 7] : s1[e & 7]);
+            if (p.relu3) v = v < 0.0f ? 0.0f : v;
+            if (e < 8) q0[e] = (_Float16)v; else q1[e - 8] = (_Float16)v;
+          }
+        const uint32_t off = m < M ? off0 + (uint32_t)pt * 16u * rowB : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q0), ry3, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q1), ry3, (int)off, 64, 0);
+      };
+      int pt = 0;
+      for (; pt + 4 <= NPT; pt += 4) {
+        step(pt, r0, r2);
+        step(pt + 1, r1, r3);
+        step(pt + 2, r2, r0);
+        step(pt + 3, r3, r1);
+      }
+      if (NPT % 4 == 2) {
+        step(NPT - 2, r0, r2);
+        step(NPT - 1, r1, r3);
       }
     }
     return;
@@ -659,6 +700,9 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
                  "odet_conv3x3_conv1x1_f16: the 3x3 convolution must have 64, 128 or 256 output channels (got %d)", cout);
     ODET_REQUIRE(blk->n3 > 0 && blk->n3 % 64 == 0, "odet_conv3x3_conv1x1_f16: n3 %d must be a multiple of 64", blk->n3);
     ODET_REQUIRE(num_levels == 1, "odet_conv3x3_conv1x1_f16: one map");
+    // (the last convolution's shortcut and output rows are addressed through 32-bit buffer offsets)
+    ODET_REQUIRE((unsigned long long)batch * levels[0].H * levels[0].W * (unsigned long long)blk->n3 * 2ull <= 0xFFFFFFF0ull,
+                 "odet_conv3x3_conv1x1_f16: the output map must be smaller than 4 GiB");
     ODET_REQUIRE(((uintptr_t)blk->w3 | (uintptr_t)blk->res | (uintptr_t)blk->y3) % 16 == 0, "odet_conv3x3_conv1x1_f16: pointers must be 16-byte aligned");
     p.w3 = (const _Float16*)blk->w3; p.b3 = (const _Float16*)blk->b3; p.res = (const _Float16*)blk->res;
     p.y3 = (_Float16*)blk->y3; p.n3 = blk->n3; p.relu3 = blk->relu3 ? 1 : 0;

@@ -30,6 +30,8 @@ for name, H, W, cm in (('conv2', 200, 334, 64), ('conv3', 100, 167, 128), ('conv
         else: os.environ.pop('ODET_C3_TILE', None)
         res[tile or 'pick'] = timed(lambda: ops.conv3x3_conv1x1_f16(x, w2, b2, w3, b3, residual=r, relu=True, out=out))
     os.environ.pop('ODET_C3_TILE', None)
+    res['no-shortcut'] = timed(lambda: ops.conv3x3_conv1x1_f16(x, w2, b2, w3, b3, residual=None, relu=True, out=out))
+    res['n3=64'] = timed(lambda: ops.conv3x3_conv1x1_f16(x, w2, b2, w3[:64].contiguous(), b3[:64].contiguous(), residual=None, relu=True, out=y2 if cm == 64 else None))
     def two():
         ops.conv3x3_f16(x, w2, out=y2)
         if cm <= 512:
