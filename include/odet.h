@@ -432,6 +432,15 @@ int odet_stem_pack_weights_f16(const void* w, long long stride_o, long long stri
                                long long stride_x, void* packed, odet_stream_t stream);
 int odet_stem_conv7_pool3_f16(const void* images, int images_f16, const void* packed_w, const void* bias, void* out,
                               int batch, int H, int W, odet_stream_t stream);
+/* VGG16's first convolution (vgg16_faster_rcnn.py:260-342: Conv2D(64, 3x3, padding 'same') + ReLU on the 3-channel image) in
+ * one launch: NHWC image (float32: images_f16 = 0, or float16) -> NHWC float16 [batch][H][W][64], float16 products with
+ * float32 accumulation on the matrix cores, + bias (+ ReLU), one rounding.  packed_w: the weights repacked once by
+ * odet_conv3x3_rgb_pack_weights_f16 (from a float16 [64][3][3][3] tensor with the given element strides) into 4 x 2 x 64 x 8
+ * float16. */
+int odet_conv3x3_rgb_pack_weights_f16(const void* w, long long stride_o, long long stride_c, long long stride_y,
+                                      long long stride_x, void* packed, odet_stream_t stream);
+int odet_conv3x3_rgb_f16(const void* images, int images_f16, const void* packed_w, const void* bias, void* out,
+                         int batch, int H, int W, int relu, odet_stream_t stream);
 /* The float32 forms (csrc/conv_f32.hip): the detectors' PARITY mode computes in the reference's precision -- float32 x / w /
  * bias / y, exact-float32 matrix instructions (v_mfma_f32_16x16x4_f32: a chain of fmaf, no rounding the reference does
  * not have), the same tiling / staging / epilogues as the float16 entry points of the same names.  cin % 32 == 0,

@@ -853,6 +853,37 @@ def test_conv3x3_conv1x1_fused_block_tail(B, H, W, cin, n3, res, cmid):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,dt', [(1, 64, 96, torch.float32), (2, 61, 75, torch.float16), (1, 600, 800, torch.float32),
+                                      (3, 1, 1, torch.float32), (2, 9, 33, torch.float16), (1, 8, 32, torch.float32)])
+def test_conv3x3_rgb_first_convolution(B, H, W, dt):
+    """odet_conv3x3_rgb_f16 (VGG16's first convolution, vgg16_faster_rcnn.py:260-342: Conv2D(64, 3x3, 'same') + ReLU straight
+    from the 3-channel image): EXACT on integer-valued data, within float16 rounding of the float32 torch convolution on
+    random data; tiles that hang over the right / bottom edge, a one-pixel image, without the ReLU."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda')
+    g.manual_seed(H * 11 + W)
+
+    def reference(img, w, b, relu):
+        y = F.conv2d(img.permute(0, 3, 1, 2).half().float(), w.float(), b.float(), 1, 1)
+        return (F.relu(y) if relu else y).permute(0, 2, 3, 1)
+
+    img = torch.randint(-3, 4, (B, H, W, 3), device='cuda', generator=g).to(dt)
+    w = torch.randint(-2, 3, (64, 3, 3, 3), device='cuda', generator=g).half()
+    b = torch.randint(-3, 4, (64,), device='cuda', generator=g).half()
+    pw = ops.conv3x3_rgb_pack_weights(w)
+    for relu in (True, False):
+        got = ops.conv3x3_rgb(img, pw, b, relu=relu)
+        want = reference(img, w, b, relu)
+        assert got.shape == want.shape and torch.equal(got.float(), want)
+    assert torch.equal(ops.conv3x3_rgb_pack_weights(w.contiguous(memory_format=torch.channels_last)), pw)
+    img = (torch.randn((B, H, W, 3), device='cuda', generator=g) * 50).to(dt)
+    w = (torch.randn((64, 3, 3, 3), device='cuda', generator=g) * 0.05).half()
+    b = torch.randn(64, device='cuda', generator=g).half()
+    got = ops.conv3x3_rgb(img, ops.conv3x3_rgb_pack_weights(w), b)
+    torch.testing.assert_close(got.float(), reference(img, w, b, True), rtol=4e-3, atol=2e-2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('B,H,W,dt', [(1, 64, 96, torch.float32), (2, 61, 75, torch.float16), (1, 800, 1333, torch.float32),
                                       (3, 7, 9, torch.float32), (1, 33, 17, torch.float16)])
 def test_stem_conv7_pool3_fused(B, H, W, dt):

@@ -123,6 +123,8 @@ SIGNATURES = {
     'odet_conv3x3_conv1x1_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_stem_pack_weights_f16': (_i, [_vp, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp]),
     'odet_stem_conv7_pool3_f16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'odet_conv3x3_rgb_pack_weights_f16': (_i, [_vp, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp]),
+    'odet_conv3x3_rgb_f16': (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'odet_conv3x3_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_conv3x3_f32_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'odet_conv3x3_f16_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -235,3 +235,160 @@ extern "C" int odet_stem_conv7_pool3_f16(const void* images, int images_f16, con
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The first convolution of VGG16 (vgg16_faster_rcnn.py:260-342: Conv2D(64, 3x3, padding 'same') + ReLU on the 3-channel
+// image) in ONE launch from the NHWC image (float32 or float16) to the NHWC float16 map [B, H, W, 64].  As library
+// convolution + epilogue pass the 64-channel output was written, read back and written again (1.5 ms for 32 images of
+// 600 x 800 + the image's float16 copy); here it is written once: the kernel runs at the store rate of its output.
+//
+//  * WORKGROUP (4 waves) = 8 rows x 32 columns of output pixels.  The 11 x 36 image pixels around them are staged in LDS
+//    as 4 halfs per pixel (the fourth is zero; pixels outside the image are the zero padding).
+//  * Implicit GEMM on the matrix cores, the stem kernel's way: D = W_tile . X_tile^T with v_mfma_f32_16x16x32_f16, the B
+//    operand = 16 consecutive pixels of a row.  One MFMA takes TWO kernel rows: lane (pixel x, q) reads the 16 bytes of
+//    patch pixels x - 1 + 2 (q & 1), x + 2 (q & 1) of kernel row 2 kp + (q >> 1) -- k = 8 q + 4 (pixel) + channel, so
+//    K = 32 holds 2 rows x 4 pixels x 4 channels (27 of the 64 products of the two MFMAs are real, the rest meet zero
+//    weights; the matrix pipe is idle most of the time either way).
+//  * The weight rows are packed so that a lane's results of channel tiles (0, 1) / (2, 3) are 8 consecutive channels:
+//    with the four lanes of a pixel one store instruction writes 64 contiguous bytes, a pixel tile 2 KB.
+#define RG_TH 8                       // output rows of a tile
+#define RG_TW 32                      // output columns
+#define RG_PR (RG_TH + 3)             // patch rows: y0 - 1 .. y0 + 9 (kernel row "3" of the second MFMA meets zero weights)
+#define RG_PC (RG_TW + 4)             // patch columns: x0 - 1 .. x0 + 34
+#define RG_THREADS 256
+
+struct RgbConvParams {
+  const void* img; int img_f16;       // [B][H][W][3]
+  const _Float16* w;                  // packed [4 channel tiles][2 row pairs][64 lanes][8] (odet_conv3x3_rgb_pack_weights_f16)
+  const _Float16* bias;               // [64]
+  _Float16* out;                      // [B][H][W][64]
+  int B, H, W, relu;
+  int tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(RG_THREADS) k_conv3x3_rgb_f16(RgbConvParams p) {
+  __shared__ __align__(16) unsigned char patch[RG_PR * RG_PC * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  int blk = blockIdx.x;
+  const int tx = blk % p.tiles_x; blk /= p.tiles_x;
+  const int ty = blk % p.tiles_y;
+  const int b = blk / p.tiles_y;
+  const int y0 = ty * RG_TH, x0 = tx * RG_TW;
+
+  st_h8 wr[4][2];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) wr[ct][kp] = *reinterpret_cast<const st_h8*>(p.w + ((ct * 2 + kp) * 64 + lane) * 8);
+  // this lane's channels: 8 lq .. + 7 (tiles 0, 1) and 32 + 8 lq .. + 7 (tiles 2, 3)
+  const st_h8 b0 = *reinterpret_cast<const st_h8*>(p.bias + 8 * lq), b1 = *reinterpret_cast<const st_h8*>(p.bias + 32 + 8 * lq);
+
+  {
+    constexpr int TRIPS = (RG_PR * RG_PC + RG_THREADS - 1) / RG_THREADS;        // 2
+    const long long img_base = (long long)b * p.H * p.W * 3;
+    float v[TRIPS][3];
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int i = tid + RG_THREADS * k;
+      const int r = i / RG_PC, c = i - r * RG_PC;
+      const int y = y0 - 1 + r, x = x0 - 1 + c;
+      const bool ok = i < RG_PR * RG_PC && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const long long o = ok ? img_base + ((long long)y * p.W + x) * 3 : 0;
+      if (p.img_f16) {
+        const _Float16* s = reinterpret_cast<const _Float16*>(p.img) + o;
+        v[k][0] = ok ? (float)s[0] : 0.0f; v[k][1] = ok ? (float)s[1] : 0.0f; v[k][2] = ok ? (float)s[2] : 0.0f;
+      } else {
+        const float* s = reinterpret_cast<const float*>(p.img) + o;
+        v[k][0] = ok ? s[0] : 0.0f; v[k][1] = ok ? s[1] : 0.0f; v[k][2] = ok ? s[2] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int i = tid + RG_THREADS * k;
+      if (i < RG_PR * RG_PC) {
+        const st_h4 h = {(_Float16)v[k][0], (_Float16)v[k][1], (_Float16)v[k][2], (_Float16)0.0f};
+        *reinterpret_cast<st_h4*>(patch + i * 8) = h;
+      }
+    }
+  }
+  __syncthreads();
+
+  // pixel tiles: 16 consecutive pixels of a row; tile t = (row t >> 1, columns 16 (t & 1) ..); a wave takes four
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int t = wv * 4 + n;
+    const int ry = t >> 1, cx = (t & 1) * 16 + l15;                 // output pixel inside the tile
+    // patch pixel (row ry + 2 kp + (lq >> 1), column cx + 2 (lq & 1)) and its right neighbour: 16 bytes at an 8-byte
+    // aligned address (two 8-byte reads)
+    const unsigned char* src = patch + ((ry + (lq >> 1)) * RG_PC + cx + 2 * (lq & 1)) * 8;
+    st_f4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (st_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      const st_h4 lo = *reinterpret_cast<const st_h4*>(src + kp * 2 * RG_PC * 8);
+      const st_h4 hi = *reinterpret_cast<const st_h4*>(src + kp * 2 * RG_PC * 8 + 8);
+      const st_h8 xf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[ct][kp], xf, acc[ct], 0, 0, 0);
+    }
+    const int y = y0 + ry, x = x0 + cx;
+    if (y < p.H && x < p.W) {
+      st_h8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v0 = acc[e >> 2][e & 3] + (float)b0[e];
+        float v1 = acc[2 + (e >> 2)][e & 3] + (float)b1[e];
+        if (p.relu) { v0 = v0 < 0.0f ? 0.0f : v0; v1 = v1 < 0.0f ? 0.0f : v1; }
+        o0[e] = (_Float16)v0; o1[e] = (_Float16)v1;
+      }
+      _Float16* dst = p.out + (((long long)b * p.H + y) * p.W + x) * 64 + 8 * lq;
+      *reinterpret_cast<st_h8*>(dst) = o0;
+      *reinterpret_cast<st_h8*>(dst + 32) = o1;
+    }
+  }
+}
+
+// repack [64][3][3][3] (the framework's layout, any strides) -> the kernel's fragment order:
+// [channel tile ct][row pair kp][lane = 16 q + row i of the MFMA's A operand][8 halfs k = 8 q + e]; MFMA row i of tile ct is
+// output channel 32 (ct >> 1) + 8 (i >> 2) + 4 (ct & 1) + (i & 3); k = 8 q + e is kernel row 2 kp + (q >> 1), kernel column
+// 2 (q & 1) + (e >> 2), input channel e & 3 -- zero where the row or column is 3 or the channel is 3
+__global__ void __launch_bounds__(256) k_conv3x3_rgb_pack_weights(const _Float16* __restrict__ w, long long s_o, long long s_c,
+                                                                  long long s_y, long long s_x, _Float16* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 4 * 2 * 64 * 8) return;
+  const int e = idx & 7, ln = (idx >> 3) & 63, kp = (idx >> 9) & 1, ct = idx >> 10;
+  const int i = ln & 15, q = ln >> 4;
+  const int o = 32 * (ct >> 1) + 8 * (i >> 2) + 4 * (ct & 1) + (i & 3);
+  const int ky = 2 * kp + (q >> 1), kx = 2 * (q & 1) + (e >> 2), c = e & 3;
+  _Float16 v = (_Float16)0.0f;
+  if (ky < 3 && kx < 3 && c < 3) v = w[o * s_o + c * s_c + ky * s_y + kx * s_x];
+  out[idx] = v;
+}
+
+extern "C" int odet_conv3x3_rgb_pack_weights_f16(const void* w, long long stride_o, long long stride_c, long long stride_y,
+                                                 long long stride_x, void* packed, odet_stream_t stream) {
+  ODET_REQUIRE(w && packed, "odet_conv3x3_rgb_pack_weights_f16: null pointer");
+  hipLaunchKernelGGL(k_conv3x3_rgb_pack_weights, dim3((4 * 2 * 64 * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)w, stride_o, stride_c, stride_y, stride_x, (_Float16*)packed);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+extern "C" int odet_conv3x3_rgb_f16(const void* images, int images_f16, const void* packed_w, const void* bias, void* out,
+                                    int batch, int H, int W, int relu, odet_stream_t stream) {
+  ODET_REQUIRE(images && packed_w && bias && out, "odet_conv3x3_rgb_f16: null pointer");
+  ODET_REQUIRE(batch > 0 && H > 0 && W > 0, "odet_conv3x3_rgb_f16: bad image shape");
+  ODET_REQUIRE(((uintptr_t)packed_w | (uintptr_t)bias | (uintptr_t)out) % 16 == 0, "odet_conv3x3_rgb_f16: pointers must be 16-byte aligned");
+  RgbConvParams p;
+  p.img = images; p.img_f16 = images_f16 ? 1 : 0; p.w = (const _Float16*)packed_w; p.bias = (const _Float16*)bias;
+  p.out = (_Float16*)out; p.B = batch; p.H = H; p.W = W; p.relu = relu ? 1 : 0;
+  p.tiles_x = (W + RG_TW - 1) / RG_TW; p.tiles_y = (H + RG_TH - 1) / RG_TH;
+  const long long blocks = (long long)p.tiles_x * p.tiles_y * batch;
+  ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_rgb_f16: too many workgroups");
+  hipLaunchKernelGGL(k_conv3x3_rgb_f16, dim3((unsigned)blocks), dim3(RG_THREADS), 0, (hipStream_t)stream, p);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}

@@ -264,10 +264,26 @@ class Vgg16Detector(ResNetC4Detector):
 
     def features(self, images_nhwc):
         """[B,H,W,3] -> conv5_3 [B,512,ceil(H/16),ceil(W/16)] channels_last."""
-        x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
+        first = self.convs[0]
+        own_first = (images_nhwc.is_cuda and self.dtype == torch.float16 and fd._CONV3X3_MODE in ('own', 'force')
+                     and images_nhwc.dtype in (torch.float32, torch.float16) and images_nhwc.is_contiguous()
+                     and first.out_channels == 64 and 'rgb' not in fd._PW_OFF)
+        if own_first:
+            # conv1_1 straight from the image (ops.conv3x3_rgb: bias + ReLU in the launch, its output written once)
+            key = (first.weight.data_ptr(), first.weight._version)
+            packed = getattr(first, '_odet_packed', None)
+            if packed is None or packed[0] != key:
+                packed = (key, ops.conv3x3_rgb_pack_weights(first.weight))
+                first._odet_packed = packed
+            x = ops.conv3x3_rgb(images_nhwc, packed[1], first.bias, relu=True).permute(0, 3, 1, 2)
+        else:
+            x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
         i = 0
         for bi, (_, n) in enumerate(self._CFG):
             for k in range(n):
+                if own_first and i == 0:
+                    i += 1
+                    continue
                 if k == n - 1 and bi < 4:
                     # the stage's last convolution: bias + ReLU + MaxPooling2D((2,2), 2, padding='same') in one pass
                     x = _conv_relu_pool(self.convs[i], x, 2, 2, ceil_mode=True)

@@ -610,6 +610,38 @@ def stem_conv7_pool3(images_nhwc, packed_weight, bias, out=None):
     return out
 
 
+def conv3x3_rgb_pack_weights(weight):
+    """[64,3,3,3] float16 weights of a 3-channel 3x3 convolution (any strides) -> the packed [4*2*64*8] float16 layout of
+    conv3x3_rgb."""
+    if weight.dtype != torch.float16 or tuple(weight.shape) != (64, 3, 3, 3) or not weight.is_cuda:
+        raise ValueError('weight must be a float16 [64,3,3,3] GPU tensor')
+    packed = torch.empty(4 * 2 * 64 * 8, dtype=torch.float16, device=weight.device)
+    so, sc, sy, sx = (int(v) for v in weight.stride())
+    L.call('odet_conv3x3_rgb_pack_weights_f16', C.c_void_p(weight.data_ptr()), so, sc, sy, sx, L.dptr(packed), L.stream())
+    return packed
+
+
+def conv3x3_rgb(images_nhwc, packed_weight, bias, relu=True, out=None):
+    """VGG16's first convolution in ONE launch (odet_conv3x3_rgb_f16): Conv2D(64, 3x3, 'same') + bias (+ ReLU) from the NHWC
+    image [B,H,W,3] (float32 or float16) to NHWC float16 [B,H,W,64]."""
+    x = images_nhwc
+    if x.dtype not in (torch.float32, torch.float16) or not x.is_cuda or x.dim() != 4 or int(x.shape[3]) != 3 or not x.is_contiguous():
+        raise ValueError('images must be a contiguous NHWC float32 / float16 GPU tensor [B,H,W,3]')
+    if packed_weight.dtype != torch.float16 or packed_weight.numel() != 4 * 2 * 64 * 8 or not packed_weight.is_contiguous():
+        raise ValueError('packed_weight: the result of conv3x3_rgb_pack_weights')
+    if bias.dtype != torch.float16 or bias.numel() != 64 or not bias.is_contiguous():
+        raise ValueError('bias must be a contiguous float16 [64] tensor')
+    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    shape = (B, H, W, 64)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
+    L.call('odet_conv3x3_rgb_f16', L.dptr(x), 1 if x.dtype == torch.float16 else 0, L.dptr(packed_weight), L.dptr(bias),
+           L.dptr(out), B, H, W, 1 if relu else 0, L.stream())
+    return out
+
+
 def conv3x3_f32(x, weight, bias=None, relu=False, out=None):
     """conv3x3_f16 in the reference's precision: float32 operands and result, exact-float32 matrix instructions
     (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 64 == 0."""
