@@ -1182,3 +1182,36 @@ def test_float32_detector_pass_runs_no_library_convolution_or_gemm(monkeypatch):
     out = m(img)
     assert calls == [], calls
     assert int(out[0][3].item()) == int(out_ref[0][3].item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family', ['fpn', 'c4', 'vgg16'])
+def test_float16_detector_passes_run_no_library_convolution_or_gemm(monkeypatch, family):
+    """the float16 dense paths of all three model families (ResNet-FPN, ResNet-C4, VGG16 Faster R-CNN) are this repository's
+    kernels end to end: a pass calls neither torch's convolution nor its GEMMs"""
+    import torch.nn.functional as Fn
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
+    from tf_eager_object_detection_amd.model import fpn_detector as fd
+    # (the routes send maps too small to fill the chip to the library: 'force' takes the size rule out, so the test sees
+    # whether every LAYER TYPE of the family has a kernel of its own)
+    monkeypatch.setattr(fd, '_CONV3X3_MODE', 'force')
+    torch.manual_seed(2)
+    shape = (320, 480)
+    if family == 'fpn':
+        m = ResNetFpnDetector(50, 21, shape, 300, dtype=torch.float16, max_batch=2).prepare()
+    elif family == 'c4':
+        m = ResNetC4Detector(50, 21, shape, 64, dtype=torch.float16, max_batch=2).prepare()
+    else:
+        m = Vgg16Detector(21, shape, 64, dtype=torch.float16, max_batch=2).prepare()
+    img = torch.randn((2,) + shape + (3,), device='cuda') * 50
+    m(img)
+    calls = []
+    for name in ('conv2d', 'linear'):
+        real = getattr(Fn, name)
+        monkeypatch.setattr(Fn, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
+    for name in ('addmm', '_addmm_activation', 'matmul', 'mm'):
+        real = getattr(torch, name)
+        monkeypatch.setattr(torch, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
+    m(img)
+    assert calls == [], calls
