@@ -619,7 +619,7 @@ def main():
             except Exception as ex:
                 e2e['fp16_map_delta_vs_fp32'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
             e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
-                           'mode (the reference computes in float32; ~69 % of the chip\'s 157 TFLOP/s float32 matrix peak, so '
+                           'mode (the reference computes in float32; ~77 % of the chip\'s 157 TFLOP/s float32 matrix peak, so '
                            '>= 200 img/s is out of reach of exact float32 arithmetic: 684 GFLOP per image), fp16 = throughput '
                            'mode, narrower than the reference, gated by map_delta_vs_fp32')
             result['e2e'] = e2e
