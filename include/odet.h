@@ -464,6 +464,9 @@ int odet_pointwise_dual_f32(const void* x1, int cin1, const void* x2, int cin2, 
  * images NHWC float32 [batch,H,W,3] -> patches [batch * Ho * Wo][160], Ho = (H - 1) / 2 + 1.  The convolution is then
  * odet_pointwise_f32 with cin = 160 on it (weights [64][160] in the same order). */
 int odet_stem_patches_f32(const float* images, float* patches, int batch, int H, int W, odet_stream_t stream);
+/* The same for VGG16's first convolution (vgg16_faster_rcnn.py:260-342, Conv2D(64, 3x3, 'same') on the 3-channel image):
+ * patches [batch][H][W][64] float32, row = the zero-padded 3 x 3 x 3 window in (dy, dx, channel) order, 27 values + zeros. */
+int odet_rgb_patches3x3_f32(const float* images, float* patches, int batch, int H, int W, odet_stream_t stream);
 
 /* 1x1 stride-1 convolution with its whole epilogue on the matrix cores (the third convolution
  * of a bottleneck block + Add([shortcut, x]) + Activation('relu'), model/fpn/resnet_fpn.py:154-205, frozen

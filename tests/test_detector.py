@@ -1163,14 +1163,22 @@ def test_float32_lateral_merge_dual_and_small_tile_convolutions():
 
 
 @pytest.mark.gpu
-def test_float32_detector_pass_runs_no_library_convolution_or_gemm(monkeypatch):
-    """the parity mode's dense path is this repository's kernels end to end: a float32 ResNet-50-FPN pass calls neither
-    torch's convolution nor its GEMMs (the routes would fall back to them silently otherwise)"""
+@pytest.mark.parametrize('family', ['fpn', 'c4', 'vgg16'])
+def test_float32_detector_pass_runs_no_library_convolution_or_gemm(monkeypatch, family):
+    """the parity mode's dense path is this repository's kernels end to end in all three model families: a float32 pass calls
+    neither torch's convolution nor its GEMMs (the routes would fall back to them silently otherwise)"""
     import torch.nn.functional as Fn
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
     torch.manual_seed(1)
-    m = ResNetFpnDetector(50, 21, (320, 480), 300, dtype=torch.float32, max_batch=2).prepare()
-    img = torch.randn((2, 320, 480, 3), device='cuda') * 50
+    shape = (320, 480)
+    if family == 'fpn':
+        m = ResNetFpnDetector(50, 21, shape, 300, dtype=torch.float32, max_batch=2).prepare()
+    elif family == 'c4':
+        m = ResNetC4Detector(50, 21, shape, 64, dtype=torch.float32, max_batch=2).prepare()
+    else:
+        m = Vgg16Detector(21, shape, 64, dtype=torch.float32, max_batch=2).prepare()
+    img = torch.randn((2,) + shape + (3,), device='cuda') * 50
     out_ref = m(img)
     calls = []
     for name in ('conv2d', 'linear'):
@@ -1182,6 +1190,28 @@ def test_float32_detector_pass_runs_no_library_convolution_or_gemm(monkeypatch):
     out = m(img)
     assert calls == [], calls
     assert int(out[0][3].item()) == int(out_ref[0][3].item())
+
+
+@pytest.mark.gpu
+def test_rgb_patches3x3_f32_first_convolution():
+    """odet_rgb_patches3x3_f32 + the exact-float32 pointwise GEMM = VGG16's first convolution in the parity mode: exact on
+    integer data, within 2e-5 of a float64 convolution on random data (odd sizes, batch 2)"""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for B, H, W in ((2, 17, 23), (1, 64, 96)):
+        img = torch.randint(-3, 4, (B, H, W, 3), device='cuda', generator=g).float()
+        w = torch.randint(-2, 3, (64, 3, 3, 3), device='cuda', generator=g).float()
+        b = torch.randint(-3, 4, (64,), device='cuda', generator=g).float()
+        w64 = torch.zeros((64, 64), device='cuda'); w64[:, :27] = w.permute(0, 2, 3, 1).reshape(64, 27)
+        got = ops.pointwise(ops.rgb_patches3x3_f32(img), w64, b, None, True)
+        want = F.relu(F.conv2d(img.permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1)).permute(0, 2, 3, 1)
+        assert torch.equal(got.double(), want)
+        img = torch.randn((B, H, W, 3), device='cuda', generator=g) * 50
+        w = torch.randn((64, 3, 3, 3), device='cuda', generator=g) * 0.05
+        w64 = torch.zeros((64, 64), device='cuda'); w64[:, :27] = w.permute(0, 2, 3, 1).reshape(64, 27)
+        got = ops.pointwise(ops.rgb_patches3x3_f32(img), w64, b, None, True)
+        want = F.relu(F.conv2d(img.permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1)).permute(0, 2, 3, 1)
+        assert float((got.double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
 
 
 @pytest.mark.gpu

@@ -133,6 +133,7 @@ SIGNATURES = {
     'odet_lateral_merge_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'odet_stem_patches_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'odet_rgb_patches3x3_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f16': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'odet_dense_f16_out_f32': (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _vp]),
     'odet_lateral_merge_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -548,3 +548,41 @@ extern "C" int odet_stem_patches_f32(const float* images, float* patches, int ba
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
+
+// ---- VGG16's first convolution in the float32 mode (vgg16_faster_rcnn.py:260-342: Conv2D(64, 3x3, 'same') on the 3-channel
+// image) the same way: row m = (image, y, x) holds the 3 x 3 x 3 window at (y - 1, x - 1), zero outside the image, in
+// (dy, dx, channel) order, zero-padded from 27 to 64 floats (two K-steps of the pointwise GEMM).
+__global__ void __launch_bounds__(256) k_rgb_patches3x3_f32(const float* __restrict__ img, float* __restrict__ out, int B, int H,
+                                                            int W) {
+  const long long total = (long long)B * H * W * 16;            // 16 float4 per row
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i & 15);
+    long long m = i >> 4;
+    const int x = (int)(m % W);
+    m /= W;
+    const int y = (int)(m % H);
+    const int b = (int)(m / H);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = q * 4 + e;
+      float val = 0.0f;
+      if (k < 27) {
+        const int dy = k / 9, r = k - dy * 9, dx = r / 3, c = r - dx * 3;
+        const int yy = y - 1 + dy, xx = x - 1 + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) val = img[(((long long)b * H + yy) * W + xx) * 3 + c];
+      }
+      v[e] = val;
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern "C" int odet_rgb_patches3x3_f32(const float* images, float* patches, int batch, int H, int W, odet_stream_t stream) {
+  ODET_REQUIRE(images && patches && batch > 0 && H > 0 && W > 0, "odet_rgb_patches3x3_f32: bad arguments");
+  const long long total = (long long)batch * H * W * 16;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 64);
+  hipLaunchKernelGGL(k_rgb_patches3x3_f32, dim3(grid), dim3(256), 0, (hipStream_t)stream, images, patches, batch, H, W);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}

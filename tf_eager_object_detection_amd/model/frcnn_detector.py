@@ -276,6 +276,20 @@ class Vgg16Detector(ResNetC4Detector):
                 packed = (key, ops.conv3x3_rgb_pack_weights(first.weight))
                 first._odet_packed = packed
             x = ops.conv3x3_rgb(images_nhwc, packed[1], first.bias, relu=True).permute(0, 3, 1, 2)
+        elif (images_nhwc.is_cuda and self.dtype == torch.float32 and images_nhwc.dtype == torch.float32 and images_nhwc.is_contiguous()
+              and fd._CONV3X3_MODE in ('own', 'force') and first.out_channels == 64 and 'f32' not in fd._PW_OFF
+              and 'rgb' not in fd._PW_OFF):
+            # float32 (parity mode): conv1_1 as the exact-float32 GEMM on its patch matrix (ops.rgb_patches3x3_f32)
+            own_first = True
+            key = (first.weight.data_ptr(), first.weight._version)
+            packed = getattr(first, '_odet_packed32', None)
+            if packed is None or packed[0] != key:
+                with torch.no_grad():
+                    w = torch.zeros((64, 64), dtype=torch.float32, device=first.weight.device)
+                    w[:, :27] = first.weight.permute(0, 2, 3, 1).reshape(64, 27)
+                packed = (key, w)
+                first._odet_packed32 = packed
+            x = ops.pointwise(ops.rgb_patches3x3_f32(images_nhwc), packed[1], first.bias, None, True).permute(0, 3, 1, 2)
         else:
             x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
         i = 0

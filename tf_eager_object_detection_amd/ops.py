@@ -810,6 +810,19 @@ def stem_patches_f32(images_nhwc):
     return out
 
 
+def rgb_patches3x3_f32(images_nhwc):
+    """The patch matrix of a 3x3 'same' convolution on a 3-channel image for the float32 mode (odet_rgb_patches3x3_f32): NHWC
+    float32 [B,H,W,3] -> [B,H,W,64], row = the zero-padded 3 x 3 x 3 window in (dy, dx, channel) order + zeros.  The
+    convolution is then `pointwise` on it (weights [cout, 64] in the same order)."""
+    x = images_nhwc
+    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[3] != 3:
+        raise ValueError('rgb_patches3x3_f32: images must be a contiguous float32 GPU tensor [B, H, W, 3]')
+    B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    out = torch.empty((B, H, W, 64), dtype=torch.float32, device=x.device)
+    L.call('odet_rgb_patches3x3_f32', L.dptr(x), L.dptr(out), B, H, W, L.stream())
+    return out
+
+
 def dense_f16_out_f32(x, weight, bias=None, relu=False, out=None):
     """The last dense layer with float32 results (odet_dense_f16_out_f32): ``x`` [rows, cin] / ``weight`` [cout, cin]
     float16 contiguous, ``bias`` [cout] float32 -> float32 [rows, cout]; cout % 64 == 0 (pad the weight rows with zeros)."""
