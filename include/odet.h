@@ -365,6 +365,12 @@ typedef struct {
   const void* x; void* y;
   int32_t H, W;
 } odet_conv_level_t;
+/* A stage's last convolution of VGG16 with its pooling (vgg16_faster_rcnn.py:260-342: Conv2D(3x3, 'same') + ReLU +
+ * MaxPooling2D((2, 2), 2, padding='same')) in one launch: y [batch][ceil(H/2)][ceil(W/2)][cout] float16 -- the un-pooled map
+ * is never written.  Same operand rules as odet_conv3x3_f16; max commutes with the rounding, so the result equals pooling
+ * the rounded map. */
+int odet_conv3x3_relu_pool2_f16(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
+                                int cin, int cout, odet_stream_t stream);
 int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
                             int batch, int cin, int cout, int relu, odet_stream_t stream);
 /* The whole RpnHead (base_fpn_model.py:393-434, 188-200): the 3x3 convolution of every level as above, and in its

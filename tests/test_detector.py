@@ -1245,3 +1245,21 @@ def test_float16_detector_passes_run_no_library_convolution_or_gemm(monkeypatch,
         monkeypatch.setattr(torch, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
     m(img)
     assert calls == [], calls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,cin,cout', [(2, 37, 45, 64, 64), (1, 64, 96, 64, 128), (3, 9, 7, 128, 256), (1, 1, 1, 64, 64),
+                                            (2, 150, 200, 256, 256), (1, 75, 100, 512, 512)])
+def test_conv3x3_relu_pool2_fused(B, H, W, cin, cout):
+    """odet_conv3x3_relu_pool2_f16 (a VGG16 stage's last convolution with its 2x2 / 2 'same' max-pooling in the launch):
+    IDENTICAL to pooling the separately computed relu(conv + bias) map -- rounding commutes with the maximum -- on random
+    data; odd sizes (windows that hang over the bottom / right edge), every channel-tile width"""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(H * 13 + W)
+    x = torch.randn((B, H, W, cin), device='cuda', generator=g).half()
+    w = (torch.randn((cout, cin, 3, 3), device='cuda', generator=g) * (9 * cin) ** -0.5).half().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, device='cuda', generator=g).half()          # (positive biases: a phantom pixel must not win)
+    got = ops.conv3x3_relu_pool2_f16(x, w, b)
+    full = ops.conv3x3_f16(x, w, b, relu=True)
+    want = F.max_pool2d(full.permute(0, 3, 1, 2).float(), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    assert got.shape == want.shape and torch.equal(got.float(), want)

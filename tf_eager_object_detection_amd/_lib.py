@@ -115,6 +115,7 @@ SIGNATURES = {
     'odet_rpn_head_tail_f16': (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _vp, C.c_longlong, C.c_longlong, _vp,
                                     C.c_longlong, C.c_longlong, _vp]),
     'odet_conv3x3_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'odet_conv3x3_relu_pool2_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'odet_calib_read_rows': (_i, [_vp, C.c_ulonglong, _i, _vp, _vp]),
     'odet_calib_stream_mix': (_i, [_vp, C.c_ulonglong, _vp, C.c_ulonglong, _vp, _vp, _vp]),
     'odet_rpn_head_fused_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_longlong, _vp, C.c_longlong, _vp, C.c_size_t, _vp]),

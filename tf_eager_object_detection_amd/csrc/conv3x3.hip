@@ -85,6 +85,11 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   // shortcut + Add + ReLU as ONE contraction over [y2 | x(::stride)] with the weights concatenated): K-steps below k1steps
   // read x (rows m, cin channels), the others x2 (rows of the strided H x W map, cin2 channels)
   const _Float16* x2; int cin2, k1steps; long long Min2;
+  // plain 3x3 form with the 2x2 / 2 'same' max-pooling of VGG16's stages in its epilogue (vgg16_faster_rcnn.py:260-342): the
+  // launch's pixel index runs over (image, row PAIR, column, row in pair) of the map rounded up to even sizes, so that four
+  // consecutive indices are one pooling window (the four lanes of a DPP quad) and index >> 2 is the pooled pixel; M counts
+  // those indices, Min the real pixels; y is the pooled map [batch][ceil(H/2)][ceil(W/2)][cout]
+  int pool;
 };
 
 // WN = waves along the channels (4: 256-channel tile, the form described above; 2 / 1: 128 / 64-channel tiles for the
@@ -125,7 +130,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   const uint32_t PAD = TAPS == 9 ? (uint32_t)(W + 1) * pixB : 0u;   // the descriptor starts one row + one pixel before x
   const uint32_t OOB = 0xFFFFFFF0u;
   const long long M = p.M[lv];
-  const long long Min = TAPS == 9 ? M : p.Min;           // input rows (a strided pointwise layer reads more than it writes)
+  const long long Min = (TAPS == 9 && !p.pool) ? M : p.Min;   // input rows (a strided pointwise layer reads more than it writes)
   const c3_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.x[lv])) - PAD, 0, (int)((uint32_t)Min * pixB + 2u * PAD), 0x00020000);
   const bool dual = TAPS == 1 && p.x2 != nullptr;
@@ -147,17 +152,34 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     const long long m = tile_m * TM + row;
     uint32_t mk = 0;
     if constexpr (TAPS == 9) {
+      long long src = m;
       if (m < M) {
-        const long long img = m / ((long long)H * W);
-        const int rem = (int)(m - img * H * W);
-        const int yy = rem / W, xx = rem - yy * W;
+        long long img;
+        int yy, xx;
+        bool inside = true;
+        if (p.pool) {                                      // (image, row pair, column, row in pair) of the even-rounded map
+          const int Wp = (W + 1) & ~1, Hp = (H + 1) & ~1;
+          const long long Sp = (long long)Hp * Wp;
+          img = m / Sp;
+          const int rem = (int)(m - img * Sp);
+          const int pair = rem / (2 * Wp), r2 = rem - pair * 2 * Wp;
+          xx = r2 >> 1; yy = 2 * pair + (r2 & 1);
+          inside = yy < H && xx < W;
+          src = inside ? (img * H + yy) * W + xx : 0;
+        } else {
+          img = m / ((long long)H * W);
+          const int rem = (int)(m - img * H * W);
+          yy = rem / W; xx = rem - yy * W;
+        }
+        if (inside) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
+          for (int t = 0; t < 9; ++t) {
+            const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+            if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
+          }
         }
       }
-      voffA[i] = (uint32_t)m * pixB + slot;              // (+ the tap / chunk offset as soffset; PAD is in the base)
+      voffA[i] = (uint32_t)src * pixB + slot;            // (+ the tap / chunk offset as soffset; PAD is in the base)
     } else {
       long long src = m;
       if (p.stride != 1 && m < M) {
@@ -503,6 +525,40 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
+    if constexpr (TAPS == 9 && LIN) {
+      if (p.pool) {
+        // relu(conv + bias) of this lane's pixel (0 for a pixel of the even-rounded map that the real one does not have:
+        // neutral under the maximum of ReLU outputs), then the maximum over the pooling window = the DPP quad; rounding to
+        // float16 commutes with the maximum.  Lane 0 of the quad stores the pooled pixel m >> 2.
+        const int Wp = (W + 1) & ~1, Hp = (H + 1) & ~1;
+        const long long Sp = (long long)Hp * Wp;
+        const long long img = m / Sp;
+        const int rem = (int)(m - img * Sp);
+        const int pair = rem / (2 * Wp), r2 = rem - pair * 2 * Wp;
+        const bool real = m < M && (2 * pair + (r2 & 1)) < H && (r2 >> 1) < W;
+        h8 o[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[mt][t][j] + bv[t * 4 + j];
+            v = (v < 0.0f || !real) ? 0.0f : v;
+            int vi = __builtin_bit_cast(int, v);
+            float u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+            v = u > v ? u : v;
+            vi = __builtin_bit_cast(int, v);
+            u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x4E, 0xF, 0xF, false));         // quad_perm [2,3,0,1]
+            v = u > v ? u : v;
+            o[(t * 4 + j) >> 3][(t * 4 + j) & 7] = (_Float16)v;
+          }
+        if ((l15 & 3) == 0 && m < M) {
+          _Float16* dst = p.y[lv] + (m >> 2) * cout + c0;
+          *reinterpret_cast<h8*>(dst) = o[0];
+          *reinterpret_cast<h8*>(dst + HOFF) = o[1];
+        }
+        continue;
+      }
+    }
     if (m < M) {
       h8 o[2];
       if constexpr (TAPS == 1) {
@@ -641,7 +697,7 @@ struct Conv3x3Block {            // the fused bottleneck tail (nullable in conv3
 
 static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,
                           int cin, int cout, int relu, hipStream_t st, const Conv3x3Tail* tail = nullptr,
-                          const Conv3x3Block* blk = nullptr) {
+                          const Conv3x3Block* blk = nullptr, int pool = 0) {
   ODET_REQUIRE(levels && w, "odet_conv3x3_f16: null pointer");
   ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_f16: num_levels %d out of range", num_levels);
   ODET_REQUIRE(batch > 0, "odet_conv3x3_f16: bad batch");
@@ -682,9 +738,11 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     const odet_conv_level_t& L = levels[l < num_levels ? l : 0];
     ODET_REQUIRE(L.x && (L.y || tail || blk) && L.H > 0 && L.W > 0, "odet_conv3x3_f16: bad level %d", l);
-    const long long M = (long long)batch * L.H * L.W;
+    const long long Mreal = (long long)batch * L.H * L.W;
+    // (pooled form: the launch's index space is the map rounded up to even sizes)
+    const long long M = pool ? (long long)batch * ((L.H + 1) & ~1) * ((L.W + 1) & ~1) : Mreal;
     // 32-bit byte offsets into x (+ the padding rows of the descriptor) and the out-of-range marker
-    ODET_REQUIRE((unsigned long long)M * cin * 2ull + 2ull * (L.W + 1) * cin * 2ull < 0xFFFFFFF0ull,
+    ODET_REQUIRE((unsigned long long)Mreal * cin * 2ull + 2ull * (L.W + 1) * cin * 2ull < 0xFFFFFFF0ull,
                  "odet_conv3x3_f16: level %d input larger than 4 GiB", l);
     p.x[l] = (const _Float16*)L.x; p.y[l] = (_Float16*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
     p.px[l] = (long long)L.H * L.W;
@@ -694,6 +752,11 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   p.w3 = nullptr; p.b3 = nullptr; p.res = nullptr; p.y3 = nullptr; p.n3 = 0; p.relu3 = 0;
   p.stride = 1; p.Ho = p.Wo = 0; p.Min = 0; p.top = nullptr; p.th = p.tw = 0; p.tys = p.txs = 0.0f;
   p.y32 = nullptr; p.bias32 = nullptr; p.x2 = nullptr; p.cin2 = 0; p.k1steps = 0; p.Min2 = 0;
+  p.pool = pool ? 1 : 0;
+  if (pool) {
+    ODET_REQUIRE(num_levels == 1 && !tail && !blk && relu, "odet_conv3x3_relu_pool2_f16: one map, plain form, with ReLU");
+    p.Min = (long long)batch * levels[0].H * levels[0].W;
+  }
   if (blk) {
     ODET_REQUIRE(blk->w3 && blk->b3 && blk->y3 && bias, "odet_conv3x3_conv1x1_f16: null pointer");
     ODET_REQUIRE(cout == 256 || cout == 128 || cout == 64,
@@ -832,6 +895,13 @@ extern "C" int odet_conv3x3_f16(const void* x, const void* w, const void* bias, 
   return conv3x3_launch(&one, 1, w, bias, batch, cin, cout, relu, (hipStream_t)stream);
 }
 
+extern "C" int odet_conv3x3_relu_pool2_f16(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W,
+                                           int cin, int cout, odet_stream_t stream) {
+  ODET_REQUIRE(x && y, "odet_conv3x3_relu_pool2_f16: null pointer");
+  const odet_conv_level_t one{x, y, H, W};
+  return conv3x3_launch(&one, 1, w, bias, batch, cin, cout, 1, (hipStream_t)stream, nullptr, nullptr, 1);
+}
+
 extern "C" int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias,
                                        int batch, int cin, int cout, int relu, odet_stream_t stream) {
   return conv3x3_launch(levels, num_levels, w, bias, batch, cin, cout, relu, (hipStream_t)stream);
@@ -908,6 +978,7 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
   p.stride = stride; p.Ho = Ho; p.Wo = Wo; p.Min = Min;
   p.y32 = epi.y32; p.bias32 = epi.bias32;
   p.x2 = (const _Float16*)epi.x2; p.cin2 = epi.x2 ? epi.cin2 : 0; p.k1steps = cin / C3_BK; p.Min2 = (long long)batch * H * W;
+  p.pool = 0;
   // Tile: channels 256 / 128 / 64 (WN = 4 / 2 / 1 waves along the channels) x pixels (8 / WN) * 16 * MT.  One workgroup
   // per CU (128 KB of LDS), so the launch runs in rounds of 256 workgroups; per K-step a workgroup needs about
   // max(matrix cycles TM * TN / 32, staging cycles 2 * (TM + TN)).  Pick the pair with the least rounds x that.

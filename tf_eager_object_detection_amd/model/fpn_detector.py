@@ -234,6 +234,11 @@ def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=No
     """max_pool(relu(conv(x) + bias)): on the GPU the convolution runs without its bias and ONE pass
     (ops.bias_relu_maxpool) reads its output once and writes the pooled map; torch formulation elsewhere."""
     if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
+        if (_own_conv3x3(conv, x, pad) and x.dtype == torch.float16 and kernel == 2 and stride == 2 and pool_pad == 0 and ceil_mode
+                and conv.bias is not None and 'pool' not in _PW_OFF):
+            # Conv2D + ReLU + MaxPooling2D((2, 2), 2, 'same') in the convolution's own launch (its pixel order makes a pooling
+            # window four neighbouring lanes): the un-pooled map is never written
+            return ops.conv3x3_relu_pool2_f16(x.permute(0, 2, 3, 1), conv.weight, conv.bias).permute(0, 3, 1, 2)
         if _own_conv3x3(conv, x, pad):
             # the hand-written implicit GEMM without its epilogue, then the fused bias + ReLU + pooling pass
             yn = (ops.conv3x3_f32 if x.dtype == torch.float32 else ops.conv3x3_f16)(x.permute(0, 2, 3, 1), conv.weight)

@@ -491,6 +491,26 @@ def conv3x3_f16(x, weight, bias=None, relu=False, out=None):
     return _conv3x3(torch.float16, x, weight, bias, relu, out)
 
 
+def conv3x3_relu_pool2_f16(x, weight, bias, out=None):
+    """max_pool2x2/2 'same' (relu(conv3x3(x) + bias)) in ONE launch (odet_conv3x3_relu_pool2_f16; a VGG16 stage's last
+    convolution with its pooling, vgg16_faster_rcnn.py:260-342): operands as conv3x3_f16, -> NHWC float16
+    [B, ceil(H/2), ceil(W/2), cout]; the un-pooled map is never written."""
+    if x.dtype != torch.float16 or not x.is_cuda or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError('x must be a contiguous NHWC float16 GPU tensor [B,H,W,cin]')
+    B, H, W, cin = (int(v) for v in x.shape)
+    cout = int(weight.shape[0])
+    w = _conv3x3_weight(weight, cin, cout, torch.float16, 'float16')
+    if bias is None or bias.dtype != torch.float16 or bias.numel() != cout or not bias.is_contiguous():
+        raise ValueError('bias must be a contiguous float16 [cout] tensor')
+    shape = (B, (H + 1) // 2, (W + 1) // 2, cout)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float16 tensor %s' % (shape,))
+    L.call('odet_conv3x3_relu_pool2_f16', L.dptr(x), L.dptr(w), L.dptr(bias), L.dptr(out), B, H, W, cin, cout, L.stream())
+    return out
+
+
 def conv3x3_f16_levels(xs, weight, bias=None, relu=False, outs=None):
     """conv3x3_f16 with shared weights over a list of NHWC float16 maps [B,H_l,W_l,cin] (the RpnHead over the pyramid
     levels) in ONE launch; -> list of [B,H_l,W_l,cout]."""
