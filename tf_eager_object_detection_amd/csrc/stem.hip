@@ -242,7 +242,7 @@ extern "C" int odet_stem_conv7_pool3_f16(const void* images, int images_f16, con
 // convolution + epilogue pass the 64-channel output was written, read back and written again (1.5 ms for 32 images of
 // 600 x 800 + the image's float16 copy); here it is written once: the kernel runs at the store rate of its output.
 //
-//  * WORKGROUP (4 waves) = 8 rows x 32 columns of output pixels.  The 11 x 36 image pixels around them are staged in LDS
+//  * WORKGROUP (4 waves) = 16 rows x 32 columns of output pixels.  The 19 x 36 image pixels around them are staged in LDS
 //    as 4 halfs per pixel (the fourth is zero; pixels outside the image are the zero padding).
 //  * Implicit GEMM on the matrix cores, the stem kernel's way: D = W_tile . X_tile^T with v_mfma_f32_16x16x32_f16, the B
 //    operand = 16 consecutive pixels of a row.  One MFMA takes TWO kernel rows: lane (pixel x, q) reads the 16 bytes of
@@ -251,9 +251,11 @@ extern "C" int odet_stem_conv7_pool3_f16(const void* images, int images_f16, con
 //    weights; the matrix pipe is idle most of the time either way).
 //  * The weight rows are packed so that a lane's results of channel tiles (0, 1) / (2, 3) are 8 consecutive channels:
 //    with the four lanes of a pixel one store instruction writes 64 contiguous bytes, a pixel tile 2 KB.
-#define RG_TH 8                       // output rows of a tile
+#ifndef RG_TH
+#define RG_TH 16                      // output rows of a tile (8: 650 us, 16: 618 us, 32: 626 us for 32 images of 600 x 800)
+#endif
 #define RG_TW 32                      // output columns
-#define RG_PR (RG_TH + 3)             // patch rows: y0 - 1 .. y0 + 9 (kernel row "3" of the second MFMA meets zero weights)
+#define RG_PR (RG_TH + 3)             // patch rows: y0 - 1 .. y0 + RG_TH + 1 (kernel row "3" of the second MFMA meets zero weights)
 #define RG_PC (RG_TW + 4)             // patch columns: x0 - 1 .. x0 + 34
 #define RG_THREADS 256
 
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(RG_THREADS) k_conv3x3_rgb_f16(RgbConvParams p)
   const st_h8 b0 = *reinterpret_cast<const st_h8*>(p.bias + 8 * lq), b1 = *reinterpret_cast<const st_h8*>(p.bias + 32 + 8 * lq);
 
   {
-    constexpr int TRIPS = (RG_PR * RG_PC + RG_THREADS - 1) / RG_THREADS;        // 2
+    constexpr int TRIPS = (RG_PR * RG_PC + RG_THREADS - 1) / RG_THREADS;        // 3
     const long long img_base = (long long)b * p.H * p.W * 3;
     float v[TRIPS][3];
 #pragma unroll
@@ -315,10 +317,10 @@ __global__ void __launch_bounds__(RG_THREADS) k_conv3x3_rgb_f16(RgbConvParams p)
   }
   __syncthreads();
 
-  // pixel tiles: 16 consecutive pixels of a row; tile t = (row t >> 1, columns 16 (t & 1) ..); a wave takes four
+  // pixel tiles: 16 consecutive pixels of a row; tile t = (row t >> 1, columns 16 (t & 1) ..); a wave takes RG_TH / 2
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const int t = wv * 4 + n;
+  for (int n = 0; n < RG_TH / 2; ++n) {
+    const int t = wv * (RG_TH / 2) + n;
     const int ry = t >> 1, cx = (t & 1) * 16 + l15;                 // output pixel inside the tile
     // patch pixel (row ry + 2 kp + (lq >> 1), column cx + 2 (lq & 1)) and its right neighbour: 16 bytes at an 8-byte
     // aligned address (two 8-byte reads)
