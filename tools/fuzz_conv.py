@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Seeded sweep of the hand-written convolutions against torch on integer-valued data (exact comparison): random map
 sizes (incl. one-pixel rows / columns), batches, channel counts, so that every workgroup-tile choice of conv3x3_launch
-and the edge handling of the fused forms (RpnHead, bottleneck tail, stem) and of the pointwise forms (1x1 / strided /
-shortcut, lateral + merge, two sources along K; float16 and float32) are exercised.
+and the edge handling of the fused forms (RpnHead, bottleneck tail with 64 / 128 / 256 middle channels, stem, VGG16's first
+convolution, convolution + pooling) and of the pointwise forms (1x1 / strided / shortcut, lateral + merge, two sources along K;
+float16 and float32) are exercised.
 
     python tools/fuzz_conv.py [--cases N] [--seed S]"""
 import argparse, os, sys
@@ -21,9 +22,29 @@ def main():
     sparse = lambda shape, pct, lo, hi: ((torch.randint(0, 100, shape, device='cuda', generator=g) < pct).half()
                                          * torch.randint(lo, hi + 1, shape, device='cuda', generator=g).half())
     for case in range(a.cases):
-        kind = case % 7
+        kind = case % 9
         B, H, W = ri(1, 3), ri(1, 70), ri(1, 90)
-        if kind >= 4:      # pointwise forms (round 3), float16 and float32: 1x1 / strided / shortcut, lateral + merge, two sources
+        if kind == 7:      # VGG16's first convolution straight from the image (round 3)
+            img = torch.randint(-3, 4, (B, H, W, 3), device='cuda', generator=g).to(torch.float16 if case & 8 else torch.float32)
+            w = torch.randint(-2, 3, (64, 3, 3, 3), device='cuda', generator=g).half()
+            b = torch.randint(-3, 4, (64,), device='cuda', generator=g).half()
+            relu = bool(case & 16)
+            got = ops.conv3x3_rgb(img, ops.conv3x3_rgb_pack_weights(w), b, relu=relu)
+            want = F.conv2d(img.permute(0, 3, 1, 2).float(), w.float(), b.float(), 1, 1)
+            want = (F.relu(want) if relu else want).permute(0, 2, 3, 1)
+            assert torch.equal(got.float(), want), ('conv3x3_rgb', B, H, W)
+            continue
+        if kind == 8:      # 3x3 convolution + ReLU + 2x2 'same' max-pooling in one launch (round 3)
+            cin, cout = 64 * ri(1, 4), 64 * ri(1, 8)
+            x = torch.randint(-2, 3, (B, H, W, cin), device='cuda', generator=g).half()
+            w = sparse((cout, cin, 3, 3), 8, -2, 2).contiguous(memory_format=torch.channels_last)
+            b = torch.randint(-3, 4, (cout,), device='cuda', generator=g).half()
+            got = ops.conv3x3_relu_pool2_f16(x, w, b)
+            want = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b.float(), 1, 1))
+            want = F.max_pool2d(want, 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+            assert float(want.abs().max()) < 2048 and torch.equal(got.float(), want), ('conv3x3_relu_pool2', B, H, W, cin, cout)
+            continue
+        if 4 <= kind <= 6:      # pointwise forms (round 3), float16 and float32: 1x1 / strided / shortcut, lateral + merge, two sources
             f32 = bool(case & 8)
             dt = torch.float32 if f32 else torch.float16
             gran = 32 if f32 else 64
@@ -95,17 +116,18 @@ def main():
             assert float(ws.abs().max()) < 2048 and torch.equal(sc, ws) and torch.equal(dl, wd), ('rpn_head_fused', B, shapes, cin, cout, A)
         elif kind == 2:    # fused bottleneck tail
             cin, n3 = 64 * ri(1, 4), 64 * ri(1, 16)
+            cm = (64, 128, 256)[ri(0, 2)]              # the 3x3 convolution's channels (conv2 / conv3 / conv4 of ResNet)
             x = sparse((B, H, W, cin), 4, 1, 1)
-            w2 = sparse((256, cin, 3, 3), 4, -2, 2).contiguous(memory_format=torch.channels_last)
-            b2 = torch.randint(-3, 4, (256,), device='cuda', generator=g).half()
-            w3 = sparse((n3, 256), 10, -2, 2)
+            w2 = sparse((cm, cin, 3, 3), 4, -2, 2).contiguous(memory_format=torch.channels_last)
+            b2 = torch.randint(-3, 4, (cm,), device='cuda', generator=g).half()
+            w3 = sparse((n3, cm), 10, -2, 2)
             b3 = torch.randint(-3, 4, (n3,), device='cuda', generator=g).half()
             r = torch.randint(-4, 5, (B, H, W, n3), device='cuda', generator=g).half() if case & 4 else None
             got = ops.conv3x3_conv1x1_f16(x, w2, b2, w3, b3, residual=r, relu=True)
             t = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w2.float(), b2.float(), 1, 1))
-            o = F.conv2d(t, w3.float().reshape(n3, 256, 1, 1), b3.float()).permute(0, 2, 3, 1)
+            o = F.conv2d(t, w3.float().reshape(n3, cm, 1, 1), b3.float()).permute(0, 2, 3, 1)
             want = F.relu(o + r.float() if r is not None else o)
-            assert float(want.abs().max()) < 2048 and torch.equal(got.float(), want), ('block tail', B, H, W, cin, n3)
+            assert float(want.abs().max()) < 2048 and torch.equal(got.float(), want), ('block tail', B, H, W, cin, cm, n3)
         else:              # stem
             H2, W2 = ri(7, 140), ri(7, 180)
             img = torch.randint(-3, 4, (B, H2, W2, 3), device='cuda', generator=g).to(torch.float16 if case & 4 else torch.float32)
