@@ -593,10 +593,10 @@ def main():
             # (float16: 30 images per pass -- conv4's 50 x 84 maps then cut into 492 of the 256-pixel workgroup tiles, two full
             # rounds of the 256 CUs (15 images: one round); 8 / 16 images leave a fifth of a round empty: same box 930 / 975 vs
             # 1070 at 15 and 1105 img/s at 30 images per pass)
-            # (float32: 15 images per pass for the same reason -- the own exact-float32 kernels 141 img/s at 4 images, 172 at 15;
-            # the library route 158 / 171)
+            # (float32: 30 images per pass for the same reason -- the own exact-float32 kernels 141 img/s at 4 images, 177 at 15,
+            # 180 at 30; the library route 158 / 171 at 4 / 15)
             # (60 images per float16 pass: four rounds of tiles on conv4 -- +2 % over 30, which is +3 % over 15)
-            for name, b in (('fp32', 15), ('fp16', 60)):
+            for name, b in (('fp32', 30), ('fp16', 60)):
                 try:
                     e2e[name] = e2e_record(name, b)
                 except Exception as ex:               # the headline record must not depend on the second one

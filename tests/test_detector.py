@@ -1263,3 +1263,26 @@ def test_conv3x3_relu_pool2_fused(B, H, W, cin, cout):
     full = ops.conv3x3_f16(x, w, b, relu=True)
     want = F.max_pool2d(full.permute(0, 3, 1, 2).float(), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
     assert got.shape == want.shape and torch.equal(got.float(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family', ['fpn', 'vgg16'])
+def test_float32_patch_matrix_goes_through_in_groups_below_4_gib(monkeypatch, family):
+    """the float32 mode's first convolution runs as a GEMM on a patch matrix addressed with 32-bit offsets: a batch whose
+    patches would exceed the limit goes through in groups of images -- same features as in one piece"""
+    from tf_eager_object_detection_amd.model import fpn_detector as fd
+    from tf_eager_object_detection_amd.model.frcnn_detector import Vgg16Detector
+    monkeypatch.setattr(fd, '_CONV3X3_MODE', 'force')
+    torch.manual_seed(3)
+    shape = (96, 128)
+    m = (fd.ResNetFpnDetector(50, 21, shape, 64, dtype=torch.float32, max_batch=3) if family == 'fpn'
+         else Vgg16Detector(21, shape, 32, dtype=torch.float32, max_batch=3)).prepare()
+    img = torch.randn((3,) + shape + (3,), device='cuda') * 50
+    with torch.no_grad():
+        whole = m.features(img)
+        per_image = (48 * 64 * 160 * 4) if family == 'fpn' else (96 * 128 * 64 * 4)
+        monkeypatch.setattr(fd, '_PATCH_BYTES_MAX', per_image + 1)            # one image per group
+        parts = m.features(img)
+    whole = whole if isinstance(whole, (list, tuple)) else [whole]
+    parts = parts if isinstance(parts, (list, tuple)) else [parts]
+    assert len(whole) == len(parts) and all(torch.equal(a, b) for a, b in zip(whole, parts))

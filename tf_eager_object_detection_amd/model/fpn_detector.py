@@ -199,6 +199,10 @@ def _own_conv3x3(conv, x, pad=None):
     return _CONV3X3_MODE == 'force' or ((m + 127) // 128) * tiles_n >= 100
 
 
+# the float32 mode's patch matrices (stem, VGG16's first convolution) are addressed with 32-bit byte offsets
+_PATCH_BYTES_MAX = 0xF0000000
+
+
 def _stem(conv1, images_nhwc, dtype):
     """conv1_pad + 7x7/2 'valid' + folded BN + ReLU + pool1_pad + 3x3/2 max-pooling (resnet_fpn.py:262-289).  float16 on the
     GPU: ONE launch from the image (ops.stem_conv7_pool3: the 64-channel convolution output, 273 MB at batch 8, never
@@ -224,8 +228,16 @@ def _stem(conv1, images_nhwc, dtype):
                 w[:, :147] = conv1.weight.permute(0, 2, 3, 1).reshape(64, 147)
             packed = (key, w)
             conv1._odet_packed32 = packed
-        y = ops.pointwise(ops.stem_patches_f32(images_nhwc), packed[1], None)
-        return ops.bias_relu_maxpool(y, conv1.bias, 3, 2, 1, False).permute(0, 3, 1, 2)
+        # (the patch matrix is addressed with 32-bit byte offsets: images go through in groups that keep it below 4 GiB)
+        B, H, W = (int(v) for v in images_nhwc.shape[:3])
+        per_image = ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * 160 * 4
+        step = max(1, min(B, _PATCH_BYTES_MAX // per_image))
+        parts = []
+        for i in range(0, B, step):
+            y = ops.pointwise(ops.stem_patches_f32(images_nhwc[i:i + step]), packed[1], None)
+            parts.append(ops.bias_relu_maxpool(y, conv1.bias, 3, 2, 1, False))
+        y = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        return y.permute(0, 3, 1, 2)
     x = images_nhwc.to(dtype).permute(0, 3, 1, 2)                               # NHWC memory, NCHW view
     return _conv_relu_pool(conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
 

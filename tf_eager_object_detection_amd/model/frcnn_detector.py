@@ -289,7 +289,12 @@ class Vgg16Detector(ResNetC4Detector):
                     w[:, :27] = first.weight.permute(0, 2, 3, 1).reshape(64, 27)
                 packed = (key, w)
                 first._odet_packed32 = packed
-            x = ops.pointwise(ops.rgb_patches3x3_f32(images_nhwc), packed[1], first.bias, None, True).permute(0, 3, 1, 2)
+            # (32-bit byte offsets into the patch matrix: groups of images that keep it below 4 GiB)
+            Bn, Hn, Wn = (int(v) for v in images_nhwc.shape[:3])
+            step = max(1, min(Bn, fd._PATCH_BYTES_MAX // (Hn * Wn * 64 * 4)))
+            parts = [ops.pointwise(ops.rgb_patches3x3_f32(images_nhwc[i:i + step]), packed[1], first.bias, None, True)
+                     for i in range(0, Bn, step)]
+            x = (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).permute(0, 3, 1, 2)
         else:
             x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
         i = 0
