@@ -617,6 +617,12 @@ int odet_exec_submit_batch(odet_exec_t* ex, int worker, const odet_fpn_step_t* c
 int odet_exec_wait(odet_exec_t* ex);
 const char* odet_exec_last_error(odet_exec_t* ex);
 
+/* Diagnostics only (tools/exp, tools/r04; the product never calls it; no reference counterpart): forces the workgroup
+ * tile of this process's next float16 3x3 (form 0; the fused bottleneck tail included) / pointwise (form 1) launches --
+ * {nw waves, wn waves along the channels, mt 16-pixel tiles per wave, ns LDS stages}: (nw / wn) * 16 * mt pixels x 64 * wn
+ * channels; ns == 2 the half-step-pipelined loop, ns > 2 the ring forms for launches with few pixels.  nw = 0 clears. */
+int odet_debug_conv_tile(int form, int nw, int wn, int mt, int ns);
+
 #ifdef __cplusplus
 }
 #endif

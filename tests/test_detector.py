@@ -9,6 +9,8 @@ import torch.nn.functional as F
 from oracle import c_oracle as co
 from tf_eager_object_detection_amd import synthetic as syn
 
+import torch_reference as tref
+
 
 def _np_legacy_resize(x, oh, ow):
     """tf.image.resize_bilinear (TF 1.x, align_corners=False) restated with numpy loops; x [H,W]."""
@@ -123,7 +125,7 @@ def test_bias_act_epilogue(C):
 def test_detector_block_with_fused_epilogue_matches_torch_formulation():
     from tf_eager_object_detection_amd.model import fpn_detector as fd
     torch.manual_seed(5)
-    blk = fd._Block(64, 32, 2, True).cuda().to(memory_format=torch.channels_last).eval()
+    blk = fd._Block(64, 64, 2, True).cuda().to(memory_format=torch.channels_last).eval()
     with torch.no_grad():
         for m in (blk.short, blk.c1, blk.c2, blk.c3):
             m.bias.normal_(0, 0.1)
@@ -142,10 +144,11 @@ def test_feature_map_sizes_match_anchor_grids_cpu():
     m = ResNetFpnDetector(50, 21, (160, 224), 100, dtype=torch.float32).eval()
     img = torch.zeros((1, 160, 224, 3))
     with torch.no_grad():
-        ps = m.features(img)
+        ps = tref.fpn_features(m, img)             # (the product has no CPU route: the plain-torch formulation of the same modules)
     want = syn.fpn_level_shapes((160, 224))
     assert [tuple(p.shape[2:]) for p in ps] == [tuple(s) for s in want]
-    sc, dl = m.rpn(ps)
+    with torch.no_grad():
+        sc, dl = tref.fpn_rpn(m, ps)
     assert sc.shape == (1, syn.num_fpn_anchors((160, 224)), 2) and dl.shape[-1] == 4
 
 
@@ -216,8 +219,8 @@ def test_c4_feature_map_size_matches_anchor_grid_cpu():
     from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector
     m = ResNetC4Detector(50, 21, (160, 224), 50, dtype=torch.float32).eval()
     with torch.no_grad():
-        c4 = m.features(torch.zeros((1, 160, 224, 3)))
-        sc, dl = m.rpn(c4)
+        c4 = tref.c4_features(m, torch.zeros((1, 160, 224, 3)))
+        sc, dl = tref.frcnn_rpn(m, c4)
     assert tuple(c4.shape) == (1, 1024, 10, 14)
     assert sc.shape == (1, 10 * 14, 18) and dl.shape == (1, 10 * 14 * 9, 4)
 
@@ -263,8 +266,8 @@ def test_vgg16_feature_map_size_matches_anchor_grid_cpu():
     from tf_eager_object_detection_amd.model.frcnn_detector import Vgg16Detector
     m = Vgg16Detector(21, (150, 200), 50, dtype=torch.float32).eval()
     with torch.no_grad():
-        f = m.features(torch.zeros((1, 150, 200, 3)))
-        sc, dl = m.rpn(f)
+        f = tref.vgg16_features(m, torch.zeros((1, 150, 200, 3)))
+        sc, dl = tref.frcnn_rpn(m, f)
     assert tuple(f.shape) == (1, 512, 10, 13)                      # ceil(150/16) x ceil(200/16)
     assert sc.shape == (1, 130, 18) and dl.shape == (1, 130 * 9, 4)
 
@@ -714,9 +717,9 @@ def test_conv3x3_f32_implicit_gemm(B, H, W, cin, cout):
 
 
 @pytest.mark.gpu
-def test_fp32_rpn_head_own_conv_matches_library_route(monkeypatch):
-    """The float32 detector's RpnHead through the grouped hand-written convolution (ops.conv3x3_f32_levels) against the
-    same head through the library convolution: float32 accumulation-order noise only, and the same proposals."""
+def test_fp32_rpn_head_own_conv_matches_library_route():
+    """The float32 detector's RpnHead (grouped exact-float32 convolution + exact-float32 GEMM + pack) against the plain-torch
+    formulation on the library's convolutions: float32 accumulation-order noise only; and bit-reproducible."""
     from tf_eager_object_detection_amd.model import fpn_detector as fd
     torch.manual_seed(5)
     shape = (256, 352)
@@ -725,18 +728,10 @@ def test_fp32_rpn_head_own_conv_matches_library_route(monkeypatch):
     img = torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
     with torch.no_grad():
         ps = m.features(img)
-        monkeypatch.setattr(fd, '_CONV3X3_MODE', 'own')
         s_own, d_own = m.rpn(ps)
         s_own2, d_own2 = m.rpn(ps)
-        monkeypatch.setattr(fd, '_CONV3X3_MODE', 'lib')
-        s_lib, d_lib = m.rpn(ps)
-    from tf_eager_object_detection_amd import ops
-    xs = [p.permute(0, 2, 3, 1).contiguous() for p in ps]
-    h1 = ops.conv3x3_f32_levels(xs, m.rpn_conv.weight, m.rpn_conv.bias, relu=True)
-    h2 = ops.conv3x3_f32_levels(xs, m.rpn_conv.weight, m.rpn_conv.bias, relu=True)
-    assert all(torch.equal(a, b) for a, b in zip(h1, h2))                  # the hand-written kernel is deterministic
-    # (the library's 1x1 convolution behind it may split K with atomics: the head's outputs repeat to rounding only)
-    assert float((s_own - s_own2).abs().max().item()) <= 1e-4 and float((d_own - d_own2).abs().max().item()) <= 1e-4
+        s_lib, d_lib = tref.fpn_rpn(m, ps)
+    assert torch.equal(s_own, s_own2) and torch.equal(d_own, d_own2)        # the hand-written kernels are deterministic
     scale = max(1.0, float(s_lib.abs().max().item()), float(d_lib.abs().max().item()))
     assert float((s_own - s_lib).abs().max().item()) <= 1e-4 * scale
     assert float((d_own - d_lib).abs().max().item()) <= 1e-4 * scale
@@ -1180,13 +1175,7 @@ def test_float32_detector_pass_runs_no_library_convolution_or_gemm(monkeypatch, 
         m = Vgg16Detector(21, shape, 64, dtype=torch.float32, max_batch=2).prepare()
     img = torch.randn((2,) + shape + (3,), device='cuda') * 50
     out_ref = m(img)
-    calls = []
-    for name in ('conv2d', 'linear'):
-        real = getattr(Fn, name)
-        monkeypatch.setattr(Fn, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
-    for name in ('addmm', '_addmm_activation', 'matmul', 'mm'):
-        real = getattr(torch, name)
-        monkeypatch.setattr(torch, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
+    calls = _count_library_calls(monkeypatch)
     out = m(img)
     assert calls == [], calls
     assert int(out[0][3].item()) == int(out_ref[0][3].item())
@@ -1214,37 +1203,87 @@ def test_rgb_patches3x3_f32_first_convolution():
         assert float((got.double() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('family', ['fpn', 'c4', 'vgg16'])
-def test_float16_detector_passes_run_no_library_convolution_or_gemm(monkeypatch, family):
-    """the float16 dense paths of all three model families (ResNet-FPN, ResNet-C4, VGG16 Faster R-CNN) are this repository's
-    kernels end to end: a pass calls neither torch's convolution nor its GEMMs"""
+def _count_library_calls(monkeypatch):
+    """intercepts torch's convolution / GEMM entry points; returns the list their names are appended to"""
     import torch.nn.functional as Fn
-    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
-    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
-    from tf_eager_object_detection_amd.model import fpn_detector as fd
-    # (the routes send maps too small to fill the chip to the library: 'force' takes the size rule out, so the test sees
-    # whether every LAYER TYPE of the family has a kernel of its own)
-    monkeypatch.setattr(fd, '_CONV3X3_MODE', 'force')
-    torch.manual_seed(2)
-    shape = (320, 480)
-    if family == 'fpn':
-        m = ResNetFpnDetector(50, 21, shape, 300, dtype=torch.float16, max_batch=2).prepare()
-    elif family == 'c4':
-        m = ResNetC4Detector(50, 21, shape, 64, dtype=torch.float16, max_batch=2).prepare()
-    else:
-        m = Vgg16Detector(21, shape, 64, dtype=torch.float16, max_batch=2).prepare()
-    img = torch.randn((2,) + shape + (3,), device='cuda') * 50
-    m(img)
     calls = []
     for name in ('conv2d', 'linear'):
         real = getattr(Fn, name)
         monkeypatch.setattr(Fn, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
-    for name in ('addmm', '_addmm_activation', 'matmul', 'mm'):
+    for name in ('addmm', '_addmm_activation', 'matmul', 'mm', 'bmm', 'conv2d'):
         real = getattr(torch, name)
         monkeypatch.setattr(torch, name, lambda *a, _r=real, _n=name, **k: calls.append(_n) or _r(*a, **k))
+    return calls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family,shape,batch', [('fpn', (320, 480), 2), ('c4', (320, 480), 2), ('vgg16', (320, 480), 2),
+                                                ('fpn', (800, 1333), 1), ('fpn', (800, 1333), 4)])
+def test_float16_detector_passes_run_no_library_convolution_or_gemm(monkeypatch, family, shape, batch):
+    """the float16 dense paths of all three model families (ResNet-FPN, ResNet-C4, VGG16 Faster R-CNN) are this repository's
+    kernels end to end AT EVERY MAP SIZE -- small maps (every layer type), and the BASELINE configs' own shape and batch size
+    (1 x 3 x 800 x 1333, ResNet-101: conv4 / conv5 / the small neck levels on the ring form of the implicit GEMM): a pass calls
+    neither torch's convolution nor its GEMMs, and the detectors have no route that could (model/fpn_detector.py)."""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
+    torch.manual_seed(2)
+    depth = 101 if shape == (800, 1333) else 50
+    if family == 'fpn':
+        m = ResNetFpnDetector(depth, 21, shape, 300, dtype=torch.float16, max_batch=batch).prepare()
+    elif family == 'c4':
+        m = ResNetC4Detector(depth, 21, shape, 64, dtype=torch.float16, max_batch=batch).prepare()
+    else:
+        m = Vgg16Detector(21, shape, 64, dtype=torch.float16, max_batch=batch).prepare()
+    img = torch.randn((batch,) + shape + (3,), device='cuda') * 50
     m(img)
+    calls = _count_library_calls(monkeypatch)
+    out = m(img)
     assert calls == [], calls
+    assert all(int(f) == 1 for f in m._steps.nms_done_all[:batch].tolist())
+    assert torch.isfinite(out[0][0]).all()
+
+
+@pytest.mark.gpu
+def test_detectors_have_no_library_or_cpu_route():
+    """a layer no kernel takes raises (no silent library convolution, no CPU formulation inside the package)"""
+    from tf_eager_object_detection_amd.model import fpn_detector as fd
+    import inspect
+    src = inspect.getsource(fd) + inspect.getsource(__import__('tf_eager_object_detection_amd.model.frcnn_detector', fromlist=['x']))
+    for needle in ('F.conv2d', 'F.linear', 'torch.addmm', '_addmm_activation', 'torch.nn.functional', 'os.environ', 'getenv'):
+        assert needle not in src, needle
+    c = fd._conv(48, 64, 3, 1, 1).cuda().half()                          # 48 input channels: not a multiple of 64
+    x = torch.zeros(1, 48, 8, 8, device='cuda', dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(RuntimeError, match='no kernel'):
+        fd._conv_epi(c, x)
+    m = fd.ResNetFpnDetector(50, 21, (64, 64), 10, dtype=torch.float32)
+    with pytest.raises(RuntimeError, match='no kernel'):
+        m.features(torch.zeros(1, 64, 64, 3))                            # CPU tensors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.float16])
+def test_detector_dense_parts_match_the_plain_torch_formulation(dt):
+    """features / rpn / roi_head of the ResNet-FPN detector (this repository's kernels) against the plain-torch formulation of
+    the same modules (library convolutions, float32 arithmetic on the same weights)"""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(11)
+    shape = (192, 256)
+    m = ResNetFpnDetector(50, 21, shape, 64, dtype=dt, max_batch=2).prepare()
+    img = torch.randn((2,) + shape + (3,), device='cuda') * 40
+    with torch.no_grad():
+        ps = m.features(img)
+        sc, dl = m.rpn(ps)
+        ref = ResNetFpnDetector(50, 21, shape, 64, dtype=torch.float32, max_batch=2)
+        ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
+        ref = ref.cuda().eval()
+        ps_ref = tref.fpn_features(ref, img)
+        sc_ref, dl_ref = tref.fpn_rpn(ref, [p.float() for p in ps])       # (the head on the SAME maps: its own error only)
+    tol = 2e-4 if dt == torch.float32 else 3e-2
+    for a, b in zip(ps, ps_ref):
+        assert a.shape == b.shape
+        assert float((a.float() - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert float((sc - sc_ref).abs().max()) <= tol * max(1.0, float(sc_ref.abs().max()))
+    assert float((dl - dl_ref).abs().max()) <= tol * max(1.0, float(dl_ref.abs().max()))
 
 
 @pytest.mark.gpu
@@ -1272,7 +1311,6 @@ def test_float32_patch_matrix_goes_through_in_groups_below_4_gib(monkeypatch, fa
     patches would exceed the limit goes through in groups of images -- same features as in one piece"""
     from tf_eager_object_detection_amd.model import fpn_detector as fd
     from tf_eager_object_detection_amd.model.frcnn_detector import Vgg16Detector
-    monkeypatch.setattr(fd, '_CONV3X3_MODE', 'force')
     torch.manual_seed(3)
     shape = (96, 128)
     m = (fd.ResNetFpnDetector(50, 21, shape, 64, dtype=torch.float32, max_batch=3) if family == 'fpn'

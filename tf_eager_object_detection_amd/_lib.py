@@ -149,6 +149,7 @@ SIGNATURES = {
     'odet_exec_submit_batch': (_i, [_vp, _i, _vp, _i, _i]),
     'odet_exec_wait': (_i, [_vp]),
     'odet_exec_last_error': (C.c_char_p, [_vp]),
+    'odet_debug_conv_tile': (_i, [_i, _i, _i, _i, _i]),
 }
 
 

@@ -30,6 +30,8 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdio>
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -96,14 +98,30 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
 // layers with fewer output channels, the other 8 / WN waves along the pixels); MT = 16-pixel tiles per wave: the
 // workgroup tile is TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels (WN = 4, MT = 8: 256 x 256; smaller MT for
 // launches whose slabs would fill a fraction of a round of the 256 CUs -- chosen on the host, conv3x3_launch).
-template <int MT, int WN, bool TAIL, bool BLK, int TAPS>
+//
+// NW = waves of the workgroup (8; 4 for the SMALL-M tiles: 64 pixels x 64 / 128 channels), NS = LDS stages.  NS == 2 is the
+// half-step-pipelined loop described above, tuned for launches whose tiles keep the matrix pipe busy.  NS > 2 is the RING
+// form for launches with few pixels (batch 1 .. 4 on the 50 x 84 and 25 x 42 maps: the BASELINE configs' own batch size):
+// there a launch is a few hundred small workgroups, each K-step's matrix work (64 x 64 x 64: ~130 cycles per SIMD) is far
+// shorter than the round trip of its copies, and with two stages every step would wait for one.  The ring keeps NS - 1
+// K-steps of copies in flight (counted vmcnt waits: the LDS-DMA pieces of a wave land in issue order), one barrier per
+// step: the copy of step ks + NS - 1 goes where step ks - 1 was read.
+template <int N>
+__device__ __forceinline__ void c3_wait_vmcnt_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int MT, int WN, bool TAIL, bool BLK, int TAPS, int NW = 8, int NS = 2>
 __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   static_assert(TAPS == 9 || (TAPS == 1 && !TAIL && !BLK), "taps");
+  static_assert((NW == 8 || NW == 4) && NW % WN == 0 && (8 * WN) % NW == 0, "waves");
+  static_assert(NS >= 2 && (NS == 2 || (!TAIL && !BLK)), "stages");
   constexpr bool LIN = !TAIL && !BLK;                    // the order of a lane's output channels, see voffW below
-  constexpr int WM = 8 / WN;                             // waves along the pixels
+  constexpr int WM = NW / WN;                            // waves along the pixels
   constexpr int TM = WM * 16 * MT;                       // pixels of the workgroup tile (<= 256)
   constexpr int TN = 64 * WN;                            // channels of the workgroup tile
-  constexpr int XP = (TM / 8 + 7) / 8;                   // pixel pieces (8 rows x 128 B) per wave: TM / 8 over 8 waves
+  constexpr int XP = (TM / 8 + NW - 1) / NW;             // pixel pieces (8 rows x 128 B) per wave: TM / 8 over the waves
+  constexpr int WPW = 8 * WN / NW;                       // weight pieces per wave: TN / 8 over the waves
   static_assert(TM <= C3_TM && TM % 8 == 0, "tile");
   // a stage = the pixel rows, then the weight rows, 128 bytes each: (TM + TN) * 128 bytes (64 KB for the 256 x 256 tile;
   // small tiles leave room for a second workgroup on the CU -- the launch asks for 2 stages of its own tile)
@@ -143,12 +161,12 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   // ---- what this thread copies per K-step: its pieces of A (8 pixels x 128 B each; piece wv + 8 i) and 4 of W
   const int sub = lane >> 3;                             // row of the 8-row piece
   const uint32_t slot = (uint32_t)((lane & 7) ^ sub) * 16u;   // logical 16-byte slot this lane fetches (XOR swizzle)
-  uint32_t voffA[XP], voffW[WN];
+  uint32_t voffA[XP], voffW[WPW];
   uint32_t voffA2[TAPS == 1 ? XP : 1];                   // the second source's rows (pointwise form with two sources)
   uint32_t maskA[XP];                                    // bit tap: the tap of this lane's pixel is inside the map
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
-    const int row = (wv + 8 * i) * 8 + sub;              // 0..TM-1 (pieces beyond the tile are never issued)
+    const int row = (wv + NW * i) * 8 + sub;             // 0..TM-1 (pieces beyond the tile are never issued)
     const long long m = tile_m * TM + row;
     uint32_t mk = 0;
     if constexpr (TAPS == 9) {
@@ -196,8 +214,8 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     maskA[i] = mk;
   }
 #pragma unroll
-  for (int i = 0; i < WN; ++i) {
-    const int row = (wv * WN + i) * 8 + sub;             // 0..TN-1
+  for (int i = 0; i < WPW; ++i) {
+    const int row = (wv * WPW + i) * 8 + sub;            // 0..TN-1
     // LDS row rho of the W tile <- channel.  The fused forms (their second GEMM takes a lane's 16 results as K-ordered
     // operands): rows 16 t + r of a 64-channel group hold channel 16 (r >> 2) + 4 t + (r & 3) -- 16 consecutive channels
     // per lane.  The plain and pointwise forms (LIN): channel 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3) -- a lane
@@ -225,31 +243,34 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     a.stage = stage;
     return a;
   };
-  auto issue = [&](int ks, uint32_t stage) {              // 1 KB pieces: this wave's share of the pixel rows + 4 of weights
+  auto issue = [&](int ks, uint32_t stage) {              // 1 KB pieces: this wave's share of the pixel rows + of the weights
     const IssueAt a = issue_at(ks, stage);
+    // (ring form: the steps past the end are issued all the same, out of range -- no traffic, zeros into a stage nobody
+    // reads any more -- so that every step leaves the same number of copies in flight for the counted waits)
+    const bool live = NS == 2 || ks < ksteps;
     if (TAPS == 1 && ks >= k1steps) {                      // (wave-uniform) the second source's K-steps
 #pragma unroll
       for (int i = 0; i < XP; ++i) {
-        if ((wv + 8 * i) * 8 < TM) {
-          const uint32_t va = (maskA[i] & 1u) ? voffA2[i] : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + 8 * i) * 1024u), 16, (int)va,
+        if ((TM / 8) % NW == 0 || (wv + NW * i) * 8 < TM) {
+          const uint32_t va = ((maskA[i] & 1u) && live) ? voffA2[i] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + NW * i) * 1024u), 16, (int)va,
                                                    (int)((uint32_t)(ks - k1steps) * 128u), 0, 0);
         }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < XP; ++i) {
-        if ((wv + 8 * i) * 8 < TM) {                       // (TM / 8 not a multiple of 8: the last piece exists for the first waves only)
-          const uint32_t va = ((maskA[i] >> a.tap) & 1u) ? voffA[i] : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + 8 * i) * 1024u), 16, (int)va,
+        if ((TM / 8) % NW == 0 || (wv + NW * i) * 8 < TM) {   // (TM / 8 not a multiple of NW: the last piece exists for the first waves only)
+          const uint32_t va = (((maskA[i] >> a.tap) & 1u) && live) ? voffA[i] : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (c3_lds_ptr)(lds + a.stage + (uint32_t)(wv + NW * i) * 1024u), 16, (int)va,
                                                    (int)a.soA, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < WN; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + WBASE + (uint32_t)(wv * WN + i) * 1024u), 16,
-                                               (int)voffW[i], (int)a.soW, 0, 0);
+    for (int i = 0; i < WPW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (c3_lds_ptr)(lds + a.stage + WBASE + (uint32_t)(wv * WPW + i) * 1024u), 16,
+                                               (int)(live ? voffW[i] : OOB), (int)a.soW, 0, 0);
   };
   // ---- fragment addresses (bytes inside a stage)
   const int l15 = lane & 15, lq = lane >> 4;
@@ -278,7 +299,42 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[mt], acc[mt][t], 0, 0, 0);
   };
+  const int c0 = tn * TN + wn * 64 + lq * (LIN ? 8 : 16);
+  constexpr int HOFF = LIN ? 32 : 8;                     // channel offset of a lane's second group of 8 results
+  // the plain epilogue's bias slice, requested before the K loop (two 16-byte loads; a short launch cannot afford to wait for
+  // them after it)
+  h8 bh[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bh[0][e] = bh[1][e] = (_Float16)0.0f;
+  if (LIN && p.bias) {
+    bh[0] = *reinterpret_cast<const h8*>(p.bias + c0);
+    bh[1] = *reinterpret_cast<const h8*>(p.bias + c0 + HOFF);
+  }
   h8 wf0[4], xf0[MT], wf1[4], xf1[MT];
+  if constexpr (NS > 2) {
+    // ---- ring form (small-M launches): NS - 1 K-steps of copies in flight, one barrier per step
+    static_assert((TM / 8) % NW == 0, "ring form: every wave issues the same number of copies per step");
+    constexpr int PW = XP + WPW;                         // copies per wave and K-step
+    constexpr int INFLIGHT = (NS - 2) * PW;              // the copies of the NS - 2 steps younger than the one about to be read
+    static_assert(INFLIGHT <= 63, "vmcnt");
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s, (uint32_t)s * STAGE);
+    uint32_t cur = 0u, fill = (uint32_t)(NS - 1) * STAGE;
+    for (int ks = 0; ks < ksteps; ++ks) {
+      // my copies of step ks have landed; after the barrier everybody's, and everybody has read step ks - 1 (its fragments
+      // went into MFMAs issued before this point), whose stage is refilled now.  A bare s_barrier: __syncthreads() would
+      // make the compiler drain ALL copies in flight (vmcnt(0)) -- the ring's whole point is that they stay in flight
+      c3_wait_vmcnt_barrier<INFLIGHT>();
+      issue(ks + NS - 1, fill);
+      read_frags(lds + cur, 0u, wf0, xf0);
+      read_frags(lds + cur, 64u, wf1, xf1);
+      mfmas(wf0, xf0);
+      mfmas(wf1, xf1);
+      fill = cur;
+      cur = cur + STAGE == (uint32_t)NS * STAGE ? 0u : cur + STAGE;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the out-of-range copies of the last steps)
+  } else {
   issue(0, 0u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -319,8 +375,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     mfmas(wf0, xf0);
     mfmas(wf1, xf1);
   }
-  const int c0 = tn * TN + wn * 64 + lq * (LIN ? 8 : 16);
-  constexpr int HOFF = LIN ? 32 : 8;                     // channel offset of a lane's second group of 8 results
+  }
   if constexpr (TAIL) {
     // ---- fused RpnHead tail (base_fpn_model.py:401-434): t = relu(conv + b1) rounded to float16 once, then the two 1x1
     // convolutions as ONE more contraction on the matrix cores, out[o][pixel] = sum_ch W2[o][ch] . t[pixel][ch]: the MFMA's
@@ -424,7 +479,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     }
     __syncthreads();
     const int n3 = p.n3;
-    for (int g = wv; g * 64 < n3; g += 8) {
+    for (int g = wv; g * 64 < n3; g += NW) {
       h8 a[4][KS3];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
@@ -521,7 +576,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   // ---- epilogue: lane = pixel l15 of every pixel tile, channels 16 lq .. 16 lq + 15 of the wave's 64
   float bv[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = p.bias ? (float)p.bias[c0 + (e >> 3) * HOFF + (e & 7)] : 0.0f;
+  for (int e = 0; e < 16; ++e) bv[e] = (float)bh[e >> 3][e & 7];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
@@ -651,6 +706,16 @@ __global__ void __launch_bounds__(512) k_pointwise_f16(Conv3x3Params p) {
   conv_tile_f16<MT, WN, false, false, 1>(p);
 }
 
+// The RING forms (conv_tile_f16's header): 4 waves, 64 pixels x 64 channels, NS stages -- launches with few pixels.
+template <int NS>
+__global__ void __launch_bounds__(256) k_conv3x3_f16_ring(Conv3x3Params p) {
+  conv_tile_f16<1, 1, false, false, 9, 4, NS>(p);
+}
+template <int NS>
+__global__ void __launch_bounds__(256) k_pointwise_f16_ring(Conv3x3Params p) {
+  conv_tile_f16<1, 1, false, false, 1, 4, NS>(p);
+}
+
 // Second, small launch of the fused RpnHead: out = sum over the channel tiles' partial sums + bias, row R of pixel m to
 // scores (R < 2A) / deltas (R - 2A) of the level's slice.  One thread = 4 rows of a pixel slot.
 __global__ void __launch_bounds__(256) k_rpn_tail_finish(Conv3x3Params p) {
@@ -687,6 +752,102 @@ __global__ void __launch_bounds__(256) k_rpn_tail_finish(Conv3x3Params p) {
 
 // (the float32 forms -- the detectors' parity mode -- live in conv_f32.hip)
 
+// ---- host side: the tile table -------------------------------------------------------------------------------------------
+// A tile = {waves, waves along the channels, 16-pixel tiles per wave, LDS stages}: TM = (nw / wn) * 16 * mt pixels x
+// TN = 64 * wn channels.  ns == 2: the half-step-pipelined loop (launches that fill the chip); ns > 2: the ring forms.
+struct ConvTile { int nw, wn, mt, ns; };
+typedef void (*conv_kernel_t)(Conv3x3Params);
+struct TileEntry { ConvTile t; conv_kernel_t plain, pw, blk; };
+#define C3_LEGACY(MT_, WN_) \
+  {{8, WN_, MT_, 2}, k_conv3x3_f16<MT_, WN_>, k_pointwise_f16<MT_, WN_>, k_conv3x3_f16<MT_, WN_, false, true>}
+#define C3_RING(NS_) {{4, 1, 1, NS_}, k_conv3x3_f16_ring<NS_>, k_pointwise_f16_ring<NS_>, nullptr}
+static const TileEntry kTiles[] = {
+    C3_LEGACY(4, 4), C3_LEGACY(5, 4), C3_LEGACY(6, 4), C3_LEGACY(7, 4), C3_LEGACY(8, 4),       // 128 .. 256 px x 256 ch
+    C3_LEGACY(2, 2), C3_LEGACY(3, 2), C3_LEGACY(4, 2),                                         // 128 .. 256 px x 128 ch
+    C3_LEGACY(1, 1), C3_LEGACY(2, 1),                                                          // 128 / 256 px x 64 ch
+    // ring forms, 64 px x 64 ch: 8 stages (128 KB: one workgroup per CU, seven K-steps of copies in flight) and 4 stages
+    // (two workgroups per CU).  Also built and measured in round 4, not kept (tools/r04/small_tiles.py, sweep of all layer
+    // shapes at batch 1 / 2 / 4, cold L2): 64 x 128 (6 stages), 64 x 256 (3; with the fused tail), and rings for the 8-wave
+    // 128 x 256 / 128 x 128 / 128 x 64 tiles -- within 3 % of the two-stage loop or behind it wherever they applied
+    C3_RING(8), C3_RING(4),
+};
+#undef C3_LEGACY
+#undef C3_RING
+static constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
+
+static const TileEntry* find_tile(const ConvTile& t) {
+  for (const TileEntry& e : kTiles)
+    if (e.t.nw == t.nw && e.t.wn == t.wn && e.t.mt == t.mt && e.t.ns == t.ns) return &e;
+  return nullptr;
+}
+static inline int tile_tm(const ConvTile& t) { return (t.nw / t.wn) * 16 * t.mt; }
+static inline unsigned tile_lds(const ConvTile& t) { return (unsigned)t.ns * (unsigned)(tile_tm(t) + 64 * t.wn) * 128u; }
+
+static hipError_t tiles_init() {                // (more than the default 64 KB of dynamic LDS)
+  static std::once_flag once;
+  static hipError_t rc = hipSuccess;
+  std::call_once(once, [] {
+    auto set = [](const void* k_) {
+      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e_ != hipSuccess) rc = e_;
+    };
+    for (const TileEntry& e : kTiles) {
+      set((const void*)e.plain); set((const void*)e.pw);
+      if (e.blk) set((const void*)e.blk);
+    }
+    set((const void*)k_conv3x3_f16<4, 4, true>); set((const void*)k_conv3x3_f16<5, 4, true>);
+    set((const void*)k_conv3x3_f16<6, 4, true>); set((const void*)k_conv3x3_f16<7, 4, true>);
+    set((const void*)k_conv3x3_f16<8, 4, true>);
+  });
+  return rc;
+}
+
+static int launch_tile(conv_kernel_t k, const ConvTile& t, unsigned blocks, unsigned lds_bytes, Conv3x3Params& p, hipStream_t st) {
+  void* args[1] = {&p};
+  ODET_HIP(hipLaunchKernel((const void*)k, dim3(blocks), dim3((unsigned)t.nw * 64u), args, lds_bytes, st));
+  return ODET_OK;
+}
+
+// ---- tile selection for launches that do not fill the chip ---------------------------------------------------------------
+// The 8-wave tiles (128 .. 256 pixels) are picked by the measured rules inside the launchers below.  When a layer has so few
+// pixels that 64 x 64 tiles still make no more workgroups than two per CU -- batch 1 .. 2 on the 50 x 84 / 25 x 42 maps, the
+// RoI head's dense layers at 1000 rows: the BASELINE configs' own batch size -- it goes to the ring form: every CU gets
+// work, and the copies of several K-steps are in flight instead of one (a launch's operands sit in the Infinity Cache,
+// not in the XCD's L2 -- the producer ran on other XCDs --, and with two stages every K-step waited for that round trip:
+// conv4's first 1x1 at batch 1 took 22 us inside a pass, 16 K-steps of 1.3 us).  Measured with cold L2s
+// (tools/r04/small_tiles.py, profiles/r04_small_tiles.json): conv4's 3x3 at batch 1 18.8 us (two-stage 128 x 64 tiles 24.8,
+// library 25.1), its first 1x1 9.6 (12.7 / 11.7), conv5's 3x3 at batch 2 31.6 (39.9 / 31.2).  What bounds these launches is
+// a CU's intake from L2 (~30 B / clock with enough copies in flight), so a 64 x 64 x 64 K-step takes ~0.27 us whatever the
+// matrix pipe could do; beyond two workgroups per CU the larger tiles' better ratio of matrix work to copied bytes wins.
+static ConvTile pick_small(const long long* level_px, int num_levels, int cout, ConvTile pick) {
+  long long slabs64 = 0;
+  for (int l = 0; l < num_levels; ++l) slabs64 += (level_px[l] + 63) / 64;
+  const long long n64 = slabs64 * (cout / 64);
+  if (n64 <= 256) return ConvTile{4, 1, 1, 8};
+  if (n64 <= 512) return ConvTile{4, 1, 1, 4};
+  return pick;
+}
+
+// Diagnostics (tools/exp, tools/r04): force the tile of the 3x3 (form 0; the fused tail included) / pointwise (form 1)
+// launches of this process; nw = 0 clears.  Not part of the reference surface; the product never calls it.
+static std::atomic<unsigned> g_tile_override[2] = {{0u}, {0u}};
+extern "C" int odet_debug_conv_tile(int form, int nw, int wn, int mt, int ns) {
+  ODET_REQUIRE(form == 0 || form == 1, "odet_debug_conv_tile: form 0 (3x3) or 1 (pointwise)");
+  if (nw == 0) { g_tile_override[form].store(0u); return ODET_OK; }
+  ODET_REQUIRE(find_tile(ConvTile{nw, wn, mt, ns}) != nullptr, "odet_debug_conv_tile: no such tile (nw %d, wn %d, mt %d, ns %d)",
+               nw, wn, mt, ns);
+  g_tile_override[form].store((unsigned)nw << 24 | (unsigned)wn << 16 | (unsigned)mt << 8 | (unsigned)ns);
+  return ODET_OK;
+}
+static bool tile_override(int form, int cout, int need_wn, ConvTile* t) {
+  const unsigned v = g_tile_override[form].load();
+  if (!v) return false;
+  const ConvTile o{(int)(v >> 24), (int)(v >> 16 & 255), (int)(v >> 8 & 255), (int)(v & 255)};
+  if (cout % (64 * o.wn) || (need_wn && o.wn != need_wn)) return false;
+  *t = o;
+  return true;
+}
+
 struct Conv3x3Tail {             // the fused RpnHead tail (nullable in conv3x3_launch)
   const void* w; const void* b; int A; float* scores; long long s_stride; float* deltas; long long d_stride;
   void* ws; size_t ws_bytes;
@@ -704,35 +865,8 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   ODET_REQUIRE(cin > 0 && cin % C3_BK == 0, "odet_conv3x3_f16: cin %d must be a multiple of %d", cin, C3_BK);
   ODET_REQUIRE(cout > 0 && cout % 64 == 0, "odet_conv3x3_f16: cout %d must be a multiple of 64", cout);
   ODET_REQUIRE((unsigned long long)cout * 9ull * cin * 2ull < 0x7FFFFFFFull, "odet_conv3x3_f16: weights too large");
-  static std::once_flag once;
-  static hipError_t once_rc = hipSuccess;
-  std::call_once(once, [] {
-    const void* kb_[10] = {(const void*)k_conv3x3_f16<4, 4, false, true>, (const void*)k_conv3x3_f16<5, 4, false, true>,
-                           (const void*)k_conv3x3_f16<6, 4, false, true>, (const void*)k_conv3x3_f16<7, 4, false, true>,
-                           (const void*)k_conv3x3_f16<8, 4, false, true>, (const void*)k_conv3x3_f16<2, 2, false, true>,
-                           (const void*)k_conv3x3_f16<3, 2, false, true>, (const void*)k_conv3x3_f16<4, 2, false, true>,
-                           (const void*)k_conv3x3_f16<1, 1, false, true>, (const void*)k_conv3x3_f16<2, 1, false, true>};
-    for (const void* k_ : kb_) {
-      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
-      if (e_ != hipSuccess) once_rc = e_;
-    }
-    const void* kt_[5] = {(const void*)k_conv3x3_f16<4, 4, true>, (const void*)k_conv3x3_f16<5, 4, true>,
-                          (const void*)k_conv3x3_f16<6, 4, true>, (const void*)k_conv3x3_f16<7, 4, true>,
-                          (const void*)k_conv3x3_f16<8, 4, true>};
-    for (const void* k_ : kt_) {
-      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
-      if (e_ != hipSuccess) once_rc = e_;
-    }
-    const void* ks_[10] = {(const void*)k_conv3x3_f16<4, 4>, (const void*)k_conv3x3_f16<5, 4>, (const void*)k_conv3x3_f16<6, 4>,
-                           (const void*)k_conv3x3_f16<7, 4>, (const void*)k_conv3x3_f16<8, 4>, (const void*)k_conv3x3_f16<2, 2>,
-                           (const void*)k_conv3x3_f16<3, 2>, (const void*)k_conv3x3_f16<4, 2>, (const void*)k_conv3x3_f16<1, 1>,
-                           (const void*)k_conv3x3_f16<2, 1>};
-    for (const void* k_ : ks_) {
-      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
-      if (e_ != hipSuccess) once_rc = e_;
-    }
-  });
-  ODET_HIP(once_rc);
+  ODET_REQUIRE(((uintptr_t)w | (uintptr_t)bias) % 16 == 0, "odet_conv3x3_f16: weights and bias must be 16-byte aligned");
+  ODET_HIP(tiles_init());
   Conv3x3Params p;
   long long total = 0;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
@@ -787,7 +921,6 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   // Channel tile: 256 (four waves along the channels), or 128 / 64 for the layers with fewer output channels.
   const int wn_sel = (cout % 256 == 0) ? 4 : (cout % 128 == 0 ? 2 : 1);
   const int wm_sel = 8 / wn_sel;
-  p.tiles_n = cout / (64 * wn_sel);
   // Pixel-tile height: the launch runs in rounds of 256 workgroups (one per CU: 128 KB of LDS each), so a layer whose
   // 256-pixel slabs fill a round badly (ResNet's conv4 at batch 8: 132 slabs) is cut into 128 .. 224-pixel slabs
   // instead.  Cost model: rounds x (pixel tiles + 2) (a workgroup's time is its pixel tiles + the weight traffic they
@@ -800,7 +933,7 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
       const int tm = wm_sel * 16 * mt;
       long long slabs = 0;
       for (int l = 0; l < num_levels; ++l) slabs += (p.M[l] + tm - 1) / tm;
-      const long long blocks_mt = (slabs + 7) / 8 * 8 * p.tiles_n;
+      const long long blocks_mt = (slabs + 7) / 8 * 8 * (cout / (64 * wn_sel));
       // plain launches ask for two stages of their own tile: tiles of <= 80 KB run two workgroups per CU (each at ~1 / 1.7
       // of the speed it has alone: they overlap each other's staging, barriers and epilogues)
       const int occ = (!tail && !blk && 2 * (tm + 64 * wn_sel) * 128 <= 80 * 1024) ? 2 : 1;
@@ -808,13 +941,17 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
       if (cost < best * 0.97) { best = cost; mt_best = mt; }       // (smaller tiles only for a clear gain)
     }
   }
-  int wn_use = wn_sel, wm_use = wm_sel;
-  if (const char* ov = getenv("ODET_C3_TILE")) {          // experiments (tools/exp/conv3x3_small.py): "wn,mt" of the plain form
-    int a_ = 0, b_ = 0;
-    if (!tail && sscanf(ov, "%d,%d", &a_, &b_) == 2 && (a_ == 4 || a_ == 2 || a_ == 1) && cout % (64 * a_) == 0 &&
-        b_ * (8 / a_) >= 8 && b_ * (8 / a_) <= 16 && (!blk || a_ == wn_sel)) { wn_use = a_; wm_use = 8 / a_; mt_best = b_; p.tiles_n = cout / (64 * a_); }
+  ConvTile tile{8, wn_sel, mt_best, 2};
+  if (!tail && !pool) {
+    // few pixels (conv4 / conv5 / the small neck levels at batch 1 .. 2): the ring form
+    if (!blk) tile = pick_small(p.M, num_levels, cout, tile);
+    tile_override(0, cout, blk ? wn_sel : 0, &tile);
+    ODET_REQUIRE(!blk || tile.ns == 2, "odet_bottleneck_tail_f16: the fused tail has no ring form");
   }
-  const int TMsel = wm_use * 16 * mt_best;
+  const TileEntry* te = find_tile(tile);
+  ODET_REQUIRE(te != nullptr, "odet_conv3x3_f16: internal: no kernel for the picked tile");
+  p.tiles_n = cout / (64 * tile.wn);
+  const int TMsel = tile_tm(tile);
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     p.tile_start[l] = total;
     if (l < num_levels) total += (p.M[l] + TMsel - 1) / TMsel;
@@ -826,66 +963,31 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   const long long groups = (total + 7) / 8;
   const long long blocks = groups * 8 * p.tiles_n;
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
-  const dim3 grid((unsigned)blocks);
-  // (plain form: two stages of the launch's own tile; the fused tails re-use the whole 128 KB after the K loop)
-  const unsigned lds_plain = 2u * (unsigned)(TMsel + 64 * wn_use) * 128u;
-#define C3_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_>), grid, dim3(512), lds_plain, st, p)
-#define C3_LAUNCH_TAIL(MT_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, 4, true>), grid, dim3(512), C3_LDS_BYTES, st, p)
   if (tail) {
     p.slab_px = total * TMsel; p.tm = TMsel;
     const size_t need = (size_t)p.tiles_n * (size_t)p.slab_px * 32 * sizeof(float);
     ODET_REQUIRE(tail->ws && tail->ws_bytes >= need && (uintptr_t)tail->ws % 16 == 0,
                  "odet_rpn_head_fused_f16: workspace too small (%zu < %zu) or misaligned", tail->ws_bytes, need);
     p.partial = (float*)tail->ws;
+    conv_kernel_t kt = k_conv3x3_f16<8, 4, true>;
     switch (mt_best) {
-      case 4: C3_LAUNCH_TAIL(4); break;
-      case 5: C3_LAUNCH_TAIL(5); break;
-      case 6: C3_LAUNCH_TAIL(6); break;
-      case 7: C3_LAUNCH_TAIL(7); break;
-      default: C3_LAUNCH_TAIL(8); break;
+      case 4: kt = k_conv3x3_f16<4, 4, true>; break;
+      case 5: kt = k_conv3x3_f16<5, 4, true>; break;
+      case 6: kt = k_conv3x3_f16<6, 4, true>; break;
+      case 7: kt = k_conv3x3_f16<7, 4, true>; break;
+      default: break;
     }
-    ODET_LAUNCH_CHECK();
+    const int rc = launch_tile(kt, tile, (unsigned)blocks, C3_LDS_BYTES, p, st);
+    if (rc != ODET_OK) return rc;
     const long long threads = p.slab_px * 8;
     hipLaunchKernelGGL(k_rpn_tail_finish, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
     ODET_LAUNCH_CHECK();
     return ODET_OK;
   }
-#undef C3_LAUNCH_TAIL
-  if (blk) {
-    // (LDS: the K loop's two stages, re-used after it for the TM x 2 CMID-byte activation tile -- never more than the stages)
-    const unsigned lds_blk = std::max(2u * (unsigned)(TMsel + 64 * wn_use) * 128u, (unsigned)TMsel * 128u * (unsigned)wn_use);
-#define C3_LAUNCH_BLK(MT_, WN_) hipLaunchKernelGGL((k_conv3x3_f16<MT_, WN_, false, true>), grid, dim3(512), lds_blk, st, p)
-    switch (wn_use * 16 + mt_best) {
-      case 4 * 16 + 4: C3_LAUNCH_BLK(4, 4); break;
-      case 4 * 16 + 5: C3_LAUNCH_BLK(5, 4); break;
-      case 4 * 16 + 6: C3_LAUNCH_BLK(6, 4); break;
-      case 4 * 16 + 7: C3_LAUNCH_BLK(7, 4); break;
-      case 4 * 16 + 8: C3_LAUNCH_BLK(8, 4); break;
-      case 2 * 16 + 2: C3_LAUNCH_BLK(2, 2); break;
-      case 2 * 16 + 3: C3_LAUNCH_BLK(3, 2); break;
-      case 2 * 16 + 4: C3_LAUNCH_BLK(4, 2); break;
-      case 1 * 16 + 1: C3_LAUNCH_BLK(1, 1); break;
-      default: C3_LAUNCH_BLK(2, 1); break;
-    }
-#undef C3_LAUNCH_BLK
-    ODET_LAUNCH_CHECK();
-    return ODET_OK;
-  }
-  switch (wn_use * 16 + mt_best) {
-    case 4 * 16 + 4: C3_LAUNCH(4, 4); break;
-    case 4 * 16 + 5: C3_LAUNCH(5, 4); break;
-    case 4 * 16 + 6: C3_LAUNCH(6, 4); break;
-    case 4 * 16 + 7: C3_LAUNCH(7, 4); break;
-    case 4 * 16 + 8: C3_LAUNCH(8, 4); break;
-    case 2 * 16 + 2: C3_LAUNCH(2, 2); break;
-    case 2 * 16 + 3: C3_LAUNCH(3, 2); break;
-    case 2 * 16 + 4: C3_LAUNCH(4, 2); break;
-    case 1 * 16 + 1: C3_LAUNCH(1, 1); break;
-    default: C3_LAUNCH(2, 1); break;
-  }
-#undef C3_LAUNCH
-  ODET_LAUNCH_CHECK();
-  return ODET_OK;
+  // LDS: the K loop's stages of the launch's own tile; the fused tail re-uses them for the TM x 2 CMID-byte activation tile
+  unsigned lds_bytes = tile_lds(tile);
+  if (blk) lds_bytes = std::max(lds_bytes, (unsigned)TMsel * 128u * (unsigned)tile.wn);
+  return launch_tile(blk ? te->blk : te->plain, tile, (unsigned)blocks, lds_bytes, p, st);
 }
 
 extern "C" int odet_conv3x3_f16(const void* x, const void* w, const void* bias, void* y, int batch, int H, int W, int cin,
@@ -943,19 +1045,7 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
                "%s: pointers must be 16-byte aligned", who);
   ODET_REQUIRE(!(epi.res && epi.top), "%s: shortcut and top-down merge exclude each other", who);
   ODET_REQUIRE(!epi.top || (stride == 1 && epi.th > 0 && epi.tw > 0 && !relu), "%s: bad merge arguments", who);
-  static std::once_flag once;
-  static hipError_t once_rc = hipSuccess;
-  std::call_once(once, [] {
-    const void* ks_[10] = {(const void*)k_pointwise_f16<4, 4>, (const void*)k_pointwise_f16<5, 4>, (const void*)k_pointwise_f16<6, 4>,
-                           (const void*)k_pointwise_f16<7, 4>, (const void*)k_pointwise_f16<8, 4>, (const void*)k_pointwise_f16<2, 2>,
-                           (const void*)k_pointwise_f16<3, 2>, (const void*)k_pointwise_f16<4, 2>, (const void*)k_pointwise_f16<1, 1>,
-                           (const void*)k_pointwise_f16<2, 1>};
-    for (const void* k_ : ks_) {
-      const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, C3_LDS_BYTES);
-      if (e_ != hipSuccess) once_rc = e_;
-    }
-  });
-  ODET_HIP(once_rc);
+  ODET_HIP(tiles_init());
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
   const long long M = (long long)batch * Ho * Wo;
   const long long Min = epi.x2 ? M : (long long)batch * H * W;       // (two sources: x has the OUTPUT's rows)
@@ -996,14 +1086,15 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
       if (cost < best * 0.97) { best = cost; wn_best = wn; mt_best = mt; }
     }
   }
-  if (const char* ov = getenv("ODET_PW_TILE")) {          // experiments (tools/exp/pointwise_tiles.py): "wn,mt[,cin]"
-    int a_ = 0, b_ = 0, c_ = 0;
-    const int n_ = sscanf(ov, "%d,%d,%d", &a_, &b_, &c_);
-    if (n_ >= 2 && (n_ == 2 || c_ == cin) && (a_ == 4 || a_ == 2 || a_ == 1) && cout % (64 * a_) == 0 &&
-        b_ * (8 / a_) >= 8 && b_ * (8 / a_) <= 16) { wn_best = a_; mt_best = b_; }
-  }
-  const int wm_sel = 8 / wn_best, TMsel = wm_sel * 16 * mt_best;
-  p.tiles_n = cout / (64 * wn_best);
+  ConvTile tile{8, wn_best, mt_best, 2};
+  // fewer workgroups than the chip holds (few pixels: batch 1 .. 4 on the small maps, the RoI head's dense layers at 1000
+  // rows): the ring forms
+  tile = pick_small(&M, 1, cout, tile);
+  tile_override(1, cout, 0, &tile);
+  const TileEntry* te = find_tile(tile);
+  ODET_REQUIRE(te != nullptr, "%s: internal: no kernel for the picked tile", who);
+  const int TMsel = tile_tm(tile);
+  p.tiles_n = cout / (64 * tile.wn);
   const long long total = (M + TMsel - 1) / TMsel;
   p.tile_start[0] = 0;
   for (int l = 1; l <= ODET_MAX_LEVELS; ++l) p.tile_start[l] = total;
@@ -1011,24 +1102,7 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
   p.num_levels = 1; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
   const long long blocks = (total + 7) / 8 * 8 * p.tiles_n;
   ODET_REQUIRE(blocks < (1ll << 31), "%s: too many workgroups", who);
-  const dim3 grid((unsigned)blocks);
-  const unsigned lds_bytes = 2u * (unsigned)(TMsel + 64 * wn_best) * 128u;
-#define PW_LAUNCH(MT_, WN_) hipLaunchKernelGGL((k_pointwise_f16<MT_, WN_>), grid, dim3(512), lds_bytes, st, p)
-  switch (wn_best * 16 + mt_best) {
-    case 4 * 16 + 4: PW_LAUNCH(4, 4); break;
-    case 4 * 16 + 5: PW_LAUNCH(5, 4); break;
-    case 4 * 16 + 6: PW_LAUNCH(6, 4); break;
-    case 4 * 16 + 7: PW_LAUNCH(7, 4); break;
-    case 4 * 16 + 8: PW_LAUNCH(8, 4); break;
-    case 2 * 16 + 2: PW_LAUNCH(2, 2); break;
-    case 2 * 16 + 3: PW_LAUNCH(3, 2); break;
-    case 2 * 16 + 4: PW_LAUNCH(4, 2); break;
-    case 1 * 16 + 1: PW_LAUNCH(1, 1); break;
-    default: PW_LAUNCH(2, 1); break;
-  }
-#undef PW_LAUNCH
-  ODET_LAUNCH_CHECK();
-  return ODET_OK;
+  return launch_tile(te->pw, tile, (unsigned)blocks, tile_lds(tile), p, st);
 }
 
 extern "C" int odet_pointwise_f16(const void* x, const void* w, const void* bias, const void* residual, void* y, int batch,
@@ -1077,4 +1151,3 @@ extern "C" size_t odet_rpn_head_fused_workspace_bytes(const odet_conv_level_t* l
   for (int l = 0; l < num_levels; ++l) px += (size_t)batch * levels[l].H * levels[l].W + 256;
   return (size_t)((cout + 255) / 256) * px * 32 * sizeof(float);
 }
-

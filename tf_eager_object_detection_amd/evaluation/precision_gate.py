@@ -192,7 +192,8 @@ def fit_readout_heads(model, scenes, rpn_gain=2.0, cls_gain=8.0, pos_iou=0.7, ne
             k = int(hot.roi_count.item())
             rois = hot.sorted_rois[:k].contiguous()
             f = hot.roi_features[:k].reshape(k, -1).to(model.dtype)
-            h = torch.relu(model.fc2(torch.relu(model.fc1(f)))).float()
+            h = ops.dense(ops.dense(f.contiguous(), model.fc1.weight, model.fc1.bias, relu=True), model.fc2.weight, model.fc2.bias,
+                          relu=True).float()
             X = torch.cat([h, torch.ones(k, 1, device=dev)], 1)
             gt = torch.from_numpy(gt_boxes[b]).to(dev)
             gl = torch.from_numpy(gt_labels[b].astype(np.int64)).to(dev)

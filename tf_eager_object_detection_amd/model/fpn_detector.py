@@ -2,23 +2,31 @@
 model/fpn/resnet_fpn.py (ResnetV1Fpn: extractor, ResnetFpnNeck, ResnetRoiHead) + the inference
 branch of model/fpn/base_fpn_model.py (BaseFPN.call, RpnHead).
 
-SURVEY.md section 8(f) ranks 2-3 ("next"): the dense conv / FC stacks are genuine dense contractions
-and run on the MFMA units through PyTorch-ROCm's library convolutions (MIOpen / hipBLASLt) in NHWC
-(channels_last), fp32 or fp16; everything between them is the hand-written hot path (FpnHotPath).
-Weights are randomly initialised with the reference's initialisers (no checkpoints exist offline);
-frozen batch-norm (epsilon 1.001e-5, inference statistics) is folded into the convolutions.
+SURVEY.md section 8(f) ranks 2-3 ("next"): the dense conv / FC stacks are genuine dense contractions and run on the
+matrix cores through THIS REPOSITORY'S kernels -- there is no library convolution or GEMM route in this module, at any
+batch size, and no CPU path (a layer no kernel takes raises):
+
+  3x3 convolutions   ops.conv3x3_f16 / conv3x3_f32 (implicit GEMM; the ring form at batch 1-2 on the small maps), with the
+                     block's last 1x1 convolution + shortcut + ReLU in the same launch where the map is large enough
+                     (ops.conv3x3_conv1x1_f16), with the RpnHead's two 1x1 convolutions in the launch (ops.rpn_head_fused)
+  1x1 / dense        ops.pointwise / dense (the same kernel with one tap; strided; two sources along K for a stage's first
+                     block; the FPN top-down merge in the lateral's epilogue), ops.conv1x1_f16 (register-resident, short K)
+  stem               ops.stem_conv7_pool3 (float16: one launch from the image) / the patch-matrix GEMM (float32)
+
+float32 is the parity mode (exact-float32 matrix instructions), float16 the throughput mode.  Weights are randomly
+initialised with the reference's initialisers (no checkpoints exist offline); frozen batch-norm (epsilon 1.001e-5,
+inference statistics) is folded into the convolutions.  The plain-torch formulation of the same network (library
+convolutions; CPU shape bookkeeping and numerical reference) lives with the tests: tests/torch_reference.py.
 
 Shapes follow the reference exactly so that feature maps and anchor grids agree:
 conv1 = pad 3 + 7x7/2 valid, pool1 = pad 1 + 3x3/2 valid, the stride of a stage sits on the first
 1x1 convolution of its first block, P6 = P5[::2, ::2], top-down merge = 0.5 * resize_bilinear(P_{k+1})
-+ 0.5 * lateral with TF1's legacy resize (src = dst * in/out, no half-pixel offset) -- one fused HIP
-kernel per merge on the GPU (ops.fpn_topdown_merge).
++ 0.5 * lateral with TF1's legacy resize (src = dst * in/out, no half-pixel offset).
 """
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..pipeline import FpnHotPath, FpnStepBatch
@@ -54,172 +62,87 @@ def _fold_frozen_bn(conv):
     return conv
 
 
-# 1x1 stride-1 convolutions in NHWC are plain GEMMs on the [pixels, channels] view and most of them are bound by HBM
-# traffic, not by MFMA throughput (tools/exp/conv1x1_gemm.py).  Three routes, measured once per layer shape:
-#   'conv' library convolution without bias + the fused epilogue pass (ops.bias_act_)
-#   'gemm' hipBLASLt GEMM with bias (+ ReLU) in its own epilogue (no shortcut)
-#   'mfma' ops.conv1x1_f16: the hand-written MFMA kernel with bias + shortcut + ReLU fused (float16, cin <= 256)
-#   'pw'   ops.pointwise_f16: the LDS-staged GEMM form of the implicit-GEMM kernel (float16, cin >= 128; any stride)
-_GEMM_ROUTE = {}
-_ROUTE_MODE = __import__('os').environ.get('ODET_ROUTE_1X1', 'table')
-# ODET_CONV3X3=lib: the library convolution instead of the hand-written implicit GEMM (ops.conv3x3_f16) where it applies;
-# twopass: the hand-written convolution, but the RpnHead as convolution launch + tail launches (not ops.rpn_head_fused)
-_CONV3X3_MODE = __import__('os').environ.get('ODET_CONV3X3', 'own')
+def _no_kernel(what, conv, x):
+    return RuntimeError('%s: no kernel of this package takes the layer (kernel %s, stride %s, %d -> %d channels, input %s %s on '
+                        '%s); the detectors run float16 / float32 NHWC maps on the GPU and have no library or CPU route'
+                        % (what, tuple(conv.kernel_size), tuple(conv.stride), conv.in_channels, conv.out_channels,
+                           tuple(x.shape), x.dtype, x.device))
 
 
-def _gemm_1x1(conv, x, bias, relu):
-    B, cin, h, w = x.shape
-    x2 = x.permute(0, 2, 3, 1).reshape(-1, cin)
-    w2 = conv.weight.view(conv.out_channels, cin).t()
-    y2 = torch._addmm_activation(bias, x2, w2, use_gelu=False) if relu else torch.addmm(bias, x2, w2)
-    return y2.view(B, h, w, conv.out_channels).permute(0, 3, 1, 2)
+def _nhwc(x):
+    """the NHWC memory of a channels_last [B,C,H,W] tensor as a contiguous [B,H,W,C] view"""
+    y = x.permute(0, 2, 3, 1)
+    return y if y.is_contiguous() else y.contiguous()
 
 
-def _conv_1x1(conv, x, bias, relu, res):
-    y = F.conv2d(x, conv.weight, None)
-    if not y.is_contiguous(memory_format=torch.channels_last):
-        y = y.contiguous(memory_format=torch.channels_last)
-    ops.bias_act_(y.permute(0, 2, 3, 1), bias, res, relu)
-    return y
-
-
-def _mfma_1x1(conv, x, bias, relu, res, in_bias=None):
-    return ops.conv1x1_f16(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu, in_bias=in_bias).permute(0, 3, 1, 2)
-
-
-# ODET_PW=0: the layers of the pointwise GEMM kernel back on their round-2 routes (library GEMM / convolution); a comma list of
-# names from {c1, s2, short, lateral, fc, final} switches single classes of layers off (same-box A/B runs)
-_PW_OFF = set(filter(None, __import__('os').environ.get('ODET_PW_OFF', '').split(',')))
-if __import__('os').environ.get('ODET_PW', '1') == '0':
-    _PW_OFF = {'c1', 's2', 'short', 'lateral', 'fc', 'final'}
+def _mfma_ok(conv, x):
+    """ops.conv1x1_f16 (register-resident operand, weights staged per 64-channel group) takes this 1x1 stride-1 convolution"""
+    return (x.is_cuda and x.dtype == torch.float16 and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (0, 0) and conv.in_channels in (64, 128, 256, 512) and conv.out_channels % 64 == 0)
 
 
 def _pw_ok(conv, x):
     """the pointwise GEMM kernel takes this 1x1 convolution (stride 1 or 2, no padding)"""
-    if not x.is_cuda or x.dtype not in (torch.float16, torch.float32) or ('f32' in _PW_OFF and x.dtype == torch.float32):
+    if not x.is_cuda or x.dtype not in (torch.float16, torch.float32):
         return False
     gran = 64 if x.dtype == torch.float16 else 32          # channels per K-step
     return (tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0)
             and tuple(conv.stride) in ((1, 1), (2, 2)) and conv.in_channels % gran == 0 and conv.in_channels >= 2 * gran
-            and conv.out_channels % 64 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+            and conv.out_channels % 64 == 0)
 
 
-def _pw_1x1(conv, x, bias, relu, res):
-    return ops.pointwise(x.permute(0, 2, 3, 1), conv.weight, bias, res, relu, conv.stride[0]).permute(0, 3, 1, 2)
-
-
-def _time_route(fn, reps=5):
-    for _ in range(2):
-        fn()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps):
-        fn()
-    b.record()
-    b.synchronize()
-    return a.elapsed_time(b)
-
-
-def _route_1x1(conv, x, bias, relu, res):
-    """'conv', 'gemm' or 'mfma' for this layer shape.  Deterministic (the routes differ in rounding: the MFMA kernel
-    adds shortcut + W.x + bias with one rounding): the table below is what timing the three routes chose on MI355X for
-    every 1x1 layer shape of the three detectors (tools/exp/conv1x1_routes.py) -- float16 layers with a shortcut and
-    the small-K layers without one go to the hand-written MFMA kernel, layers without a shortcut otherwise to the GEMM
-    with its own epilogue, the rest to the library convolution + epilogue pass.  ODET_ROUTE_1X1=measure re-times the
-    routes at first use (per device and shape), ODET_ROUTE_1X1=conv|gemm|mfma forces one where it applies."""
-    mfma_ok = x.dtype == torch.float16 and conv.in_channels in (64, 128, 256, 512) and conv.out_channels % 64 == 0
-    mode = _ROUTE_MODE
-    if mode == 'measure':
-        key = (x.device.index, tuple(x.shape), conv.out_channels, x.dtype, bool(relu), res is not None)
-        r = _GEMM_ROUTE.get(key)
-        if r is None:
-            if torch.cuda.is_current_stream_capturing():
-                mode = 'table'
-            else:
-                cand = {'conv': lambda: _conv_1x1(conv, x, bias, relu, res)}
-                if res is None:
-                    cand['gemm'] = lambda: _gemm_1x1(conv, x, bias, relu)
-                if mfma_ok:
-                    cand['mfma'] = lambda: _mfma_1x1(conv, x, bias, relu, res)
-                if _pw_ok(conv, x):
-                    cand['pw'] = lambda: _pw_1x1(conv, x, bias, relu, res)
-                times = {k: _time_route(f) for k, f in cand.items()}
-                r = min(times, key=times.get)
-                _GEMM_ROUTE[key] = r
-                return r
-        else:
-            return r
-    if mode == 'mfma' and mfma_ok:
+def _route_1x1(conv, x):
+    """'mfma' (ops.conv1x1_f16) or 'pw' (ops.pointwise) for this 1x1 convolution.  A fixed rule (the two kernels differ in
+    rounding order, so the route must not depend on timing): the LDS-staged GEMM wherever it applies (K >= 128; every first
+    1x1 of a bottleneck, the last one with its shortcut, the neck's P5, strided layers, float32) except for 64-channel
+    outputs, which -- like the K = 64 layers the GEMM does not take -- go to the register-resident kernel
+    (tools/exp/pointwise_layers.py; round 4, cold L2, inside a HIP graph: conv4's last 1x1 with its shortcut at batch 1 / 4
+    12.1 / 20.5 us on the GEMM, 13.3 / 30.9 on the register-resident kernel, tools/r04/small_tiles.py)."""
+    mfma, pw = _mfma_ok(conv, x), _pw_ok(conv, x)
+    if mfma and (conv.out_channels <= 64 or not pw):
         return 'mfma'
-    if mode == 'gemm' and res is None:
-        return 'gemm'
-    if mode == 'conv':
-        return 'conv'
-    pw_ok = _pw_ok(conv, x) and 'c1' not in _PW_OFF
-    # (tools/exp/pointwise_layers.py, pointwise_tiles.py: the register-resident kernel keeps the layers with a shortcut up
-    # to 256 input channels and the 64-channel outputs; everything else -- every first 1x1 of a bottleneck, K = 512 with a
-    # shortcut (38 vs 49 us), the neck's P5 -- is ahead or level on the LDS-staged GEMM)
-    if mfma_ok and conv.in_channels <= 256 and (res is not None or conv.out_channels <= 64 or not pw_ok):
-        return 'mfma'
-    if pw_ok:
+    if pw:
         return 'pw'
-    if mfma_ok:
-        return 'mfma'
-    if res is None:
-        return 'gemm'
-    return 'conv'
+    raise _no_kernel('1x1 convolution', conv, x)
 
 
-def _own_conv3x3(conv, x, pad=None):
-    """True when the hand-written implicit-GEMM kernel (ops.conv3x3_f16) takes this 3x3 convolution: float16 NHWC,
-    stride 1, padding 1, cin % 64 == 0, cout % 128 == 0, and enough output tiles to fill the chip (the kernel cuts the
-    pixels into 128 .. 256-row slabs; measured on the detectors' layer shapes at batch 1 / 4 / 8,
-    tools/exp/conv3x3_layers.py: 1.3-1.9x ahead of the library from ~100 workgroups of the smallest tile on, behind it
-    on the small maps)."""
-    if _CONV3X3_MODE == 'lib' or x.dtype not in (torch.float16, torch.float32) or pad is not None or not x.is_cuda:
+def _own_conv3x3(conv, x):
+    """the implicit-GEMM kernel (ops.conv3x3_f16 / conv3x3_f32) takes this 3x3 stride-1 'same' convolution: float16 with
+    cin % 64 == 0 and cout % 64 == 0, float32 with cin % 32 == 0 and cout % 64 == 0 -- at every map size (the launcher picks
+    the workgroup tile: 128 .. 256-pixel slabs, or the 64 x 64 ring form when the map has few pixels)"""
+    if not x.is_cuda or x.dtype not in (torch.float16, torch.float32):
         return False
     if tuple(conv.kernel_size) != (3, 3) or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1):
         return False
-    if x.dtype == torch.float32:
-        # the parity mode: exact-float32 matrix instructions, always the own kernel (ops.conv3x3_f32; on a par with the
-        # library's float32 rate, and no solver search whose choice could change the summation order between runs)
-        return ('f32' not in _PW_OFF and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
-                and x.is_contiguous(memory_format=torch.channels_last))
-    # (ResNet conv2's 64 -> 64 layer on 64-channel tiles: 82 vs 87 us at batch 8, 138 vs 160 at 15, since the LDS stages are
-    # sized by the tile and several of the small workgroups share a CU)
-    if conv.in_channels % 64 != 0 or conv.out_channels % 64 != 0:
-        return False
-    if not x.is_contiguous(memory_format=torch.channels_last):
-        return False
-    m = int(x.shape[0]) * int(x.shape[2]) * int(x.shape[3])
-    co = conv.out_channels
-    tiles_n = co // 256 if co % 256 == 0 else (co // 128 if co % 128 == 0 else co // 64)
-    if 'c3x3_64' in _PW_OFF and co % 128 != 0:
-        return False
-    return _CONV3X3_MODE == 'force' or ((m + 127) // 128) * tiles_n >= 100
+    gran = 64 if x.dtype == torch.float16 else 32
+    return conv.in_channels % gran == 0 and conv.out_channels % 64 == 0
 
+
+# a fused bottleneck tail (3x3 + last 1x1 + shortcut + ReLU in one launch) pays from this many 128-pixel slabs on: its
+# workgroup must hold ALL middle channels of its pixels, so a small map makes few workgroups (conv4 at batch 1: 33) and the
+# two launches -- 64 x 64 ring tiles for the 3x3, 528 workgroups for the 1x1 -- win (38.7 vs 61.5 us; at batch 4 / 132 slabs
+# the fused launch: 65.4 vs 71.9 us; conv3 at batch 1 / 131 slabs: 27.4 vs 33.9 us; tools/r04/small_tiles.py)
+_FUSED_TAIL_MIN_SLABS = 128
 
 # the float32 mode's patch matrices (stem, VGG16's first convolution) are addressed with 32-bit byte offsets
 _PATCH_BYTES_MAX = 0xF0000000
 
 
 def _stem(conv1, images_nhwc, dtype):
-    """conv1_pad + 7x7/2 'valid' + folded BN + ReLU + pool1_pad + 3x3/2 max-pooling (resnet_fpn.py:262-289).  float16 on the
-    GPU: ONE launch from the image (ops.stem_conv7_pool3: the 64-channel convolution output, 273 MB at batch 8, never
-    goes to memory); otherwise the library convolution + the fused bias / ReLU / pooling pass."""
-    if (_CONV3X3_MODE in ('own', 'force') and images_nhwc.is_cuda and dtype == torch.float16 and conv1.out_channels == 64
-            and images_nhwc.dtype in (torch.float32, torch.float16) and images_nhwc.is_contiguous()):
+    """conv1_pad + 7x7/2 'valid' + folded BN + ReLU + pool1_pad + 3x3/2 max-pooling (resnet_fpn.py:262-289).  float16: ONE
+    launch from the image (ops.stem_conv7_pool3: the 64-channel convolution output, 273 MB at batch 8, never goes to
+    memory); float32 (parity mode): the 7x7 / 2 convolution as the exact-float32 GEMM on its patch matrix
+    (ops.stem_patches_f32: 160 floats per output pixel), then bias + ReLU + the 3x3 / 2 pooling in one pass."""
+    ok = (images_nhwc.is_cuda and images_nhwc.is_contiguous() and conv1.out_channels == 64
+          and tuple(conv1.kernel_size) == (7, 7) and tuple(conv1.stride) == (2, 2))
+    if ok and dtype == torch.float16 and images_nhwc.dtype in (torch.float32, torch.float16):
         key = (conv1.weight.data_ptr(), conv1.weight._version)
         packed = getattr(conv1, '_odet_packed', None)
         if packed is None or packed[0] != key:
             packed = (key, ops.stem_pack_weights(conv1.weight))
             conv1._odet_packed = packed
         return ops.stem_conv7_pool3(images_nhwc, packed[1], conv1.bias).permute(0, 3, 1, 2)
-    if (images_nhwc.is_cuda and dtype == torch.float32 and images_nhwc.dtype == torch.float32 and images_nhwc.is_contiguous()
-            and conv1.out_channels == 64 and tuple(conv1.kernel_size) == (7, 7) and 'f32' not in _PW_OFF
-            and _CONV3X3_MODE in ('own', 'force')):
-        # float32 (parity mode): the 7x7 / 2 convolution as the exact-float32 GEMM on its patch matrix (ops.stem_patches_f32:
-        # 160 floats per output pixel), then bias + ReLU + the 3x3 / 2 pooling in one pass -- no library convolution
+    if ok and dtype == torch.float32 and images_nhwc.dtype == torch.float32:
         key = (conv1.weight.data_ptr(), conv1.weight._version)
         packed = getattr(conv1, '_odet_packed32', None)
         if packed is None or packed[0] != key:
@@ -238,92 +161,37 @@ def _stem(conv1, images_nhwc, dtype):
             parts.append(ops.bias_relu_maxpool(y, conv1.bias, 3, 2, 1, False))
         y = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
         return y.permute(0, 3, 1, 2)
-    x = images_nhwc.to(dtype).permute(0, 3, 1, 2)                               # NHWC memory, NCHW view
-    return _conv_relu_pool(conv1, x, 3, 2, pool_pad=1, pad=(3, 3, 3, 3))
+    raise _no_kernel('stem', conv1, images_nhwc)
 
 
-def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False, pad=None):
-    """max_pool(relu(conv(x) + bias)): on the GPU the convolution runs without its bias and ONE pass
-    (ops.bias_relu_maxpool) reads its output once and writes the pooled map; torch formulation elsewhere."""
-    if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
-        if (_own_conv3x3(conv, x, pad) and x.dtype == torch.float16 and kernel == 2 and stride == 2 and pool_pad == 0 and ceil_mode
-                and conv.bias is not None and 'pool' not in _PW_OFF):
-            # Conv2D + ReLU + MaxPooling2D((2, 2), 2, 'same') in the convolution's own launch (its pixel order makes a pooling
-            # window four neighbouring lanes): the un-pooled map is never written
-            return ops.conv3x3_relu_pool2_f16(x.permute(0, 2, 3, 1), conv.weight, conv.bias).permute(0, 3, 1, 2)
-        if _own_conv3x3(conv, x, pad):
-            # the hand-written implicit GEMM without its epilogue, then the fused bias + ReLU + pooling pass
-            yn = (ops.conv3x3_f32 if x.dtype == torch.float32 else ops.conv3x3_f16)(x.permute(0, 2, 3, 1), conv.weight)
-            return ops.bias_relu_maxpool(yn, conv.bias, kernel, stride, pool_pad, ceil_mode).permute(0, 3, 1, 2)
-        padding = conv.padding
-        if pad is not None:
-            if pad[0] == pad[1] == pad[2] == pad[3] and tuple(conv.padding) == (0, 0):
-                padding = (pad[0], pad[0])
-            else:
-                x = F.pad(x, pad)
-        y = F.conv2d(x, conv.weight, None, conv.stride, padding)
-        if not y.is_contiguous(memory_format=torch.channels_last):
-            y = y.contiguous(memory_format=torch.channels_last)
-        return ops.bias_relu_maxpool(y.permute(0, 2, 3, 1), conv.bias, kernel, stride, pool_pad, ceil_mode).permute(0, 3, 1, 2)
-    y = _conv_epi(conv, x, relu=True, pad=pad)
-    return F.max_pool2d(y, kernel, stride, padding=pool_pad, ceil_mode=ceil_mode)
+def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False):
+    """max_pool(relu(conv3x3(x) + bias)) (vgg16_faster_rcnn.py:260-342).  float16 with the 2x2 / 2 'same' pooling: in the
+    convolution's own launch (its pixel order makes a pooling window four neighbouring lanes: the un-pooled map is never
+    written); otherwise the convolution without its epilogue, then ONE pass (ops.bias_relu_maxpool) that reads its output
+    once and writes the pooled map."""
+    if not _own_conv3x3(conv, x) or conv.bias is None:
+        raise _no_kernel('3x3 convolution + pooling', conv, x)
+    if x.dtype == torch.float16 and kernel == 2 and stride == 2 and pool_pad == 0 and ceil_mode:
+        return ops.conv3x3_relu_pool2_f16(_nhwc(x), conv.weight, conv.bias).permute(0, 3, 1, 2)
+    yn = (ops.conv3x3_f32 if x.dtype == torch.float32 else ops.conv3x3_f16)(_nhwc(x), conv.weight)
+    return ops.bias_relu_maxpool(yn, conv.bias, kernel, stride, pool_pad, ceil_mode).permute(0, 3, 1, 2)
 
 
-def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, pad=None):
-    """conv (+ zero padding `pad`) -> + bias (+ extra_bias) (+ residual) -> ReLU.  On the GPU the convolution
-    runs without its bias and everything after it is ONE in-place pass of the fused HIP epilogue
-    (ops.bias_act_) over the NHWC output; the torch formulation serves the CPU shape-bookkeeping test."""
-    padding = conv.padding
-    if pad is not None:
-        if pad[0] == pad[1] == pad[2] == pad[3] and tuple(conv.padding) == (0, 0):
-            padding = (pad[0], pad[0])           # symmetric ZeroPadding2D + 'valid' == the convolution's own zero padding
-        else:
-            x = F.pad(x, pad)
+def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None):
+    """conv -> + bias (+ extra_bias) (+ residual) -> ReLU in ONE launch of this package's kernels; x / residual / result are
+    channels_last [B,C,H,W] tensors (= NHWC in memory)."""
     bias = conv.bias if extra_bias is None else conv.bias + extra_bias
-    if x.is_cuda and x.dtype in (torch.float32, torch.float16) and conv.out_channels % 8 == 0:
-        if (pad is None and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
-                and tuple(conv.padding) == (0, 0) and x.is_contiguous(memory_format=torch.channels_last)):
-            res = None
-            if residual is not None:
-                res = residual.permute(0, 2, 3, 1)
-                if not res.is_contiguous():
-                    res = res.contiguous()
-            route = _route_1x1(conv, x, bias, relu, res)
-            if route == 'pw':
-                return _pw_1x1(conv, x, bias, relu, res)
-            if route == 'gemm':
-                return _gemm_1x1(conv, x, bias, relu)
-            if route == 'mfma':
-                return _mfma_1x1(conv, x, bias, relu, res)
-            return _conv_1x1(conv, x, bias, relu, res)
-        if pad is None and _ROUTE_MODE == 'table' and 's2' not in _PW_OFF and tuple(conv.stride) == (2, 2) and _pw_ok(conv, x):
-            # Conv2D(1x1, strides 2, 'valid') = the same GEMM over every second pixel (the first block of a stage)
-            res = None
-            if residual is not None:
-                res = residual.permute(0, 2, 3, 1)
-                if not res.is_contiguous():
-                    res = res.contiguous()
-            return _pw_1x1(conv, x, bias, relu, res)
-        if residual is None and _own_conv3x3(conv, x, pad):
-            # hand-written implicit GEMM on the matrix cores with bias (+ ReLU) in its epilogue
-            if x.dtype == torch.float32:
-                return ops.conv3x3_f32(x.permute(0, 2, 3, 1), conv.weight, bias, relu=relu).permute(0, 3, 1, 2)
-            b16 = bias if bias.dtype == torch.float16 else bias.half()
-            return ops.conv3x3_f16(x.permute(0, 2, 3, 1), conv.weight, b16, relu=relu).permute(0, 3, 1, 2)
-        y = F.conv2d(x, conv.weight, None, conv.stride, padding)
-        if not y.is_contiguous(memory_format=torch.channels_last):
-            y = y.contiguous(memory_format=torch.channels_last)
-        res = None
-        if residual is not None:
-            res = residual.permute(0, 2, 3, 1)
-            if not res.is_contiguous():
-                res = res.contiguous()
-        ops.bias_act_(y.permute(0, 2, 3, 1), bias, res, relu)
-        return y
-    y = F.conv2d(x, conv.weight, bias, conv.stride, padding)
-    if residual is not None:
-        y = y + residual
-    return F.relu(y) if relu else y
+    if tuple(conv.kernel_size) == (1, 1):
+        res = None if residual is None else _nhwc(residual)
+        xn = _nhwc(x)
+        if _route_1x1(conv, x) == 'mfma':
+            return ops.conv1x1_f16(xn, conv.weight, bias, res, relu).permute(0, 3, 1, 2)
+        return ops.pointwise(xn, conv.weight, bias, res, relu, conv.stride[0]).permute(0, 3, 1, 2)
+    if residual is None and _own_conv3x3(conv, x):
+        # the implicit GEMM with bias (+ ReLU) in its epilogue
+        fn = ops.conv3x3_f32 if x.dtype == torch.float32 else ops.conv3x3_f16
+        return fn(_nhwc(x), conv.weight, bias, relu=relu).permute(0, 3, 1, 2)
+    raise _no_kernel('convolution', conv, x)
 
 
 class _Block(nn.Module):
@@ -342,7 +210,7 @@ class _Block(nn.Module):
             self.c3.weight.mul_(0.2)
 
     def _dual_weights(self):
-        """[w3 | w_shortcut] along K and b3 + b_shortcut (ops.pointwise_dual_f16), cached until a parameter changes"""
+        """[w3 | w_shortcut] along K and b3 + b_shortcut (ops.pointwise_dual), cached until a parameter changes"""
         ps = (self.c3.weight, self.c3.bias, self.short.weight, self.short.bias)
         key = tuple((t._version, t.data_ptr(), t.dtype) for t in ps)
         c = getattr(self, '_dual_cache', None)
@@ -356,60 +224,30 @@ class _Block(nn.Module):
         return c[1], c[2]
 
     def forward(self, x):
-        # Add([shortcut, x]) + ReLU ride on c3's epilogue; a convolutional shortcut runs without its bias,
-        # which is added to c3's instead
-        if (self.short is not None and x.is_cuda and x.dtype in (torch.float16, torch.float32) and _ROUTE_MODE == 'table'
-                and 'dual' not in _PW_OFF and not ('f32' in _PW_OFF and x.dtype == torch.float32)
-                and self.c3.in_channels % 64 == 0 and self.short.in_channels % 64 == 0 and self.c3.out_channels % 64 == 0
-                and tuple(self.short.stride) in ((1, 1), (2, 2)) and x.is_contiguous(memory_format=torch.channels_last)):
-            # a stage's first block, float16: the last 1x1 convolution AND the convolutional shortcut as ONE contraction
-            # over [c2's output | the block's (strided) input] with the weights concatenated along K
-            # (ops.pointwise_dual_f16) -- the shortcut map is never written or re-read, one launch instead of two
-            y = _conv_epi(self.c2, _conv_epi(self.c1, x, relu=True), relu=True)
-            w, b = self._dual_weights()
-            return ops.pointwise_dual(y.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1), w, b, self.short.stride[0],
-                                      relu=True).permute(0, 3, 1, 2)
-        if self.short is None:
-            sc, sb = x, None
-        elif x.is_cuda and x.dtype == torch.float16 and _ROUTE_MODE == 'table' and 'short' not in _PW_OFF and (
-                _pw_ok(self.short, x) or (tuple(self.short.stride) == (1, 1) and self.short.in_channels == 64
-                                          and x.is_contiguous(memory_format=torch.channels_last))):
-            # float16: the shortcut convolution WITH its bias on the own kernels (strided or long K: the pointwise GEMM;
-            # ResNet conv2's 64 -> 256: the register-resident kernel) -- no library convolution, no separate bias add
-            sc, sb = _conv_epi(self.short, x, relu=False), None
-        else:
-            sc, sb = F.conv2d(x, self.short.weight, None, self.short.stride, self.short.padding), self.short.bias
         y = _conv_epi(self.c1, x, relu=True)
-        if y.is_cuda and y.dtype == torch.float16 and self.c3.in_channels in (64, 128, 256, 512):
-            # c2 (3x3) runs WITHOUT bias / ReLU; if c3 takes the MFMA route for this shape, c2's epilogue is applied
-            # to c3's operand fragments as they are loaded (ops.conv1x1_f16(in_bias=...)) and its pass disappears
-            if self.c2.out_channels in ((256,) if 'tail' in _PW_OFF else (64, 128, 256)) and _CONV3X3_MODE in ('own', 'force') \
-                    and _own_conv3x3(self.c2, y) and (int(y.shape[0]) * int(y.shape[2]) * int(y.shape[3]) + 127) // 128 >= 128:
+        if self.short is not None:
+            # a stage's first block: the last 1x1 convolution AND the convolutional shortcut + Add + ReLU as ONE contraction
+            # over [c2's output | the block's (strided) input] with the weights concatenated along K (ops.pointwise_dual) --
+            # the shortcut map is never written or re-read, one launch instead of two
+            gran = 64 if x.dtype == torch.float16 else 32
+            if (self.c3.in_channels % gran or self.short.in_channels % gran or self.c3.out_channels % 64
+                    or tuple(self.short.stride) not in ((1, 1), (2, 2))):
+                raise _no_kernel('bottleneck with a convolutional shortcut', self.short, x)
+            y = _conv_epi(self.c2, y, relu=True)
+            w, b = self._dual_weights()
+            return ops.pointwise_dual(_nhwc(y), _nhwc(x), w, b, self.short.stride[0], relu=True).permute(0, 3, 1, 2)
+        # Add([shortcut, x]) + ReLU ride on c3's epilogue
+        if y.dtype == torch.float16 and _own_conv3x3(self.c2, y) and self.c2.out_channels in (64, 128, 256):
+            m = int(y.shape[0]) * int(y.shape[2]) * int(y.shape[3])
+            if (m + 127) // 128 >= _FUSED_TAIL_MIN_SLABS:
                 # the 3x3 convolution AND the block's last 1x1 convolution + bias + shortcut + ReLU in one launch
-                # (ops.conv3x3_conv1x1_f16: the 64 / 128 / 256-channel activation between them stays in LDS): conv4 83 vs 108 us
-                # at batch 8 (253 vs 320 at 30), conv3 122 vs 134 (400 vs 477), conv2 198 vs 226 (640-700 vs 787); behind the
-                # two launches on smaller maps (tools/exp/block_tail_layers.py)
-                res = sc.permute(0, 2, 3, 1)
-                if not res.is_contiguous():
-                    res = res.contiguous()
-                b3 = self.c3.bias if sb is None else self.c3.bias + sb
-                out = ops.conv3x3_conv1x1_f16(y.permute(0, 2, 3, 1), self.c2.weight, self.c2.bias, self.c3.weight, b3,
-                                              residual=res, relu=True)
+                # (ops.conv3x3_conv1x1_f16: the 64 / 128 / 256-channel activation between them stays in LDS): conv4 83 vs
+                # 108 us at batch 8 (253 vs 320 at 30), conv3 122 vs 134 (400 vs 477), conv2 198 vs 226 (640-700 vs 787)
+                out = ops.conv3x3_conv1x1_f16(_nhwc(y), self.c2.weight, self.c2.bias, self.c3.weight, self.c3.bias,
+                                              residual=_nhwc(x), relu=True)
                 return out.permute(0, 3, 1, 2)
-            res = sc.permute(0, 2, 3, 1)
-            if not res.is_contiguous():
-                res = res.contiguous()
-            b3 = self.c3.bias if sb is None else self.c3.bias + sb
-            if _route_1x1(self.c3, y, b3, True, res) == 'mfma':           # (c2's output has y's shape)
-                if _own_conv3x3(self.c2, y):
-                    y2 = ops.conv3x3_f16(y.permute(0, 2, 3, 1), self.c2.weight).permute(0, 3, 1, 2)
-                else:
-                    y2 = F.conv2d(y, self.c2.weight, None, self.c2.stride, self.c2.padding)
-                    if not y2.is_contiguous(memory_format=torch.channels_last):
-                        y2 = y2.contiguous(memory_format=torch.channels_last)
-                return _mfma_1x1(self.c3, y2, b3, True, res, in_bias=self.c2.bias)
         y = _conv_epi(self.c2, y, relu=True)
-        return _conv_epi(self.c3, y, relu=True, residual=sc, extra_bias=sb)
+        return _conv_epi(self.c3, y, relu=True, residual=x)
 
 
 def _stack(cin, filters, blocks, stride1):
@@ -500,19 +338,14 @@ class _FinalLayer:
         """x [rows, K] (the head's last activation) -> (class logits [rows, Ccls], box regressions [rows, 4 Ccls])"""
         n1 = self.score.out_features
         n5 = n1 + self.bbox.out_features
-        own = (x.is_cuda and x.dtype in (torch.float16, torch.float32) and _ROUTE_MODE == 'table' and x.is_contiguous()
-               and 'final' not in _PW_OFF and not ('f32' in _PW_OFF and x.dtype == torch.float32))
-        if own:
-            wpad, b32 = self._final_layer()
-            if wpad is not None:
-                y = ops.dense(x, wpad, b32) if x.dtype == torch.float32 else ops.dense_f16_out_f32(x, wpad, b32)
-                return y[:, :n1], y[:, n1:n5]
-        if x.dtype == torch.float16:
-            wpad, b32 = self._final_layer()
-            wsrc = torch.cat([self.score.weight, self.bbox.weight], 0) if wpad is None else wpad[:n5]
-            y = torch.addmm(b32[:n5], x.float(), wsrc.float().t())
-            return y[:, :n1], y[:, n1:n5]
-        return self.score(x), self.bbox(x)
+        wpad, b32 = self._final_layer()
+        if not x.is_cuda or x.dtype not in (torch.float16, torch.float32) or wpad is None:
+            raise RuntimeError('RoI head: the last layer needs a float16 / float32 GPU activation with a multiple of %d >= %d '
+                               'channels (got %s %s on %s)' % (64 if x.dtype == torch.float16 else 32,
+                                                                128 if x.dtype == torch.float16 else 64, tuple(x.shape), x.dtype, x.device))
+        x = x if x.is_contiguous() else x.contiguous()
+        y = ops.dense(x, wpad, b32) if x.dtype == torch.float32 else ops.dense_f16_out_f32(x, wpad, b32)
+        return y[:, :n1], y[:, n1:n5]
 
 
 class _NmsCompleteness:
@@ -634,91 +467,49 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         return _conv_epi(self.s2, p2), _conv_epi(self.s3, p3), _conv_epi(self.s4, p4), p5, p6
 
     def _lateral_merge(self, top, conv, c):
-        """P_k = 0.5 * resize_bilinear(P_{k+1}) + 0.5 * lateral(C_k) (resnet_fpn.py:385-398).  float16: ONE launch -- the
-        merge rides in the epilogue of the lateral 1x1 convolution (ops.lateral_merge_f16: the lateral map is never
-        written; 226 vs 301 us for P2 at batch 8); otherwise the convolution, then the merge launch."""
-        if _ROUTE_MODE == 'table' and 'lateral' not in _PW_OFF and _pw_ok(conv, c) and tuple(conv.stride) == (1, 1) \
-                and top.dtype == c.dtype:
-            t = top.permute(0, 2, 3, 1)
-            t = t if t.is_contiguous() else t.contiguous()
-            return ops.lateral_merge(c.permute(0, 2, 3, 1), conv.weight, conv.bias, t).permute(0, 3, 1, 2)
-        return self._merge(top, _conv_epi(conv, c))
+        """P_k = 0.5 * resize_bilinear(P_{k+1}) + 0.5 * lateral(C_k) (resnet_fpn.py:385-398) in ONE launch: the merge rides in
+        the epilogue of the lateral 1x1 convolution (ops.lateral_merge: the lateral map is never written; 226 vs 301 us for
+        P2 at batch 8)."""
+        if not _pw_ok(conv, c) or tuple(conv.stride) != (1, 1) or top.dtype != c.dtype:
+            raise _no_kernel('lateral convolution + top-down merge', conv, c)
+        return ops.lateral_merge(_nhwc(c), conv.weight, conv.bias, _nhwc(top)).permute(0, 3, 1, 2)
 
     @staticmethod
     def _merge(top, lateral):
-        """0.5 * resize_bilinear(top) + 0.5 * lateral (resnet_fpn.py:385-398).  On the GPU one launch of the
-        fused HIP kernel (odet_fpn_topdown_merge) on the NHWC memory of the channels_last tensors; the torch
-        formulation only serves the CPU shape-bookkeeping test and dtypes the kernel does not take."""
-        if top.is_cuda and top.dtype in (torch.float32, torch.float16):
-            out = ops.fpn_topdown_merge(top.permute(0, 2, 3, 1), lateral.permute(0, 2, 3, 1))
-            return out.permute(0, 3, 1, 2)
-        return tf_legacy_resize_bilinear(top, lateral.shape[2:]) * 0.5 + lateral * 0.5
+        """0.5 * resize_bilinear(top) + 0.5 * lateral (resnet_fpn.py:385-398) as a launch of its own (ops.fpn_topdown_merge,
+        float32 bit-identical to the TF1 restatement): for callers that already hold the lateral map."""
+        return ops.fpn_topdown_merge(_nhwc(top), _nhwc(lateral)).permute(0, 3, 1, 2)
 
     def rpn(self, p_list):
         """shared RpnHead on every level; outputs concatenated P2->P6 in (y, x, anchor) order
-        (base_fpn_model.py:188-200, 427-432): scores [B, N, 2], deltas [B, N, 4]."""
-        if p_list[0].is_cuda and p_list[0].dtype in (torch.float32, torch.float16):
-            # GPU: the two 1x1 convolutions run as ONE contraction (weights concatenated: the 512-channel activation
-            # is read once) without bias, and ONE pass per level (ops.rpn_pack_pair) adds the bias, widens to float32
-            # and writes the level's slices of the concatenated arrays the proposal stage reads
-            w, b = self._rpn_pair_weights()
-            B = p_list[0].shape[0]
-            n = sum(int(p.shape[2]) * int(p.shape[3]) for p in p_list) * self.A
-            scores = torch.empty((B, n, 2), dtype=torch.float32, device=p_list[0].device)
-            deltas = torch.empty((B, n, 4), dtype=torch.float32, device=p_list[0].device)
-            off = 0
-            fused = p_list[0].dtype == torch.float16 and self.rpn_conv.out_channels == 512 and self.A <= 4
-            convs = None
-            if fused and _CONV3X3_MODE in ('own', 'force') and self.rpn_conv.in_channels % 64 == 0:
-                # the WHOLE head in one launch: the 3x3 convolution of all levels with bias + ReLU + both 1x1 convolutions
-                # in its epilogue (ops.rpn_head_fused): the 512-channel activation is never written
-                xs = [p.permute(0, 2, 3, 1) for p in p_list]
-                xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
-                return ops.rpn_head_fused(xs, self.rpn_conv.weight, self.rpn_conv.bias, w, b, self.A, scores, deltas)
-            if fused and _CONV3X3_MODE != 'lib' and self.rpn_conv.in_channels % 64 == 0:
-                # the 3x3 convolution of ALL levels in one launch of the hand-written implicit-GEMM kernel
-                # (ops.conv3x3_f16_levels: the small levels' workgroups fill the tail of the big ones'), without bias
-                xs = [p.permute(0, 2, 3, 1) for p in p_list]
-                xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
-                convs = ops.conv3x3_f16_levels(xs, self.rpn_conv.weight)
-            heads = None
-            if not fused and p_list[0].dtype == torch.float32 and _CONV3X3_MODE != 'lib' \
-                    and self.rpn_conv.in_channels % 32 == 0 and self.rpn_conv.out_channels % 256 == 0:
-                # float32 (the parity mode): the same grouped launch on exact-float32 matrix instructions, bias + ReLU
-                # in its epilogue (ops.conv3x3_f32_levels; on a par with the library on P2 alone, ahead of its five
-                # separate launches because the small levels fill the tail: tools/exp/conv3x3_layers.py 8 f32)
-                xs = [p.permute(0, 2, 3, 1) for p in p_list]
-                xs = [x if x.is_contiguous() else x.contiguous() for x in xs]
-                heads = ops.conv3x3_f32_levels(xs, self.rpn_conv.weight, self.rpn_conv.bias, relu=True)
-            for li, p in enumerate(p_list):
-                if fused:
-                    # float16: the 3x3 convolution without bias, then ONE MFMA pass does bias + ReLU + both 1x1
-                    # convolutions + their biases + the float32 re-layout (ops.rpn_head_tail)
-                    if convs is not None:
-                        ops.rpn_head_tail(convs[li], self.rpn_conv.bias, w, b, self.A, scores, deltas, off)
-                        off += int(p.shape[2]) * int(p.shape[3]) * self.A
-                        continue
-                    c = F.conv2d(p, self.rpn_conv.weight, None, 1, self.rpn_conv.padding)
-                    if not c.is_contiguous(memory_format=torch.channels_last):
-                        c = c.contiguous(memory_format=torch.channels_last)
-                    ops.rpn_head_tail(c.permute(0, 2, 3, 1), self.rpn_conv.bias, w, b, self.A, scores, deltas, off)
-                else:
-                    x = heads[li].permute(0, 3, 1, 2) if heads is not None else _conv_epi(self.rpn_conv, p, relu=True)
-                    if heads is not None and 'f32' not in _PW_OFF and self.rpn_conv.out_channels % 32 == 0:
-                        # float32: the two 1x1 convolutions as the exact-float32 GEMM (weight rows zero-padded to 64)
-                        sd = ops.pointwise(heads[li], self._rpn_pair_padded(w), None)[..., :6 * self.A]
-                    else:
-                        sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
-                    ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, off)
-                off += int(p.shape[2]) * int(p.shape[3]) * self.A
-            return scores, deltas
-        scores, deltas = [], []
-        for p in p_list:
-            x = _conv_epi(self.rpn_conv, p, relu=True)
-            B = x.shape[0]
-            scores.append(self.rpn_score(x).permute(0, 2, 3, 1).reshape(B, -1, 2))
-            deltas.append(self.rpn_bbox(x).permute(0, 2, 3, 1).reshape(B, -1, 4))
-        return torch.cat(scores, 1), torch.cat(deltas, 1)
+        (base_fpn_model.py:188-200, 427-432): scores [B, N, 2], deltas [B, N, 4] (float32)."""
+        p0 = p_list[0]
+        if not _own_conv3x3(self.rpn_conv, p0) or self.rpn_conv.out_channels % 256:
+            raise _no_kernel('RpnHead', self.rpn_conv, p0)
+        # the two 1x1 convolutions run as ONE contraction (weights concatenated: the 512-channel activation is read once)
+        w, b = self._rpn_pair_weights()
+        B = p0.shape[0]
+        n = sum(int(p.shape[2]) * int(p.shape[3]) for p in p_list) * self.A
+        scores = torch.empty((B, n, 2), dtype=torch.float32, device=p0.device)
+        deltas = torch.empty((B, n, 4), dtype=torch.float32, device=p0.device)
+        xs = [_nhwc(p) for p in p_list]
+        if p0.dtype == torch.float16:
+            if 6 * self.A > 32 or self.rpn_conv.out_channels > 512:
+                raise _no_kernel('RpnHead (more than 5 anchors per cell or more than 512 channels)', self.rpn_conv, p0)
+            # the WHOLE head in one launch: the 3x3 convolution of all levels with bias + ReLU + both 1x1 convolutions in its
+            # epilogue (ops.rpn_head_fused): the 512-channel activation is never written
+            return ops.rpn_head_fused(xs, self.rpn_conv.weight, self.rpn_conv.bias, w, b, self.A, scores, deltas)
+        # float32 (the parity mode): the 3x3 convolution of all levels in one launch on exact-float32 matrix instructions,
+        # bias + ReLU in its epilogue (ops.conv3x3_f32_levels: the small levels' workgroups fill the tail of the big ones'),
+        # the two 1x1 convolutions as the exact-float32 GEMM (weight rows zero-padded to 64), then ONE pass per level adds
+        # the bias and writes the level's slices of the concatenated arrays (ops.rpn_pack_pair)
+        heads = ops.conv3x3_f32_levels(xs, self.rpn_conv.weight, self.rpn_conv.bias, relu=True)
+        off = 0
+        for h in heads:
+            sd = ops.pointwise(h, self._rpn_pair_padded(w), None)[..., :6 * self.A]
+            ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, off)
+            off += int(h.shape[1]) * int(h.shape[2]) * self.A
+        return scores, deltas
 
     def _rpn_pair_weights(self):
         return rpn_pair_weights(self)
@@ -727,22 +518,17 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         return rpn_pair_padded(self, w)
 
     def roi_head(self, roi_features):
+        """flatten(7,7,256) -> fc 1024 -> fc 1024 -> score / boxes (resnet_fpn.py:292-336): the Dense layers on the pointwise
+        GEMM kernel with bias + ReLU in its epilogue, the last layer with float32 results"""
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)
-        own = (x.is_cuda and x.dtype in (torch.float16, torch.float32) and _ROUTE_MODE == 'table' and x.is_contiguous()
-               and not ('f32' in _PW_OFF and x.dtype == torch.float32))
-        if own and 'fc' not in _PW_OFF:
-            # the Dense layers on the pointwise GEMM kernel with bias + ReLU in its epilogue (resnet_fpn.py:292-336)
-            x = ops.dense(x, self.fc1.weight, self.fc1.bias, relu=True)
-            x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
-        else:
-            x = F.relu(self.fc1(x))
-            x = F.relu(self.fc2(x))
+        x = ops.dense(x if x.is_contiguous() else x.contiguous(), self.fc1.weight, self.fc1.bias, relu=True)
+        x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
         return self._final_outputs(x)
 
     # ---- HIP-graph replay ---------------------------------------------------------------------------
     def capture(self, batch, warmup=3):
         """Captures forward() for `batch` images of self.image_shape into ONE HIP graph (the whole detector:
-        library convolutions, fused epilogues / neck merges, the sync-free hot path, the RoI head) and
+        convolutions, neck merges, the sync-free hot path, the RoI head) and
         returns `run(images_nhwc) -> outputs`: the images are copied into the graph's static input and the
         graph is replayed -- a few hundred launches cost one host call, which is what a batch-1 latency
         step is bound by.  Needs the sync-free proposal stage (blind_chunks >= 1: no host check inside)."""
@@ -753,7 +539,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):                  # MIOpen solver search + every lazy allocation
+            for _ in range(max(1, warmup)):                  # every lazy allocation (weight packs, workspaces)
                 self.forward(static_in)
             side.synchronize()
             graph = torch.cuda.CUDAGraph()

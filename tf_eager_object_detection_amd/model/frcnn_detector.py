@@ -3,21 +3,20 @@ model/faster_rcnn/resnet_faster_rcnn.py (ResNetFasterRcnn: extractor conv1..conv
 global average pool + two dense layers) + the inference branch of model/faster_rcnn/base_faster_rcnn_model.py
 (BaseFasterRcnn.call :126-198, RpnHead :309-350).  BASELINE config "ResNet-50 Faster R-CNN, 1x3x800x1333".
 
-Same arrangement as model/fpn_detector.py: the convolutions are genuine dense contractions and run through
-PyTorch-ROCm's library convolutions (NHWC, fp32 / fp16) with the fused HIP epilogue behind each of them;
-everything between them is FrcnnHotPath (anchors in registers -> [A bg | A fg] softmax -> decode / clip ->
-exact NMS over all anchors -> 7x7 crop (ResNet) / 14x14 crop + 2x2 max (VGG16) on the stride-16 map ->
-post_ops_prediction).  Weights are
-randomly initialised with the reference's initialisers (no checkpoints offline), frozen batch-norm folded."""
+Same arrangement as model/fpn_detector.py: the convolutions are genuine dense contractions and run on the matrix cores
+through this repository's kernels (NHWC, float32 = parity mode / float16 = throughput mode; no library convolution or GEMM
+route, no CPU path); everything between them is FrcnnHotPath (anchors in registers -> [A bg | A fg] softmax -> decode /
+clip -> exact NMS over all anchors -> 7x7 crop (ResNet) / 14x14 crop + 2x2 max (VGG16) on the stride-16 map ->
+post_ops_prediction).  Weights are randomly initialised with the reference's initialisers (no checkpoints offline), frozen
+batch-norm folded.  The plain-torch formulation of the same networks lives with the tests (tests/torch_reference.py)."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from ..pipeline import FrcnnHotPath, FrcnnStepBatch
-from . import fpn_detector as fd
+from . import fpn_detector as fpn
 from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _FinalLayer, _conv, _conv_epi, _stem, \
-    _conv_relu_pool, _fold_frozen_bn, _stack, rpn_pair_weights
+    _conv_relu_pool, _fold_frozen_bn, _nhwc, _no_kernel, _stack, rpn_pair_weights
 
 __all__ = ['ResNetC4Detector', 'Vgg16Detector']
 
@@ -65,12 +64,12 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         `batched=False` in the hot-path keywords selects one FrcnnHotPath per image on a stream of its own."""
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
         # float16 maps go straight into the RoI kernel (pooled 14x14 + max and un-pooled 7x7 crop alike)
-        fd = torch.float16 if self.dtype == torch.float16 else torch.float32
-        self._feature_dtype = fd
+        feat_dtype = torch.float16 if self.dtype == torch.float16 else torch.float32
+        self._feature_dtype = feat_dtype
         kw = dict(self._hot_kwargs)
         self._steps = None
         if self._max_batch <= 64 and kw.pop('batched', True):
-            self._steps = FrcnnStepBatch(self._max_batch, *self._hot_args, feature_dtype=fd, **kw)
+            self._steps = FrcnnStepBatch(self._max_batch, *self._hot_args, feature_dtype=feat_dtype, **kw)
             self._hot = self._steps.slots
             self._roi_feat_all = self._steps.roi_features
             K = self._hot_args[2]
@@ -79,10 +78,10 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
             self._dlt = torch.zeros((self._max_batch, K, 4 * self.num_classes), dtype=torch.float32, device=dev)
             self._bound = False
             return self
-        self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=fd, **kw) for _ in range(self._max_batch)]
+        self._hot = [FrcnnHotPath(*self._hot_args, feature_dtype=feat_dtype, **kw) for _ in range(self._max_batch)]
         # the images' RoI features are consecutive blocks of one buffer: the RoI head takes the whole batch at once
         h0 = self._hot[0]
-        self._roi_feat_all = torch.zeros((self._max_batch,) + tuple(h0.roi_features.shape), dtype=fd, device=h0.device)
+        self._roi_feat_all = torch.zeros((self._max_batch,) + tuple(h0.roi_features.shape), dtype=feat_dtype, device=h0.device)
         for b, h in enumerate(self._hot):
             h.roi_features = self._roi_feat_all[b]
         # one stream per image: the hot path of an image is a chain of small launches (~130 us), the images'
@@ -117,29 +116,21 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         return self.conv4(self.conv3(self.conv2(x)))
 
     def rpn(self, c4):
-        """RpnHead: scores [B, fh*fw, 2A] ([A bg | A fg] per location), deltas [B, fh*fw*A, 4]."""
+        """RpnHead: scores [B, fh*fw, 2A] ([A bg | A fg] per location), deltas [B, fh*fw*A, 4] (float32)."""
         x = _conv_epi(self.rpn_conv, c4, relu=True)
         B = x.shape[0]
-        if x.is_cuda and x.dtype in (torch.float32, torch.float16):
-            # the two 1x1 convolutions as one contraction, then ONE pass: + bias, float32, split (ops.rpn_pack_pair;
-            # [fh*fw, 2A] and [fh*fw*A, 2] are the same memory)
-            w, b = rpn_pair_weights(self)
-            xn = x.permute(0, 2, 3, 1)
-            gran = 64 if x.dtype == torch.float16 else 32
-            if ('c1' not in fd._PW_OFF and not ('f32' in fd._PW_OFF and x.dtype == torch.float32) and xn.is_contiguous()
-                    and x.shape[1] % gran == 0 and x.shape[1] >= 2 * gran):
-                # the two 1x1 convolutions as ONE contraction on the pointwise GEMM kernel (weight rows zero-padded to 64)
-                sd = ops.pointwise(xn, fd.rpn_pair_padded(self, w), None)[..., :6 * self.A]
-            else:
-                sd = F.conv2d(x, w, None).permute(0, 2, 3, 1)
-            n = int(sd.shape[1]) * int(sd.shape[2]) * self.A
-            scores = torch.empty((B, n, 2), dtype=torch.float32, device=x.device)
-            deltas = torch.empty((B, n, 4), dtype=torch.float32, device=x.device)
-            ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, 0)
-            return scores.view(B, -1, 2 * self.A), deltas
-        scores = self.rpn_score(x).permute(0, 2, 3, 1).reshape(B, -1, 2 * self.A)
-        deltas = self.rpn_bbox(x).permute(0, 2, 3, 1).reshape(B, -1, 4)
-        return scores, deltas
+        gran = 64 if x.dtype == torch.float16 else 32
+        if x.shape[1] % gran or x.shape[1] < 2 * gran:
+            raise _no_kernel('RpnHead 1x1 pair', self.rpn_score, x)
+        # the two 1x1 convolutions as ONE contraction on the pointwise GEMM kernel (weight rows zero-padded to 64), then ONE
+        # pass: + bias, float32, split (ops.rpn_pack_pair; [fh*fw, 2A] and [fh*fw*A, 2] are the same memory)
+        w, b = rpn_pair_weights(self)
+        sd = ops.pointwise(_nhwc(x), fpn.rpn_pair_padded(self, w), None)[..., :6 * self.A]
+        n = int(sd.shape[1]) * int(sd.shape[2]) * self.A
+        scores = torch.empty((B, n, 2), dtype=torch.float32, device=x.device)
+        deltas = torch.empty((B, n, 4), dtype=torch.float32, device=x.device)
+        ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, 0)
+        return scores.view(B, -1, 2 * self.A), deltas
 
     def roi_head(self, roi_features):
         """[R,7,7,1024] NHWC -> conv5 -> global average pool -> (score logits [R,C], box deltas [R,4C])."""
@@ -265,10 +256,9 @@ class Vgg16Detector(ResNetC4Detector):
     def features(self, images_nhwc):
         """[B,H,W,3] -> conv5_3 [B,512,ceil(H/16),ceil(W/16)] channels_last."""
         first = self.convs[0]
-        own_first = (images_nhwc.is_cuda and self.dtype == torch.float16 and fd._CONV3X3_MODE in ('own', 'force')
-                     and images_nhwc.dtype in (torch.float32, torch.float16) and images_nhwc.is_contiguous()
-                     and first.out_channels == 64 and 'rgb' not in fd._PW_OFF)
-        if own_first:
+        if not images_nhwc.is_cuda or not images_nhwc.is_contiguous() or first.out_channels != 64:
+            raise _no_kernel('first convolution', first, images_nhwc)
+        if self.dtype == torch.float16 and images_nhwc.dtype in (torch.float32, torch.float16):
             # conv1_1 straight from the image (ops.conv3x3_rgb: bias + ReLU in the launch, its output written once)
             key = (first.weight.data_ptr(), first.weight._version)
             packed = getattr(first, '_odet_packed', None)
@@ -276,11 +266,8 @@ class Vgg16Detector(ResNetC4Detector):
                 packed = (key, ops.conv3x3_rgb_pack_weights(first.weight))
                 first._odet_packed = packed
             x = ops.conv3x3_rgb(images_nhwc, packed[1], first.bias, relu=True).permute(0, 3, 1, 2)
-        elif (images_nhwc.is_cuda and self.dtype == torch.float32 and images_nhwc.dtype == torch.float32 and images_nhwc.is_contiguous()
-              and fd._CONV3X3_MODE in ('own', 'force') and first.out_channels == 64 and 'f32' not in fd._PW_OFF
-              and 'rgb' not in fd._PW_OFF):
+        elif self.dtype == torch.float32 and images_nhwc.dtype == torch.float32:
             # float32 (parity mode): conv1_1 as the exact-float32 GEMM on its patch matrix (ops.rgb_patches3x3_f32)
-            own_first = True
             key = (first.weight.data_ptr(), first.weight._version)
             packed = getattr(first, '_odet_packed32', None)
             if packed is None or packed[0] != key:
@@ -291,16 +278,16 @@ class Vgg16Detector(ResNetC4Detector):
                 first._odet_packed32 = packed
             # (32-bit byte offsets into the patch matrix: groups of images that keep it below 4 GiB)
             Bn, Hn, Wn = (int(v) for v in images_nhwc.shape[:3])
-            step = max(1, min(Bn, fd._PATCH_BYTES_MAX // (Hn * Wn * 64 * 4)))
+            step = max(1, min(Bn, fpn._PATCH_BYTES_MAX // (Hn * Wn * 64 * 4)))
             parts = [ops.pointwise(ops.rgb_patches3x3_f32(images_nhwc[i:i + step]), packed[1], first.bias, None, True)
                      for i in range(0, Bn, step)]
             x = (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).permute(0, 3, 1, 2)
         else:
-            x = images_nhwc.to(self.dtype).permute(0, 3, 1, 2)
+            raise _no_kernel('first convolution', first, images_nhwc)
         i = 0
         for bi, (_, n) in enumerate(self._CFG):
             for k in range(n):
-                if own_first and i == 0:
+                if i == 0:                                    # (conv1_1: above)
                     i += 1
                     continue
                 if k == n - 1 and bi < 4:
@@ -313,12 +300,7 @@ class Vgg16Detector(ResNetC4Detector):
 
     def roi_head(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)        # Flatten() of NHWC crops
-        if (x.is_cuda and x.dtype in (torch.float16, torch.float32) and x.is_contiguous() and 'fc' not in fd._PW_OFF
-                and not ('f32' in fd._PW_OFF and x.dtype == torch.float32)):
-            # fc6 / fc7 on the pointwise GEMM kernel, bias + ReLU in its epilogue (dropout: inference)
-            x = ops.dense(x, self.fc1.weight, self.fc1.bias, relu=True)
-            x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
-        else:
-            x = F.relu(self.fc1(x))                                               # (dropout: inference)
-            x = F.relu(self.fc2(x))
+        # fc6 / fc7 on the pointwise GEMM kernel, bias + ReLU in its epilogue (dropout: inference)
+        x = ops.dense(x if x.is_contiguous() else x.contiguous(), self.fc1.weight, self.fc1.bias, relu=True)
+        x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
         return self._final_outputs(x)

@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Round 4: every workgroup tile of the float16 implicit-GEMM kernel (legacy half-step loop and the ring forms) on the
+ResNet-101-FPN layer shapes at the BASELINE configs' own batch sizes, against the library and against the tile the launcher
+picks by itself; every result checked for exactness on integer data first.
+
+    python tools/r04/small_tiles.py [batches, default 1,2,4] [--json out]"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch, torch.nn.functional as F
+from tf_eager_object_detection_amd import ops, _lib
+
+torch.backends.cudnn.benchmark = True
+BATCHES = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('--') else '1,2,4').split(',')]
+OUT = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
+TILES = [(8, 4, 4, 2), (8, 4, 8, 2), (8, 2, 2, 2), (8, 2, 4, 2), (8, 1, 1, 2), (8, 1, 2, 2),
+         (4, 1, 1, 8), (4, 1, 1, 4), (4, 2, 2, 6), (4, 4, 4, 3), (8, 4, 4, 3), (8, 2, 2, 4), (8, 1, 1, 6)]
+
+
+def timed(fns, n=24):
+    """us per call inside a HIP graph of n back-to-back calls cycling through the closures `fns` -- each on its OWN copy of
+    the layer's tensors, ~100 MB in all, so that a call finds its operands in the Infinity Cache but not in the L2s, as in a
+    real pass (a Python call costs ~13 us of host time: an eager loop of short kernels measures the host; one set of
+    tensors re-used by every call measures L2 hits: 8 us where the same kernel takes 22 us inside a pass)"""
+    if callable(fns):
+        fns = [fns]
+    n = max(n, len(fns))
+    for f in fns[:3]:
+        f()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fns[0]()
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(n):
+                fns[i % len(fns)]()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(3):
+        g.replay()
+    b.record(); b.synchronize()
+    return a.elapsed_time(b) / (3 * n) * 1e3
+
+
+def copies_for(nbytes):
+    return int(max(2, min(24, -(-100e6 // nbytes))))
+
+
+def clones(n, *ts):
+    return [tuple(None if t is None else t.clone() for t in ts) for _ in range(n)]
+
+
+def force(form, tile):
+    _lib.call('odet_debug_conv_tile', form, *(tile if tile else (0, 0, 0, 0)))
+
+
+def ints(shape, lo, hi):
+    return torch.randint(lo, hi + 1, shape, device='cuda').half()
+
+
+res = {}
+for B in BATCHES:
+    # ---- 3x3 layers (plain form, bias + ReLU epilogue)
+    for name, h, wd, cin, cout in (('conv4_c2 (x23)', 50, 84, 256, 256), ('conv5_c2 (x3)', 25, 42, 512, 512),
+                                   ('neck_s4', 50, 84, 256, 256), ('neck_s3', 100, 167, 256, 256),
+                                   ('conv3_c2 (x4)', 100, 167, 128, 128), ('conv2_c2 (x3)', 200, 334, 64, 64)):
+        x = ints((B, h, wd, cin), -2, 2)
+        w = ints((cout, cin, 3, 3), -1, 1).contiguous(memory_format=torch.channels_last)
+        b = ints((cout,), -3, 3)
+        ref = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w.float(), b.float(), 1, 1)).permute(0, 2, 3, 1)
+        row = {}
+        sets = clones(copies_for(2 * (x.numel() + w.numel() + ref.numel())), x, w, torch.empty_like(x[..., :1]).expand(B, h, wd, cout).contiguous())
+        for tile in [None] + TILES:
+            if tile and cout % (64 * tile[1]):
+                continue
+            force(0, tile)
+            try:
+                y = ops.conv3x3_f16(x, w, b, relu=True)
+                torch.cuda.synchronize()
+                exact = bool((y.float() == ref).all().item())
+                t = timed([(lambda s_=s_: ops.conv3x3_f16(s_[0], s_[1], b, relu=True, out=s_[2])) for s_ in sets])
+                row['pick' if tile is None else '%d,%d,%d,%d' % tile] = [round(t, 1), exact]
+            except Exception as ex:
+                row['%s' % (tile,)] = 'error: %s' % ex
+        force(0, None)
+        row['library'] = [round(timed([(lambda s_=s_: F.conv2d(s_[0].permute(0, 3, 1, 2), s_[1], None, 1, 1)) for s_ in sets]), 1), True]
+        res['b%d 3x3 %s %dx%d %d->%d' % (B, name, h, wd, cin, cout)] = row
+        print(B, name, json.dumps(row), flush=True)
+    # ---- pointwise layers
+    for name, rows, K, N, with_res in (('conv4_c1 (x23)', B * 50 * 84, 1024, 256, False), ('conv4_c3 (x23)', B * 50 * 84, 256, 1024, True),
+                                       ('conv5_c1', B * 25 * 42, 2048, 512, False), ('conv5_c3', B * 25 * 42, 512, 2048, True),
+                                       ('conv3_c1', B * 100 * 167, 512, 128, False), ('conv3_c3', B * 100 * 167, 128, 512, True),
+                                       ('neck_p5', B * 25 * 42, 2048, 256, False), ('fc1', B * 1000, 12544, 1024, False),
+                                       ('fc2', B * 1000, 1024, 1024, False)):
+        x = ints((1, 1, rows, K), -2, 2)
+        w = ints((N, K), -1, 1)
+        b = ints((N,), -3, 3)
+        r = ints((1, 1, rows, N), -4, 4) if with_res else None
+        ref = x.view(rows, K).float() @ w.float().t() + b.float()
+        if r is not None:
+            ref = ref + r.view(rows, N).float()
+        ref = F.relu(ref)
+        ok_range = bool((ref.abs() < 2048).all().item())        # (exactly representable in float16)
+        row = {}
+        yo = torch.empty((1, 1, rows, N), dtype=torch.float16, device='cuda')
+        sets = clones(copies_for(2 * (x.numel() + w.numel() + yo.numel() * (2 if with_res else 1))), x, w, r, yo)
+        for tile in [None] + TILES:
+            if tile and N % (64 * tile[1]):
+                continue
+            force(1, tile)
+            try:
+                y = ops.pointwise(x, w, b, r, True, 1)
+                torch.cuda.synchronize()
+                exact = bool((y.view(rows, N).float() == ref).all().item()) if ok_range else None
+                t = timed([(lambda s_=s_: ops.pointwise(s_[0], s_[1], b, s_[2], True, 1, out=s_[3])) for s_ in sets])
+                row['pick' if tile is None else '%d,%d,%d,%d' % tile] = [round(t, 1), exact]
+            except Exception as ex:
+                row['%s' % (tile,)] = 'error: %s' % ex
+        force(1, None)
+        if K <= 512 and with_res:
+            row['conv1x1_f16 (register-resident)'] = [round(timed([(lambda s_=s_: ops.conv1x1_f16(s_[0], s_[1], b, residual=s_[2], relu=True, out=s_[3])) for s_ in sets]), 1), True]
+        row['library'] = [round(timed([(lambda s_=s_: torch._addmm_activation(b, s_[0].view(rows, K), s_[1].t(), use_gelu=False)) for s_ in sets]), 1), True]
+        res['b%d 1x1 %s %d x %d->%d' % (B, name, rows, K, N)] = row
+        print(B, name, json.dumps(row), flush=True)
+    # ---- fused bottleneck tails (3x3 + last 1x1 + shortcut + ReLU)
+    for name, h, wd, cm in (('conv4 tail', 50, 84, 256), ('conv3 tail', 100, 167, 128), ('conv2 tail', 200, 334, 64)):
+        n3 = 4 * cm
+        x = ints((B, h, wd, cm), -2, 2)
+        w2 = ints((cm, cm, 3, 3), -1, 1).contiguous(memory_format=torch.channels_last)
+        b2 = ints((cm,), -3, 3)
+        w3 = (ints((n3, cm), -1, 1) * (torch.rand(n3, cm, device='cuda') < 0.05)).half()      # sparse: results stay small
+        b3 = ints((n3,), -3, 3)
+        r = ints((B, h, wd, n3), -4, 4)
+        t = F.relu(F.conv2d(x.permute(0, 3, 1, 2).float(), w2.float(), b2.float(), 1, 1)).permute(0, 2, 3, 1)
+        ok_mid = bool((t < 2048).all().item())
+        ref = F.relu(t.reshape(-1, cm) @ w3.float().t() + b3.float() + r.view(-1, n3).float())
+        ok_range = ok_mid and bool((ref < 2048).all().item())
+        row = {}
+        wn = cm // 64
+        sets = clones(copies_for(2 * (x.numel() + w2.numel() + w3.numel() + 2 * r.numel())), x, w2, w3, r, torch.empty_like(r))
+        for tile in [None] + [tl for tl in TILES if tl[1] == wn]:
+            force(0, tile)
+            try:
+                y = ops.conv3x3_conv1x1_f16(x, w2, b2, w3, b3, residual=r, relu=True)
+                torch.cuda.synchronize()
+                exact = bool((y.view(-1, n3).float() == ref).all().item()) if ok_range else None
+                tt = timed([(lambda s_=s_: ops.conv3x3_conv1x1_f16(s_[0], s_[1], b2, s_[2], b3, residual=s_[3], relu=True, out=s_[4])) for s_ in sets])
+                row['pick' if tile is None else '%d,%d,%d,%d' % tile] = [round(tt, 1), exact]
+            except Exception as ex:
+                row['%s' % (tile,)] = 'error: %s' % ex
+        force(0, None)
+        y2s = [torch.empty_like(s_[0]) for s_ in sets]
+        row['two launches (3x3 pick + conv1x1_f16)'] = [round(2 * timed([f for s_, y2 in zip(sets, y2s) for f in (
+            (lambda s_=s_, y2=y2: ops.conv3x3_f16(s_[0], s_[1], out=y2)),
+            (lambda s_=s_, y2=y2: ops.conv1x1_f16(y2, s_[2], b3, residual=s_[3], relu=True, out=s_[4], in_bias=b2)))]), 1), None]
+        res['b%d tail %s %dx%d %d' % (B, name, h, wd, cm)] = row
+        print(B, name, json.dumps(row), flush=True)
+if OUT:
+    json.dump(res, open(OUT, 'w'), indent=1)
