@@ -765,6 +765,7 @@ static const TileEntry kTiles[] = {
     C3_LEGACY(4, 4), C3_LEGACY(5, 4), C3_LEGACY(6, 4), C3_LEGACY(7, 4), C3_LEGACY(8, 4),       // 128 .. 256 px x 256 ch
     C3_LEGACY(2, 2), C3_LEGACY(3, 2), C3_LEGACY(4, 2),                                         // 128 .. 256 px x 128 ch
     C3_LEGACY(1, 1), C3_LEGACY(2, 1),                                                          // 128 / 256 px x 64 ch
+    C3_LEGACY(2, 4), C3_LEGACY(3, 4), C3_LEGACY(1, 2),                                         // 64 / 96 px x 256 ch, 64 px x 128 ch
     // ring forms, 64 px x 64 ch: 8 stages (128 KB: one workgroup per CU, seven K-steps of copies in flight) and 4 stages
     // (two workgroups per CU).  Also built and measured in round 4, not kept (tools/r04/small_tiles.py, sweep of all layer
     // shapes at batch 1 / 2 / 4, cold L2): 64 x 128 (6 stages), 64 x 256 (3; with the fused tail), and rings for the 8-wave

@@ -118,11 +118,13 @@ def _own_conv3x3(conv, x):
     return conv.in_channels % gran == 0 and conv.out_channels % 64 == 0
 
 
-# a fused bottleneck tail (3x3 + last 1x1 + shortcut + ReLU in one launch) pays from this many 128-pixel slabs on: its
-# workgroup must hold ALL middle channels of its pixels, so a small map makes few workgroups (conv4 at batch 1: 33) and the
-# two launches -- 64 x 64 ring tiles for the 3x3, 528 workgroups for the 1x1 -- win (38.7 vs 61.5 us; at batch 4 / 132 slabs
-# the fused launch: 65.4 vs 71.9 us; conv3 at batch 1 / 131 slabs: 27.4 vs 33.9 us; tools/r04/small_tiles.py)
-_FUSED_TAIL_MIN_SLABS = 128
+# A fused bottleneck tail (3x3 + last 1x1 + shortcut + ReLU in one launch) pays from this many 128-pixel slabs on: its
+# workgroup must hold ALL middle channels of its pixels, so a small map makes few workgroups (conv4 at batch 1 / 4: 33 /
+# 132 on 256 CUs) and the two launches -- 3x3 with its epilogue (ring tiles at batch 1), then the 1x1 GEMM with the shortcut
+# in its epilogue -- win: conv4 30.4 vs 53.0 us at batch 1, 48.5 vs 53.0 at batch 2, 55.5 vs 59.0 at batch 4; at batch 8 (263
+# slabs) the fused launch: 84.1 vs 90.7; conv3 (cmid 128) at batch 2 / 263 slabs: 33.9 vs 39.6; conv2 from batch 1 on
+# (tools/r04/small_tiles.py --only tail, cold L2, inside a HIP graph; profiles/r04_small_tiles_tail.json)
+_FUSED_TAIL_MIN_SLABS = 200
 
 # the float32 mode's patch matrices (stem, VGG16's first convolution) are addressed with 32-bit byte offsets
 _PATCH_BYTES_MAX = 0xF0000000

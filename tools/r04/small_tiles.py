@@ -12,8 +12,9 @@ from tf_eager_object_detection_amd import ops, _lib
 torch.backends.cudnn.benchmark = True
 BATCHES = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('--') else '1,2,4').split(',')]
 OUT = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
-TILES = [(8, 4, 4, 2), (8, 4, 8, 2), (8, 2, 2, 2), (8, 2, 4, 2), (8, 1, 1, 2), (8, 1, 2, 2),
-         (4, 1, 1, 8), (4, 1, 1, 4), (4, 2, 2, 6), (4, 4, 4, 3), (8, 4, 4, 3), (8, 2, 2, 4), (8, 1, 1, 6)]
+TILES = [(8, 4, 2, 2), (8, 4, 3, 2), (8, 4, 4, 2), (8, 4, 6, 2), (8, 4, 8, 2), (8, 2, 1, 2), (8, 2, 2, 2), (8, 2, 3, 2), (8, 2, 4, 2),
+         (8, 1, 1, 2), (8, 1, 2, 2), (4, 1, 1, 8), (4, 1, 1, 4)]
+ONLY = sys.argv[sys.argv.index('--only') + 1].split(',') if '--only' in sys.argv else None      # 3x3, 1x1, tail
 
 
 def timed(fns, n=24):
@@ -66,7 +67,7 @@ def ints(shape, lo, hi):
 res = {}
 for B in BATCHES:
     # ---- 3x3 layers (plain form, bias + ReLU epilogue)
-    for name, h, wd, cin, cout in (('conv4_c2 (x23)', 50, 84, 256, 256), ('conv5_c2 (x3)', 25, 42, 512, 512),
+    for name, h, wd, cin, cout in () if ONLY and '3x3' not in ONLY else (('conv4_c2 (x23)', 50, 84, 256, 256), ('conv5_c2 (x3)', 25, 42, 512, 512),
                                    ('neck_s4', 50, 84, 256, 256), ('neck_s3', 100, 167, 256, 256),
                                    ('conv3_c2 (x4)', 100, 167, 128, 128), ('conv2_c2 (x3)', 200, 334, 64, 64)):
         x = ints((B, h, wd, cin), -2, 2)
@@ -92,7 +93,7 @@ for B in BATCHES:
         res['b%d 3x3 %s %dx%d %d->%d' % (B, name, h, wd, cin, cout)] = row
         print(B, name, json.dumps(row), flush=True)
     # ---- pointwise layers
-    for name, rows, K, N, with_res in (('conv4_c1 (x23)', B * 50 * 84, 1024, 256, False), ('conv4_c3 (x23)', B * 50 * 84, 256, 1024, True),
+    for name, rows, K, N, with_res in () if ONLY and '1x1' not in ONLY else (('conv4_c1 (x23)', B * 50 * 84, 1024, 256, False), ('conv4_c3 (x23)', B * 50 * 84, 256, 1024, True),
                                        ('conv5_c1', B * 25 * 42, 2048, 512, False), ('conv5_c3', B * 25 * 42, 512, 2048, True),
                                        ('conv3_c1', B * 100 * 167, 512, 128, False), ('conv3_c3', B * 100 * 167, 128, 512, True),
                                        ('neck_p5', B * 25 * 42, 2048, 256, False), ('fc1', B * 1000, 12544, 1024, False),
@@ -128,7 +129,7 @@ for B in BATCHES:
         res['b%d 1x1 %s %d x %d->%d' % (B, name, rows, K, N)] = row
         print(B, name, json.dumps(row), flush=True)
     # ---- fused bottleneck tails (3x3 + last 1x1 + shortcut + ReLU)
-    for name, h, wd, cm in (('conv4 tail', 50, 84, 256), ('conv3 tail', 100, 167, 128), ('conv2 tail', 200, 334, 64)):
+    for name, h, wd, cm in () if ONLY and 'tail' not in ONLY else (('conv4 tail', 50, 84, 256), ('conv3 tail', 100, 167, 128), ('conv2 tail', 200, 334, 64)):
         n3 = 4 * cm
         x = ints((B, h, wd, cm), -2, 2)
         w2 = ints((cm, cm, 3, 3), -1, 1).contiguous(memory_format=torch.channels_last)
@@ -158,6 +159,10 @@ for B in BATCHES:
         row['two launches (3x3 pick + conv1x1_f16)'] = [round(2 * timed([f for s_, y2 in zip(sets, y2s) for f in (
             (lambda s_=s_, y2=y2: ops.conv3x3_f16(s_[0], s_[1], out=y2)),
             (lambda s_=s_, y2=y2: ops.conv1x1_f16(y2, s_[2], b3, residual=s_[3], relu=True, out=s_[4], in_bias=b2)))]), 1), None]
+        row['two launches (3x3 pick with epilogue + pointwise with shortcut)'] = [round(2 * timed([f for s_, y2 in zip(sets, y2s) for f in (
+            (lambda s_=s_, y2=y2: ops.conv3x3_f16(s_[0], s_[1], b2, relu=True, out=y2)),
+            (lambda s_=s_, y2=y2: (ops.pointwise(y2, s_[2], b3, s_[3], True, 1, out=s_[4]) if cm >= 128 else
+                                   ops.conv1x1_f16(y2, s_[2], b3, residual=s_[3], relu=True, out=s_[4]))))]), 1), None]
         res['b%d tail %s %dx%d %d' % (B, name, h, wd, cm)] = row
         print(B, name, json.dumps(row), flush=True)
 if OUT:
