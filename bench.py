@@ -35,6 +35,12 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
                  (`value`) and one thread (`value_1thread`); it also carries the mAP delta of the evaluation loop.
   `value_clustered` the same path, same protocol, on trained-like (clustered) RPN scores: a second timed region; the
                  sync-free NMS plan is widened by itself, rung by rung, when a distribution needs it (`config.replanned`).
+  `config5`      (N = 1) BASELINE configs[4] as a measured record: the same hot path at 1333x1333 (446 118 anchors, 1000
+                 proposals), 81 classes, caps 100 per class / 300 per image (config/faster_rcnn_config.py:93-113's COCO caps),
+                 float16 feature maps into the RoI kernel -- throughput, its RoI launch alone, its roofline fractions.
+  `multi_rank`   what a 2 / 4 / 8-GPU run needs to validate itself: the backend's world size (RCCL), per-rank img/s min / max,
+                 the number of all-gathers issued and their record bytes.
+  `summary`      LAST key, <= 1 KB, values only: every headline figure of this line (the driver keeps the tail of stdout).
   `e2e`          (N = 1) a second, separately labelled record: the assembled detectors end to end (hand-written
                  convolutions around the hot path, no library convolution or GEMM): ResNet-101-FPN fp32 = the reference's precision,
                  fp16 = throughput mode (narrower than the reference; eager and as one HIP graph) with its accuracy gate
@@ -122,25 +128,29 @@ def _cpu_leg(host, image_shape, threads, budget_s, max_images):
     return t_all
 
 
-def cpu_baseline(host, image_shape, budget_s=12.0, max_images=24):
+def cpu_baseline(host, image_shape, budget_s=8.0, max_images=24):
     """The reference path as the TF-eager CPU code runs it (C restatement, oracle/oracle.c): heap NMS
     over all anchors, un-fused 14x14 crop -> max-pool, sequential per-class loop.  Bounded sample, in both thread modes
-    of BASELINE.md section 3: all host cores (`value`, what TF's intra-op pool would use) and one thread."""
+    of BASELINE.md section 3: many threads (what TF's intra-op pool would use; capped at the PHYSICAL cores -- the 128
+    hardware threads of these hosts are shared with other tenants and the OpenMP crops lost to their own fork / join) and
+    one thread.  `value` quotes the FASTER leg (min-of-N per leg is reported beside the medians)."""
     from oracle import c_oracle as co
-    threads = max(1, min(os.cpu_count() or 1, co.max_threads()))
-    _cpu_leg(host, image_shape, threads, 5.0, 1)                               # (page-in / OpenMP pool start-up)
+    logical = os.cpu_count() or 1
+    threads = max(1, min(logical // 2 if logical >= 4 else logical, co.max_threads(), 64))
+    _cpu_leg(host, image_shape, threads, 4.0, 1)                               # (page-in / OpenMP pool start-up)
     t_all = _cpu_leg(host, image_shape, threads, budget_s, max_images)
     t_one = _cpu_leg(host, image_shape, 1, budget_s, max_images)
     t, t1 = float(np.median(t_all)), float(np.median(t_one))
     md = map_delta_vs_port()
-    return dict(map_delta=md, value=1.0 / t, unit='img/s', cores=threads, kind='port',
-                value_1thread=1.0 / t1, ms_per_image_1thread=t1 * 1e3, samples=len(t_all), samples_1thread=len(t_one),
-                ms_per_image_min=float(np.min(t_all)) * 1e3, ms_per_image_max=float(np.max(t_all)) * 1e3,
-                sample='%d (all cores) + %d (one thread) images of the same 800x1333 FPN hot-path workload, medians; C '
-                       'restatement of the reference path (heap NMS over 267069 anchors single-threaded, un-fused crop '
-                       '14x14 + max-pool on %d OpenMP threads / 1 thread, sequential class loop)'
-                       % (len(t_all), len(t_one), threads),
-                ms_per_image=t * 1e3)
+    fast_threads = threads if t <= t1 else 1
+    return dict(map_delta=md, value=1.0 / min(t, t1), unit='img/s', cores=fast_threads, kind='port',
+                value_threads=1.0 / t, threads=threads, value_1thread=1.0 / t1,
+                ms_per_image=min(t, t1) * 1e3, ms_per_image_threads=t * 1e3, ms_per_image_1thread=t1 * 1e3,
+                ms_per_image_min_threads=float(np.min(t_all)) * 1e3, ms_per_image_min_1thread=float(np.min(t_one)) * 1e3,
+                samples=len(t_all), samples_1thread=len(t_one), logical_cpus=logical,
+                sample='%d (%d threads) + %d (one thread) images of the same 800x1333 FPN hot-path workload, medians, the faster '
+                       'leg quoted; C restatement of the reference path (heap NMS over 267069 anchors single-threaded, un-fused '
+                       'crop 14x14 + max-pool on OpenMP threads, sequential class loop)' % (len(t_all), threads, len(t_one)))
 
 
 def map_delta_vs_port(num_images=16):
@@ -184,15 +194,15 @@ def load_traffic(workload_key, images_per_launch):
     return None
 
 
-def e2e_record(dtype_name, batch, budget_s=8.0, family='fpn'):
+def e2e_record(dtype_name, batch, budget_s=6.0, family='fpn', graph=False, eager=True):
     """An assembled detector end to end on synthetic images (random-init weights): backbone (+ neck) + RPN head + hot
     path + RoI head + post-ops; not the headline metric (that one is the hot path): a second, separately labelled
     record.  family = 'fpn': ResNet-101-FPN @ 800x1333 (BASELINE config 3); 'c4': ResNet-50 C4 Faster R-CNN @ 800x1333
-    (config 2); 'vgg16': VGG16 Faster R-CNN @ 600x800 (config 1).  fp32 = the reference's precision (parity mode)."""
+    (config 2); 'vgg16': VGG16 Faster R-CNN @ 600x800 (config 1).  fp32 = the reference's precision (parity mode).
+    graph: also replay the pass as ONE HIP graph (what a batch-1 latency step needs: ~140 launches = one host call)."""
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
     from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
     dt = {'fp32': torch.float32, 'fp16': torch.float16}[dtype_name]
-    torch.backends.cudnn.benchmark = True                 # MIOpen find mode (its default solver is naive on some shapes)
     torch.manual_seed(0)
     image_shape = (600, 800) if family == 'vgg16' else IMAGE_SHAPE
     if family == 'fpn':
@@ -210,59 +220,59 @@ def e2e_record(dtype_name, batch, budget_s=8.0, family='fpn'):
         out = model(img)
     torch.cuda.synchronize()
     warm_s = time.perf_counter() - t0
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        out = model(img)
-        steps += 1
-        if steps >= 5 and (steps % 5) == 0:
-            torch.cuda.synchronize()
-            if time.perf_counter() - t0 > budget_s or steps >= 200:
-                break
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    done = [int(h.nms_done.item()) for h in model._hot]
-    graph_rate = None
-    if family == 'fpn' and dtype_name == 'fp16':
-        # the same pass replayed as ONE HIP graph (the detector's capture(): a few hundred launches = one host call)
+    rec = dict(unit='img/s', batch=batch, dtype=dtype_name,
+               model={'fpn': 'ResNet-101-FPN', 'c4': 'ResNet-50 C4 Faster R-CNN', 'vgg16': 'VGG16 Faster R-CNN'}[family],
+               image=list(image_shape), weights='random init', data='synthetic', warmup_s=warm_s)
+    if eager:
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            out = model(img)
+            steps += 1
+            if steps >= 5 and (steps % 5) == 0:
+                torch.cuda.synchronize()
+                if time.perf_counter() - t0 > budget_s or steps >= 400:
+                    break
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        rec.update(value=steps * batch / el, steps=steps, ms_per_image=el / (steps * batch) * 1e3)
+    rec['nms_done'] = int(all(int(v) == 1 for v in model._steps.nms_done_all[:batch].tolist()))
+    rec['detections_image0'] = int(out[0][3].item())
+    if graph:
         try:
             run = model.capture(batch)
             for _ in range(3):
                 run(img)
             torch.cuda.synchronize()
             n_g, t0 = 0, time.perf_counter()
-            while n_g < 200:
+            while n_g < 2000:
                 run(img)
                 n_g += 1
                 if n_g % 10 == 0:
                     torch.cuda.synchronize()
-                    if time.perf_counter() - t0 > 4.0:
+                    if time.perf_counter() - t0 > min(budget_s, 4.0):
                         break
             torch.cuda.synchronize()
-            graph_rate = n_g * batch / (time.perf_counter() - t0)
+            rec['value_hip_graph'] = n_g * batch / (time.perf_counter() - t0)
+            rec['ms_per_pass_hip_graph'] = 1e3 * batch / rec['value_hip_graph']
         except Exception as ex:
-            graph_rate = 'capture failed: %s' % ex
-    rec = dict(value=steps * batch / el, unit='img/s', batch=batch, steps=steps, ms_per_image=el / (steps * batch) * 1e3,
-               dtype=dtype_name, model={'fpn': 'ResNet-101-FPN', 'c4': 'ResNet-50 C4 Faster R-CNN', 'vgg16': 'VGG16 Faster R-CNN'}[family],
-               image=list(image_shape), weights='random init', data='synthetic',
-               conv_path='hand-written HIP convolutions (float16: 3x3 implicit GEMM incl. the fused RpnHead and bottleneck tails, its '
-                         'pointwise GEMM form for the 1x1 / strided / dense layers and the laterals with the top-down merge in their '
-                         'epilogue, the register-resident 1x1 kernel, the fused stem; float32: the same implicit-GEMM forms on '
-                         'exact-float32 matrix instructions, the stem as a GEMM on its patch matrix) -- no library convolution or '
-                         'GEMM in a ResNet-101-FPN pass of either precision -- around the HIP hot path',
-               warmup_s=warm_s, nms_done=done, detections_image0=int(out[0][3].item()))
-    if graph_rate is not None:
-        rec['value_hip_graph'] = graph_rate
+            rec['value_hip_graph'] = 'capture failed: %s' % ex
+        if not eager:
+            rec['value'] = rec['value_hip_graph']
     del model
     torch.cuda.empty_cache()
     return rec
 
 
+E2E_CONV_PATH = ('hand-written HIP kernels only, at every batch size (float16: 3x3 implicit GEMM incl. the fused RpnHead and '
+                 'bottleneck tails and its 64 x 64 ring form for the small maps at batch 1-2, the pointwise GEMM form for the 1x1 / '
+                 'strided / dense layers and the laterals with the top-down merge in their epilogue, the register-resident 1x1 '
+                 'kernel, the fused stem; float32: the same forms on exact-float32 matrix instructions) -- the detectors have '
+                 'no library convolution / GEMM route (model/fpn_detector.py)')
+
+
 def main():
     # (before anything initialises HSA: dmabuf IPC is the only kind the host driver supports)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    # (the end-to-end record's find-mode warm-up: MIOpen's naive reference convolutions are never the fastest solver
-    # and cost the search a minute at 800x1333)
-    os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -273,9 +283,12 @@ def main():
                     help='RPN score distribution (SURVEY 8d: distinct; clustered = trained-like)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end detector record')
+    ap.add_argument('--no-config5', action='store_true', help='skip the BASELINE config-5 record (1333x1333, 81 classes, fp16 maps)')
     ap.add_argument('--no-second-distribution', action='store_true',
                     help='skip the second timed region (the other RPN score distribution: value_clustered)')
-    ap.add_argument('--gate-images', type=int, default=1024, help='held-out scenes of the float16-vs-float32 mAP gate (e2e)')
+    ap.add_argument('--gate-images', type=int, default=4096,
+                    help='held-out scenes of the float16-vs-float32 mAP gate of the ResNet-101-FPN detector (e2e); the C4 / VGG16 '
+                         'gates run a quarter of it')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams (stream groups) per GPU')
     ap.add_argument('--batch', type=int, default=8, help='images that share the kernel launches of a stream (1..8)')
     ap.add_argument('--blind-chunks', type=int, default=1, help='NMS chunks enqueued without a host check')
@@ -321,7 +334,6 @@ def main():
     # stream (one grid dimension = image)
     S, B = max(1, args.streams), max(1, min(8, args.batch))
     R = max(1, args.rounds_per_step)
-    fdt = torch.float16 if args.maps == 'f16' else torch.float32
     images_per_step = R * S * B
 
     trace_on = os.environ.get('ODET_BENCH_TRACE') == '1'
@@ -332,12 +344,16 @@ def main():
             print('[bench %.3f] %s' % (time.perf_counter(), what), file=sys.stderr, flush=True)
 
     class Workload:
-        """One score distribution's inputs (resident in HBM) + the stream pool that runs them."""
+        """One configuration's inputs for one score distribution (resident in HBM) + the stream pool that runs them.
+        cfg: image_shape, num_classes, max_per_class, max_per_image, maps ('f32' / 'f16')."""
 
-        def __init__(self, score_kind, nms_first_chunk, blind_chunks):
+        def __init__(self, cfg, score_kind, nms_first_chunk, blind_chunks):
+            self.cfg = cfg
+            self.fdt = torch.float16 if cfg['maps'] == 'f16' else torch.float32
+            fdt = self.fdt
             self.score_kind, self.nms_first_chunk, self.blind_chunks = score_kind, nms_first_chunk, blind_chunks
-            self.host, dev = synthetic_fpn_inputs(IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, seed=1234 + rank,
-                                                  score_kind=score_kind)
+            self.host, dev = synthetic_fpn_inputs(cfg['image_shape'], cfg['num_classes'], NUM_PROPOSALS, CHANNELS,
+                                                  seed=1234 + rank, score_kind=score_kind)
             if fdt != torch.float32:
                 dev['feats'] = [f.to(fdt) for f in dev['feats']]
             # every in-flight image has its OWN inputs in HBM (slot 0 = the seeded numpy set the CPU baseline also
@@ -354,14 +370,21 @@ def main():
                     feats=[torch.randn(f.shape, device='cuda', dtype=torch.float32, generator=gen).to(fdt) for f in dev['feats']],
                     cls_scores=dev['cls_scores'][pr].contiguous(), cls_deltas=dev['cls_deltas'][pr].contiguous()))
             self.pool = None
+            self.exchange = None
+            self.allgathers = 0
             self.plan(nms_first_chunk, blind_chunks)
 
         def plan(self, nms_first_chunk, blind_chunks):
             if self.pool is not None:
                 self.pool.close()
+            if self.exchange is not None:                       # (its communication buffers: one exchange at a time)
+                self.exchange.synchronize()
+                self.exchange = None
+            cfg = self.cfg
             self.nms_first_chunk, self.blind_chunks = nms_first_chunk, blind_chunks
-            pool = FpnStreamPool(S, IMAGE_SHAPE, NUM_CLASSES, NUM_PROPOSALS, CHANNELS, batch=B, blind_chunks=blind_chunks,
-                                 feature_dtype=fdt, nms_first_chunk=nms_first_chunk)
+            pool = FpnStreamPool(S, cfg['image_shape'], cfg['num_classes'], NUM_PROPOSALS, CHANNELS, batch=B,
+                                 blind_chunks=blind_chunks, feature_dtype=self.fdt, nms_first_chunk=nms_first_chunk,
+                                 max_per_class=cfg['max_per_class'], max_per_image=cfg['max_per_image'])
             rec_len = pool.slots[0].record.numel()
             self.records = torch.zeros((pool.n, rec_len), dtype=torch.float32, device='cuda')
             for k in range(pool.n):
@@ -390,6 +413,7 @@ def main():
                 for g in range(S):
                     pool.enqueue_group(g)
                     self.exchange.gather(g, self.records[g * B:(g + 1) * B], producer_stream=gstreams[g])
+                    self.allgathers += 1
 
         def fence(self):
             self.pool.wait()
@@ -410,7 +434,7 @@ def main():
         def measure(self, steps, warmup):
             """warm-up (re-planning the sync-free NMS if the score distribution needs more candidates than the plan's first
             chunk holds: first chunks of 2048 / 2560 / 3072 / 4096 candidates, then a second chunk from the ranked
-            selection), then exactly `steps` timed steps between fences; max over ranks."""
+            selection), then exactly `steps` timed steps between fences; max over ranks (+ every rank's own time)."""
             replans = []
             # (the ladder is fine-grained because the selection kernels' cost grows with the chunk: trained-like clustered scores
             # complete from 2560 candidates on and run 11 % faster there than with 4096; the slots' inputs are the same in the
@@ -430,46 +454,44 @@ def main():
                     break
             else:
                 raise SystemExit('NMS did not complete inside the sync-free chunks of any plan -- result would be invalid')
+            self.allgathers = 0
             t0 = time.perf_counter()
             self.run_steps(steps)
             self.fence()
             elapsed = time.perf_counter() - t0
             mark('timed region done')
+            per_rank = [elapsed]
             if use_dist:
-                t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                elapsed = float(t.item())
+                mine = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+                allt = torch.zeros(dist.get_world_size(), dtype=torch.float64, device='cuda')
+                dist.all_gather_into_tensor(allt, mine)
+                per_rank = [float(v) for v in allt.tolist()]
+                elapsed = max(per_rank)
             if not self.complete():
                 raise SystemExit('NMS did not complete inside the sync-free chunks -- result would be invalid')
+            self.per_rank_s = per_rank
             return elapsed, replans
 
-    # ---- the headline: SURVEY 8(d)'s distribution (or --scores), then the OTHER distribution beside it
-    wl = Workload(args.scores, args.nms_first_chunk, args.blind_chunks)
-    elapsed, replans = wl.measure(args.steps, args.warmup)
-    other_kind = 'clustered' if args.scores == 'distinct' else 'distinct'
-    other = None
-    if not args.no_second_distribution:
-        wl2 = Workload(other_kind, args.nms_first_chunk, args.blind_chunks)
-        el2, rp2 = wl2.measure(args.steps, args.warmup)
-        other = {'value': args.steps * images_per_step * world / el2, 'unit': 'img/s', 'ms_per_step': el2 / args.steps * 1e3,
-                 'rpn_scores': other_kind, 'timed_region_s': el2, 'nms_first_chunk': wl2.nms_first_chunk,
-                 'blind_chunks': wl2.blind_chunks, 'replanned': rp2,
-                 'proposals_kept': int(wl2.pool.slots[0].roi_count.item())}
-        wl2.pool.close()
-        del wl2
-        torch.cuda.empty_cache()
-    host, pool, records = wl.host, wl.pool, wl.records
-    hot = pool.slots[0]
-    gstreams = pool._group_streams
+        def close(self):
+            if self.pool is not None:
+                self.pool.close()
+                self.pool = None
+            if self.exchange is not None:
+                self.exchange.synchronize()
+                self.exchange = None
+            self.slot_inputs = None
 
-    if rank == 0:
-        # ---- roofline phase (untimed): the B-image RoI launch of stream group 0, ALONE on the GPU, cold maps.  Before
-        # every sample the other groups run once (their 2/3 of the 2.3 GB of inputs go through the caches; with one
-        # group a 1 GiB buffer is written instead), then group 0's stream waits (on the GPU) for the others.
+    def roofline_phase(wl, samples, kernel_label, workload_key):
+        """(untimed) the B-image RoI launch of stream group 0 of workload `wl`, ALONE on the GPU, cold maps.  Before every
+        sample the other groups run once (their 2/3 of the inputs go through the caches; with one group a 1 GiB buffer is
+        written instead), then group 0's stream waits (on the GPU) for the others.  Then the calibration kernel under the
+        same protocol.  -> the `roofline` object."""
         from tf_eager_object_detection_amd import ops
+        pool, cfg = wl.pool, wl.cfg
+        gstreams = pool._group_streams
         flush = torch.empty(1 << 28, dtype=torch.float32, device='cuda') if S == 1 else None
-        ev_roi = []
-        for _ in range(max(3, args.roofline_samples)):
+
+        def isolate():
             if S > 1:
                 for g in range(1, S):
                     pool.submit_group(g)
@@ -480,6 +502,11 @@ def main():
             mine = gstreams[0]
             for st in gstreams[1:]:
                 mine.wait_stream(st)
+            return mine
+
+        ev_roi = []
+        for _ in range(max(3, samples)):
+            isolate()
             ev = (ops.ProfEvent(), ops.ProfEvent())
             first = pool.steps[0]
             first.roi_start_event, first.roi_stop_event = ev[0].handle, ev[1].handle
@@ -489,11 +516,10 @@ def main():
                 first.roi_start_event, first.roi_stop_event = None, None
             torch.cuda.synchronize()
             ev_roi.append(ev)
-        mark('roofline samples done')
         times = [a.elapsed_ms(b) for a, b in ev_roi][2:]      # (the first two settle clocks / caches)
         roi_ms = float(np.mean(times))
 
-        def calibrate(read_bytes, write_bytes, samples=8):
+        def calibrate(read_bytes, write_bytes, n=8):
             """odet_calib_stream_mix (csrc/calib.hip: a kernel that only moves these bytes with the RoI kernel's
             instructions, cache policy and image -> XCD pinning) under the SAME protocol as the RoI samples above: what
             this box's memory system needs for the launch's read : write mix."""
@@ -501,17 +527,8 @@ def main():
             src = torch.zeros(rb // 4, dtype=torch.float32, device='cuda')
             dst = torch.empty(wb // 4, dtype=torch.float32, device='cuda')
             evs = []
-            for _ in range(samples):
-                if S > 1:
-                    for g in range(1, S):
-                        pool.submit_group(g)
-                    pool.wait()
-                else:
-                    with torch.cuda.stream(gstreams[0]):
-                        flush.fill_(1.0)
-                mine = gstreams[0]
-                for st in gstreams[1:]:
-                    mine.wait_stream(st)
+            for _ in range(n):
+                mine = isolate()
                 ev = (ops.ProfEvent(), ops.ProfEvent())
                 _lib.call('odet_calib_stream_mix', src.data_ptr(), rb, dst.data_ptr(), wb, mine.cuda_stream,
                           ev[0].handle, ev[1].handle)
@@ -521,20 +538,67 @@ def main():
             del src, dst
             return rb, wb, float(np.mean(ts)), len(ts)
 
-        k = int(hot.roi_count.item())
         # algorithmic bytes of the timed launch = the sum over its images (the slots of stream group 0; SURVEY 8d per image)
+        elem = 2 if cfg['maps'] == 'f16' else 4
         per_slot = []
         for h_ in pool.slots[:B]:
             kk = int(h_.roi_count.item())
             per_slot.append(algorithmic_roi_bytes(h_.sorted_rois[:kk].cpu().numpy(), h_.roi_level[:kk].cpu().numpy(),
-                                                  syn.fpn_level_shapes(IMAGE_SHAPE)[:4], IMAGE_SHAPE, CHANNELS,
-                                                  elem=2 if args.maps == 'f16' else 4))
+                                                  syn.fpn_level_shapes(cfg['image_shape'])[:4], cfg['image_shape'], CHANNELS,
+                                                  elem=elem))
         algo = {q: sum(a_[q] for a_ in per_slot) for q in per_slot[0]}
         achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
-        workload = 'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps')
-        images_per_step = R * S * B
-        traffic = load_traffic(workload, B)
-        ft = 'float' if args.maps == 'f32' else '__half'
+        traffic = load_traffic(workload_key, B)
+        ft = 'float' if cfg['maps'] == 'f32' else '__half'
+        rf = {'bound': 'hbm', 'kernel': '%s, the %d-image launch of one stream group, alone on the GPU, cold maps' % (kernel_label, B),
+              'rocprof_kernel_name': 'void k_roi_pool<1, 1, %s, 1>(RoiParams)' % ft,
+              'images_per_launch': B,
+              'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+              'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+              'kernel_ms': roi_ms, 'kernel_ms_samples': len(times), 'kernel_ms_min': float(np.min(times)),
+              'kernel_ms_max': float(np.max(times)), 'algorithmic_bytes': algo['B_roi'],
+              'B_min': algo['B_min'], 'B_taps': algo['B_taps'], 'bytes_output': algo['out']}
+        # the same launch priced on the HBM bytes the PMC counters saw (reuse between RoIs served from L2 / Infinity
+        # Cache is not in them; SURVEY 8d's algorithmic bytes count every RoI's cells): the plain bandwidth figure
+        rf['measured_traffic_GBps'] = (traffic / (roi_ms * 1e-3) / 1e9) if (traffic and roi_ms) else None
+        rf['hbm_frac_measured'] = (rf['measured_traffic_GBps'] / HBM_PEAK_GBS) if rf['measured_traffic_GBps'] else None
+        rf['frac_on_B_min'] = algo['B_min'] / (roi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # what the memory system of this box does with the same bytes and nothing else: B_min = every distinct map
+        # cell once + the output once, moved by a kernel without arithmetic, gathers or reuse (see calibrate())
+        rb, wb, cal_ms, cal_n = calibrate(algo['B_min'] - algo['out'], algo['out'])
+        rf['calibration'] = {'kernel': 'k_calib_stream_mix: reads B_min - output bytes once in 1 KB rows and writes the '
+                                       'output bytes (nontemporal), interleaved, XCD-pinned like the RoI launch; same '
+                                       'cold protocol',
+                             'bytes_read': rb, 'bytes_written': wb, 'ms': cal_ms, 'samples': cal_n,
+                             'GBps': (rb + wb) / (cal_ms * 1e-3) / 1e9,
+                             'roi_kernel_vs_calibration': cal_ms / roi_ms}
+        return rf
+
+    # ---- the headline: SURVEY 8(d)'s distribution (or --scores), then the OTHER distribution beside it
+    cfg3 = dict(image_shape=IMAGE_SHAPE, num_classes=NUM_CLASSES, max_per_class=50, max_per_image=50, maps=args.maps)
+    wl = Workload(cfg3, args.scores, args.nms_first_chunk, args.blind_chunks)
+    elapsed, replans = wl.measure(args.steps, args.warmup)
+    per_rank_s, allgathers = wl.per_rank_s, wl.allgathers
+    other_kind = 'clustered' if args.scores == 'distinct' else 'distinct'
+    other = None
+    if not args.no_second_distribution:
+        wl2 = Workload(cfg3, other_kind, args.nms_first_chunk, args.blind_chunks)
+        el2, rp2 = wl2.measure(args.steps, args.warmup)
+        other = {'value': args.steps * images_per_step * world / el2, 'unit': 'img/s', 'ms_per_step': el2 / args.steps * 1e3,
+                 'rpn_scores': other_kind, 'timed_region_s': el2, 'nms_first_chunk': wl2.nms_first_chunk,
+                 'blind_chunks': wl2.blind_chunks, 'replanned': rp2,
+                 'proposals_kept': int(wl2.pool.slots[0].roi_count.item())}
+        wl2.close()
+        del wl2
+        torch.cuda.empty_cache()
+    host = wl.host
+
+    result = None
+    if rank == 0:
+        rf = roofline_phase(wl, args.roofline_samples, 'k_roi_pool<MAX2, NORM_IMAGE> (fused crop_and_resize 14x14 + 2x2 max)',
+                            'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps'))
+        mark('roofline + calibration done')
+        k = int(wl.pool.slots[0].roi_count.item())
         result = {
             'metric': 'images/sec', 'value': args.steps * images_per_step * world / elapsed, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -552,15 +616,7 @@ def main():
                        'blind_chunks': wl.blind_chunks, 'replanned': replans,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_roi_pool<MAX2, NORM_IMAGE> (fused crop_and_resize 14x14 + 2x2 max), the '
-                                                   '%d-image launch of one stream group, alone on the GPU, cold maps' % B,
-                         'rocprof_kernel_name': 'void k_roi_pool<1, 1, %s, 1>(RoiParams)' % ft,
-                         'images_per_launch': B,
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel_ms': roi_ms, 'kernel_ms_samples': len(times), 'kernel_ms_min': float(np.min(times)),
-                         'kernel_ms_max': float(np.max(times)), 'algorithmic_bytes': algo['B_roi'],
-                         'B_min': algo['B_min'], 'B_taps': algo['B_taps'], 'bytes_output': algo['out']},
+            'roofline': rf,
         }
         if other is not None:
             # the same path on the other RPN score distribution, its own timed region of the same length (a trained RPN
@@ -568,70 +624,123 @@ def main():
             result['value_%s' % other_kind] = other['value']
             result['ms_per_step_%s' % other_kind] = other['ms_per_step']
             result['config']['second_distribution'] = other
-        # the same launch priced on the HBM bytes the PMC counters saw (reuse between RoIs served from L2 / Infinity
-        # Cache is not in them; SURVEY 8d's algorithmic bytes count every RoI's cells): the plain bandwidth figure
-        rf = result['roofline']
-        rf['measured_traffic_GBps'] = (traffic / (roi_ms * 1e-3) / 1e9) if (traffic and roi_ms) else None
-        rf['hbm_frac_measured'] = (rf['measured_traffic_GBps'] / HBM_PEAK_GBS) if rf['measured_traffic_GBps'] else None
-        rf['frac_on_B_min'] = algo['B_min'] / (roi_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        # what the memory system of this box does with the same bytes and nothing else: B_min = every distinct map
-        # cell once + the output once, moved by a kernel without arithmetic, gathers or reuse (see calibrate())
-        rb, wb, cal_ms, cal_n = calibrate(algo['B_min'] - algo['out'], algo['out'])
-        mark('calibration done')
-        rf['calibration'] = {'kernel': 'k_calib_stream_mix: reads B_min - output bytes once in 1 KB rows and writes the '
-                                       'output bytes (nontemporal), interleaved, XCD-pinned like the RoI launch; same '
-                                       'cold protocol',
-                             'bytes_read': rb, 'bytes_written': wb, 'ms': cal_ms, 'samples': cal_n,
-                             'GBps': (rb + wb) / (cal_ms * 1e-3) / 1e9,
-                             'roi_kernel_vs_calibration': cal_ms / roi_ms}
-        pool.close()
-        del pool
+        # what a multi-GPU run needs to validate itself against its N ranks (weak scaling: every rank times the same number
+        # of images; `value` divides by the slowest rank)
+        rates = [args.steps * images_per_step / t for t in per_rank_s]
+        result['multi_rank'] = {
+            'world_size_env': world, 'ranks_timed': len(per_rank_s),
+            'backend': (dist.get_backend() if use_dist else None),
+            'rccl_world': (dist.get_world_size() if use_dist else 1),
+            'collective': 'all_gather_into_tensor of the %d records of a stream group from every rank (parallel.GroupExchange)' % B
+                          if use_dist else 'none (one rank: no exchange in the loop)',
+            'allgathers_in_timed_region': allgathers, 'allgathers_expected': (args.steps * R * S if use_dist else 0),
+            'record_bytes_per_rank_per_allgather': B * wl.rec_len * 4,
+            'per_rank_img_s_min': min(rates), 'per_rank_img_s_max': max(rates),
+            'per_rank_spread': (max(rates) - min(rates)) / max(rates),
+            'images_per_rank': args.steps * images_per_step,
+        }
+    wl.close()
+    del wl
+    torch.cuda.empty_cache()
+
+    if rank == 0:
+        summary = {'hot_path_img_s': round(result['value'], 1), 'hot_path_clustered_img_s': round(other['value'], 1) if other else None,
+                   'roi_frac_B_roi': round(result['roofline']['frac'], 3),
+                   'roi_frac_counter_bytes': (round(result['roofline']['hbm_frac_measured'], 3)
+                                              if result['roofline']['hbm_frac_measured'] else None),
+                   'roi_kernel_us': round(result['roofline']['kernel_ms'] * 1e3, 1),
+                   'roi_vs_calibration': round(result['roofline']['calibration']['roi_kernel_vs_calibration'], 3)}
+        if not args.no_config5 and world == 1:
+            # ---- BASELINE configs[4]: 1333 x 1333, 446 118 anchors, 1000 proposals, 81 classes, caps 100 / 300 (the COCO
+            # configuration's per-class / per-image caps: config/faster_rcnn_config.py:112-113), float16 feature maps
+            try:
+                cfg5 = dict(image_shape=(1333, 1333), num_classes=81, max_per_class=100, max_per_image=300, maps='f16')
+                w5 = Workload(cfg5, 'distinct', args.nms_first_chunk, args.blind_chunks)
+                steps5 = max(2, args.steps // 4)
+                el5, rp5 = w5.measure(steps5, max(1, args.warmup // 2))
+                rf5 = roofline_phase(w5, max(6, args.roofline_samples // 2),
+                                     'k_roi_pool<MAX2, NORM_IMAGE, __half> (float16 maps: float32 lerps, float16 in / out)',
+                                     'fpn_hot_path_1333x1333_r101fpn_81cls_f16maps')
+                result['config5'] = {
+                    'workload': 'BASELINE configs[4]: ResNet-101-FPN hot path @ 1333x1333 (446118 anchors -> 1000 proposals), 81 '
+                                'classes, max 100 per class / 300 per image, float16 feature maps into the RoI kernel',
+                    'value': steps5 * images_per_step / el5, 'unit': 'img/s', 'steps': steps5, 'timed_images': steps5 * images_per_step,
+                    'timed_region_s': el5, 'ms_per_image': el5 / (steps5 * images_per_step) * 1e3, 'dtype': 'f16',
+                    'anchors': syn.num_fpn_anchors((1333, 1333)), 'num_classes': 81, 'max_per_class': 100, 'max_per_image': 300,
+                    'nms_first_chunk': w5.nms_first_chunk, 'blind_chunks': w5.blind_chunks, 'replanned': rp5,
+                    'proposals_kept': int(w5.pool.slots[0].roi_count.item()),
+                    'detections_image0': int(w5.pool.slots[0].det_count.item()), 'roofline': rf5}
+                # [img/s, us of the 8-image RoI launch, its fraction of 8 TB/s on B_min]
+                summary['cfg5_hot_path'] = [round(result['config5']['value'], 1), round(rf5['kernel_ms'] * 1e3, 1), round(rf5['frac_on_B_min'], 3)]
+                w5.close()
+                del w5
+            except Exception as ex:                   # the headline record must not depend on this one
+                result['config5'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+            torch.cuda.empty_cache()
+            mark('config 5 done')
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
+            cb = result['cpu_baseline']
+            summary['cpu_port_img_s'] = [round(cb['value'], 1), cb['cores']]
+            mark('cpu baseline done')
         if not args.no_e2e and world == 1:
-            e2e = {}
-            # (float16: 30 images per pass -- conv4's 50 x 84 maps then cut into 492 of the 256-pixel workgroup tiles, two full
-            # rounds of the 256 CUs (15 images: one round); 8 / 16 images leave a fifth of a round empty: same box 930 / 975 vs
-            # 1070 at 15 and 1105 img/s at 30 images per pass)
-            # (float32: 30 images per pass for the same reason -- the own exact-float32 kernels 141 img/s at 4 images, 177 at 15,
-            # 180 at 30; the library route 158 / 171 at 4 / 15)
-            # (60 images per float16 pass: four rounds of tiles on conv4 -- +2 % over 30, which is +3 % over 15)
-            for name, b in (('fp32', 30), ('fp16', 60)):
+            e2e = {'conv_path': E2E_CONV_PATH}
+            # (float16: 60 images per pass -- conv4's 50 x 84 maps then cut into four full rounds of 256-pixel workgroup tiles:
+            # +2 % over 30, +5 % over 15; 8 / 16 images leave a fifth of a round empty; batch 1 -- the BASELINE configs' own
+            # batch -- replayed as ONE HIP graph (a pass is ~140 launches), batch 4 / 8 eager and as a graph;
+            # float32: 30 images per pass for the same reason)
+            legs = (('fp16', 'fp16', 60, 'fpn', False, True), ('fp16_b1', 'fp16', 1, 'fpn', True, True),
+                    ('fp16_b4', 'fp16', 4, 'fpn', True, True), ('fp16_b8', 'fp16', 8, 'fpn', True, True),
+                    ('fp32', 'fp32', 30, 'fpn', False, True),
+                    ('fp16_resnet50_c4', 'fp16', 60, 'c4', False, True), ('fp16_vgg16_600x800', 'fp16', 64, 'vgg16', False, True))
+            for name, dtn, b, fam, gr, eg in legs:
                 try:
-                    e2e[name] = e2e_record(name, b)
+                    e2e[name] = e2e_record(dtn, b, budget_s=(6.0 if name in ('fp16', 'fp32') else 3.0), family=fam, graph=gr, eager=eg)
                 except Exception as ex:               # the headline record must not depend on the second one
                     e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
-            for name, fam, b in (('fp16_resnet50_c4', 'c4', 60), ('fp16_vgg16_600x800', 'vgg16', 64)):     # BASELINE configs 2 and 1
-                try:
-                    e2e[name] = e2e_record('fp16', b, budget_s=4.0, family=fam)
-                except Exception as ex:
-                    e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+                mark('e2e %s done' % name)
+
+            def rate(name, key='value'):
+                v = e2e.get(name, {}).get(key)
+                return round(v, 1) if isinstance(v, (int, float)) else None
+            summary.update(e2e_fp16=[rate('fp16'), 60], e2e_fp16_b1_graph=rate('fp16_b1', 'value_hip_graph'),
+                           e2e_fp16_b1_eager=rate('fp16_b1'), e2e_fp16_b4=[rate('fp16_b4'), rate('fp16_b4', 'value_hip_graph')],
+                           e2e_fp16_b8=[rate('fp16_b8'), rate('fp16_b8', 'value_hip_graph')], e2e_fp32=[rate('fp32'), 30],
+                           c4_fp16=[rate('fp16_resnet50_c4'), 60], vgg16_fp16=[rate('fp16_vgg16_600x800'), 64])
             # the accuracy side of the throughput mode: float16 vs float32 detector, same weights, same annotated scenes,
-            # the reference's evaluation loop (evaluation/precision_gate.py)
-            try:
-                from tf_eager_object_detection_amd.evaluation import precision_gate
-                gate = precision_gate.fp16_vs_fp32(num_images=args.gate_images, batch16=30)
-                if isinstance(e2e.get('fp16'), dict):
-                    e2e['fp16']['map_delta_vs_fp32'] = gate
-                    if 'value' in e2e['fp16']:
-                        ok_rate = e2e['fp16']['value'] >= 200.0
-                        e2e['fp16']['target'] = ('%s the north star\'s >= 200 img/s on one MI355X (%.0f img/s); mAP delta vs the '
-                                                 'float32 mode on identical weights and images = %+.4f (paired bootstrap std %.4f, '
-                                                 '%d held-out scenes; bar +-0.002)'
-                                                 % ('meets' if ok_rate else 'misses', e2e['fp16']['value'], gate['map_delta'],
-                                                    gate['map_delta_bootstrap_std'], gate['images']))
-                else:
-                    e2e['fp16_map_delta_vs_fp32'] = gate
-            except Exception as ex:
-                e2e['fp16_map_delta_vs_fp32'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+            # the reference's evaluation loop (evaluation/precision_gate.py) -- for all three families
+            from tf_eager_object_detection_amd.evaluation import precision_gate
+            for name, fam, n_img in (('fp16', 'fpn', args.gate_images), ('fp16_resnet50_c4', 'c4', max(256, args.gate_images // 4)),
+                                     ('fp16_vgg16_600x800', 'vgg16', max(256, args.gate_images // 4))):
+                try:
+                    gate = precision_gate.fp16_vs_fp32(num_images=n_img, batch32=30, batch16=30, family=fam)
+                    gate.pop('protocol', None) if fam != 'fpn' else None
+                    if isinstance(e2e.get(name), dict):
+                        e2e[name]['map_delta_vs_fp32'] = gate
+                    else:
+                        e2e[name + '_map_delta_vs_fp32'] = gate
+                    lo, hi = gate['map_delta_ci95_paired_bootstrap']
+                    summary['map_delta_' + fam] = [round(gate['map_delta'], 4), round(lo, 4), round(hi, 4), gate['images']]
+                except Exception as ex:
+                    e2e[name + '_map_delta_vs_fp32'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+                mark('gate %s done' % fam)
+            if isinstance(e2e.get('fp16'), dict) and 'value' in e2e['fp16'] and 'map_delta_vs_fp32' in e2e['fp16']:
+                g = e2e['fp16']['map_delta_vs_fp32']
+                e2e['fp16']['target'] = ('%s the north star\'s >= 200 img/s on one MI355X (%.0f img/s); mAP delta vs the float32 mode on '
+                                         'identical weights and images = %+.4f, paired-bootstrap CI95 [%+.4f, %+.4f] on %d held-out '
+                                         'scenes (bar +-0.002: point estimate %s, interval %s)'
+                                         % ('meets' if e2e['fp16']['value'] >= 200.0 else 'misses', e2e['fp16']['value'], g['map_delta'],
+                                            g['map_delta_ci95_paired_bootstrap'][0], g['map_delta_ci95_paired_bootstrap'][1], g['images'],
+                                            'inside' if g['within_bar'] else 'OUTSIDE', 'resolves it' if g['resolves_bar'] else 'wider than it'))
             e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
                            'mode (the reference computes in float32; ~77 % of the chip\'s 157 TFLOP/s float32 matrix peak, so '
                            '>= 200 img/s is out of reach of exact float32 arithmetic: 684 GFLOP per image), fp16 = throughput '
                            'mode, narrower than the reference, gated by map_delta_vs_fp32')
             result['e2e'] = e2e
+        mr = result['multi_rank']
+        summary['ranks'] = [mr['rccl_world'], round(mr['per_rank_img_s_min'], 1), round(mr['per_rank_img_s_max'], 1), mr['allgathers_in_timed_region']]
+        result['summary'] = summary                   # LAST key: the tail of the line carries every headline figure
         print(json.dumps(result))
-    else:
-        pool.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys():
-    # (the driver's own command line plus --no-e2e: the end-to-end detector record takes a minute of MIOpen searches)
+    # (the driver's own command line plus --no-e2e: the end-to-end detector records and their accuracy gates take minutes)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5',
                         '--no-e2e'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -41,7 +41,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert c['kind'] == 'port' and c['unit'] == 'img/s' and c['value'] > 0 and c['cores'] >= 1 and 'sample' in c
     assert abs(c['map_delta']['delta']) <= 0.002
     # both thread modes of BASELINE.md section 3, a bounded sample of each
-    assert c['value_1thread'] > 0 and c['samples'] >= 16 and c['samples_1thread'] >= 4
+    assert c['value_1thread'] > 0 and c['value_threads'] > 0 and c['samples'] >= 8 and c['samples_1thread'] >= 4
+    assert abs(c['value'] - max(c['value_1thread'], c['value_threads'])) < 1e-9 and c['cores'] in (1, c['threads'])   # the faster leg
     # the other RPN score distribution (trained-like clusters) in the same line, its own timed region; the bench widens
     # its sync-free NMS plan by itself instead of aborting
     assert d['value_clustered'] > 0 and d['ms_per_step_clustered'] > 0
@@ -53,3 +54,43 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert ips == 48 * d['config']['streams_per_gpu'] * d['config']['images_per_launch']
     assert d['value'] > 0 and abs(d['ms_per_step'] * d['value'] / (1000.0 * ips * d['n_gpus']) - 1.0) < 1e-6
     assert d['config']['timed_region_s'] >= 0.3 and d['config']['timed_images'] == 20 * ips
+    # BASELINE configs[4] as a measured record: 1333 x 1333, 446 118 anchors, 81 classes, caps 100 / 300, float16 maps
+    c5 = d['config5']
+    assert 'error' not in c5, c5
+    assert c5['anchors'] == 446118 and c5['num_classes'] == 81 and c5['max_per_class'] == 100 and c5['max_per_image'] == 300
+    assert c5['value'] > 0 and c5['dtype'] == 'f16' and c5['proposals_kept'] == 1000 and 0 < c5['detections_image0'] <= 300
+    r5 = c5['roofline']
+    assert r5['kernel_ms'] > 0 and '__half' in r5['rocprof_kernel_name'] and r5['B_min'] <= r5['algorithmic_bytes']
+    # what a multi-GPU run needs to check itself (one rank here: no exchange in the loop)
+    mr = d['multi_rank']
+    assert mr['rccl_world'] == 1 and mr['ranks_timed'] == 1 and mr['allgathers_in_timed_region'] == 0
+    assert abs(mr['per_rank_img_s_min'] - d['value']) < 1e-6 * d['value'] and mr['per_rank_spread'] == 0
+    # the compact LAST key: every headline figure inside the tail of the line the driver keeps
+    assert list(d.keys())[-1] == 'summary'
+    sm = d['summary']
+    assert len(json.dumps(sm)) <= 1024
+    assert sm['hot_path_img_s'] == round(d['value'], 1) and sm['cfg5_hot_path'][0] == round(c5['value'], 1)
+    assert sm['ranks'][0] == 1 and sm['cpu_port_img_s'][0] == round(c['value'], 1)
+
+
+@pytest.mark.gpu
+def test_bench_e2e_summary_keys():
+    """the end-to-end part of the line on a reduced gate (256 scenes): batch-1 (HIP graph) / 4 / 8 legs, all three families,
+    their accuracy gates, and the summary that carries them"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-config5', '--no-second-distribution', '--gate-images', '256'], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][-1])
+    e = d['e2e']
+    for leg in ('fp16', 'fp16_b1', 'fp16_b4', 'fp16_b8', 'fp32', 'fp16_resnet50_c4', 'fp16_vgg16_600x800'):
+        assert 'error' not in e[leg], (leg, e[leg])
+        assert e[leg]['value'] > 0 and e[leg]['nms_done'] == 1
+    assert e['fp16_b1']['batch'] == 1 and e['fp16_b1']['value_hip_graph'] > e['fp16_b1']['value'] * 0.9
+    for leg, fam in (('fp16', 'fpn'), ('fp16_resnet50_c4', 'c4'), ('fp16_vgg16_600x800', 'vgg16')):
+        g = e[leg]['map_delta_vs_fp32']
+        assert g['family'] == fam and g['images'] >= 256 and abs(g['map_delta']) < 0.02
+    sm = d['summary']
+    assert list(d.keys())[-1] == 'summary' and len(json.dumps(sm)) <= 1024
+    assert sm['e2e_fp16_b1_graph'] == round(e['fp16_b1']['value_hip_graph'], 1) and sm['e2e_fp16'][0] == round(e['fp16']['value'], 1)
+    assert sm['map_delta_fpn'][3] == 256 and len(sm['map_delta_c4']) == 4 and len(sm['map_delta_vgg16']) == 4

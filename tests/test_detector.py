@@ -940,27 +940,51 @@ def test_paired_map_delta_matcher_equals_the_reference_routine_cpu():
     pair = pg.paired_map_delta(dets, dets2, gb, gl, resamples=50)
     assert 0.0 < pair['map_a'] < pair['map_b'] <= 1.0 + 1e-12 and pair['delta'] > 0
     assert pair['delta_ci95'][0] <= pair['delta_boot_mean'] <= pair['delta_ci95'][1]
+    # the bootstrap's re-weighting form (every detection of image i counts counts[i] times) against the expanded index list
+    m, f = pg._image_matches(dets, gb, gl, 21), pg._flat_matches(pg._image_matches(dets, gb, gl, 21))
+    for _ in range(20):
+        idx = rng.integers(0, 10, 10)
+        for m07 in (True, False):
+            assert abs(pg._map_from_matches(m, idx, m07) - pg._map_weighted(f, np.bincount(idx, minlength=10), m07)) < 1e-12
+
+
+def _report_gate(rec):
+    print('\n  %s fp16 vs fp32 on %d scenes: mAP %.4f -> %.4f, delta %+.4f (bootstrap std %.4f, CI95 [%+.4f, %+.4f]); reproduction: '
+          '%.1f %% of the fp32 detections matched, RPN kept-index agreement %.3f, median |dscore| %.1e'
+          % (rec['model'], rec['images'], rec['map_fp32'], rec['map_fp16'], rec['map_delta'], rec['map_delta_bootstrap_std'],
+             rec['map_delta_ci95_paired_bootstrap'][0], rec['map_delta_ci95_paired_bootstrap'][1],
+             100 * rec['reproduction']['matched_fraction'], rec['rpn_kept_index_agreement_mean'], rec['median_abs_dscore']))
 
 
 @pytest.mark.gpu
 def test_fp16_detector_map_delta_vs_fp32_on_identical_weights_and_images():
     """BASELINE metric's second half for the mode that meets the throughput target: ResNet-101-FPN @ 800x1333, float16
     against float32 on the same seeded weights (last linear layers fitted on annotated scenes: a genuine detector,
-    mAP ~0.5) and the same 256 held-out scenes, through im_detect -> detect_image -> VOC07 mAP against the annotations.
-    Bar: |mAP(fp16) - mAP(fp32)| <= 0.002 (north star), at the resolution this sample has (paired bootstrap)."""
+    mAP ~0.5) and the same 1024 held-out scenes, through im_detect -> detect_image -> VOC07 mAP against the annotations.
+    Bar (north star): the POINT ESTIMATE |mAP(fp16) - mAP(fp32)| <= 0.002, and the paired-bootstrap 95 % interval inside
+    +-0.004 (bench.py runs 4096 scenes, where the interval's half-width is ~0.0014: profiles/r04_bench_driver_cmd.json)."""
     from tf_eager_object_detection_amd.evaluation import precision_gate as pg
-    rec = pg.fp16_vs_fp32(num_images=256, resamples=200)
-    print('\n  fp16 vs fp32: mAP %.4f -> %.4f, delta %+.4f (bootstrap std %.4f, CI95 [%+.4f, %+.4f]); reproduction: %.1f %% of '
-          'the fp32 detections matched, RPN kept-index agreement %.3f, median |dscore| %.1e'
-          % (rec['map_fp32'], rec['map_fp16'], rec['map_delta'], rec['map_delta_bootstrap_std'],
-             rec['map_delta_ci95_paired_bootstrap'][0], rec['map_delta_ci95_paired_bootstrap'][1],
-             100 * rec['reproduction']['matched_fraction'], rec['rpn_kept_index_agreement_mean'], rec['median_abs_dscore']))
+    rec = pg.fp16_vs_fp32(num_images=1024, resamples=300, batch32=16, batch16=32)
+    _report_gate(rec)
     assert rec['classes_scored'] == 20 and rec['map_fp32'] >= 0.3            # the fitted detector has real signal
-    assert abs(rec['map_delta']) <= 0.002 + 3.0 * rec['map_delta_bootstrap_std']
+    assert abs(rec['map_delta']) <= 0.002, rec['map_delta']
     lo, hi = rec['map_delta_ci95_paired_bootstrap']
-    assert lo - 0.002 <= 0.0 <= hi + 0.002                                    # +-0.002 is inside what the sample allows
+    assert -0.004 <= lo <= hi <= 0.004, (lo, hi)
     assert rec['reproduction']['matched_fraction'] >= 0.95 and rec['rpn_kept_index_agreement_mean'] >= 0.96
     assert rec['median_abs_dscore'] <= 2e-3 and rec['median_abs_dbox_px'] <= 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family', ['c4', 'vgg16'])
+def test_fp16_single_level_detectors_map_delta_vs_fp32(family):
+    """the same gate for the float16 ResNet-50 C4 (800x1333) and VGG16 (600x800) detectors -- BASELINE configs 2 and 1: their
+    throughput records carry accuracy evidence too.  512 held-out scenes: |delta| <= 0.002 + 2 sigma of the paired bootstrap."""
+    from tf_eager_object_detection_amd.evaluation import precision_gate as pg
+    rec = pg.fp16_vs_fp32(num_images=512, resamples=300, batch32=16, batch16=32, family=family)
+    _report_gate(rec)
+    assert rec['classes_scored'] == 20 and rec['map_fp32'] >= 0.2
+    assert abs(rec['map_delta']) <= 0.002 + 2.0 * rec['map_delta_bootstrap_std'], rec['map_delta']
+    assert rec['reproduction']['matched_fraction'] >= 0.93
 
 
 # ---- pointwise form of the implicit-GEMM kernel (odet_pointwise_f16 / odet_lateral_merge_f16) -----------------------------

@@ -111,19 +111,70 @@ def _ridge(G, R, lam_rel=1e-3):
     return torch.linalg.solve(G + lam * torch.eye(d, dtype=torch.float64, device=G.device), R.double())
 
 
+def _family(model):
+    return 'fpn' if hasattr(model, 'l4') else 'frcnn'
+
+
+def _rpn_anchors(model):
+    """[N,4] float32 anchors on the device in the RpnHead's output order (location-major, anchor-minor)"""
+    from .. import synthetic as syn
+    from ..utils.anchor_generator import make_fpn_anchors, generate_by_anchor_base_tf
+    if _family(model) == 'fpn':
+        return make_fpn_anchors(model.image_shape, syn.FPN_STRIDES, syn.FPN_BASE_SIZES, syn.FPN_SCALES, syn.FPN_RATIOS)
+    hot = model._hot[0]
+    return generate_by_anchor_base_tf(hot.anchor_base, hot.stride, hot.fh, hot.fw).contiguous()
+
+
+def _rpn_activations(model, x):
+    """relu(rpn_conv(map)) of every RPN location, [B, locations, cin] float32 in the anchors' location order"""
+    from ..model import fpn_detector as fd
+    maps = model.features(x)
+    maps = maps if isinstance(maps, (list, tuple)) else [maps]
+    cin = model.rpn_score.in_channels
+    acts = []
+    for p in maps:
+        a = fd._conv_epi(model.rpn_conv, p if p.is_contiguous(memory_format=torch.channels_last)
+                         else p.contiguous(memory_format=torch.channels_last), relu=True)
+        acts.append(a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, cin).float())
+    return torch.cat(acts, 1)
+
+
+def _head_inputs(model, x):
+    """one pass up to the RoI head: per image (rois [k,4] in the order of the head's rows, head activation [k,d] float32)"""
+    B = x.shape[0]
+    out = []
+    if _family(model) == 'fpn':
+        rpn_s, rpn_d, maps = model._dense(x)
+        model._hot_to_head(B, rpn_s, rpn_d, maps)
+    else:
+        model._run_to_head(x)
+    model._last_batch = B
+    model.check_complete(B)
+    for b in range(B):
+        hot = model._hot[b]
+        k = int(hot.roi_count.item())
+        rois = (hot.sorted_rois if _family(model) == 'fpn' else hot.rois)[:k].contiguous()
+        out.append((rois, model.head_activation(hot.roi_features[:k]).float()))
+    return out
+
+
 @torch.no_grad()
 def fit_readout_heads(model, scenes, rpn_gain=2.0, cls_gain=8.0, pos_iou=0.7, neg_iou=0.3, fg_iou=0.5, ridge=1e-3):
-    """Fits model.rpn_score / rpn_bbox / score / bbox (float32 ResNetFpnDetector after prepare()) on annotated scenes
+    """Fits model.rpn_score / rpn_bbox / score / bbox (a float32 detector of any family after prepare()) on annotated scenes
     (`scenes`: a callable returning a fresh labelled_scenes generator with batches <= the model's max batch; it is walked
     twice: RPN first, then the RoI head on the fitted RPN's proposals).  Everything before those layers stays the seeded
-    random network.  Returns fit statistics."""
+    random network.  RPN: per anchor shape a class-balanced ridge regression on +-1 labels (AnchorTarget's rules: IoU >=
+    pos_iou or the best anchor of an object positive, < neg_iou negative; model/anchor_target.py) and a ridge regression of
+    the encoded box targets on the positives; the fg / bg logits are +-rpn_gain times the regressed label, written in the
+    family's channel layout (FPN: (bg, fg) interleaved per anchor, base_fpn_model.py:429; Faster R-CNN: [A bg | A fg],
+    base_faster_rcnn_model.py:149-152).  RoI head: one-vs-rest ridge classifiers over the proposals' labels (ProposalTarget's
+    rule: IoU >= fg_iou with an object -> its class, model/proposal_target.py) scaled by cls_gain, class-agnostic box
+    regression replicated per class."""
     from .. import ops
-    from ..model import fpn_detector as fd
-    from ..utils.anchor_generator import make_fpn_anchors
-    from .. import synthetic as syn
     dev = next(model.parameters()).device
-    A, mb = model.A, model._max_batch
-    anchors = make_fpn_anchors(model.image_shape, syn.FPN_STRIDES, syn.FPN_BASE_SIZES, syn.FPN_SCALES, syn.FPN_RATIOS)
+    A = model.A
+    fpn = _family(model) == 'fpn'
+    anchors = _rpn_anchors(model)
     n = 0
     cin = model.rpn_score.in_channels
     d = cin + 1
@@ -136,12 +187,7 @@ def fit_readout_heads(model, scenes, rpn_gain=2.0, cls_gain=8.0, pos_iou=0.7, ne
     nneg = torch.zeros(A, dtype=torch.float64, device=dev)
     for x, gt_boxes, gt_labels in scenes():
         n += int(x.shape[0])
-        p_list = model.features(x)
-        acts = []
-        for p in p_list:
-            a = fd._conv_epi(model.rpn_conv, p, relu=True)
-            acts.append(a.permute(0, 2, 3, 1).reshape(a.shape[0], -1, cin).float())
-        F_ = torch.cat(acts, 1)                                            # [B, pixels, 512], pixel-major like the anchors
+        F_ = _rpn_activations(model, x)                                    # [B, locations, cin], location-major like the anchors
         ones = torch.ones(F_.shape[1], 1, device=dev)
         for b in range(F_.shape[0]):
             gt = torch.from_numpy(gt_boxes[b]).to(dev)
@@ -151,7 +197,7 @@ def fit_readout_heads(model, scenes, rpn_gain=2.0, cls_gain=8.0, pos_iou=0.7, ne
             pos[iou.argmax(dim=0)] = True                                  # the best anchor of every object (AnchorTarget)
             neg = (best < neg_iou) & ~pos
             tgt = ops.encode(anchors, gt[arg].contiguous(), [0, 0, 0, 0], [1, 1, 1, 1])
-            X = torch.cat([F_[b], ones], 1)                                # [pixels, 513]
+            X = torch.cat([F_[b], ones], 1)                                # [locations, cin + 1]
             pos, neg, tgt = pos.view(-1, A), neg.view(-1, A), tgt.view(-1, A, 4)
             for a in range(A):
                 Xp, Xn = X[pos[:, a]], X[neg[:, a]]
@@ -164,10 +210,13 @@ def fit_readout_heads(model, scenes, rpn_gain=2.0, cls_gain=8.0, pos_iou=0.7, ne
                 nneg[a] += Xn.shape[0]
     ws, bs, wb, bb = model.rpn_score.weight, model.rpn_score.bias, model.rpn_bbox.weight, model.rpn_bbox.bias
     for a in range(A):
+        if float(npos[a]) < 1 or float(nneg[a]) < 1:
+            continue                                                       # (an anchor shape no object ever matched: stays random)
         th = _ridge(Gp[a] / npos[a] + Gn[a] / nneg[a], (sp[a] / npos[a] - sn[a] / nneg[a]).unsqueeze(1), ridge)[:, 0].float()
-        ws[2 * a + 1, :, 0, 0], bs[2 * a + 1] = rpn_gain * th[:cin], rpn_gain * th[cin]
-        ws[2 * a, :, 0, 0], bs[2 * a] = -rpn_gain * th[:cin], -rpn_gain * th[cin]
-        tb = _ridge(Gp[a] / npos[a], Bt[a] / npos[a], max(ridge, 1e-2)).float()        # [513, 4]
+        i_fg, i_bg = (2 * a + 1, 2 * a) if fpn else (A + a, a)
+        ws[i_fg, :, 0, 0], bs[i_fg] = rpn_gain * th[:cin], rpn_gain * th[cin]
+        ws[i_bg, :, 0, 0], bs[i_bg] = -rpn_gain * th[:cin], -rpn_gain * th[cin]
+        tb = _ridge(Gp[a] / npos[a], Bt[a] / npos[a], max(ridge, 1e-2)).float()        # [cin + 1, 4]
         for k in range(4):
             wb[4 * a + k, :, 0, 0], bb[4 * a + k] = tb[:cin, k], tb[cin, k]
     model._rpn_pair = None
@@ -182,18 +231,8 @@ def fit_readout_heads(model, scenes, rpn_gain=2.0, cls_gain=8.0, pos_iou=0.7, ne
     nfg = 0
     stds = list(model._hot[0].cfg['roi_stds'])
     for x, gt_boxes, gt_labels in scenes():
-        B = x.shape[0]
-        rpn_s, rpn_d, maps = model._dense(x)
-        model._hot_to_head(B, rpn_s, rpn_d, maps)
-        model._last_batch = B
-        model.check_complete(B)
-        for b in range(B):
-            hot = model._hot[b]
-            k = int(hot.roi_count.item())
-            rois = hot.sorted_rois[:k].contiguous()
-            f = hot.roi_features[:k].reshape(k, -1).to(model.dtype)
-            h = ops.dense(ops.dense(f.contiguous(), model.fc1.weight, model.fc1.bias, relu=True), model.fc2.weight, model.fc2.bias,
-                          relu=True).float()
+        for b, (rois, h) in enumerate(_head_inputs(model, x)):
+            k = rois.shape[0]
             X = torch.cat([h, torch.ones(k, 1, device=dev)], 1)
             gt = torch.from_numpy(gt_boxes[b]).to(dev)
             gl = torch.from_numpy(gt_labels[b].astype(np.int64)).to(dev)
@@ -337,6 +376,37 @@ def _map_from_matches(matches, idx, use_07_metric=True):
     return float(np.mean(aps)) if aps else 0.0
 
 
+def _flat_matches(matches):
+    """per class: (scores, tp flags, image index) of all images' detections sorted by score (stable), ground-truth boxes per
+    image -- what a resample needs to re-weight"""
+    out = []
+    for per in matches:
+        sc = np.concatenate([p_[0] for p_ in per]) if per else np.zeros(0)
+        tp = np.concatenate([p_[1] for p_ in per]) if per else np.zeros(0, bool)
+        im = np.concatenate([np.full(len(p_[0]), i, np.int64) for i, p_ in enumerate(per)]) if per else np.zeros(0, np.int64)
+        order = np.argsort(-sc, kind='stable')
+        out.append((tp[order], im[order], np.asarray([p_[2] for p_ in per], np.float64)))
+    return out
+
+
+def _map_weighted(flat, counts, use_07_metric=True):
+    """mAP of the image multiset `counts` (image i drawn counts[i] times): every detection of image i counts counts[i] times.
+    Equal to _map_from_matches on the expanded index list -- the copies of a detection are adjacent in the score order and
+    only the last copy of a true positive / the point before the first copy of a false positive can be a maximum of the
+    precision envelope -- in O(detections) per class instead of a Python loop over images."""
+    aps = []
+    for tp, im, npos_img in flat:
+        npos = float(np.dot(counts, npos_img))
+        if npos == 0:
+            continue
+        w = counts[im].astype(np.float64)
+        ctp, cfp = np.cumsum(tp * w), np.cumsum((~tp) * w)
+        rec = ctp / npos
+        prec = ctp / np.maximum(ctp + cfp, np.finfo(np.float64).eps)
+        aps.append(pe.voc_ap(rec, prec, use_07_metric))
+    return float(np.mean(aps)) if aps else 0.0
+
+
 def paired_map_delta(dets_a, dets_b, gt_boxes, gt_labels, num_classes=21, resamples=400, seed=0, use_07_metric=True):
     """mAP of two detection sets against the same annotations, their difference, and a paired bootstrap over images
     (the same resampled image set for both) of that difference."""
@@ -345,29 +415,48 @@ def paired_map_delta(dets_a, dets_b, gt_boxes, gt_labels, num_classes=21, resamp
     n = len(dets_a)
     full = np.arange(n)
     a, b = _map_from_matches(ma, full, use_07_metric), _map_from_matches(mb, full, use_07_metric)
+    fa, fb = _flat_matches(ma), _flat_matches(mb)
     rng = np.random.default_rng(seed)
     ds = []
     for _ in range(resamples):
-        idx = rng.integers(0, n, n)
-        ds.append(_map_from_matches(mb, idx, use_07_metric) - _map_from_matches(ma, idx, use_07_metric))
-    ds = np.asarray(ds)
+        counts = np.bincount(rng.integers(0, n, n), minlength=n)
+        ds.append(_map_weighted(fb, counts, use_07_metric) - _map_weighted(fa, counts, use_07_metric))
+    ds = np.asarray(ds) if ds else np.zeros(1)
     return dict(map_a=a, map_b=b, delta=b - a, delta_boot_mean=float(ds.mean()), delta_boot_std=float(ds.std()),
                 delta_ci95=[float(np.percentile(ds, 2.5)), float(np.percentile(ds, 97.5))], resamples=resamples)
 
 
-def fp16_vs_fp32(num_images=256, image_shape=(800, 1333), depth=101, num_classes=21, num_proposals=1000, batch32=4,
-                 batch16=8, seed=0, train_images=64, ridge=1e-3, resamples=400, **hot_kwargs):
-    """The whole gate.  -> dict for bench.py's `e2e.fp16.map_delta_vs_fp32` and the GPU test."""
+_FAMILIES = {'fpn': ('ResNet-%d-FPN', (800, 1333), 1000), 'c4': ('ResNet-%d C4 Faster R-CNN', (800, 1333), 300),
+             'vgg16': ('VGG16 Faster R-CNN', (600, 800), 300)}
+
+
+def _build(family, depth, num_classes, image_shape, num_proposals, dtype, max_batch, hot_kwargs):
     from ..model.fpn_detector import ResNetFpnDetector
+    from ..model.frcnn_detector import ResNetC4Detector, Vgg16Detector
+    if family == 'fpn':
+        return ResNetFpnDetector(depth, num_classes, image_shape, num_proposals, dtype=dtype, max_batch=max_batch, **hot_kwargs)
+    if family == 'c4':
+        return ResNetC4Detector(depth, num_classes, image_shape, num_proposals, dtype=dtype, max_batch=max_batch, **hot_kwargs)
+    return Vgg16Detector(num_classes, image_shape, num_proposals, dtype=dtype, max_batch=max_batch, **hot_kwargs)
+
+
+def fp16_vs_fp32(num_images=256, image_shape=None, depth=None, num_classes=21, num_proposals=None, batch32=4,
+                 batch16=8, seed=0, train_images=64, ridge=1e-3, resamples=400, family='fpn', **hot_kwargs):
+    """The whole gate for one detector family ('fpn': ResNet-101-FPN @ 800x1333, 'c4': ResNet-50 C4 @ 800x1333, 'vgg16':
+    VGG16 @ 600x800 -- BASELINE configs 3 / 2 / 1).  -> dict for bench.py's `e2e.*.map_delta_vs_fp32` and the GPU tests;
+    `within_bar` = the point estimate is inside the north star's +-0.002, `resolves_bar` = the paired-bootstrap 95 % interval
+    is narrower than the bar on both sides (the gate can tell +-0.002 from noise at this number of scenes)."""
+    name, shape0, prop0 = _FAMILIES[family]
+    image_shape = tuple(shape0 if image_shape is None else image_shape)
+    num_proposals = prop0 if num_proposals is None else num_proposals
+    depth = (101 if family == 'fpn' else 50) if depth is None else depth
     torch.manual_seed(seed)
-    m32 = ResNetFpnDetector(depth, num_classes, image_shape, num_proposals, dtype=torch.float32, max_batch=batch32,
-                            **hot_kwargs).prepare()
+    m32 = _build(family, depth, num_classes, image_shape, num_proposals, torch.float32, batch32, hot_kwargs).prepare()
     fit = fit_readout_heads(m32, lambda: labelled_scenes(train_images, image_shape, seed=seed + 5, num_classes=num_classes,
                                                          batch=batch32), ridge=ridge)
     fit['ridge'] = ridge
     state = {k: v.detach().clone() for k, v in m32.state_dict().items()}
-    m16 = ResNetFpnDetector(depth, num_classes, image_shape, num_proposals, dtype=torch.float16, max_batch=batch16,
-                            **hot_kwargs)
+    m16 = _build(family, depth, num_classes, image_shape, num_proposals, torch.float16, batch16, hot_kwargs)
     m16.load_state_dict(state)
     m16.prepare()
     d32, k32, d16, k16, gtb, gtl = [], [], [], [], [], []
@@ -382,10 +471,12 @@ def fp16_vs_fp32(num_images=256, image_shape=(800, 1333), depth=101, num_classes
         gtb += gb
         gtl += gl
     pair = paired_map_delta(d32, d16, gtb, gtl, num_classes, resamples=resamples, seed=seed)
-    pair_area = paired_map_delta(d32, d16, gtb, gtl, num_classes, resamples=1, seed=seed, use_07_metric=False)
+    pair_area = paired_map_delta(d32, d16, gtb, gtl, num_classes, resamples=0, seed=seed, use_07_metric=False)
     repro = compare_detections(d32, d16, num_classes, 0.0)
     agree = [len(np.intersect1d(a, b, assume_unique=True)) / max(len(a), 1) for a, b in zip(k32, k16)]
-    rec = dict(images=num_images, image=list(image_shape), model='ResNet-%d-FPN' % depth, metric='VOC07 11-point mAP',
+    lo, hi = pair['delta_ci95']
+    rec = dict(images=num_images, image=list(image_shape), model=(name % depth) if '%d' in name else name, family=family,
+               metric='VOC07 11-point mAP',
                protocol='annotated synthetic scenes (coloured rectangles / ellipses, class = colour); float32 (parity mode) '
                         'and float16 detector with the SAME weights on the SAME images: im_detect -> detect_image (score >= '
                         '0.05, per-class NMS 0.3, 50 per image; evaluation/pascal_eval_files_utils.py:76-106) -> VOC07 mAP '
@@ -395,6 +486,8 @@ def fp16_vs_fp32(num_images=256, image_shape=(800, 1333), depth=101, num_classes
                        % train_images,
                data='synthetic', map_fp32=pair['map_a'], map_fp16=pair['map_b'], map_delta=pair['delta'],
                map_delta_ci95_paired_bootstrap=pair['delta_ci95'], map_delta_bootstrap_std=pair['delta_boot_std'],
+               bar=0.002, within_bar=bool(abs(pair['delta']) <= 0.002),
+               resolves_bar=bool(max(abs(lo - pair['delta_boot_mean']), abs(hi - pair['delta_boot_mean'])) <= 0.002),
                map_delta_area_metric=pair_area['delta'], gt_boxes=int(sum(len(g) for g in gtl)),
                classes_scored=len(set(int(l) for g in gtl for l in g)),
                reproduction={'protocol': 'the float32 detections themselves as ground truth (mAP fp32 = 1 by construction): '

@@ -519,13 +519,16 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
     def _rpn_pair_padded(self, w):
         return rpn_pair_padded(self, w)
 
-    def roi_head(self, roi_features):
-        """flatten(7,7,256) -> fc 1024 -> fc 1024 -> score / boxes (resnet_fpn.py:292-336): the Dense layers on the pointwise
-        GEMM kernel with bias + ReLU in its epilogue, the last layer with float32 results"""
+    def head_activation(self, roi_features):
+        """flatten(7,7,256) -> fc 1024 -> fc 1024 (resnet_fpn.py:292-326): the input of the score / bbox layers; the Dense
+        layers on the pointwise GEMM kernel with bias + ReLU in its epilogue"""
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)
         x = ops.dense(x if x.is_contiguous() else x.contiguous(), self.fc1.weight, self.fc1.bias, relu=True)
-        x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
-        return self._final_outputs(x)
+        return ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
+
+    def roi_head(self, roi_features):
+        """RoI features [R,7,7,256] -> (class logits [R,Ccls], box regressions [R,4 Ccls]), float32 (resnet_fpn.py:292-336)"""
+        return self._final_outputs(self.head_activation(roi_features))
 
     # ---- HIP-graph replay ---------------------------------------------------------------------------
     def capture(self, batch, warmup=3):

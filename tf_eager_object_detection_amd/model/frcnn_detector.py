@@ -132,14 +132,19 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         ops.rpn_pack_pair(sd if sd.is_contiguous() else sd.contiguous(), b, self.A, scores, deltas, 0)
         return scores.view(B, -1, 2 * self.A), deltas
 
-    def roi_head(self, roi_features):
-        """[R,7,7,1024] NHWC -> conv5 -> global average pool -> (score logits [R,C], box deltas [R,4C])."""
+    def head_activation(self, roi_features):
+        """[R,7,7,1024] NHWC -> conv5 -> global average pool [R,2048] (resnet_faster_rcnn.py:156-183): the input of the score /
+        bbox layers"""
         x = roi_features.permute(0, 3, 1, 2).to(self.dtype)                      # NCHW view of NHWC memory
         R = x.shape[0]
         step = self._roi_chunk if self._roi_chunk > 0 else R
         outs = [self.conv5(x[i:i + step]).mean(dim=(2, 3)) for i in range(0, R, step)]
         y = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
-        return self._final_outputs(y.contiguous())
+        return y.contiguous()
+
+    def roi_head(self, roi_features):
+        """-> (score logits [R,C], box deltas [R,4C]), float32"""
+        return self._final_outputs(self.head_activation(roi_features))
 
     capture = ResNetFpnDetector.capture          # whole forward pass as one HIP graph (generic over self.forward)
 
@@ -298,9 +303,8 @@ class Vgg16Detector(ResNetC4Detector):
                 i += 1
         return x
 
-    def roi_head(self, roi_features):
+    def head_activation(self, roi_features):
         x = roi_features.reshape(roi_features.shape[0], -1).to(self.dtype)        # Flatten() of NHWC crops
         # fc6 / fc7 on the pointwise GEMM kernel, bias + ReLU in its epilogue (dropout: inference)
         x = ops.dense(x if x.is_contiguous() else x.contiguous(), self.fc1.weight, self.fc1.bias, relu=True)
-        x = ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
-        return self._final_outputs(x)
+        return ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
