@@ -579,6 +579,15 @@ def main():
     wl = Workload(cfg3, args.scores, args.nms_first_chunk, args.blind_chunks)
     elapsed, replans = wl.measure(args.steps, args.warmup)
     per_rank_s, allgathers = wl.per_rank_s, wl.allgathers
+    host = wl.host
+    rf, k_kept, plan0, rec_len0 = None, int(wl.pool.slots[0].roi_count.item()), (wl.nms_first_chunk, wl.blind_chunks), wl.rec_len
+    if rank == 0:
+        rf = roofline_phase(wl, args.roofline_samples, 'k_roi_pool<MAX2, NORM_IMAGE> (fused crop_and_resize 14x14 + 2x2 max)',
+                            'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps'))
+        mark('roofline + calibration done')
+    wl.close()                                                    # (its 2.3 GB of inputs go before the next workload is built)
+    del wl
+    torch.cuda.empty_cache()
     other_kind = 'clustered' if args.scores == 'distinct' else 'distinct'
     other = None
     if not args.no_second_distribution:
@@ -591,14 +600,10 @@ def main():
         wl2.close()
         del wl2
         torch.cuda.empty_cache()
-    host = wl.host
 
     result = None
     if rank == 0:
-        rf = roofline_phase(wl, args.roofline_samples, 'k_roi_pool<MAX2, NORM_IMAGE> (fused crop_and_resize 14x14 + 2x2 max)',
-                            'fpn_hot_path_800x1333_r101fpn_%s%s' % (args.scores, '' if args.maps == 'f32' else '_f16maps'))
-        mark('roofline + calibration done')
-        k = int(wl.pool.slots[0].roi_count.item())
+        k = k_kept
         result = {
             'metric': 'images/sec', 'value': args.steps * images_per_step * world / elapsed, 'unit': 'img/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -612,8 +617,8 @@ def main():
                        'step': '%d rounds over the %d x %d in-flight image slots of a GPU' % (R, S, B),
                        'images_per_step_per_gpu': images_per_step, 'global_batch': images_per_step * world,
                        'timed_images': args.steps * images_per_step * world, 'timed_region_s': elapsed,
-                       'rpn_scores': args.scores, 'feature_maps': args.maps, 'nms_first_chunk': wl.nms_first_chunk,
-                       'blind_chunks': wl.blind_chunks, 'replanned': replans,
+                       'rpn_scores': args.scores, 'feature_maps': args.maps, 'nms_first_chunk': plan0[0],
+                       'blind_chunks': plan0[1], 'replanned': replans,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': rf,
@@ -634,15 +639,11 @@ def main():
             'collective': 'all_gather_into_tensor of the %d records of a stream group from every rank (parallel.GroupExchange)' % B
                           if use_dist else 'none (one rank: no exchange in the loop)',
             'allgathers_in_timed_region': allgathers, 'allgathers_expected': (args.steps * R * S if use_dist else 0),
-            'record_bytes_per_rank_per_allgather': B * wl.rec_len * 4,
+            'record_bytes_per_rank_per_allgather': B * rec_len0 * 4,
             'per_rank_img_s_min': min(rates), 'per_rank_img_s_max': max(rates),
             'per_rank_spread': (max(rates) - min(rates)) / max(rates),
             'images_per_rank': args.steps * images_per_step,
         }
-    wl.close()
-    del wl
-    torch.cuda.empty_cache()
-
     if rank == 0:
         summary = {'hot_path_img_s': round(result['value'], 1), 'hot_path_clustered_img_s': round(other['value'], 1) if other else None,
                    'roi_frac_B_roi': round(result['roofline']['frac'], 3),

@@ -334,9 +334,6 @@ extern "C" int odet_conv1x1_f16(const void* x, const void* in_bias, const void* 
   // channels per wave tile: the whole row up to 256 channels; wider outputs are split so that small feature maps
   // still give the chip enough waves (the waves of a pixel slab sit in one workgroup and share its x lines in L1)
   p.nt = cout <= 256 ? cout : (cout % 256 == 0 ? 256 : 64);
-#ifdef ODET_C1_NT                                    /* diagnostic builds: channels per workgroup tile */
-  if (cout % ODET_C1_NT == 0 && ODET_C1_NT <= 256) p.nt = ODET_C1_NT;
-#endif
   p.tiles_n = cout / p.nt;
   const long long blocks = (((npix + 127) / 128 + 7) / 8) * 8 * p.tiles_n;      // slabs padded to the 8 XCDs
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv1x1_f16: too many workgroups");

@@ -44,9 +44,7 @@ typedef __attribute__((address_space(3))) void* c3_lds_ptr;
 
 #define C3_TM 256                 // pixels per workgroup tile
 #define C3_TN 256                 // channels per workgroup tile
-#ifndef C3_EARLY_WAVES
-#define C3_EARLY_WAVES 4      // waves below this issue their copies right after the barrier, the others half a step later
-#endif
+#define C3_EARLY_WAVES 4          // waves below this issue their copies right after the barrier, the others half a step later
 #define C3_BK 64                  // input channels per K-step (128 bytes per row)
 #define C3_STAGE_BYTES ((C3_TM + C3_TN) * C3_BK * 2)      // 64 KB
 #define C3_LDS_BYTES (2 * C3_STAGE_BYTES)

@@ -355,11 +355,6 @@ static void f32_pick_tile(const long long* M, int num_levels, int cout, int* wn_
       if (cost < best * 0.98) { best = cost; wn_best = wn; mt_best = mt; }
     }
   }
-  if (const char* ov = getenv("ODET_F32_TILE")) {          // experiments: "wn,mt"
-    int a_ = 0, b_ = 0;
-    if (sscanf(ov, "%d,%d", &a_, &b_) == 2 && (a_ == 4 || a_ == 2 || a_ == 1) && cout % (64 * a_) == 0 &&
-        b_ * (8 / a_) >= 8 && b_ * (8 / a_) <= 16) { wn_best = a_; mt_best = b_; }
-  }
   *wn_out = wn_best; *mt_out = mt_best;
 }
 

@@ -91,25 +91,10 @@ struct NmsHeader {
   NmsState st;
   int32_t n_invalid_acc;               // fed by k_rp_prepare; k_sel_find1 moves it into st.n_invalid
   int32_t pad_acc[15];
-  u64 stamps[64];                      // diagnostic builds only (-DODET_STAMPS)
   uint32_t hist1[SEL_REPL][SEL_BINS];  // replica r is fed by blocks with blockIdx % SEL_REPL == r
   uint32_t hist2[SEL_BINS];
   uint32_t hist3[256];                 // tie split: the last 8 key bits inside the boundary bin (zeroed again by k_sel_rank)
 };
-
-#ifdef ODET_STAMPS
-#define STAMP(hdr_, k_)                                                            \
-  do {                                                                             \
-    if (threadIdx.x == 0 && blockIdx.x == 0) (hdr_)->stamps[k_] = wall_clock64();  \
-  } while (0)
-#define WSTAMP(hdr_, k_)                                                           \
-  do {                                                                             \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) (hdr_)->stamps[k_] = wall_clock64();  \
-  } while (0)
-#else
-#define STAMP(hdr_, k_) do { } while (0)
-#define WSTAMP(hdr_, k_) do { } while (0)
-#endif
 
 // ------------------------------------------------------------------------- 1. prepare -------
 enum { PREP_NMS = 0, PREP_RP = 1, PREP_FPN = 2, PREP_FRCNN = 3 };
@@ -778,12 +763,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     if (sp.fail_empty && threadIdx.x == 0) scan_fail_empty(out_count, out_done, ao.counts, ao.max_level - ao.min_level + 1);
     return;
   }
-  NmsHeader* hdr = reinterpret_cast<NmsHeader*>(st);   // the state is the header's first member
-  (void)hdr;
-  STAMP(hdr, 0);
-#ifdef ODET_STAMPS
-  if (threadIdx.x == 0) hdr->stamps[60] = clock64();
-#endif
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int m = LDSMAT ? min(st->chunk_m, SCAN_LDS_CAND) : st->chunk_m;   // (<= by construction)
   const int pos0 = st->pos;
@@ -841,7 +820,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
       }
     }
     __syncthreads();
-    STAMP(hdr, 1);
     if (b_own < nblk) {
       for (int b = 0; b < b_own; ++b) {
         if (stop) break;
@@ -855,7 +833,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
         for (int q = 0; q < SCAN_Q; ++q) supm[q] |= __ballot((wd[q] & kb) != 0ull);
         if (nk >= K) stop = true;
       }
-      WSTAMP(hdr, 16 + w);
 #pragma unroll
       for (int a = 0; a < SCAN_Q; ++a) {
         const int b = b_own + a;
@@ -873,7 +850,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
           if (nk >= K) stop = true;
         }
       }
-      WSTAMP(hdr, 32 + w);
     }
   } else {
     u64 ring[SCAN_RING][SCAN_Q];
@@ -894,7 +870,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
       }
     }
     __syncthreads();
-    STAMP(hdr, 1);
     if (b_own < nblk) {
       for (int b0 = 0; b0 < b_own; b0 += SCAN_RING) {      // b_own is a multiple of SCAN_RING
 #pragma unroll
@@ -928,8 +903,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     }
   }
   __syncthreads();
-  STAMP(hdr, 2);
-
   // outputs: kept candidates in score order
   if (w == 0) {
     const int pc = (int)__popcll(keepw[lane]);
@@ -938,7 +911,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     if (lane == 63) keptpre[NMS_WORDS] = nk0 + inc;
   }
   __syncthreads();
-  STAMP(hdr, 6);
   const int nkf = keptpre[NMS_WORDS];
   const int np = pos0 + m;
   const int done = (nkf >= K || np >= n - st->n_invalid) ? 1 : 0;
@@ -959,7 +931,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
       obox[q] = iskept[q] ? sorig[c] : make_float4(0, 0, 0, 0);
     }
   }
-  STAMP(hdr, 7);
 #pragma unroll
   for (int q = 0; q < SCAN_Q; ++q) {
     const int c = jbase + 64 * q;
@@ -983,7 +954,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
       }
     }
   }
-  STAMP(hdr, 3);
   __syncthreads();                 // everyone has read the state before it changes
   if (threadIdx.x == 0) {
     st->kept = nkf;
@@ -996,7 +966,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
       if (out_done) *out_done = done;
     }
   }
-  STAMP(hdr, 4);
   if (fused_lv) {
     // _assign_levels (base_fpn_model.py:303-324) as a stable partition by level without re-reading
     // anything: per (level, block) counts -> exclusive scan over the 64 blocks (wave L scans level L),
@@ -1027,7 +996,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     d_assign_levels_block<SCAN_THREADS>(out_boxes, nkf, ao.min_level, ao.max_level, ao.rois, ao.level, ao.perm,
                                         ao.counts, lds_al);
   }
-  STAMP(hdr, 5);
   // Spatial processing order of the RoIs for the RoI kernel, in this launch instead of one of its own (odet_roi_order):
   // the assigned RoIs were written by this workgroup just above.  A counting sort by (level, y band of 1/32 of the
   // image) -- 256 buckets: what the order is for is that the RoIs in flight at a time tap one band of one pyramid
@@ -1079,9 +1047,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
       if (tid + SCAN_THREADS < K) order[tid + SCAN_THREADS] = tid + SCAN_THREADS;
     }
   }
-#ifdef ODET_STAMPS
-  if (threadIdx.x == 0) hdr->stamps[61] = clock64();
-#endif
 }
 
 // ------------------------------------------------------------------------------ host side --
@@ -1263,6 +1228,9 @@ static int nms_run(NmsJob& J, hipStream_t st) {
     if (wide) {
       // a boundary bin too large for the selection (thousands of equal keys: a saturated RPN) is split exactly in
       // (key, index) order; both launches exit at once when the bin fitted.  Scratch: the bit-matrix buffer (idle here).
+      // (per block 256 counters of 2 bytes: fits the 2 MiB of the matrix buffer up to ~8.4 M anchors)
+      ODET_REQUIRE((size_t)grid.x * 256 * sizeof(unsigned short) <= (size_t)NMS_WORDS * NMS_CHUNK * sizeof(u64),
+                   "odet_nms: %d anchors exceed the tie split's scratch (the bit-matrix buffer)", n);
       const PerImg<unsigned short*> bh = per_img<unsigned short*>(J, [&](int i) { return (unsigned short*)w[i].Lt; });
       hipLaunchKernelGGL(k_sel_tie_hist, grid, block, 0, st, hdrs, keys, n, bh);
       ODET_LAUNCH_CHECK();

@@ -149,10 +149,14 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
 template <typename FT> struct Cell;
 template <> struct Cell<float> {
   static constexpr uint32_t LANE_BYTES = 16;
-  static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) {
-    const u4v u = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  typedef u4v raw_t;              // a cell's 4 channels of this lane as they come out of memory
+  static __device__ __forceinline__ raw_t load_raw(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  }
+  static __device__ __forceinline__ float4 widen(raw_t u) {
     return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
   }
+  static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) { return widen(load_raw(r, voff, soff)); }
   // Pooled features are written once and not read again by this path: non-temporal stores keep the 50 MB per
   // image out of L2 / Infinity Cache, where they would evict the feature-map lines neighbouring RoIs share.
   static __device__ __forceinline__ void store(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
@@ -162,13 +166,17 @@ template <> struct Cell<float> {
 };
 template <> struct Cell<__half> {
   static constexpr uint32_t LANE_BYTES = 8;
-  static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) {
-    const u2v u = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  typedef u2v raw_t;
+  static __device__ __forceinline__ raw_t load_raw(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  }
+  static __device__ __forceinline__ float4 widen(raw_t u) {
     const uint32_t ux = u.x, uy = u.y;
     const __half2 a = *reinterpret_cast<const __half2*>(&ux), b = *reinterpret_cast<const __half2*>(&uy);
     const float2 fa = __half22float2(a), fb = __half22float2(b);
     return make_float4(fa.x, fa.y, fb.x, fb.y);
   }
+  static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) { return widen(load_raw(r, voff, soff)); }
   static __device__ __forceinline__ void store(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
     const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
     u2v u;
@@ -325,6 +333,109 @@ __device__ __forceinline__ void roi_row_carry(const RowCtx& rc0, rsrc_t out, int
   }
 }
 
+// ---- two bins in flight (round 4) -----------------------------------------------------------------------------------
+// A wave's bins used to be a serial chain: a bin's cell loads, the wait for them, its lerps, its store, then the next
+// bin's loads.  With two 7-wave workgroups per CU (3.5 waves per SIMD) that chain leaves the memory pipe idle during
+// every bin's arithmetic: the pooled single-level forms and the float16 maps ran at 0.26 .. 0.41 of the HBM peak with no
+// wasted traffic (profiles/r03_roi_forms.json).  Here the loads of bin px + 1 are ISSUED before the lerps of bin px: a bin
+// is split into its loads (into a register block of up to 4 x 4 cells) and its arithmetic, and the row loop alternates
+// between two blocks.  Same loads, same lerps, same order of operations inside a bin: bit-identical.
+template <int DY, typename FT>
+__device__ __forceinline__ void roi_bin_issue(const RowCtx& rc, int xc, uint32_t c0, const uint32_t (&crel)[4],
+                                              typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
+  constexpr int NR = (DY == 2) ? 4 : 2 + DY;
+  uint32_t soff[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) soff[i] = rc.row[i] + c0;                              // scalar
+  // columns 0 and 1 always, column 2 for the classes 1 and 2, column 3 for the general class (wave-uniform conditions
+  // around loads with FIXED register indices: separate branches per class made the compiler merge their stores into one
+  // with a variable index -- the block then lived in scratch memory)
+  uint32_t voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) voff[j] = rc.vlane + (xc == 2 ? crel[j] : (uint32_t)j * rc.cellB);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    blk[i][0] = Cell<FT>::load_raw(rc.feat, voff[0], soff[i]);
+    blk[i][1] = Cell<FT>::load_raw(rc.feat, voff[1], soff[i]);
+  }
+  if (xc >= 1) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) blk[i][2] = Cell<FT>::load_raw(rc.feat, voff[2], soff[i]);
+  }
+  if (xc == 2) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) blk[i][3] = Cell<FT>::load_raw(rc.feat, voff[3], soff[i]);
+  }
+}
+
+template <int POOL, int DY, int DX, typename FT>
+__device__ __forceinline__ float4 roi_bin_lerps(const RowCtx& rc, const float (&xw)[2],
+                                                const typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
+  constexpr int NR = (DY == 2) ? 4 : 2 + DY, NC = (DX == 2) ? 4 : 2 + DX;
+  float4 w[NR][NC];                     // (widened here, after the wait: the block in flight stays narrow)
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) w[i][j] = Cell<FT>::widen(blk[i][j]);
+  float4 v[2][2];
+#pragma unroll
+  for (int sy = 0; sy < 2; ++sy) {
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int rt = (DY == 2) ? 2 * sy : sy * DY, rb = rt + 1;
+      const int cl = (DX == 2) ? 2 * sx : sx * DX, cr = cl + 1;
+      v[sy][sx] = lerp_tap(w[rt][cl], w[rt][cr], w[rb][cl], w[rb][cr], xw[sx], rc.yw[sy]);
+    }
+  }
+  return pool4<POOL>(v);
+}
+
+template <int POOL, int DY, typename FT>
+__device__ __forceinline__ float4 roi_bin_finish(const RowCtx& rc, int xc, const float (&xw)[2],
+                                                 const typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
+  if (xc == 0) return roi_bin_lerps<POOL, DY, 0, FT>(rc, xw, blk);
+  if (xc == 1) return roi_bin_lerps<POOL, DY, 1, FT>(rc, xw, blk);
+  return roi_bin_lerps<POOL, DY, 2, FT>(rc, xw, blk);
+}
+
+// One 256-channel slice of an output row, every lane active, two bins in flight.  (Plain forceinline functions, not
+// lambdas: a lambda the compiler decides not to inline takes the register blocks by reference, i.e. through scratch.)
+struct ColCtx { uint32_t xcls_l, c0_l, crel1_l, crel2_l, crel3_l; float xw0_l, xw1_l; };
+
+template <int DY, typename FT>
+__device__ __forceinline__ void roi_pipe_issue(const RowCtx& rc, const ColCtx& cc, int px,
+                                               typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
+  const int xc = rl_i((int)cc.xcls_l, px);
+  const uint32_t crel[4] = {0u, rl_u(cc.crel1_l, px), rl_u(cc.crel2_l, px), rl_u(cc.crel3_l, px)};
+  roi_bin_issue<DY, FT>(rc, xc, rl_u(cc.c0_l, px), crel, blk);
+}
+
+template <int POOL, int DY, typename FT>
+__device__ __forceinline__ void roi_pipe_finish(const RowCtx& rc, const ColCtx& cc, rsrc_t out, int px,
+                                                const typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
+  const float xw[2] = {rl_f(cc.xw0_l, px), rl_f(cc.xw1_l, px)};
+  const float4 o = roi_bin_finish<POOL, DY, FT>(rc, rl_i((int)cc.xcls_l, px), xw, blk);
+  Cell<FT>::store(out, rc.vlane, (uint32_t)px * rc.cellB, o);
+}
+
+template <int POOL, int DY, typename FT>
+__device__ __forceinline__ void roi_row_pipelined(const RowCtx& rc, rsrc_t out, int P, uint32_t xcls_l, uint32_t c0_l,
+                                                  const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
+  constexpr int NR = (DY == 2) ? 4 : 2 + DY;
+  typedef typename Cell<FT>::raw_t raw_t;
+  const ColCtx cc{xcls_l, c0_l, crel_l[1], crel_l[2], crel_l[3], xw0_l, xw1_l};
+  raw_t a[NR][4], b[NR][4];
+  roi_pipe_issue<DY, FT>(rc, cc, 0, a);
+  for (int px = 0; px < P; px += 2) {
+    if (px + 1 < P) roi_pipe_issue<DY, FT>(rc, cc, px + 1, b);
+    roi_pipe_finish<POOL, DY, FT>(rc, cc, out, px, a);
+    if (px + 1 < P) {
+      if (px + 2 < P) roi_pipe_issue<DY, FT>(rc, cc, px + 2, a);
+      roi_pipe_finish<POOL, DY, FT>(rc, cc, out, px + 1, b);
+    }
+  }
+}
+
 // The bins of one output row whose row class is DY, every sample of the row inside the map.  FULL: C is a
 // multiple of 256 (no lane is ever idle).
 template <int POOL, int DY, bool FULL, typename FT>
@@ -332,6 +443,14 @@ __device__ __forceinline__ void roi_row(const RowCtx& rc0, rsrc_t out, int P, in
                                         const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
   RowCtx rc = rc0;
   const int lane = threadIdx.x & 63;
+  if (FULL && DY < 2) {          // one pipelined pass per 256-channel slice (the general row class, rare, stays serial:
+                                 //  its 4 x 4-cell blocks would not fit two at a time)
+    for (int ch = ch0; ch < ch1; ch += 256) {
+      rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
+      roi_row_pipelined<POOL, DY, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
+    }
+    return;
+  }
   for (int px = 0; px < P; ++px) {
     const int xc = rl_i((int)xcls_l, px);
     const uint32_t c0 = rl_u(c0_l, px);

@@ -251,9 +251,7 @@ extern "C" int odet_stem_conv7_pool3_f16(const void* images, int images_f16, con
 //    weights; the matrix pipe is idle most of the time either way).
 //  * The weight rows are packed so that a lane's results of channel tiles (0, 1) / (2, 3) are 8 consecutive channels:
 //    with the four lanes of a pixel one store instruction writes 64 contiguous bytes, a pixel tile 2 KB.
-#ifndef RG_TH
 #define RG_TH 16                      // output rows of a tile (8: 650 us, 16: 618 us, 32: 626 us for 32 images of 600 x 800)
-#endif
 #define RG_TW 32                      // output columns
 #define RG_PR (RG_TH + 3)             // patch rows: y0 - 1 .. y0 + RG_TH + 1 (kernel row "3" of the second MFMA meets zero weights)
 #define RG_PC (RG_TW + 4)             // patch columns: x0 - 1 .. x0 + 34

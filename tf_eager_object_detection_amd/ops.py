@@ -717,9 +717,11 @@ def _pw_args(x, weight, bias, who, min_k=True):
     if not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
         raise ValueError('%s: x must be a contiguous %s GPU tensor [batch, H, W, cin]' % (who, name))
     cin, cout = int(x.shape[-1]), int(weight.shape[0])
-    if weight.dtype != x.dtype or weight.numel() % cout or weight.numel() // cout < cin:
+    if weight.dtype != x.dtype or weight.numel() % cout:
         raise ValueError('%s: weight must be a %s [cout, cin(, 1, 1)] tensor' % (who, name))
     w = weight.reshape(cout, -1)
+    if w.shape[1] != cin:             # (the kernels read the weight rows with stride cin)
+        raise ValueError('%s: weight has %d input channels, x %d' % (who, w.shape[1], cin))
     if not w.is_contiguous():
         w = w.contiguous()
     if bias is not None and (bias.dtype != x.dtype or bias.numel() != cout or not bias.is_contiguous()):
@@ -735,8 +737,6 @@ def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=Non
     [cout, cin(, 1, 1)], ``residual`` / ``out`` [B, ceil(H/stride), ceil(W/stride), cout];
     relu?(x[:, ::stride, ::stride] . w^T + bias + residual).  float32: exact-float32 matrix instructions."""
     w, cin, cout, sfx = _pw_args(x, weight, bias, 'pointwise')
-    if w.shape[1] != cin:
-        raise ValueError('pointwise: weight has %d input channels, x %d' % (w.shape[1], cin))
     B, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
     stride = int(stride)
     shape = (B, (H + stride - 1) // stride, (W + stride - 1) // stride, cout)
