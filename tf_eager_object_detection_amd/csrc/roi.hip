@@ -147,6 +147,9 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
 }
 
 template <typename FT> struct Cell;
+// t = l + (r - l) * w: the horizontal half of TF's bilinear sample (crop_and_resize_op.cc), one IEEE operation each
+__device__ __forceinline__ float lerp1(float l, float r, float w) { return l + (r - l) * w; }
+
 template <> struct Cell<float> {
   static constexpr uint32_t LANE_BYTES = 16;
   typedef u4v raw_t;              // a cell's 4 channels of this lane as they come out of memory
@@ -157,6 +160,11 @@ template <> struct Cell<float> {
     return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
   }
   static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) { return widen(load_raw(r, voff, soff)); }
+  // l + (r - l) * w per channel
+  static __device__ __forceinline__ float4 hlerp(raw_t l, raw_t r, float w) {
+    const float4 a = widen(l), b = widen(r);
+    return make_float4(lerp1(a.x, b.x, w), lerp1(a.y, b.y, w), lerp1(a.z, b.z, w), lerp1(a.w, b.w, w));
+  }
   // Pooled features are written once and not read again by this path: non-temporal stores keep the 50 MB per
   // image out of L2 / Infinity Cache, where they would evict the feature-map lines neighbouring RoIs share.
   static __device__ __forceinline__ void store(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
@@ -164,6 +172,23 @@ template <> struct Cell<float> {
     __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, /*nt*/ 2);
   }
 };
+// float16 maps: the horizontal lerp of one channel straight from the packed halves, WITHOUT separate conversions --
+// v_fma_mix_f32 reads a float16 operand (low / high half of a register by op_sel) widened exactly to float32 inside the
+// instruction, and  a * 1.0 + (-b)  is the correctly rounded float32 difference a - b,  a * 1.0 + m  the correctly
+// rounded sum: the same three IEEE operations (sub, mul, add) on the same float32 values as convert-then-lerp, bit for
+// bit, minus the conversions (36 of ~170 vector instructions of a 3 x 3-cell bin: the float16 kernel is bound by its
+// vector-instruction issue).
+template <int HI>
+__device__ __forceinline__ float lerp1_f16(uint32_t l, uint32_t r, float w) {
+  float d, o;
+  if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(r), "v"(l));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(r), "v"(l));
+  const float m = d * w;
+  if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(l), "v"(m));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(l), "v"(m));
+  return o;
+}
+
 template <> struct Cell<__half> {
   static constexpr uint32_t LANE_BYTES = 8;
   typedef u2v raw_t;
@@ -177,6 +202,9 @@ template <> struct Cell<__half> {
     return make_float4(fa.x, fa.y, fb.x, fb.y);
   }
   static __device__ __forceinline__ float4 load(rsrc_t r, uint32_t voff, uint32_t soff) { return widen(load_raw(r, voff, soff)); }
+  static __device__ __forceinline__ float4 hlerp(raw_t l, raw_t r, float w) {
+    return make_float4(lerp1_f16<0>(l.x, r.x, w), lerp1_f16<1>(l.x, r.x, w), lerp1_f16<0>(l.y, r.y, w), lerp1_f16<1>(l.y, r.y, w));
+  }
   static __device__ __forceinline__ void store(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
     const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
     u2v u;
@@ -224,12 +252,24 @@ __device__ __forceinline__ float4 roi_bin(const RowCtx& rc, uint32_t c0, const u
   for (int i = 0; i < NR; ++i) soff[i] = rc.row[i] + c0;                              // scalar
 #pragma unroll
   for (int j = 0; j < NC; ++j) voff[j] = rc.vlane + ((DX == 2) ? crel[j] : (uint32_t)j * rc.cellB);
-  float4 blk[NR][NC];
+  typename Cell<FT>::raw_t blk[NR][NC];
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      blk[i][j] = Cell<FT>::load(rc.feat, voff[j], soff[i]);
+      blk[i][j] = Cell<FT>::load_raw(rc.feat, voff[j], soff[i]);
+    }
+  }
+  // TF's sample = top + (bottom - top) * y_lerp with top / bottom = left + (right - left) * x_lerp (crop_and_resize_op.cc):
+  // the horizontal lerp of every tapped row for both sample columns (a row shared by the bin's two sample rows is
+  // lerped once: same operands, same result), then the vertical ones
+  float4 h[NR][2];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) {
+      const int cl = (DX == 2) ? 2 * sx : sx * DX;
+      h[i][sx] = Cell<FT>::hlerp(blk[i][cl], blk[i][cl + 1], xw[sx]);
     }
   }
   float4 v[2][2];
@@ -237,9 +277,10 @@ __device__ __forceinline__ float4 roi_bin(const RowCtx& rc, uint32_t c0, const u
   for (int sy = 0; sy < 2; ++sy) {
 #pragma unroll
     for (int sx = 0; sx < 2; ++sx) {
-      const int rt = (DY == 2) ? 2 * sy : sy * DY, rb = rt + 1;
-      const int cl = (DX == 2) ? 2 * sx : sx * DX, cr = cl + 1;
-      v[sy][sx] = lerp_tap(blk[rt][cl], blk[rt][cr], blk[rb][cl], blk[rb][cr], xw[sx], rc.yw[sy]);
+      const int rt = (DY == 2) ? 2 * sy : sy * DY;
+      const float4 t = h[rt][sx], b = h[rt + 1][sx];
+      const float yw = rc.yw[sy];
+      v[sy][sx] = make_float4(lerp1(t.x, b.x, yw), lerp1(t.y, b.y, yw), lerp1(t.z, b.z, yw), lerp1(t.w, b.w, yw));
     }
   }
   return pool4<POOL>(v);
@@ -333,109 +374,6 @@ __device__ __forceinline__ void roi_row_carry(const RowCtx& rc0, rsrc_t out, int
   }
 }
 
-// ---- two bins in flight (round 4) -----------------------------------------------------------------------------------
-// A wave's bins used to be a serial chain: a bin's cell loads, the wait for them, its lerps, its store, then the next
-// bin's loads.  With two 7-wave workgroups per CU (3.5 waves per SIMD) that chain leaves the memory pipe idle during
-// every bin's arithmetic: the pooled single-level forms and the float16 maps ran at 0.26 .. 0.41 of the HBM peak with no
-// wasted traffic (profiles/r03_roi_forms.json).  Here the loads of bin px + 1 are ISSUED before the lerps of bin px: a bin
-// is split into its loads (into a register block of up to 4 x 4 cells) and its arithmetic, and the row loop alternates
-// between two blocks.  Same loads, same lerps, same order of operations inside a bin: bit-identical.
-template <int DY, typename FT>
-__device__ __forceinline__ void roi_bin_issue(const RowCtx& rc, int xc, uint32_t c0, const uint32_t (&crel)[4],
-                                              typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
-  constexpr int NR = (DY == 2) ? 4 : 2 + DY;
-  uint32_t soff[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) soff[i] = rc.row[i] + c0;                              // scalar
-  // columns 0 and 1 always, column 2 for the classes 1 and 2, column 3 for the general class (wave-uniform conditions
-  // around loads with FIXED register indices: separate branches per class made the compiler merge their stores into one
-  // with a variable index -- the block then lived in scratch memory)
-  uint32_t voff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) voff[j] = rc.vlane + (xc == 2 ? crel[j] : (uint32_t)j * rc.cellB);
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    blk[i][0] = Cell<FT>::load_raw(rc.feat, voff[0], soff[i]);
-    blk[i][1] = Cell<FT>::load_raw(rc.feat, voff[1], soff[i]);
-  }
-  if (xc >= 1) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) blk[i][2] = Cell<FT>::load_raw(rc.feat, voff[2], soff[i]);
-  }
-  if (xc == 2) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) blk[i][3] = Cell<FT>::load_raw(rc.feat, voff[3], soff[i]);
-  }
-}
-
-template <int POOL, int DY, int DX, typename FT>
-__device__ __forceinline__ float4 roi_bin_lerps(const RowCtx& rc, const float (&xw)[2],
-                                                const typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
-  constexpr int NR = (DY == 2) ? 4 : 2 + DY, NC = (DX == 2) ? 4 : 2 + DX;
-  float4 w[NR][NC];                     // (widened here, after the wait: the block in flight stays narrow)
-#pragma unroll
-  for (int i = 0; i < NR; ++i)
-#pragma unroll
-    for (int j = 0; j < NC; ++j) w[i][j] = Cell<FT>::widen(blk[i][j]);
-  float4 v[2][2];
-#pragma unroll
-  for (int sy = 0; sy < 2; ++sy) {
-#pragma unroll
-    for (int sx = 0; sx < 2; ++sx) {
-      const int rt = (DY == 2) ? 2 * sy : sy * DY, rb = rt + 1;
-      const int cl = (DX == 2) ? 2 * sx : sx * DX, cr = cl + 1;
-      v[sy][sx] = lerp_tap(w[rt][cl], w[rt][cr], w[rb][cl], w[rb][cr], xw[sx], rc.yw[sy]);
-    }
-  }
-  return pool4<POOL>(v);
-}
-
-template <int POOL, int DY, typename FT>
-__device__ __forceinline__ float4 roi_bin_finish(const RowCtx& rc, int xc, const float (&xw)[2],
-                                                 const typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
-  if (xc == 0) return roi_bin_lerps<POOL, DY, 0, FT>(rc, xw, blk);
-  if (xc == 1) return roi_bin_lerps<POOL, DY, 1, FT>(rc, xw, blk);
-  return roi_bin_lerps<POOL, DY, 2, FT>(rc, xw, blk);
-}
-
-// One 256-channel slice of an output row, every lane active, two bins in flight.  (Plain forceinline functions, not
-// lambdas: a lambda the compiler decides not to inline takes the register blocks by reference, i.e. through scratch.)
-struct ColCtx { uint32_t xcls_l, c0_l, crel1_l, crel2_l, crel3_l; float xw0_l, xw1_l; };
-
-template <int DY, typename FT>
-__device__ __forceinline__ void roi_pipe_issue(const RowCtx& rc, const ColCtx& cc, int px,
-                                               typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
-  const int xc = rl_i((int)cc.xcls_l, px);
-  const uint32_t crel[4] = {0u, rl_u(cc.crel1_l, px), rl_u(cc.crel2_l, px), rl_u(cc.crel3_l, px)};
-  roi_bin_issue<DY, FT>(rc, xc, rl_u(cc.c0_l, px), crel, blk);
-}
-
-template <int POOL, int DY, typename FT>
-__device__ __forceinline__ void roi_pipe_finish(const RowCtx& rc, const ColCtx& cc, rsrc_t out, int px,
-                                                const typename Cell<FT>::raw_t (&blk)[(DY == 2) ? 4 : 2 + DY][4]) {
-  const float xw[2] = {rl_f(cc.xw0_l, px), rl_f(cc.xw1_l, px)};
-  const float4 o = roi_bin_finish<POOL, DY, FT>(rc, rl_i((int)cc.xcls_l, px), xw, blk);
-  Cell<FT>::store(out, rc.vlane, (uint32_t)px * rc.cellB, o);
-}
-
-template <int POOL, int DY, typename FT>
-__device__ __forceinline__ void roi_row_pipelined(const RowCtx& rc, rsrc_t out, int P, uint32_t xcls_l, uint32_t c0_l,
-                                                  const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
-  constexpr int NR = (DY == 2) ? 4 : 2 + DY;
-  typedef typename Cell<FT>::raw_t raw_t;
-  const ColCtx cc{xcls_l, c0_l, crel_l[1], crel_l[2], crel_l[3], xw0_l, xw1_l};
-  raw_t a[NR][4], b[NR][4];
-  roi_pipe_issue<DY, FT>(rc, cc, 0, a);
-  for (int px = 0; px < P; px += 2) {
-    if (px + 1 < P) roi_pipe_issue<DY, FT>(rc, cc, px + 1, b);
-    roi_pipe_finish<POOL, DY, FT>(rc, cc, out, px, a);
-    if (px + 1 < P) {
-      if (px + 2 < P) roi_pipe_issue<DY, FT>(rc, cc, px + 2, a);
-      roi_pipe_finish<POOL, DY, FT>(rc, cc, out, px + 1, b);
-    }
-  }
-}
-
 // The bins of one output row whose row class is DY, every sample of the row inside the map.  FULL: C is a
 // multiple of 256 (no lane is ever idle).
 template <int POOL, int DY, bool FULL, typename FT>
@@ -443,14 +381,6 @@ __device__ __forceinline__ void roi_row(const RowCtx& rc0, rsrc_t out, int P, in
                                         const uint32_t (&crel_l)[4], float xw0_l, float xw1_l) {
   RowCtx rc = rc0;
   const int lane = threadIdx.x & 63;
-  if (FULL && DY < 2) {          // one pipelined pass per 256-channel slice (the general row class, rare, stays serial:
-                                 //  its 4 x 4-cell blocks would not fit two at a time)
-    for (int ch = ch0; ch < ch1; ch += 256) {
-      rc.vlane = rc0.vlane + (uint32_t)ch * (Cell<FT>::LANE_BYTES / 4);
-      roi_row_pipelined<POOL, DY, FT>(rc, out, P, xcls_l, c0_l, crel_l, xw0_l, xw1_l);
-    }
-    return;
-  }
   for (int px = 0; px < P; ++px) {
     const int xc = rl_i((int)xcls_l, px);
     const uint32_t c0 = rl_u(c0_l, px);
@@ -530,11 +460,13 @@ __device__ __forceinline__ void roi_row_single(const RowCtx& rc0, rsrc_t out, in
       if (lane * 4 + ch < C) {
         float4 o = make_float4(0, 0, 0, 0);
         if (ok) {
-          const float4 tl = Cell<FT>::load(rc.feat, rc.vlane, rc.row[0] + cl);
-          const float4 tr = Cell<FT>::load(rc.feat, rc.vlane, rc.row[0] + cr);
-          const float4 bl = Cell<FT>::load(rc.feat, rc.vlane, rc.row[1] + cl);
-          const float4 br = Cell<FT>::load(rc.feat, rc.vlane, rc.row[1] + cr);
-          o = lerp_tap(tl, tr, bl, br, xw, rc.yw[0]);
+          const auto tl = Cell<FT>::load_raw(rc.feat, rc.vlane, rc.row[0] + cl);
+          const auto tr = Cell<FT>::load_raw(rc.feat, rc.vlane, rc.row[0] + cr);
+          const auto bl = Cell<FT>::load_raw(rc.feat, rc.vlane, rc.row[1] + cl);
+          const auto br = Cell<FT>::load_raw(rc.feat, rc.vlane, rc.row[1] + cr);
+          const float4 t = Cell<FT>::hlerp(tl, tr, xw), b = Cell<FT>::hlerp(bl, br, xw);
+          const float yw = rc.yw[0];
+          o = make_float4(lerp1(t.x, b.x, yw), lerp1(t.y, b.y, yw), lerp1(t.z, b.z, yw), lerp1(t.w, b.w, yw));
         }
         Cell<FT>::store(out, rc.vlane, so_out, o);
       }
