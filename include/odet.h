@@ -284,8 +284,10 @@ int odet_roi_pool_f16_timed(const odet_level_t* levels, int num_levels, int C, c
 #define ODET_POSTOPS_MAX_ROIS 4096
 #define ODET_POSTOPS_MAX_CANDIDATES 8192 /* (num_classes-1) * max_per_class */
 size_t odet_post_ops_workspace_bytes(int num_classes, int max_per_class);
-/* model/prediction.py:103-163 post_ops_prediction, all classes in one launch + one merge
- * launch.  scores [R,Ccls] softmax, deltas [R,Ccls,4], rois [R,4] (count_dev overrides R).
+/* model/prediction.py:103-163 post_ops_prediction in ONE launch: a workgroup per class (filter, decode, clip,
+ * sort, exact NMS); the last class workgroup of an image to finish merges the lists (concatenation, top-k) -- no
+ * second launch, no host sync.  scores [R,Ccls] softmax, deltas [R,Ccls,4] (16-byte aligned), rois [R,4]
+ * (count_dev overrides R).
  * Loops classes 1..num_classes-1 (num_classes <= Ccls).  means/stds host [4].
  * Outputs (capacity max_per_image): out_boxes [.,4], out_labels int32, out_scores in
  * (score desc, class asc, NMS order) order, out_count device int32[1]
@@ -574,8 +576,9 @@ typedef struct {
   /* profiling (nullable): HIP events (odet_prof_event_create) attached to the RoI dispatch of this step -- in a
    * batch those of the first step bracket the one launch all its images share */
   void* roi_start_event; void* roi_stop_event;
-  /* != 0: the caller promises that ws_rpn was zero-filled once after its allocation and has only ever been handed to
-   * this library since: every call leaves its header clean again, so no launch is spent on zeroing it */
+  /* != 0: the caller promises that ws_rpn AND ws_post were zero-filled once after their allocation and have only ever
+   * been handed to this library since: every call leaves the proposal stage's header and the post-ops' ticket counter
+   * clean again, so no launch / memset is spent on zeroing them */
   int32_t ws_rpn_clean;
   /* != 0: a single-level Faster R-CNN step (model/faster_rcnn/base_faster_rcnn_model.py:126-198 minus the dense
    * parts) instead of an FPN step: num_levels = num_maps = 1; fh[0] x fw[0] cells of stride[0] with A anchors each,

@@ -57,11 +57,13 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_DETECT) {
-    rc = odet_post_ops_record(s->cls_scores, s->cls_deltas, s->sorted_rois, s->num_proposals, s->roi_count, s->ccls,
-                              s->num_classes, s->image_h, s->image_w, s->roi_means, s->roi_stds, s->max_per_class,
-                              s->max_per_image, s->nms_iou, s->score_threshold, s->min_edge, s->det_boxes,
-                              s->det_labels, s->det_scores, s->det_count, s->record, s->ws_post, s->ws_post_bytes,
-                              s->stream);
+    ODET_REQUIRE(s->record, "odet_fpn_step_enqueue: null record");
+    const PostOpsImageIO one{s->cls_scores, s->cls_deltas, s->sorted_rois, s->roi_count, s->det_boxes, s->det_labels,
+                             s->det_scores, s->det_count, s->record, s->ws_post, s->ws_post_bytes};
+    rc = odet_post_ops_batch(&one, 1, s->num_proposals, s->ccls, s->num_classes,
+                             PostOpsExtra{(float)(s->image_w - 1), (float)(s->image_h - 1), 1.0f, 0}, s->roi_means,
+                             s->roi_stds, s->max_per_class, s->max_per_image, s->nms_iou, s->score_threshold,
+                             s->min_edge, (hipStream_t)s->stream, s->ws_rpn_clean);
   }
   return rc;
 }
@@ -103,15 +105,14 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
   }
   hipStream_t st = (hipStream_t)s->stream;
   int rc = ODET_OK;
+  bool clean_all = true;                       // every step's workspaces are promised clean (odet_fpn_step_t.ws_rpn_clean)
+  for (int i = 0; i < count; ++i) clean_all = clean_all && steps[i]->ws_rpn_clean != 0;
   if (stages & ODET_STAGE_PROPOSALS) {
     int fh[ODET_MAX_LEVELS], fw[ODET_MAX_LEVELS], sd[ODET_MAX_LEVELS];
     for (int l = 0; l < ODET_MAX_LEVELS; ++l) { fh[l] = s->fh[l]; fw[l] = s->fw[l]; sd[l] = s->stride[l]; }
     FpnProposalIO io[ODET_MAX_BATCH];
-    bool ordered_all = true, clean_all = true;
-    for (int i = 0; i < count; ++i) {
-      ordered_all = ordered_all && steps[i]->roi_order != nullptr;
-      clean_all = clean_all && steps[i]->ws_rpn_clean != 0;
-    }
+    bool ordered_all = true;
+    for (int i = 0; i < count; ++i) ordered_all = ordered_all && steps[i]->roi_order != nullptr;
     for (int i = 0; i < count; ++i) {
       const odet_fpn_step_t* t = steps[i];
       io[i] = FpnProposalIO{t->rpn_logits, t->rpn_deltas, t->rois, t->roi_idx, t->roi_count,
@@ -162,7 +163,7 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
     rc = odet_post_ops_batch(io, count, s->num_proposals, s->ccls, s->num_classes,
                              PostOpsExtra{(float)(s->image_w - 1), (float)(s->image_h - 1), 1.0f, 0}, s->roi_means,
                              s->roi_stds, s->max_per_class, s->max_per_image, s->nms_iou, s->score_threshold,
-                             s->min_edge, st);
+                             s->min_edge, st, clean_all ? 1 : 0);
   }
   return rc;
 }

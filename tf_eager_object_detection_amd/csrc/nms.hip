@@ -35,6 +35,7 @@
 //
 // Every decision is the predicate TF evaluates (d_iou_gt), so kept indices are identical to the
 // serial algorithm, including the early stop at max_output.
+#include <stddef.h>
 #include <string.h>
 
 #include <algorithm>
@@ -85,12 +86,16 @@ struct NmsState {
 
 // Starts the workspace.  Zeroed by k_zero_headers at the start of a call -- or, for callers that promise a workspace
 // that was zero-filled once and is only ever used by this library (odet_fpn_step_t.ws_rpn_clean), left clean by the
-// call itself: hist1 is zeroed again by k_sel_hist2 (after k_sel_find1 has read it), hist2 by k_sel_rank (after
-// k_sel_compact), n_invalid_acc is moved into the state by k_sel_find1, which also resets the state.
+// call itself: hist0 / hist1 are zeroed again by k_sel_compact (k_sel_hist2's blocks were their last readers), hist2 by
+// k_sel_rank (after k_sel_compact), n_invalid_acc is moved into the state by k_sel_hist2, which also resets the state.
+#define SEL_COARSE 64                   // coarse bins: 64 fine bins each
 struct NmsHeader {
   NmsState st;
-  int32_t n_invalid_acc;               // fed by k_rp_prepare; k_sel_find1 moves it into st.n_invalid
+  int32_t n_invalid_acc;               // fed by k_rp_prepare; k_sel_hist2 moves it into st.n_invalid
   int32_t pad_acc[15];
+  // sums of 64 consecutive first-level bins: with them a block finds the threshold bin from 2 x 64 x SEL_REPL counters
+  // instead of 4096 x SEL_REPL (round 4: k_sel_find1, a launch of its own for one workgroup's work, is gone)
+  uint32_t hist0[SEL_REPL][SEL_COARSE];
   uint32_t hist1[SEL_REPL][SEL_BINS];  // replica r is fed by blocks with blockIdx % SEL_REPL == r
   uint32_t hist2[SEL_BINS];
   uint32_t hist3[256];                 // tie split: the last 8 key bits inside the boundary bin (zeroed again by k_sel_rank)
@@ -166,7 +171,9 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
   uint32_t* __restrict__ out_keys = p.keys.v[img];
   NmsHeader* hdr = p.hdr.v[img];
   __shared__ uint32_t h[SEL_BINS];
+  __shared__ uint32_t h0[SEL_COARSE];          // sums of 64 consecutive bins, fed beside them (k_sel_hist2's prologue)
   for (int k = threadIdx.x; k < SEL_BINS; k += 256) h[k] = 0;
+  if (threadIdx.x < SEL_COARSE) h0[threadIdx.x] = 0;
   // all loads of the tile first (independent, in flight together), then the arithmetic
   float sc[PREP_ITEMS];
   float2 lg[PREP_ITEMS];
@@ -200,6 +207,7 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
       out_keys[e] = k;
       invalid += valid ? 0 : 1;
       atomicAdd(&h[k >> 20], 1u);
+      atomicAdd(&h0[k >> 26], 1u);
     }
   }
   __syncthreads();
@@ -207,7 +215,11 @@ __global__ void __launch_bounds__(256) k_rp_prepare(PrepParams p) {
     const uint32_t c = h[k];
     if (c) atomicAdd(&hdr->hist1[blockIdx.x % SEL_REPL][k], c);
   }
-  if (invalid) atomicAdd(&hdr->n_invalid_acc, invalid);            // rare (k_sel_find1 moves it into the state)
+  if (threadIdx.x < SEL_COARSE) {
+    const uint32_t c = h0[threadIdx.x];
+    if (c) atomicAdd(&hdr->hist0[blockIdx.x % SEL_REPL][threadIdx.x], c);
+  }
+  if (invalid) atomicAdd(&hdr->n_invalid_acc, invalid);            // rare (k_sel_hist2 moves it into the state)
 }
 
 // ------------------------------------------------------------------------- 2. select --------
@@ -249,41 +261,68 @@ __device__ __forceinline__ void sel_find(const uint32_t* __restrict__ hist, uint
   __syncthreads();
 }
 
-// First-level threshold bin, once per image: a thousand blocks each re-deriving it from the 8 histogram replicas
-// (128 KB per block, 1 GB of L2 reads per 8-image batch) cost more than this launch.
-__global__ void __launch_bounds__(SEL_BLOCK) k_sel_find1(PerImg<NmsHeader*> hdr_, uint32_t target) {
-  NmsHeader* hdr = hdr_.v[blockIdx.y];
-  __shared__ uint32_t res[3];
-  __shared__ int lds17[17];
-  sel_find<SEL_REPL>(&hdr->hist1[0][0], target, res, lds17);
-  if (threadIdx.x == 0) {
-    // the state of a new job (a workspace kept clean between calls is not zeroed by a launch of its own)
-    NmsState z;
-    memset(&z, 0, sizeof(z));
-    z.n_invalid = hdr->n_invalid_acc;
-    z.sel_b1 = (int32_t)res[0]; z.sel_below1 = res[1];
-    hdr->st = z;
-    hdr->n_invalid_acc = 0;
+// First-level threshold bin (the bin holding the target-th best key, and the count below it), found by EVERY block of
+// k_sel_hist2 in its prologue from the coarse sums: wave 0 scans the 64 coarse bins, then the 64 fine bins of the coarse
+// bin that holds the target -- 2 x 64 x SEL_REPL counters from L2 (a block re-deriving it from all 4096 x SEL_REPL fine
+// counters cost more than a launch of its own, which is what k_sel_find1 was until round 4: 5.5 us + a kernel boundary
+// per image in the latency arrangement for one workgroup's work).  res[0] = bin, res[1] = count below.
+__device__ __forceinline__ void sel_find1_coarse(const NmsHeader* hdr, uint32_t target, uint32_t* res) {
+  if (threadIdx.x < 64) {
+    const int t = threadIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < SEL_REPL; ++r) c += (int)hdr->hist0[r][t];
+    const int inc = wave_incl_scan(c);
+    const int total = __shfl(inc, 63);
+    if (total == 0) {
+      if (t == 0) { res[0] = SEL_BINS - 1; res[1] = 0; }
+    } else {
+      const int tgt = (int)(target > (uint32_t)total ? (uint32_t)total : target);
+      const u64 hitc = __ballot(c > 0 && inc - c < tgt && tgt <= inc);
+      const int cb = __builtin_ctzll(hitc);
+      const int below_c = __shfl(inc - c, cb);
+      int v = 0;
+#pragma unroll
+      for (int r = 0; r < SEL_REPL; ++r) v += (int)hdr->hist1[r][cb * 64 + t];
+      const int inc2 = wave_incl_scan(v);
+      const u64 hitf = __ballot(v > 0 && below_c + inc2 - v < tgt && tgt <= below_c + inc2);
+      const int fb = __builtin_ctzll(hitf);
+      const int below_f = __shfl(inc2 - v, fb);
+      if (t == 0) { res[0] = (uint32_t)(cb * 64 + fb); res[1] = (uint32_t)(below_c + below_f); }
+    }
   }
+  __syncthreads();
 }
 
-__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n) {
+__global__ void __launch_bounds__(SEL_BLOCK) k_sel_hist2(PerImg<NmsHeader*> hdr_, PerImg<const uint32_t*> keys_, int n,
+                                                         uint32_t target) {
   NmsHeader* hdr = hdr_.v[blockIdx.y];
   const uint32_t* __restrict__ keys = keys_.v[blockIdx.y];
   __shared__ uint32_t h[SEL_BINS];
-  const uint32_t b1 = (uint32_t)hdr->st.sel_b1;
-  // k_sel_find1 was the last reader of the first-level histogram: leave it clean for the next call
-  {
-    uint4* z = reinterpret_cast<uint4*>(&hdr->hist1[0][0]);
-    for (int i = blockIdx.x * SEL_BLOCK + threadIdx.x; i < SEL_REPL * SEL_BINS / 4; i += gridDim.x * SEL_BLOCK)
-      z[i] = make_uint4(0, 0, 0, 0);
-  }
+  __shared__ uint32_t res[2];
+  // the tile's keys first (in flight while wave 0 finds the threshold bin)
   uint32_t key[SEL_ITEMS];
-  bool match = false;
 #pragma unroll
   for (int it = 0; it < SEL_ITEMS; ++it) {
     const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
     key[it] = (e < n) ? keys[e] : 0u;
+  }
+  sel_find1_coarse(hdr, target, res);
+  const uint32_t b1 = res[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the state of a new job (a workspace kept clean between calls is not zeroed by a launch of its own); the other
+    // blocks of this launch use their own copy of b1, the later kernels read it from here
+    NmsState z;
+    memset(&z, 0, sizeof(z));
+    z.n_invalid = hdr->n_invalid_acc;
+    z.sel_b1 = (int32_t)b1; z.sel_below1 = res[1];
+    hdr->st = z;
+    hdr->n_invalid_acc = 0;
+  }
+  bool match = false;
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int e = blockIdx.x * SEL_TILE + it * SEL_BLOCK + threadIdx.x;
     match = match || (e < n && (key[it] >> 20) == b1);
   }
   if (!__syncthreads_or(match ? 1 : 0)) return;
@@ -310,6 +349,13 @@ __global__ void __launch_bounds__(SEL_BLOCK) k_sel_compact(PerImg<NmsHeader*> hd
   __shared__ int lds17[17];
   const uint32_t b1 = (uint32_t)hdr->st.sel_b1;
   const uint32_t below1 = hdr->st.sel_below1;
+  // k_sel_hist2's blocks were the last readers of the first-level histograms: leave them clean for the next call
+  {
+    static_assert(offsetof(NmsHeader, hist1) == offsetof(NmsHeader, hist0) + sizeof(uint32_t) * SEL_REPL * SEL_COARSE, "layout");
+    uint4* z = reinterpret_cast<uint4*>(&hdr->hist0[0][0]);
+    for (int i = blockIdx.x * SEL_BLOCK + threadIdx.x; i < SEL_REPL * (SEL_COARSE + SEL_BINS) / 4; i += gridDim.x * SEL_BLOCK)
+      z[i] = make_uint4(0, 0, 0, 0);
+  }
   uint32_t total_n = (uint32_t)n;
   uint32_t t2 = (target > total_n ? total_n : target) - below1;   // >= 1 by construction of b1
   sel_find<1>(hdr->hist2, t2, res, lds17);
@@ -1218,9 +1264,7 @@ static int nms_run(NmsJob& J, hipStream_t st) {
   const PerImg<float4*> sorig = per_img<float4*>(J, [&](int i) { return w[i].sorig; });
   {
     dim3 grid((n + SEL_TILE - 1) / SEL_TILE, B), block(SEL_BLOCK);
-    hipLaunchKernelGGL(k_sel_find1, dim3(1, B), block, 0, st, hdrs, sel_target);
-    ODET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, hdrs, keys, n);
+    hipLaunchKernelGGL(k_sel_hist2, grid, block, 0, st, hdrs, keys, n, sel_target);
     ODET_LAUNCH_CHECK();
     const PerImg<u64*> cand = per_img<u64*>(J, [&](int i) { return w[i].cand; });
     hipLaunchKernelGGL(k_sel_compact, grid, block, 0, st, hdrs, keys, n, sel_target, sel_limit, cand);

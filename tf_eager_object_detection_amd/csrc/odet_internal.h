@@ -365,7 +365,7 @@ struct PostOpsImageIO {     // per-image arguments
 };
 int odet_post_ops_batch(const PostOpsImageIO* io, int B, int R, int Ccls, int num_classes, PostOpsExtra ex,
                         const float* means, const float* stds, int max_per_class, int max_per_image,
-                        float nms_iou_threshold, float score_threshold, float min_edge, hipStream_t st);
+                        float nms_iou_threshold, float score_threshold, float min_edge, hipStream_t st, int ws_clean);
 
 // shared between translation units
 struct OdetSortImage {     // one image of odet_sort_keys_desc_batch

@@ -71,7 +71,7 @@ class FpnHotPath:
         self.det_labels = torch.zeros(M, dtype=torch.int32, device=dev)
         self.det_scores = torch.zeros(M, dtype=torch.float32, device=dev)
         self.det_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.ws_post = torch.empty(ops.L.lib().odet_post_ops_workspace_bytes(num_classes, max_per_class),
+        self.ws_post = torch.zeros(ops.L.lib().odet_post_ops_workspace_bytes(num_classes, max_per_class),
                                    dtype=torch.uint8, device=dev)
         self.record = torch.zeros(M * 6 + 1, dtype=torch.float32, device=dev)
         self._plans = {}
@@ -207,7 +207,7 @@ class FrcnnHotPath:
         self.det_labels = torch.zeros(M, dtype=torch.int32, device=dev)
         self.det_scores = torch.zeros(M, dtype=torch.float32, device=dev)
         self.det_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.ws_post = torch.empty(ops.L.lib().odet_post_ops_workspace_bytes(num_classes, max_per_class),
+        self.ws_post = torch.zeros(ops.L.lib().odet_post_ops_workspace_bytes(num_classes, max_per_class),
                                    dtype=torch.uint8, device=dev)
         self.record = torch.zeros(M * 6 + 1, dtype=torch.float32, device=dev)
 
