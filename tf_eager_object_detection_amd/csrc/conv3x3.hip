@@ -818,6 +818,36 @@ static int launch_tile(conv_kernel_t k, const ConvTile& t, unsigned blocks, unsi
 // library 25.1), its first 1x1 9.6 (12.7 / 11.7), conv5's 3x3 at batch 2 31.6 (39.9 / 31.2).  What bounds these launches is
 // a CU's intake from L2 (~30 B / clock with enough copies in flight), so a 64 x 64 x 64 K-step takes ~0.27 us whatever the
 // matrix pipe could do; beyond two workgroups per CU the larger tiles' better ratio of matrix work to copied bytes wins.
+// A pick that makes fewer workgroups than the chip has CUs (a "sub-round" launch: batch 2 .. 8 on the 50 x 84 maps, batch
+// 1 on the 100 x 167 ones): the 128 x 128 and 128 x 64 tiles make two or four times as many, and their 64 / 48 KB of
+// stages let two share a CU.  Priced with the launchers' own per-K-step model plus what sharing a CU costs (measured,
+// tools/r04/small_tiles.py, cold L2: conv4's 3x3 at batch 4 33.0 vs 37.6 us, its first 1x1 16.8 vs 20.3, its last 1x1 at
+// batch 1 10.2 vs 12.1, the neck's 100 x 167 smoothing convolution at batch 1 32.0 vs 38.0).
+static ConvTile refine_sub_round(const long long* level_px, int num_levels, int cout, int ksteps, ConvTile pick) {
+  auto blocks_of = [&](const ConvTile& t) {
+    long long slabs = 0;
+    for (int l = 0; l < num_levels; ++l) slabs += (level_px[l] + tile_tm(t) - 1) / tile_tm(t);
+    return (slabs + 7) / 8 * 8 * (long long)(cout / (64 * t.wn));
+  };
+  if (blocks_of(pick) >= 256) return pick;
+  auto cost_of = [&](const ConvTile& t) {
+    const int tm = tile_tm(t), tn = 64 * t.wn;
+    const long long blocks = blocks_of(t);
+    const int occ = tile_lds(t) <= 80u * 1024u ? 2 : 1;
+    const long long rounds = (blocks + 256ll * occ - 1) / (256ll * occ);
+    const double share = (double)std::min<long long>(occ, (blocks + 255) / 256);
+    return (double)rounds * (ksteps * std::max(tm * tn / 32.0, 2.0 * (tm + tn)) + 150.0) * (1.0 + 0.3 * (share - 1.0));
+  };
+  double best = cost_of(pick);
+  const ConvTile cands[2] = {{8, 2, 2, 2}, {8, 1, 1, 2}};
+  for (const ConvTile& c : cands) {
+    if (cout % (64 * c.wn)) continue;
+    const double cost = cost_of(c);
+    if (cost < best * 0.95) { best = cost; pick = c; }
+  }
+  return pick;
+}
+
 static ConvTile pick_small(const long long* level_px, int num_levels, int cout, ConvTile pick) {
   long long slabs64 = 0;
   for (int l = 0; l < num_levels; ++l) slabs64 += (level_px[l] + 63) / 64;
@@ -943,7 +973,7 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   ConvTile tile{8, wn_sel, mt_best, 2};
   if (!tail && !pool) {
     // few pixels (conv4 / conv5 / the small neck levels at batch 1 .. 2): the ring form
-    if (!blk) tile = pick_small(p.M, num_levels, cout, tile);
+    if (!blk) tile = pick_small(p.M, num_levels, cout, refine_sub_round(p.M, num_levels, cout, 9 * (cin / C3_BK), tile));
     tile_override(0, cout, blk ? wn_sel : 0, &tile);
     ODET_REQUIRE(!blk || tile.ns == 2, "odet_bottleneck_tail_f16: the fused tail has no ring form");
   }
@@ -1088,7 +1118,7 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
   ConvTile tile{8, wn_best, mt_best, 2};
   // fewer workgroups than the chip holds (few pixels: batch 1 .. 4 on the small maps, the RoI head's dense layers at 1000
   // rows): the ring forms
-  tile = pick_small(&M, 1, cout, tile);
+  tile = pick_small(&M, 1, cout, refine_sub_round(&M, 1, cout, (cin + (epi.x2 ? epi.cin2 : 0)) / C3_BK, tile));
   tile_override(1, cout, 0, &tile);
   const TileEntry* te = find_tile(tile);
   ODET_REQUIRE(te != nullptr, "%s: internal: no kernel for the picked tile", who);

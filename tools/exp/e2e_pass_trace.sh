@@ -10,8 +10,8 @@ python3 - "$f" > $out/pass.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# a pass ends with k_postops_merge; take the kernels between the 3rd-last and 2nd-last merge of the timed loop
-idx = [i for i, r in enumerate(rows) if 'k_postops_merge' in r['Kernel_Name']]
+# a pass ends with k_postops (one launch: the last class workgroup merges); take the kernels between the 3rd-last and 2nd-last one of the timed loop
+idx = [i for i, r in enumerate(rows) if 'k_postops' in r['Kernel_Name']]
 # e2e_bench runs per-part timing passes after the loop (features x5, rpn x5): use merges only; a pass of B images ends
 # with ceil(B / 8) merge launches (one per launch sequence of 8 images)
 import os
