@@ -379,14 +379,13 @@ int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_levels, con
  * epilogue relu(conv + conv_b) (one float16 rounding) . w^T + b for the 2A score and 4A delta rows (w [6A][cout] float16,
  * b [6A] float16: rpn_score's rows, then rpn_bbox's), written as float32 into the concatenated arrays scores
  * [batch][N][2] / deltas [batch][N][4] (image strides in VALUES; the levels follow each other in the order given, H*W*A
- * anchors each).  levels[].y is not used: the cout-channel activation never goes to memory -- the channel tiles of a
- * pixel slab leave 32 float32 partial sums per pixel in the workspace and a second, small launch adds them (fixed
- * order: deterministic) with the bias.  cout = 256 or 512, 1 <= A <= 5. */
-size_t odet_rpn_head_fused_workspace_bytes(const odet_conv_level_t* levels, int num_levels, int batch, int cout);
+ * anchors each).  levels[].y is not used: the cout-channel activation never goes to memory -- a workgroup walks the
+ * channel tiles of its pixel slab and keeps the 32 float32 sums per pixel in registers (fixed order: deterministic; one
+ * launch, no workspace).  cout = 256 or 512, 1 <= A <= 5. */
 int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_levels, const void* conv_w, const void* conv_b,
                             const void* w, const void* b, int A, int batch, int cin, int cout, float* scores,
                             long long scores_image_stride, float* deltas, long long deltas_image_stride,
-                            void* workspace, size_t workspace_bytes, odet_stream_t stream);
+                            odet_stream_t stream);
 /* A bottleneck block's 3x3 convolution AND its last 1x1 convolution in one launch (resnet_fpn.py:154-205 with the frozen
  * batch norms folded): y = relu( relu(conv3x3(x, w2) + b2) . w3^T + b3 + residual ), x NHWC float16 [batch,H,W,cin],
  * w2 [256][3][3][cin], b2 [256], w3 [n3][256], b3 [n3], residual (nullable) / y NHWC float16 [batch,H,W,n3]; the

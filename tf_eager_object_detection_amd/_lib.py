@@ -118,8 +118,7 @@ SIGNATURES = {
     'odet_conv3x3_relu_pool2_f16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'odet_calib_read_rows': (_i, [_vp, C.c_ulonglong, _i, _vp, _vp]),
     'odet_calib_stream_mix': (_i, [_vp, C.c_ulonglong, _vp, C.c_ulonglong, _vp, _vp, _vp]),
-    'odet_rpn_head_fused_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_longlong, _vp, C.c_longlong, _vp, C.c_size_t, _vp]),
-    'odet_rpn_head_fused_workspace_bytes': (C.c_size_t, [_vp, _i, _i, _i]),
+    'odet_rpn_head_fused_f16': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_longlong, _vp, C.c_longlong, _vp]),
     'odet_bottleneck_tail_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_conv3x3_conv1x1_f16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_stem_pack_weights_f16': (_i, [_vp, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _vp, _vp]),

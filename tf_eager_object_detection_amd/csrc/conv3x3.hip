@@ -62,9 +62,6 @@ struct Conv3x3Params {           // up to ODET_MAX_LEVELS maps (the pyramid leve
   const _Float16* tail_w;         // [6A][cout]: 2A score rows, then 4A delta rows
   const _Float16* tail_b;         // [6A]
   float* scores; float* deltas;   // [batch][N][2] / [batch][N][4]
-  float* partial;                 // workspace [tiles_n][slab pixels of the launch][32 rows]: a channel tile's partial sums
-  long long slab_px;              // slabs * TM of the launch (pixels incl. the padding of every level's last slab)
-  int tm;                         // TM of the launch (for k_rpn_tail_finish)
   // fused bottleneck tail (k_conv3x3_f16<.., false, true>): y3 = relu(relu(conv + bias) . w3^T + b3 + res), cout == 256
   const _Float16* w3; const _Float16* b3; const _Float16* res; _Float16* y3;
   int n3, relu3;
@@ -133,8 +130,10 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
   // workgroup -> (pixel slab, channel tile): the channel tiles of a slab on one XCD
   const long long blk = blockIdx.x;
   const long long q8 = blk >> 3;
-  const long long slab = (blk & 7) + 8 * (q8 / p.tiles_n);
-  const int tn = (int)(q8 % p.tiles_n);
+  // (fused RpnHead: one workgroup per slab, its channel tiles one after the other -- see the TAIL section)
+  const int tiles_grid = TAIL ? 1 : p.tiles_n;
+  const long long slab = (blk & 7) + 8 * (q8 / tiles_grid);
+  int tn = (int)(q8 % tiles_grid);
   if (slab >= p.tile_start[p.num_levels]) return;        // (padding workgroups of the last group of 8 slabs)
   int lv = 0;                                            // the level this slab belongs to (big levels first: the small
 #pragma unroll                                           //  ones fill the tail of the launch)
@@ -211,6 +210,8 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     }
     maskA[i] = mk;
   }
+  for (int tn_pass = 0; tn_pass < (TAIL ? p.tiles_n : 1); ++tn_pass) {
+  if (TAIL) tn = tn_pass;
 #pragma unroll
   for (int i = 0; i < WPW; ++i) {
     const int row = (wv * WPW + i) * 8 + sub;            // 0..TN-1
@@ -380,10 +381,16 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     // A operand = 16 rows of W2 (o = 2A score rows, then 4A delta rows, zero rows up to 32), its B operand = the 16 pixels
     // of a tile; a lane's 16 channels are two K groups of 8 (the K order inside an MFMA is free as long as both operands
     // agree).  A wave has 64 of the tile's 256 channels: the four waves along the channels add up through LDS (the
-    // stages are free after the K loop); the channel tiles of a slab (two for 512 channels) each leave their partial
-    // sums in the workspace and k_rpn_tail_finish adds them in a fixed order, with the bias, into the arrays (float32
-    // atomics onto the arrays instead cost as much as the separate tail pass: 26 M of them at batch 8).
+    // stages are free after the K loop); the workgroup walks the channel tiles of its slab (two for 512 channels) one
+    // after the other and keeps the sums in registers (round 4; before, every channel tile had its own workgroup and
+    // left partial sums in a workspace for a second launch -- 2 GB and 225 us at 30 images).
     static_assert(WN == 4, "the fused tail is for 256-channel tiles");
+    // (the lane's and the wave's coordinates again, opaque: or everything below that does not depend on the channel tile --
+    // LDS addresses, the pixel's image / offset division, the output pointers -- is hoisted out of the channel-tile loop
+    // and has to live through the K loop, which spills)
+    int lane_o = lane, wv_o = wv;
+    asm volatile("" : "+v"(lane_o), "+s"(wv_o));
+    const int lane = lane_o, l15 = lane_o & 15, lq = lane_o >> 4, wm = wv_o / WN, wn = wv_o % WN;
     const int rows = 6 * p.A;
     h8 w2[2][2];
 #pragma unroll
@@ -422,21 +429,50 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
       }
     }
     __syncthreads();
-    // wave (wm, wn) adds up the pixel tiles mt = wn, wn + 4, ... of its half (lane = rows 4 lq .. 4 lq + 3 of a row
-    // tile, pixel l15) and stores this channel tile's partial sums: 16 bytes per lane, a 128-byte line per pixel
-    for (int mt = wn; mt < MT; mt += 4) {
-      const long long gm = slab * TM + wm * 16 * MT + mt * 16 + l15;      // pixel slot of the launch
+    // wave (wm, wn) adds up the pixel tiles mt = wn, wn + 4 of its half (lane = rows 4 lq .. 4 lq + 3 of a row tile,
+    // pixel l15) over the four waves along the channels, and over the channel tiles of the slab (this loop): the sums so
+    // far wait in the 128 bytes per pixel of LDS behind the stages (a lane reads back what it wrote itself; registers
+    // would have to survive the K loop, which has none to spare).  The last channel tile adds the bias and writes row R of
+    // pixel m to scores (R < 2A) / deltas (R - 2A) of the level's slice of the concatenated arrays
+    // (base_fpn_model.py:188-200, 427-432).
+    f4* keep = reinterpret_cast<f4*>(lds + 2u * STAGE);  // [wm][mt][rt][lane]
+    const bool first = tn_pass == 0, last = tn_pass + 1 == p.tiles_n;
+    const int nS = 2 * p.A;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const f4* src = red + (((wm * MT + mt) * 2 + rt) * 4) * 64 + lane;
-        const f4 a0 = src[0], a1 = src[64], a2 = src[128], a3 = src[192];
-        f4 v;
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int mt = wn + 4 * s2;
+      if (mt < MT) {
+        const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
+        const long long b = m / p.px[lv], pi = m - b * p.px[lv];
+        float* so = p.scores + b * p.s_stride + (p.aoff[lv] + pi * p.A) * 2;
+        float* dO = p.deltas + b * p.d_stride + (p.aoff[lv] + pi * p.A) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ((a0[j] + a1[j]) + a2[j]) + a3[j];
-        *reinterpret_cast<f4*>(p.partial + ((long long)tn * p.slab_px + gm) * 32 + rt * 16 + 4 * lq) = v;
+        for (int rt = 0; rt < 2; ++rt) {
+          const f4* src = red + (((wm * MT + mt) * 2 + rt) * 4) * 64 + lane;
+          f4* kp = keep + ((wm * MT + mt) * 2 + rt) * 64 + lane;
+          const f4 a0 = src[0], a1 = src[64], a2 = src[128], a3 = src[192];
+          f4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ((a0[j] + a1[j]) + a2[j]) + a3[j];
+          if (!first) v += *kp;
+          if (!last) {
+            *kp = v;
+          } else if (m < M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int R = rt * 16 + 4 * lq + j;
+              if (R < rows) {
+                const float o = v[j] + (float)p.tail_b[R];
+                if (R < nS) so[R] = o; else dO[R - nS] = o;
+              }
+            }
+          }
+        }
       }
     }
-    return;
+    if (last) return;
+    __syncthreads();                                     // (the next channel tile's copies overwrite `red`)
+    continue;
   }
   if constexpr (BLK) {
     // ---- fused bottleneck tail (resnet_fpn.py:154-205: conv 3x3 -> BN -> ReLU -> conv 1x1 -> BN -> Add -> ReLU with the
@@ -689,6 +725,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
       *reinterpret_cast<h8*>(dst + HOFF) = o[1];
     }
   }
+  }   // tn_pass (one pass unless TAIL)
 }
 
 template <int MT, int WN, bool TAIL = false, bool BLK = false>
@@ -712,40 +749,6 @@ __global__ void __launch_bounds__(256) k_conv3x3_f16_ring(Conv3x3Params p) {
 template <int NS>
 __global__ void __launch_bounds__(256) k_pointwise_f16_ring(Conv3x3Params p) {
   conv_tile_f16<1, 1, false, false, 1, 4, NS>(p);
-}
-
-// Second, small launch of the fused RpnHead: out = sum over the channel tiles' partial sums + bias, row R of pixel m to
-// scores (R < 2A) / deltas (R - 2A) of the level's slice.  One thread = 4 rows of a pixel slot.
-__global__ void __launch_bounds__(256) k_rpn_tail_finish(Conv3x3Params p) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long gm = idx >> 3;
-  const int g = (int)(idx & 7);
-  if (gm >= p.slab_px) return;
-  const long long slab = gm / p.tm;
-  int lv = 0;
-#pragma unroll
-  for (int l = 1; l < ODET_MAX_LEVELS; ++l)
-    if (l < p.num_levels && slab >= p.tile_start[l]) lv = l;
-  const long long m = (slab - p.tile_start[lv]) * p.tm + (gm - slab * p.tm);
-  if (m >= p.M[lv]) return;
-  const int rows = 6 * p.A, nS = 2 * p.A;
-  if (4 * g >= rows) return;
-  f4 v = *reinterpret_cast<const f4*>(p.partial + gm * 32 + 4 * g);
-  for (int t = 1; t < p.tiles_n; ++t) {
-    const f4 u = *reinterpret_cast<const f4*>(p.partial + ((long long)t * p.slab_px + gm) * 32 + 4 * g);
-    v += u;
-  }
-  const long long b = m / p.px[lv], pi = m - b * p.px[lv];
-  float* so = p.scores + b * p.s_stride + (p.aoff[lv] + pi * p.A) * 2;
-  float* dO = p.deltas + b * p.d_stride + (p.aoff[lv] + pi * p.A) * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int R = 4 * g + j;
-    if (R < rows) {
-      const float o = v[j] + (float)p.tail_b[R];
-      if (R < nS) so[R] = o; else dO[R - nS] = o;
-    }
-  }
 }
 
 // (the float32 forms -- the detectors' parity mode -- live in conv_f32.hip)
@@ -879,7 +882,6 @@ static bool tile_override(int form, int cout, int need_wn, ConvTile* t) {
 
 struct Conv3x3Tail {             // the fused RpnHead tail (nullable in conv3x3_launch)
   const void* w; const void* b; int A; float* scores; long long s_stride; float* deltas; long long d_stride;
-  void* ws; size_t ws_bytes;
 };
 struct Conv3x3Block {            // the fused bottleneck tail (nullable in conv3x3_launch)
   const void* w3; const void* b3; const void* res; void* y3; int n3; int relu3;
@@ -911,7 +913,6 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
     p.px[l] = (long long)L.H * L.W;
   }
   p.tail_w = nullptr; p.tail_b = nullptr; p.scores = nullptr; p.deltas = nullptr; p.s_stride = p.d_stride = 0; p.A = 0;
-  p.partial = nullptr; p.slab_px = 0; p.tm = 0;
   p.w3 = nullptr; p.b3 = nullptr; p.res = nullptr; p.y3 = nullptr; p.n3 = 0; p.relu3 = 0;
   p.stride = 1; p.Ho = p.Wo = 0; p.Min = 0; p.top = nullptr; p.th = p.tw = 0; p.tys = p.txs = 0.0f;
   p.y32 = nullptr; p.bias32 = nullptr; p.x2 = nullptr; p.cin2 = 0; p.k1steps = 0; p.Min2 = 0;
@@ -936,7 +937,6 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   if (tail) {
     ODET_REQUIRE(tail->w && tail->b && tail->scores && tail->deltas && bias, "odet_rpn_head_fused_f16: null pointer");
     ODET_REQUIRE(tail->A >= 1 && 6 * tail->A <= 32, "odet_rpn_head_fused_f16: 1 <= A <= 5");
-    // (two channel tiles at most: their two float32 partial sums commute; three or more would not add up in a fixed order)
     ODET_REQUIRE(cout == 256 || cout == 512, "odet_rpn_head_fused_f16: cout must be 256 or 512 (got %d)", cout);
     long long a0 = 0;
     for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
@@ -962,11 +962,13 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
       const int tm = wm_sel * 16 * mt;
       long long slabs = 0;
       for (int l = 0; l < num_levels; ++l) slabs += (p.M[l] + tm - 1) / tm;
-      const long long blocks_mt = (slabs + 7) / 8 * 8 * (cout / (64 * wn_sel));
+      // (fused RpnHead: a workgroup walks the channel tiles of its slab itself)
+      const int tiles_mt = cout / (64 * wn_sel);
+      const long long blocks_mt = (slabs + 7) / 8 * 8 * (tail ? 1 : tiles_mt);
       // plain launches ask for two stages of their own tile: tiles of <= 80 KB run two workgroups per CU (each at ~1 / 1.7
       // of the speed it has alone: they overlap each other's staging, barriers and epilogues)
       const int occ = (!tail && !blk && 2 * (tm + 64 * wn_sel) * 128 <= 80 * 1024) ? 2 : 1;
-      const double cost = (double)((blocks_mt + 256 * occ - 1) / (256 * occ)) * (tm / 32 + 2) * (occ == 2 ? 1.7 : 1.0);
+      const double cost = (double)((blocks_mt + 256 * occ - 1) / (256 * occ)) * (tm / 32 + 2) * (occ == 2 ? 1.7 : 1.0) * (tail ? tiles_mt : 1);
       if (cost < best * 0.97) { best = cost; mt_best = mt; }       // (smaller tiles only for a clear gain)
     }
   }
@@ -990,14 +992,9 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
   p.w = (const _Float16*)w; p.bias = (const _Float16*)bias;
   p.num_levels = num_levels; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
   const long long groups = (total + 7) / 8;
-  const long long blocks = groups * 8 * p.tiles_n;
+  const long long blocks = groups * 8 * (tail ? 1 : p.tiles_n);
   ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_f16: too many workgroups");
   if (tail) {
-    p.slab_px = total * TMsel; p.tm = TMsel;
-    const size_t need = (size_t)p.tiles_n * (size_t)p.slab_px * 32 * sizeof(float);
-    ODET_REQUIRE(tail->ws && tail->ws_bytes >= need && (uintptr_t)tail->ws % 16 == 0,
-                 "odet_rpn_head_fused_f16: workspace too small (%zu < %zu) or misaligned", tail->ws_bytes, need);
-    p.partial = (float*)tail->ws;
     conv_kernel_t kt = k_conv3x3_f16<8, 4, true>;
     switch (mt_best) {
       case 4: kt = k_conv3x3_f16<4, 4, true>; break;
@@ -1006,12 +1003,8 @@ static int conv3x3_launch(const odet_conv_level_t* levels, int num_levels, const
       case 7: kt = k_conv3x3_f16<7, 4, true>; break;
       default: break;
     }
-    const int rc = launch_tile(kt, tile, (unsigned)blocks, C3_LDS_BYTES, p, st);
-    if (rc != ODET_OK) return rc;
-    const long long threads = p.slab_px * 8;
-    hipLaunchKernelGGL(k_rpn_tail_finish, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
-    ODET_LAUNCH_CHECK();
-    return ODET_OK;
+    // (the K loop's stages + 128 bytes per pixel for the sums over the channel tiles)
+    return launch_tile(kt, tile, (unsigned)blocks, C3_LDS_BYTES + (unsigned)TMsel * 128u, p, st);
   }
   // LDS: the K loop's stages of the launch's own tile; the fused tail re-uses them for the TM x 2 CMID-byte activation tile
   unsigned lds_bytes = tile_lds(tile);
@@ -1041,9 +1034,9 @@ extern "C" int odet_conv3x3_f16_levels(const odet_conv_level_t* levels, int num_
 extern "C" int odet_rpn_head_fused_f16(const odet_conv_level_t* levels, int num_levels, const void* conv_w, const void* conv_b,
                                        const void* w, const void* b, int A, int batch, int cin, int cout, float* scores,
                                        long long scores_image_stride, float* deltas, long long deltas_image_stride,
-                                       void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+                                       odet_stream_t stream) {
   ODET_REQUIRE(((uintptr_t)w | (uintptr_t)conv_b) % 16 == 0, "odet_rpn_head_fused_f16: pointers must be 16-byte aligned");
-  const Conv3x3Tail t{w, b, A, scores, scores_image_stride, deltas, deltas_image_stride, workspace, workspace_bytes};
+  const Conv3x3Tail t{w, b, A, scores, scores_image_stride, deltas, deltas_image_stride};
   return conv3x3_launch(levels, num_levels, conv_w, conv_b, batch, cin, cout, 1, (hipStream_t)stream, &t);
 }
 
@@ -1088,7 +1081,6 @@ static int pointwise_launch(const char* who, const void* x, const void* w, const
     p.aoff[l] = 0;
   }
   p.tail_w = nullptr; p.tail_b = nullptr; p.scores = nullptr; p.deltas = nullptr; p.s_stride = p.d_stride = 0; p.A = 0;
-  p.partial = nullptr; p.slab_px = 0; p.tm = 0;
   p.w3 = nullptr; p.b3 = nullptr; p.y3 = nullptr; p.n3 = 0; p.relu3 = 0;
   p.res = (const _Float16*)epi.res;
   p.top = (const _Float16*)epi.top; p.th = epi.th; p.tw = epi.tw;
@@ -1173,10 +1165,3 @@ extern "C" int odet_bottleneck_tail_f16(const void* x, const void* w2, const voi
   return conv3x3_launch(&one, 1, w2, b2, batch, cin, cmid, 1, (hipStream_t)stream, nullptr, &b);
 }
 
-// upper bound of the workspace of odet_rpn_head_fused_f16: every level's pixels rounded up to a whole slab of any height
-extern "C" size_t odet_rpn_head_fused_workspace_bytes(const odet_conv_level_t* levels, int num_levels, int batch, int cout) {
-  if (!levels || num_levels < 1 || num_levels > ODET_MAX_LEVELS || batch < 1 || cout < 1) return 0;
-  size_t px = 0;
-  for (int l = 0; l < num_levels; ++l) px += (size_t)batch * levels[l].H * levels[l].W + 256;
-  return (size_t)((cout + 255) / 256) * px * 32 * sizeof(float);
-}

@@ -521,9 +521,8 @@ def rpn_head_fused(xs, conv_weight, conv_bias, weight, bias, num_anchors, scores
     """The whole RpnHead over the pyramid levels in ONE launch (odet_rpn_head_fused_f16): ``xs`` NHWC float16 maps
     [B,H_l,W_l,cin] in concatenation order, ``conv_weight`` [cout,cin,3,3] (channels_last) / ``conv_bias`` [cout] of the
     3x3 convolution, ``weight`` [6A,cout(,1,1)] / ``bias`` [6A] = the score rows then the delta rows of the two 1x1
-    convolutions; relu(conv + conv_bias) . weight^T + bias -> ``scores`` [B,N,2] / ``deltas`` [B,N,4] float32 (the
-    kernel's channel tiles leave partial sums in a cached workspace, a small second launch adds them).  cout in
-    {256, 512}."""
+    convolutions; relu(conv + conv_bias) . weight^T + bias -> ``scores`` [B,N,2] / ``deltas`` [B,N,4] float32 (a
+    workgroup walks the channel tiles of its pixel slab: no workspace, no second launch).  cout in {256, 512}."""
     A = int(num_anchors)
     if not 1 <= len(xs) <= MAX_LEVELS:
         raise ValueError('between 1 and %d maps expected' % MAX_LEVELS)
@@ -549,19 +548,9 @@ def rpn_head_fused(xs, conv_weight, conv_bias, weight, bias, num_anchors, scores
     for t, k in ((scores, 2), (deltas, 4)):
         if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (B, n, k):
             raise ValueError('scores / deltas must be contiguous float32 [B, N, 2] / [B, N, 4] tensors, N = sum H*W*A')
-    need = int(L.lib().odet_rpn_head_fused_workspace_bytes(lv, len(xs), B, cout))
-    key = (xs[0].device, need, torch.cuda.current_stream(xs[0].device).cuda_stream)     # (one per stream: calls on two streams may overlap)
-    ws = _RPN_FUSED_WS.get(key)
-    if ws is None:
-        if len(_RPN_FUSED_WS) >= 8:
-            _RPN_FUSED_WS.clear()
-        ws = _RPN_FUSED_WS[key] = torch.empty(need, dtype=torch.uint8, device=xs[0].device)
     L.call('odet_rpn_head_fused_f16', lv, len(xs), L.dptr(w3), L.dptr(conv_bias), L.dptr(w1), L.dptr(bias), A, B, cin, cout,
-           L.dptr(scores), n * 2, L.dptr(deltas), n * 4, C.c_void_p(ws.data_ptr()), need, L.stream())
+           L.dptr(scores), n * 2, L.dptr(deltas), n * 4, L.stream())
     return scores, deltas
-
-
-_RPN_FUSED_WS = {}      # (device, bytes, stream) -> the partial-sum workspace of rpn_head_fused (a few shapes at most)
 
 
 def conv3x3_conv1x1_f16(x, weight2, bias2, weight3, bias3, residual=None, relu=True, out=None):
