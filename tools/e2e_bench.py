@@ -21,7 +21,7 @@ ap.add_argument('--model', default='fpn', choices=['fpn', 'c4', 'vgg16'],
                 help='fpn: ResNet-FPN (1000 proposals); c4: ResNet-C4 Faster R-CNN (300 proposals); vgg16: VGG16 Faster R-CNN')
 ap.add_argument('--h', type=int, default=800)
 ap.add_argument('--w', type=int, default=1333)
-ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True (no effect since round 4: the detectors launch no library convolution)')
 ap.add_argument('--graph', action='store_true', help='replay the whole forward pass as one HIP graph')
 ap.add_argument('--blind-chunks', type=int, default=3, help='FPN: sync-free NMS chunks (3: the third one on the full order)')
 ap.add_argument('--per-image', action='store_true', help='FPN: every image through its own hot-path launches and RoI-head call '

@@ -3,8 +3,7 @@
 set -u
 cd "$(dirname "$0")/../.."
 out=gpurun_out/e2e_pass; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp
-export MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD=0
-timeout -s KILL 900 rocprofv3 --kernel-trace -d $out/tr --output-format csv -- python3 tools/e2e_bench.py --dtype ${DT:-fp16} --batch ${BATCH:-8} --steps 6 --warmup 5 --miopen-find ${EXTRA:-} > $out/run.log 2>&1
+timeout -s KILL 900 rocprofv3 --kernel-trace -d $out/tr --output-format csv -- python3 tools/e2e_bench.py --dtype ${DT:-fp16} --batch ${BATCH:-8} --steps 6 --warmup 5 ${EXTRA:-} > $out/run.log 2>&1
 f=$(find $out -name "*_kernel_trace.csv" | head -1)
 python3 - "$f" > $out/pass.txt <<'PY'
 import csv, sys

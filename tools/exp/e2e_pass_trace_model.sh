@@ -5,9 +5,8 @@ set -u
 cd "$(dirname "$0")/../.."
 m=${MODEL:-c4}
 out=gpurun_out/e2e_pass_$m; rm -rf $out; mkdir -p $out; export TMPDIR=/tmp
-export MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD=0
 extra=""; [ "$m" = "vgg16" ] && extra="--h 600 --w 800"; [ "$m" = "c4" ] && extra="--depth 50"
-timeout -s KILL 600 rocprofv3 --kernel-trace -d $out/tr --output-format csv -- python3 tools/e2e_bench.py --model $m $extra --dtype ${DT:-fp16} --batch ${BATCH:-30} --steps 8 --warmup 5 --miopen-find > $out/run.log 2>&1
+timeout -s KILL 600 rocprofv3 --kernel-trace -d $out/tr --output-format csv -- python3 tools/e2e_bench.py --model $m $extra --dtype ${DT:-fp16} --batch ${BATCH:-30} --steps 8 --warmup 5 > $out/run.log 2>&1
 f=$(find $out -name "*_kernel_trace.csv" | head -1)
 python3 - "$f" > $out/summary.txt <<'PY'
 import csv, sys, collections

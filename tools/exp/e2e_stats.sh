@@ -6,8 +6,7 @@ cd "$(dirname "$0")/../.."
 out=gpurun_out/e2e_${DT:-fp32}_stats
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-export MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD=0
-timeout -s KILL 900 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 tools/e2e_bench.py --dtype ${DT:-fp32} --batch ${BATCH:-4} --steps ${STEPS:-40} --warmup 5 --miopen-find > $out/run.log 2>&1
+timeout -s KILL 900 rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 tools/e2e_bench.py --dtype ${DT:-fp32} --batch ${BATCH:-4} --steps ${STEPS:-40} --warmup 5 > $out/run.log 2>&1
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*_agent_info.csv" -delete
 tail -3 $out/run.log | cut -c1-600
 f=$(find $out -name "*_kernel_stats.csv" | head -1)

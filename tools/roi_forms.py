@@ -132,7 +132,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--reps', type=int, default=14)
     ap.add_argument('--cold-only', action='store_true')
-    ap.add_argument('--pmc', default=os.path.join(ROOT, 'profiles', 'r03_roi_forms_pmc.json'))
+    ap.add_argument('--pmc', default=os.path.join(ROOT, 'profiles', 'r04_roi_forms_pmc.json'))
     a = ap.parse_args()
     _lib.lib()
     flush = torch.ones(1 << 28, dtype=torch.float32, device='cuda')
