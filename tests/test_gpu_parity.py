@@ -531,6 +531,24 @@ def test_post_ops_edge_cases():
     _check_post(got, co.post_ops(St, D[:, :21], rois, shape, M0, S2, 50, 150, 0.3, 0.0, 16, 21))
 
 
+@pytest.mark.parametrize('R,mpc,mpi,sthr,decimals', [(1000, 50, 50, 0.05, 2), (1000, 50, 50, 0.0, 1), (1000, 5, 5, 0.05, 2),
+                                                      (1000, 50, 64, 0.05, 2), (200, 50, 50, 0.2, 2), (1000, 51, 64, 0.0, 2),
+                                                      (40, 50, 50, 0.0, 3), (1000, 50, 65, 0.05, 2)])
+def test_post_ops_ties_through_both_merge_forms(R, mpc, mpi, sthr, decimals):
+    """Scores quantised to a few distinct values: the per-class order and the image's top-k are decided by the tie rule
+    (row / position order), and the max_per_image-th best score is shared by many entries.  20 classes x <= 51 per class
+    with max_per_image <= 64 goes through the one-wave merge, the others through the workgroup merge; the packed sort
+    of the rows that pass the filters covers 64 .. 1024 keys over the cases."""
+    from tf_eager_object_detection_amd.model.prediction import post_ops_prediction
+    rng = np.random.default_rng(R + mpc + mpi)
+    shape = (800, 1333)
+    S = np.round(syn.class_scores(R, 21, rng), decimals).astype(np.float32)
+    D = (syn.class_deltas(R, 21, rng) * np.float32(0.3)).astype(np.float32)
+    rois = syn.random_boxes(R, shape, rng, 16, 300)
+    got = post_ops_prediction(g(S), g(D), g(rois), list(shape), M0, S2, mpc, mpi, 0.3, sthr, 16, num_classes=21)
+    _check_post(got, co.post_ops(S, D, rois, shape, M0, S2, mpc, mpi, 0.3, sthr, 16, 21))
+
+
 def test_predict_after_roi_matches_oracle():
     from tf_eager_object_detection_amd.model.prediction import predict_after_roi
     rng = np.random.default_rng(9)
