@@ -21,7 +21,9 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/stats_s1b1 --output
 # 4. HBM-side traffic of the 8-image RoI launch (separate --pmc passes; FETCH_SIZE x 2 on gfx950)
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py --no-cpu-baseline --no-e2e --streams 1 --batch 8 --rounds-per-step 4 --steps 4 --warmup 1 > $out/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 bench.py --no-cpu-baseline --no-e2e --streams 1 --batch 8 --rounds-per-step 4 --steps 4 --warmup 1 > $out/pmc_write.log 2>&1
-python3 tools/pmc_traffic.py --fetch $out/pmc_fetch/*/*_counter_collection.csv --write $out/pmc_write/*/*_counter_collection.csv --kernel k_roi_pool --workload fpn_hot_path_800x1333_r101fpn_distinct --images-per-launch 8 --out $out/roi_pool_traffic.json > /dev/null
+# (the run has two workloads: rows are told apart by the kernel's template arguments)
+python3 tools/pmc_traffic.py --fetch $out/pmc_fetch/*/*_counter_collection.csv --write $out/pmc_write/*/*_counter_collection.csv --kernel "k_roi_pool<1, 1, float" --workload fpn_hot_path_800x1333_r101fpn_distinct --images-per-launch 8 --out $out/roi_pool_traffic.json > /dev/null
+python3 tools/pmc_traffic.py --fetch $out/pmc_fetch/*/*_counter_collection.csv --write $out/pmc_write/*/*_counter_collection.csv --kernel "k_roi_pool<1, 1, __half" --workload fpn_hot_path_1333x1333_r101fpn_81cls_f16maps --images-per-launch 8 --out $out/roi_pool_traffic_config5.json > /dev/null
 # the per-dispatch traces are tens of MB: only the summaries travel back
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*_agent_info.csv" -delete
 find $out -name "*_kernel_stats.csv" | head
