@@ -45,6 +45,19 @@ typedef float st_f4 __attribute__((ext_vector_type(4)));
 #define ST_CONV_BYTES (ST_CONV_TILES * 16 * 128)      // 38 912
 #define ST_LDS_BYTES (ST_PATCH_BYTES + ST_CONV_BYTES)
 
+typedef unsigned int st_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int st_u2 __attribute__((ext_vector_type(2)));
+// m = max(m, [a | b]) per float16 element
+__device__ __forceinline__ void st_pk_max(st_h8& m, const st_h4& a, const st_h4& b) {
+  st_u4 mm = __builtin_bit_cast(st_u4, m);
+  const st_u2 ua = __builtin_bit_cast(st_u2, a), ub = __builtin_bit_cast(st_u2, b);
+  asm("v_pk_max_f16 %0, %0, %1" : "+v"(mm[0]) : "v"(ua[0]));
+  asm("v_pk_max_f16 %0, %0, %1" : "+v"(mm[1]) : "v"(ua[1]));
+  asm("v_pk_max_f16 %0, %0, %1" : "+v"(mm[2]) : "v"(ub[0]));
+  asm("v_pk_max_f16 %0, %0, %1" : "+v"(mm[3]) : "v"(ub[1]));
+  m = __builtin_bit_cast(st_h8, mm);
+}
+
 struct StemParams {
   const void* img; int img_f16;       // [B][H][W][3] float32 (0) or float16 (1)
   const _Float16* w;                  // packed in fragment order [4 channel tiles][7 kernel rows][64 lanes][8]: lane (q, channel)
@@ -89,21 +102,36 @@ __global__ void __launch_bounds__(ST_THREADS) k_stem_conv7_pool3(StemParams p) {
     constexpr int TRIPS = (ST_IH * ST_IW + ST_THREADS - 1) / ST_THREADS;        // 7
     const long long img_base = (long long)b * p.H * p.W * 3;
     float v[TRIPS][3];
+    long long off[TRIPS];
+    bool ok[TRIPS];
 #pragma unroll
     for (int k = 0; k < TRIPS; ++k) {
       const int i = tid + ST_THREADS * k;
       const int r = i / ST_IW, c = i - r * ST_IW;
       const int y = iy0 + r, x = ix0 + c;
-      const bool ok = i < ST_IH * ST_IW && y >= 0 && y < p.H && x >= 0 && x < p.W;
-      const long long o = ok ? img_base + ((long long)y * p.W + x) * 3 : 0;     // (a valid address either way)
-      if (p.img_f16) {
-        const _Float16* s = reinterpret_cast<const _Float16*>(p.img) + o;
-        v[k][0] = ok ? (float)s[0] : 0.0f; v[k][1] = ok ? (float)s[1] : 0.0f; v[k][2] = ok ? (float)s[2] : 0.0f;
-      } else {
-        const float* s = reinterpret_cast<const float*>(p.img) + o;
-        v[k][0] = ok ? s[0] : 0.0f; v[k][1] = ok ? s[1] : 0.0f; v[k][2] = ok ? s[2] : 0.0f;
+      ok[k] = i < ST_IH * ST_IW && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      off[k] = ok[k] ? img_base + ((long long)y * p.W + x) * 3 : 0;     // (a valid address either way)
+    }
+    // (the loads are UNCONDITIONAL -- the address is valid either way -- and the padding is selected afterwards: behind
+    // `ok ? s[0] : 0` every trip was a branch of its own around three loads)
+    if (p.img_f16) {
+#pragma unroll
+      for (int k = 0; k < TRIPS; ++k) {
+        const _Float16* s = reinterpret_cast<const _Float16*>(p.img) + off[k];
+        const _Float16 a0 = s[0], a1 = s[1], a2 = s[2];
+        v[k][0] = (float)a0; v[k][1] = (float)a1; v[k][2] = (float)a2;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < TRIPS; ++k) {
+        const float* s = reinterpret_cast<const float*>(p.img) + off[k];
+        const float a0 = s[0], a1 = s[1], a2 = s[2];
+        v[k][0] = a0; v[k][1] = a1; v[k][2] = a2;
       }
     }
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k)
+      if (!ok[k]) { v[k][0] = 0.0f; v[k][1] = 0.0f; v[k][2] = 0.0f; }
 #pragma unroll
     for (int k = 0; k < TRIPS; ++k) {
       const int i = tid + ST_THREADS * k;
@@ -173,13 +201,10 @@ __global__ void __launch_bounds__(ST_THREADS) k_stem_conv7_pool3(StemParams p) {
           const st_h4 q1 = *reinterpret_cast<const st_h4*>(s + (((c0 + 1) ^ sw) * 8));
           const st_h4 q2 = *reinterpret_cast<const st_h4*>(s + (((c0 + 2) ^ sw) * 8));
           const st_h4 q3 = *reinterpret_cast<const st_h4*>(s + (((c0 + 3) ^ sw) * 8));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            m0[e] = q0[e] > m0[e] ? q0[e] : m0[e];
-            m0[4 + e] = q1[e] > m0[4 + e] ? q1[e] : m0[4 + e];
-            m1[e] = q2[e] > m1[e] ? q2[e] : m1[e];
-            m1[4 + e] = q3[e] > m1[4 + e] ? q3[e] : m1[4 + e];
-          }
+          // (packed maxima: the values are ReLU outputs or the zero padding, so v_pk_max_f16 == the comparison; written as
+          // the instruction itself: the generic maximum canonicalises both operands first, twice the instructions)
+          st_pk_max(m0, q0, q1);
+          st_pk_max(m1, q2, q3);
         }
       _Float16* dst = p.out + (((long long)b * p.PH + py) * p.PW + px) * 64 + cg;
       *reinterpret_cast<st_h8*>(dst) = m0;
