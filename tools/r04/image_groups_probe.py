@@ -49,9 +49,12 @@ with torch.no_grad():
         def to_conv3():
             return [det.conv3(det.conv2(fpn._stem(det.conv1, images[a:b], det.dtype))) for a, b in groups]
 
+        def conv4_only():
+            return [det.conv4(c3_all[a:b]) for a, b in groups]
+
         same = all(torch.equal(y, c2_all[a:b]) for y, (a, b) in zip(conv2_only(), groups))
         row = {'stem+conv2': round(timed(stem_conv2), 3), 'conv2': round(timed(conv2_only), 3),
-               'conv3': round(timed(conv3_only), 3), 'stem+conv2+conv3': round(timed(to_conv3), 3), 'identical': same}
+               'conv3': round(timed(conv3_only), 3), 'stem+conv2+conv3': round(timed(to_conv3), 3), 'conv4': round(timed(conv4_only), 3), 'identical': same}
         res['groups of %d' % g] = row
         print(g, json.dumps(row), flush=True)
 os.makedirs('gpurun_out', exist_ok=True)
