@@ -14,6 +14,8 @@ BATCHES = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1]
 OUT = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
 TILES = [(8, 4, 2, 2), (8, 4, 3, 2), (8, 4, 4, 2), (8, 4, 6, 2), (8, 4, 8, 2), (8, 2, 1, 2), (8, 2, 2, 2), (8, 2, 3, 2), (8, 2, 4, 2),
          (8, 1, 1, 2), (8, 1, 2, 2), (4, 1, 1, 8), (4, 1, 1, 4)]
+if '--ring8' in sys.argv:      # the experimental 8-wave ring forms of the pointwise kernel (a build that has them)
+    TILES += [(8, 2, 4, 3), (8, 4, 4, 3), (8, 1, 2, 4), (8, 2, 2, 4)]
 ONLY = sys.argv[sys.argv.index('--only') + 1].split(',') if '--only' in sys.argv else None      # 3x3, 1x1, tail
 
 
