@@ -173,14 +173,15 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16(Conv1x1Params p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const h8 bv = *reinterpret_cast<const h8*>(bp + 8 * q);
-      h8 ov;
+      float fv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int idx = (q & 1) * 8 + e;
         float v = (q < 2 ? acc0[idx] : acc1[idx]) + (float)bv[e];
         if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-        ov[e] = (_Float16)v;
+        fv[e] = v;
       }
+      const h8 ov = d_cvt8_f16<h8>(fv);
       if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
     }
     if (more) {
@@ -296,13 +297,14 @@ __global__ void __launch_bounds__(256, 2) k_conv1x1_f16_k512(Conv1x1Params p) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const h8 bv = *reinterpret_cast<const h8*>(bp + 8 * q);
-      h8 ov;
+      float fv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v = acc[8 * q + e] + (float)bv[e];
         if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-        ov[e] = (_Float16)v;
+        fv[e] = v;
       }
+      const h8 ov = d_cvt8_f16<h8>(fv);
       if (store) *reinterpret_cast<h8*>(p.y + off + 8 * q) = ov;
     }
     if (more) {

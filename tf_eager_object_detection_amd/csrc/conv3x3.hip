@@ -412,14 +412,15 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       h8 t0, t1;
+      float tf[16];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = acc[mt][t][j] + b1[t * 4 + j];
-          v = v < 0.0f ? 0.0f : v;
-          if (t < 2) t0[t * 4 + j] = (_Float16)v; else t1[(t - 2) * 4 + j] = (_Float16)v;
+          tf[t * 4 + j] = v < 0.0f ? 0.0f : v;
         }
+      t0 = d_cvt8_f16<h8>(tf); t1 = d_cvt8_f16<h8>(tf + 8);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         f4 o = (f4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -498,14 +499,15 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       h8 t0, t1;
+      float tf[16];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = acc[mt][t][j] + b2v[t * 4 + j];
-          v = v < 0.0f ? 0.0f : v;
-          if (t < 2) t0[t * 4 + j] = (_Float16)v; else t1[(t - 2) * 4 + j] = (_Float16)v;
+          tf[t * 4 + j] = v < 0.0f ? 0.0f : v;
         }
+      t0 = d_cvt8_f16<h8>(tf); t1 = d_cvt8_f16<h8>(tf + 8);
       const int prow = wm * 16 * MT + mt * 16 + l15;
       const int slot0 = wn * 8 + lq * 2;
       *reinterpret_cast<h8*>(lds + taddr(prow, slot0)) = t0;
@@ -580,6 +582,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
         __builtin_amdgcn_sched_barrier(0);               // (the shortcut's conversions stay behind the MFMAs: so does their wait)
         const h8 s0 = __builtin_bit_cast(h8, cur[0]), s1 = __builtin_bit_cast(h8, cur[1]);
         h8 q0, q1;
+        float qf[16];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -587,8 +590,9 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
             const int e = tt * 4 + j;
             float v = (o[tt][j] + b3v[e]) + (float)(e < 8 ? s0[e & 7] : s1[e & 7]);
             if (p.relu3) v = v < 0.0f ? 0.0f : v;
-            if (e < 8) q0[e] = (_Float16)v; else q1[e - 8] = (_Float16)v;
+            qf[e] = v;
           }
+        q0 = d_cvt8_f16<h8>(qf); q1 = d_cvt8_f16<h8>(qf + 8);
         const uint32_t off = m < M ? off0 + (uint32_t)pt * 16u * rowB : OOB;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q0), ry3, (int)off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, q1), ry3, (int)off, 64, 0);
@@ -626,6 +630,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
         const int pair = rem / (2 * Wp), r2 = rem - pair * 2 * Wp;
         const bool real = m < M && (2 * pair + (r2 & 1)) < H && (r2 >> 1) < W;
         h8 o[2];
+        float of[16];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -638,8 +643,9 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
             vi = __builtin_bit_cast(int, v);
             u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x4E, 0xF, 0xF, false));         // quad_perm [2,3,0,1]
             v = u > v ? u : v;
-            o[(t * 4 + j) >> 3][(t * 4 + j) & 7] = (_Float16)v;
+            of[t * 4 + j] = v;
           }
+        o[0] = d_cvt8_f16<h8>(of); o[1] = d_cvt8_f16<h8>(of + 8);
         if ((l15 & 3) == 0 && m < M) {
           _Float16* dst = p.y[lv] + (m >> 2) * cout + c0;
           *reinterpret_cast<h8*>(dst) = o[0];
@@ -650,6 +656,7 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
     }
     if (m < M) {
       h8 o[2];
+      unsigned ou[8];
       if constexpr (TAPS == 1) {
         if (p.y32) {                                       // float32 out: the accumulators as they are, + float32 bias
           float* dst = p.y32 + m * cout + c0;
@@ -687,18 +694,25 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
             br[hh] = *reinterpret_cast<const h8*>(tb + ((long long)y1 * p.tw + x1) * cout + HOFF * hh);
           }
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+          for (int e2 = 0; e2 < 8; ++e2) {
+            float w2[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int e = t * 4 + j;
+            for (int k = 0; k < 2; ++k) {
+              const int e = 2 * e2 + k, t = e >> 2, j = e & 3;
               const float lat = acc[mt][t][j] + bv[e];
               const float a = (float)tl[e >> 3][e & 7], b = (float)tr[e >> 3][e & 7];
               const float c = (float)bl[e >> 3][e & 7], d = (float)br[e >> 3][e & 7];
               const float tp = a + (b - a) * xl;
               const float bt = c + (d - c) * xl;
               const float up = tp + (bt - tp) * yl;
-              o[e >> 3][e & 7] = (_Float16)(up * 0.5f + lat * 0.5f);
+              w2[k] = up * 0.5f + lat * 0.5f;
             }
+            // (the compiler's own conversions here: with the packed instruction as inline asm this path holds 28 more registers)
+            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+            const h2v q2 = {(_Float16)w2[0], (_Float16)w2[1]};
+            ou[e2] = __builtin_bit_cast(unsigned, q2);
+          }
+          o[0] = d_pack8_f16<h8>(ou); o[1] = d_pack8_f16<h8>(ou + 4);
           _Float16* dst = p.y[lv] + m * cout + c0;
           *reinterpret_cast<h8*>(dst) = o[0];
           *reinterpret_cast<h8*>(dst + HOFF) = o[1];
@@ -712,14 +726,19 @@ __device__ __forceinline__ void conv_tile_f16(const Conv3x3Params& p) {
         rs[1] = *reinterpret_cast<const h8*>(p.res + m * cout + c0 + HOFF);
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int e2 = 0; e2 < 8; ++e2) {
+        float w2[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[mt][t][j] + bv[t * 4 + j];
-          if (has_res) v += (float)rs[(t * 4 + j) >> 3][(t * 4 + j) & 7];
+        for (int k = 0; k < 2; ++k) {
+          const int e = 2 * e2 + k;
+          float v = acc[mt][e >> 2][e & 3] + bv[e];
+          if (has_res) v += (float)rs[e >> 3][e & 7];
           if (p.relu) v = v < 0.0f ? 0.0f : v;
-          o[(t * 4 + j) >> 3][(t * 4 + j) & 7] = (_Float16)v;
+          w2[k] = v;
         }
+        ou[e2] = d_cvt_pk_f16(w2[0], w2[1]);
+      }
+      o[0] = d_pack8_f16<h8>(ou); o[1] = d_pack8_f16<h8>(ou + 4);
       _Float16* dst = p.y[lv] + m * cout + c0;
       *reinterpret_cast<h8*>(dst) = o[0];
       *reinterpret_cast<h8*>(dst + HOFF) = o[1];

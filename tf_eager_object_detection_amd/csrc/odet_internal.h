@@ -213,6 +213,30 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int P
   }
 }
 
+// Two float32 -> one dword of two float16 (round to nearest even) in ONE instruction: gfx950's v_cvt_pk_f16_f32.  hipcc emits
+// two v_cvt_f16_f32 and a v_pack_b32_f16 for the same thing; bit-identical over all 2^32 inputs (tools/exp/cvt_pk_probe.hip).
+__device__ __forceinline__ unsigned d_cvt_pk_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// eight float32 -> eight float16 (any 16-byte vector type)
+template <typename H8>
+__device__ __forceinline__ H8 d_cvt8_f16(const float* f) {
+  typedef unsigned cvt_u4 __attribute__((ext_vector_type(4)));
+  cvt_u4 r;
+  r[0] = d_cvt_pk_f16(f[0], f[1]); r[1] = d_cvt_pk_f16(f[2], f[3]);
+  r[2] = d_cvt_pk_f16(f[4], f[5]); r[3] = d_cvt_pk_f16(f[6], f[7]);
+  return __builtin_bit_cast(H8, r);
+}
+// four such dwords as one 16-byte vector
+template <typename H8>
+__device__ __forceinline__ H8 d_pack8_f16(const unsigned* u) {
+  typedef unsigned cvt_u4 __attribute__((ext_vector_type(4)));
+  const cvt_u4 r = {u[0], u[1], u[2], u[3]};
+  return __builtin_bit_cast(H8, r);
+}
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
   uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask);
   uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask);

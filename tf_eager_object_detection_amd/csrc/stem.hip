@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(ST_THREADS) k_stem_conv7_pool3(StemParams p) {
     for (int k = 0; k < TRIPS; ++k) {
       const int i = tid + ST_THREADS * k;
       if (i < ST_IH * ST_IW) {
-        const st_h4 h = {(_Float16)v[k][0], (_Float16)v[k][1], (_Float16)v[k][2], (_Float16)0.0f};
+        const st_u2 hu = {d_cvt_pk_f16(v[k][0], v[k][1]), d_cvt_pk_f16(v[k][2], 0.0f)};
+        const st_h4 h = __builtin_bit_cast(st_h4, hu);
         *reinterpret_cast<st_h4*>(patch + i * 8) = h;
       }
     }
@@ -166,13 +167,14 @@ __global__ void __launch_bounds__(ST_THREADS) k_stem_conv7_pool3(StemParams p) {
       const bool inside = cy >= 0 && cy < p.CH && cx >= 0 && cx < p.CW;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        st_h4 o;
+        float vf[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = acc[ct][j] + bv[ct][j];
-          v = (v < 0.0f || !inside) ? 0.0f : v;
-          o[j] = (_Float16)v;
+          const float v = acc[ct][j] + bv[ct][j];
+          vf[j] = (v < 0.0f || !inside) ? 0.0f : v;
         }
+        const st_u2 ou = {d_cvt_pk_f16(vf[0], vf[1]), d_cvt_pk_f16(vf[2], vf[3])};
+        const st_h4 o = __builtin_bit_cast(st_h4, ou);
         // (8-byte chunk ct * 4 + lq of the pixel's 128 bytes, XOR-swizzled by the pixel: the 16 pixels of a tile would
         // otherwise all write the same LDS bank -- 16-way conflicts that made this the longest phase of the kernel)
         *reinterpret_cast<st_h4*>(conv + op * 128 + (((ct * 4 + lq) ^ (op & 15)) * 8)) = o;
@@ -333,7 +335,8 @@ __global__ void __launch_bounds__(RG_THREADS) k_conv3x3_rgb_f16(RgbConvParams p)
     for (int k = 0; k < TRIPS; ++k) {
       const int i = tid + RG_THREADS * k;
       if (i < RG_PR * RG_PC) {
-        const st_h4 h = {(_Float16)v[k][0], (_Float16)v[k][1], (_Float16)v[k][2], (_Float16)0.0f};
+        const st_u2 hu = {d_cvt_pk_f16(v[k][0], v[k][1]), d_cvt_pk_f16(v[k][2], 0.0f)};
+        const st_h4 h = __builtin_bit_cast(st_h4, hu);
         *reinterpret_cast<st_h4*>(patch + i * 8) = h;
       }
     }
@@ -361,14 +364,15 @@ __global__ void __launch_bounds__(RG_THREADS) k_conv3x3_rgb_f16(RgbConvParams p)
     }
     const int y = y0 + ry, x = x0 + cx;
     if (y < p.H && x < p.W) {
-      st_h8 o0, o1;
+      float f0[8], f1[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float v0 = acc[e >> 2][e & 3] + (float)b0[e];
         float v1 = acc[2 + (e >> 2)][e & 3] + (float)b1[e];
         if (p.relu) { v0 = v0 < 0.0f ? 0.0f : v0; v1 = v1 < 0.0f ? 0.0f : v1; }
-        o0[e] = (_Float16)v0; o1[e] = (_Float16)v1;
+        f0[e] = v0; f1[e] = v1;
       }
+      const st_h8 o0 = d_cvt8_f16<st_h8>(f0), o1 = d_cvt8_f16<st_h8>(f1);
       _Float16* dst = p.out + (((long long)b * p.H + y) * p.W + x) * 64 + 8 * lq;
       *reinterpret_cast<st_h8*>(dst) = o0;
       *reinterpret_cast<st_h8*>(dst + 32) = o1;
