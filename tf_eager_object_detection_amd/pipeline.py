@@ -455,13 +455,12 @@ class FpnStreamPool:
         if not 1 <= self.batch <= 8:
             raise ValueError('batch must be in 1..8 (ODET_MAX_STEP_BATCH)')
         self.n = self.n_streams * self.batch            # slots; slot k belongs to group k // batch
+        sw = kw.pop('single_worker', None)              # (None: the measured rule below; True / False: for experiments)
         self.slots = [self._slot_class(image_shape, num_classes, num_proposals, channels, **kw) for _ in range(self.n)]
         # Batched groups need ~1.4 launches per image, far below one thread's launch rate, and ONE enqueue thread
         # issuing the groups in turn measured 3-4 % faster than one thread per stream (less contention inside the
         # HIP runtime); single-image launches (batch < 4) keep a thread per stream for the launch rate.
-        import os
-        sw = os.environ.get('ODET_POOL_SINGLE_WORKER')
-        self._single_worker = (sw == '1') if sw is not None else self.batch >= 4
+        self._single_worker = bool(sw) if sw is not None else self.batch >= 4
         self._group_streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
         self.streams = [self._group_streams[k // self.batch] for k in range(self.n)]
         self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
