@@ -188,10 +188,14 @@ def load_traffic(workload_key, images_per_launch):
         d = json.load(open(p))
         for rec in [d] + list(d.get('also', [])):             # (one record per workload: float32 maps, float16 maps)
             if rec.get('workload') == workload_key:
-                return rec.get('hbm_bytes_per_launch') / float(rec.get('images_per_launch', 1)) * images_per_launch
+                # provenance: the counters need their own rocprofv3 --pmc passes, so this figure is NOT from the run that
+                # prints it -- a reader sees the file, the round / box it was collected on and how
+                src = {'measured_in_this_run': False, 'file': 'profiles/roi_pool_traffic.json',
+                       'collected': d.get('collected', d.get('note')), 'corrections': rec.get('corrections')}
+                return rec.get('hbm_bytes_per_launch') / float(rec.get('images_per_launch', 1)) * images_per_launch, src
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def e2e_record(dtype_name, batch, budget_s=6.0, family='fpn', graph=False, eager=True):
@@ -270,6 +274,24 @@ E2E_CONV_PATH = ('hand-written HIP kernels only, at every batch size (float16: 3
                  'no library convolution / GEMM route (model/fpn_detector.py)')
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher's environment: start `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process (never an
+    exec, and before this process made any GPU call), pass its stdout (rank 0's one JSON line) and stderr through, and
+    return its exit code.  The torchrun form of the driver keeps working: it sets WORLD_SIZE and never reaches this."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     # (before anything initialises HSA: dmabuf IPC is the only kind the host driver supports)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -301,23 +323,29 @@ def main():
     ap.add_argument('--roofline-samples', type=int, default=12, help='isolated RoI launches timed after the timed region')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; "
                     "'gloo' only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument('--trace', action='store_true', help='phase time stamps on stderr (synchronises at every mark)')
+    ap.add_argument('--force-collective', action='store_true',
+                    help='with ONE rank under torch.distributed.run: still issue the all-gather of every stream group (the RCCL '
+                         'call path rehearsed on a 1-GPU box)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (importing torch and counting devices do
+        # not initialise it), so it starts the N ranks as fresh children and relays rank 0's line and the exit code
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' %
-                             (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but the launcher started %d rank(s) (WORLD_SIZE)' % (args.gpus, world))
     ndev = torch.cuda.device_count()
     if args.backend == 'nccl' and local_rank >= ndev:
         raise SystemExit('rank %d: local rank %d but only %d GPU(s) visible' % (rank, local_rank, ndev))
     local_dev = local_rank % max(ndev, 1)                     # (rehearsal with gloo: ranks may share a GPU)
     torch.cuda.set_device(local_dev)
     dist = None
-    # (ODET_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1: the RCCL exchange path with one rank, a rehearsal)
-    use_dist = world > 1 or (os.environ.get('ODET_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
+    # (--force-collective under torchrun --nproc-per-node 1: the RCCL exchange path with one rank, a rehearsal)
+    use_dist = world > 1 or (args.force_collective and 'RANK' in os.environ)
     if use_dist:
         import torch.distributed as dist
         if args.backend == 'nccl':
@@ -336,7 +364,7 @@ def main():
     R = max(1, args.rounds_per_step)
     images_per_step = R * S * B
 
-    trace_on = os.environ.get('ODET_BENCH_TRACE') == '1'
+    trace_on = args.trace
 
     def mark(what):
         if trace_on:
@@ -424,7 +452,7 @@ def main():
             torch.cuda.synchronize()
 
         def complete(self):
-            ok = 1 if all(int(h.nms_done.item()) == 1 for h in self.pool.slots) else 0
+            ok = 1 if all(f == 1 for f in self.pool.nms_done_all.tolist()) else 0       # (one device -> host copy)
             if use_dist:                                          # (every rank re-plans or none does)
                 t = torch.tensor([ok], dtype=torch.int32, device='cuda')
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -455,9 +483,14 @@ def main():
             else:
                 raise SystemExit('NMS did not complete inside the sync-free chunks of any plan -- result would be invalid')
             self.allgathers = 0
+            self.pool.nms_reruns = 0
             t0 = time.perf_counter()
             self.run_steps(steps)
             self.fence()
+            # (inside the timed region) images whose sync-free NMS did not complete go through the exact mode again -- the
+            # reference's NMS is always exact (model/region_proposal.py:73-81); counted in config.nms_reruns.  The plan was
+            # chosen in the warm-up on the same inputs, so this finds none unless the distribution changed under it.
+            self.nms_reruns = len(self.pool.recover_incomplete())
             elapsed = time.perf_counter() - t0
             mark('timed region done')
             per_rank = [elapsed]
@@ -468,7 +501,7 @@ def main():
                 per_rank = [float(v) for v in allt.tolist()]
                 elapsed = max(per_rank)
             if not self.complete():
-                raise SystemExit('NMS did not complete inside the sync-free chunks -- result would be invalid')
+                raise SystemExit('NMS incomplete after the exact-mode recovery -- result would be invalid')
             self.per_rank_s = per_rank
             return elapsed, replans
 
@@ -548,13 +581,13 @@ def main():
                                                   elem=elem))
         algo = {q: sum(a_[q] for a_ in per_slot) for q in per_slot[0]}
         achieved = algo['B_roi'] / (roi_ms * 1e-3) / 1e9
-        traffic = load_traffic(workload_key, B)
+        traffic, traffic_source = load_traffic(workload_key, B)
         ft = 'float' if cfg['maps'] == 'f32' else '__half'
         rf = {'bound': 'hbm', 'kernel': '%s, the %d-image launch of one stream group, alone on the GPU, cold maps' % (kernel_label, B),
               'rocprof_kernel_name': 'void k_roi_pool<1, 1, %s, 1>(RoiParams)' % ft,
               'images_per_launch': B,
               'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-              'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+              'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
               'kernel_ms': roi_ms, 'kernel_ms_samples': len(times), 'kernel_ms_min': float(np.min(times)),
               'kernel_ms_max': float(np.max(times)), 'algorithmic_bytes': algo['B_roi'],
               'B_min': algo['B_min'], 'B_taps': algo['B_taps'], 'bytes_output': algo['out']}
@@ -578,7 +611,7 @@ def main():
     cfg3 = dict(image_shape=IMAGE_SHAPE, num_classes=NUM_CLASSES, max_per_class=50, max_per_image=50, maps=args.maps)
     wl = Workload(cfg3, args.scores, args.nms_first_chunk, args.blind_chunks)
     elapsed, replans = wl.measure(args.steps, args.warmup)
-    per_rank_s, allgathers = wl.per_rank_s, wl.allgathers
+    per_rank_s, allgathers, nms_reruns = wl.per_rank_s, wl.allgathers, wl.nms_reruns
     host = wl.host
     rf, k_kept, plan0, rec_len0 = None, int(wl.pool.slots[0].roi_count.item()), (wl.nms_first_chunk, wl.blind_chunks), wl.rec_len
     if rank == 0:
@@ -595,7 +628,7 @@ def main():
         el2, rp2 = wl2.measure(args.steps, args.warmup)
         other = {'value': args.steps * images_per_step * world / el2, 'unit': 'img/s', 'ms_per_step': el2 / args.steps * 1e3,
                  'rpn_scores': other_kind, 'timed_region_s': el2, 'nms_first_chunk': wl2.nms_first_chunk,
-                 'blind_chunks': wl2.blind_chunks, 'replanned': rp2,
+                 'blind_chunks': wl2.blind_chunks, 'replanned': rp2, 'nms_reruns': wl2.nms_reruns,
                  'proposals_kept': int(wl2.pool.slots[0].roi_count.item())}
         wl2.close()
         del wl2
@@ -618,7 +651,7 @@ def main():
                        'images_per_step_per_gpu': images_per_step, 'global_batch': images_per_step * world,
                        'timed_images': args.steps * images_per_step * world, 'timed_region_s': elapsed,
                        'rpn_scores': args.scores, 'feature_maps': args.maps, 'nms_first_chunk': plan0[0],
-                       'blind_chunks': plan0[1], 'replanned': replans,
+                       'blind_chunks': plan0[1], 'replanned': replans, 'nms_reruns': nms_reruns,
                        'streams_per_gpu': S, 'images_per_launch': B, 'images_in_flight_per_gpu': S * B,
                        'proposals_kept': k, 'parallelism': 'image-parallel x%d' % world},
             'roofline': rf,
@@ -649,6 +682,7 @@ def main():
                    'roi_frac_B_roi': round(result['roofline']['frac'], 3),
                    'roi_frac_counter_bytes': (round(result['roofline']['hbm_frac_measured'], 3)
                                               if result['roofline']['hbm_frac_measured'] else None),
+                   'roi_frac_physical': 'roi_frac_counter_bytes (PMC HBM bytes); B_roi is reuse-blind',
                    'roi_kernel_us': round(result['roofline']['kernel_ms'] * 1e3, 1),
                    'roi_vs_calibration': round(result['roofline']['calibration']['roi_kernel_vs_calibration'], 3)}
         if not args.no_config5 and world == 1:
@@ -734,9 +768,8 @@ def main():
                                             g['map_delta_ci95_paired_bootstrap'][0], g['map_delta_ci95_paired_bootstrap'][1], g['images'],
                                             'inside' if g['within_bar'] else 'OUTSIDE', 'resolves it' if g['resolves_bar'] else 'wider than it'))
             e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
-                           'mode (the reference computes in float32; ~77 % of the chip\'s 157 TFLOP/s float32 matrix peak, so '
-                           '>= 200 img/s is out of reach of exact float32 arithmetic: 684 GFLOP per image), fp16 = throughput '
-                           'mode, narrower than the reference, gated by map_delta_vs_fp32')
+                           'mode (the reference computes in float32; exact-float32 matrix instructions, 157 TFLOP/s peak, 684 GFLOP '
+                           'per image), fp16 = throughput mode, narrower than the reference, gated by map_delta_vs_fp32')
             result['e2e'] = e2e
         mr = result['multi_rank']
         summary['ranks'] = [mr['rccl_world'], round(mr['per_rank_img_s_min'], 1), round(mr['per_rank_img_s_max'], 1), mr['allgathers_in_timed_region']]

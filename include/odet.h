@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ODET_VERSION 100
+#define ODET_VERSION 101
 
 #define ODET_OK 0
 #define ODET_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -575,9 +575,9 @@ typedef struct {
   /* profiling (nullable): HIP events (odet_prof_event_create) attached to the RoI dispatch of this step -- in a
    * batch those of the first step bracket the one launch all its images share */
   void* roi_start_event; void* roi_stop_event;
-  /* != 0: the caller promises that ws_rpn AND ws_post were zero-filled once after their allocation and have only ever
-   * been handed to this library since: every call leaves the proposal stage's header and the post-ops' ticket counter
-   * clean again, so no launch / memset is spent on zeroing them */
+  /* != 0: the caller promises that ws_rpn was zero-filled once after its allocation and has only ever been handed to
+   * this library since: every call leaves the proposal stage's header clean again, so no launch / memset is spent on
+   * zeroing it.  (ws_post has its own promise, ws_post_clean, since version 101.) */
   int32_t ws_rpn_clean;
   /* != 0: a single-level Faster R-CNN step (model/faster_rcnn/base_faster_rcnn_model.py:126-198 minus the dense
    * parts) instead of an FPN step: num_levels = num_maps = 1; fh[0] x fw[0] cells of stride[0] with A anchors each,
@@ -586,7 +586,11 @@ typedef struct {
    * RoI crops normalised by maps[0].stride (ODET_ROI_NORM_STRIDE) with roi_pool_mode; min_edge = the stride. */
   int32_t single_level;
   int32_t roi_pool_mode;     /* single_level: ODET_ROI_POOL_MAX2 (VGG16) | ODET_ROI_POOL_NONE (ResNet C4); FPN: MAX2 */
-  int32_t reserved_flags;
+  /* != 0: the same promise for ws_post (zero-filled once, only ever handed to this library): the post-processing
+   * launch keeps a wrapping ticket counter at its end, which every COMPLETED call leaves at 0.  With 0 here the library
+   * issues the 4-byte memset on the stream before the launch (the default; costs nothing at graph replay).  After a
+   * failed call (an error from odet_exec_wait / a launch error) zero-fill ws_post again before promising this. */
+  int32_t ws_post_clean;
 } odet_fpn_step_t;
 
 size_t odet_fpn_step_sizeof(void);

@@ -1,0 +1,227 @@
+"""The CALLER objects of the hot path with the reference's surface (VERDICT r4 missing #4): BaseFPN / ResnetV1Fpn
+(model/fpn/base_fpn_model.py:14-390, resnet_fpn.py:410-543) and BaseFasterRcnn / ResNetFasterRcnn / Vgg16FasterRcnn
+(model/faster_rcnn/base_faster_rcnn_model.py:16-306): constructor arguments on CPU; on the GPU `call(image)` composes the
+reference-NAMED layers in the reference's order at BASELINE config-3 / config-2 size and is compared with the oracle end to
+end (dense parts replaced by synthetic tensors: they are not part of the path), and the models with the real dense kernels
+agree with the static-shape detectors on the same weights."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as co
+from tf_eager_object_detection_amd import synthetic as syn
+
+
+def test_constructor_surface_matches_reference_names_cpu():
+    """same keyword names and defaults as the reference's constructors (read from its source text: study, not import)"""
+    from tf_eager_object_detection_amd.model.base_fpn_model import BaseFPN, ResnetV1Fpn
+    from tf_eager_object_detection_amd.model.base_faster_rcnn_model import BaseFasterRcnn, _COMMON
+    p = inspect.signature(BaseFPN.__init__).parameters
+    want = dict(roi_feature_size=(7, 7, 256), num_classes=21, weight_decay=0.0001, level_name_list=('p2', 'p3', 'p4', 'p5', 'p6'),
+                min_level=2, max_level=5, anchor_stride_list=(4, 8, 16, 32, 64), base_anchor_size_list=(32, 64, 128, 256, 512),
+                ratios=(0.5, 1.0, 2.0), scales=(1.,), rpn_proposal_num_post_nms_test=300, rpn_proposal_nms_iou_threshold=0.7,
+                roi_proposal_stds=(0.1, 0.1, 0.2, 0.2), roi_pool_size=7, prediction_max_objects_per_image=50,
+                prediction_max_objects_per_class=50, prediction_nms_iou_threshold=0.3, prediction_score_threshold=0.)
+    for k, v in want.items():
+        assert p[k].default == v, k
+    q = inspect.signature(ResnetV1Fpn.__init__).parameters
+    assert q['depth'].default == 50 and q['rpn_proposal_num_post_nms_test'].default == 1000
+    assert q['prediction_score_threshold'].default == 0.3 and q['roi_training_total_num_samples'].default == 256
+    r = list(inspect.signature(BaseFasterRcnn.__init__).parameters)[1:]
+    assert r == list(_COMMON.keys())                           # positional order of base_faster_rcnn_model.py:17-56
+    assert _COMMON['scales'] == (8, 16, 32) and _COMMON['rpn_proposal_num_post_nms_test'] == 300
+    for cls in (BaseFPN, BaseFasterRcnn):
+        assert cls.call is cls.forward and hasattr(cls, 'im_detect')
+
+
+def _check_detections(got, want, tol=1e-4):
+    boxes, labels, scores = got
+    wb, wl, ws = want
+    if len(ws) == 0:
+        assert boxes is None and labels is None and scores is None
+        return
+    b, l, s = boxes.cpu().numpy(), labels.cpu().numpy(), scores.cpu().numpy()
+    assert len(s) == len(ws)
+    order, worder = np.lexsort((l, -s)), np.lexsort((wl, -ws))
+    np.testing.assert_array_equal(l[order], wl[worder])
+    np.testing.assert_array_equal(s[order], ws[worder])
+    assert np.max(np.abs(b[order] - wb[worder])) <= tol * max(1.0, float(np.abs(wb).max()))
+
+
+@pytest.mark.gpu
+def test_base_fpn_call_composes_reference_layers_config3_size_vs_oracle():
+    """BaseFPN.call (base_fpn_model.py:202-276) at BASELINE configs[2]: 800 x 1333, 267 069 anchors, 1000 proposals, P2..P5 x
+    256 channels, through RegionProposal -> _assign_levels -> per-level RoiPoolingCropAndResize2 + concat ->
+    post_ops_prediction; dense parts (extractor / neck / heads) are synthetic tensors."""
+    from tf_eager_object_detection_amd.model.base_fpn_model import BaseFPN
+    from tf_eager_object_detection_amd.pipeline import synthetic_fpn_inputs
+    shape, K, ncls, ch = (800, 1333), 1000, 21, 256
+    host, dev = synthetic_fpn_inputs(shape, ncls, K, ch, seed=77)
+    shapes = syn.fpn_level_shapes(shape)
+    p_list = list(dev['feats']) + [dev['feats'][3][:, ::2, ::2].contiguous()]                 # P6 = P5[::2, ::2] (never pooled)
+    cells = [h * w * 3 for h, w in shapes]
+    offs = np.concatenate([[0], np.cumsum(cells)])
+    cls_logits = torch.log(dev['cls_scores'])                                                   # roi_score: softmax gives ~the scores back
+    seen = {}
+
+    class SyntheticDenseFpn(BaseFPN):
+        def _get_extractor(self):
+            return lambda image, training=None: image
+
+        def _get_neck(self):
+            return lambda c_list, training=None: p_list
+
+        def _get_rpn_head(self, weight_decay):
+            def head(p):
+                l = [id(q) for q in p_list].index(id(p))
+                return dev['rpn_logits'][offs[l]:offs[l + 1]], dev['rpn_deltas'][offs[l]:offs[l + 1]]
+            return head
+
+        def _get_roi_head(self):
+            def head(roi_features, training=None):
+                seen['features'] = roi_features
+                k = roi_features.shape[0]
+                return cls_logits[:k], dev['cls_deltas'][:k].reshape(k, -1)
+            return head
+
+    m = SyntheticDenseFpn(rpn_proposal_num_post_nms_test=K, num_classes=ncls)
+    image = torch.zeros((1,) + shape + (3,), device='cuda')
+    got = m.call(image, training=False)
+    torch.cuda.synchronize()
+    # the oracle, stage by stage in the same order
+    anchors = co.fpn_anchors(shape)
+    np.testing.assert_array_equal(m._get_anchors(list(shape)).cpu().numpy(), anchors)
+    fg = co.rpn_fg_fpn(host['rpn_logits'])
+    rois, idx = co.region_proposal(host['rpn_deltas'], anchors, fg, shape, K, 0.7)
+    lv, perm, cnt = co.assign_levels(rois)
+    srois, slv = rois[perm], lv[perm]
+    want_feats = np.concatenate([co.roi_pool(host['feats'][l], srois[slv == l + 2], image_shape=shape, pool=7, threads=8)
+                                 for l in range(4) if np.any(slv == l + 2)], axis=0)
+    k = rois.shape[0]
+    assert seen['features'].shape[0] == k == K
+    np.testing.assert_array_equal(seen['features'].cpu().numpy(), want_feats)                   # 0 ulp
+    soft = torch.softmax(cls_logits[:k].float(), dim=-1).cpu().numpy()                          # (the reference's tf.nn.softmax: a TF op, not the path)
+    want = co.post_ops(soft, host['cls_deltas'][:k], srois, shape, [0, 0, 0, 0], [.1, .1, .2, .2], 50, 50, 0.3, 0.0, 16, ncls)
+    _check_detections(got, want)
+    # im_detect (:364-390): the level-sorted RoIs with empty levels dropped, divided by the scale
+    s, d, r = m.im_detect(image, 1.6)
+    assert s.shape == (k, ncls) and d.shape == (k, 4 * ncls)
+    np.testing.assert_array_equal(r.cpu().numpy(), srois / np.float32(1.6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('pool_flag,ch', [(False, 1024), (True, 512)], ids=['resnet-c4-7x7', 'vgg16-14x14-max'])
+def test_base_faster_rcnn_call_composes_reference_layers_config2_size_vs_oracle(pool_flag, ch):
+    """BaseFasterRcnn.call (base_faster_rcnn_model.py:126-198) at BASELINE configs[1] size: 800 x 1333, stride 16, 9 anchors
+    per cell (37 800 anchors), 300 proposals; ResNet C4 (7x7 crop, 1024 ch) and the VGG16 form (14x14 + 2x2 max, 512 ch)."""
+    from tf_eager_object_detection_amd.model.base_faster_rcnn_model import BaseFasterRcnn, _COMMON
+    from tf_eager_object_detection_amd.pipeline import synthetic_frcnn_inputs
+    shape, K, ncls = (800, 1333), 300, 21
+    host, dev = synthetic_frcnn_inputs(shape, ncls, K, ch, seed=78)
+    cls_logits = torch.log(dev['cls_scores'])
+    seen = {}
+
+    class SyntheticDenseFrcnn(BaseFasterRcnn):
+        def _get_extractor(self):
+            return lambda image, training=None: dev['feat']
+
+        def _get_rpn_head(self, weight_decay):
+            return lambda x, training=None: (dev['rpn_logits'], dev['rpn_deltas'])
+
+        def _get_roi_head(self):
+            def head(roi_features, training=None):
+                seen['features'] = roi_features
+                k = roi_features.shape[0]
+                return cls_logits[:k], dev['cls_deltas'][:k].reshape(k, -1)
+            return head
+
+    kw = dict(_COMMON)
+    kw.update(roi_pooling_max_pooling_flag=pool_flag, prediction_score_threshold=0.0)
+    m = SyntheticDenseFrcnn(**kw)
+    image = torch.zeros((1,) + shape + (3,), device='cuda')
+    got = m.call(image, training=False)
+    torch.cuda.synchronize()
+    from tf_eager_object_detection_amd.utils.anchor_generator import generate_anchor_base
+    fh, fw = -(-shape[0] // 16), -(-shape[1] // 16)
+    anchors = co.anchors_shift(generate_anchor_base(16, (0.5, 1.0, 2.0), (8, 16, 32)).astype(np.float32), 16, fh, fw)
+    fg = co.rpn_fg_frcnn(host['rpn_logits'], 9)
+    rois, idx = co.region_proposal(host['rpn_deltas'], anchors, fg, shape, K, 0.7)
+    k = rois.shape[0]
+    want_feats = co.roi_pool(host['feat'], rois, stride=16, pool=7, max_pool=pool_flag, threads=8)
+    assert seen['features'].shape[0] == k
+    np.testing.assert_array_equal(seen['features'].cpu().numpy(), want_feats)
+    soft = torch.softmax(cls_logits[:k].float(), dim=-1).cpu().numpy()
+    want = co.post_ops(soft, host['cls_deltas'][:k], rois, shape, [0, 0, 0, 0], [.1, .1, .2, .2], 50, 50, 0.3, 0.0, 16, ncls)
+    _check_detections(got, want)
+    s, d, r = m.im_detect(image, 0.625)
+    np.testing.assert_array_equal(r.cpu().numpy(), rois / np.float32(0.625))
+
+
+def _image(shape, seed):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+
+
+@pytest.mark.gpu
+def test_resnet_v1_fpn_call_agrees_with_the_static_shape_detector_on_the_same_weights():
+    """ResnetV1Fpn(...)(image, training=False): the hand-written dense kernels behind the reference's layer names; its
+    detections = those of model/fpn_detector.ResNetFpnDetector (the sync-free arrangement) carrying the same weights."""
+    from tf_eager_object_detection_amd.model.base_fpn_model import ResnetV1Fpn
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(31)
+    shape, K = (256, 352), 300
+    m = ResnetV1Fpn(depth=50, rpn_proposal_num_post_nms_test=K, prediction_score_threshold=0.0)
+    det = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32)
+    det.load_state_dict(m.dense.state_dict())
+    det.prepare()
+    img = _image(shape, 3)
+    boxes, labels, scores = m(img, training=False)
+    db, dl, ds, dc = det(img)[0]
+    n = int(dc.item())
+    assert n == scores.shape[0] > 0
+    o1 = np.lexsort((labels.cpu().numpy(), -scores.cpu().numpy()))
+    o2 = np.lexsort((dl[:n].cpu().numpy(), -ds[:n].cpu().numpy()))
+    np.testing.assert_array_equal(labels.cpu().numpy()[o1], dl[:n].cpu().numpy()[o2])
+    np.testing.assert_allclose(scores.cpu().numpy()[o1], ds[:n].cpu().numpy()[o2], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(boxes.cpu().numpy()[o1], db[:n].cpu().numpy()[o2], rtol=0, atol=1e-2)
+    s, d, r = m.im_detect(img, 1.25)
+    assert s.shape[0] == r.shape[0] == d.shape[0] and s.shape[1] == 21 and d.shape[1] == 84
+    # training=True: the four losses of the forward pass (:232-264), finite
+    gt = torch.tensor([[30., 40., 200., 180.], [100., 60., 330., 250.]], device='cuda')
+    gl = torch.tensor([3, 7], device='cuda')
+    losses = m((img, gt, gl), training=True)
+    assert len(losses) == 4 and all(bool(torch.isfinite(x)) for x in losses)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['resnet', 'vgg16'])
+def test_faster_rcnn_models_call_agrees_with_the_static_shape_detectors(kind):
+    from tf_eager_object_detection_amd.model.base_faster_rcnn_model import ResNetFasterRcnn, Vgg16FasterRcnn
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
+    torch.manual_seed(32)
+    shape, K = (256, 352), 100
+    if kind == 'resnet':
+        m = ResNetFasterRcnn(depth=50, rpn_proposal_num_post_nms_test=K, prediction_score_threshold=0.0,
+                             roi_pooling_max_pooling_flag=False)
+        det = ResNetC4Detector(50, 21, shape, K, dtype=torch.float32)
+    else:
+        m = Vgg16FasterRcnn(rpn_proposal_num_post_nms_test=K, prediction_score_threshold=0.0)
+        det = Vgg16Detector(21, shape, K, dtype=torch.float32)
+    det.load_state_dict(m.dense.state_dict())
+    det.prepare()
+    img = _image(shape, 4)
+    got = m(img, training=False)
+    db, dl, ds, dc = det(img)[0]
+    n = int(dc.item())
+    if n == 0:
+        assert got == (None, None, None)
+        return
+    boxes, labels, scores = got
+    assert scores.shape[0] == n
+    o1 = np.lexsort((labels.cpu().numpy(), -scores.cpu().numpy()))
+    o2 = np.lexsort((dl[:n].cpu().numpy(), -ds[:n].cpu().numpy()))
+    np.testing.assert_array_equal(labels.cpu().numpy()[o1], dl[:n].cpu().numpy()[o2])
+    np.testing.assert_allclose(scores.cpu().numpy()[o1], ds[:n].cpu().numpy()[o2], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(boxes.cpu().numpy()[o1], db[:n].cpu().numpy()[o2], rtol=0, atol=1e-2)

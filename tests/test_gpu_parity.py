@@ -932,6 +932,20 @@ def test_batched_full_order_chunks_match_oracle():
                     np.testing.assert_array_equal(h(slot.roi_idx[:m]), wants[k])
                 else:
                     assert m == 0
+            if blind == 2:
+                # the flagged images -- and only those -- go through the exact mode again and end with the
+                # oracle's proposals and non-empty detections; nothing raises
+                before = h(pool.slots[1].roi_idx).copy()
+                assert pool.recover_incomplete() == [0, 2] and pool.nms_reruns == 2
+                torch.cuda.synchronize()
+                assert pool.nms_done_all.tolist() == [1, 1, 1] and pool.recover_incomplete() == []
+                np.testing.assert_array_equal(h(pool.slots[1].roi_idx), before)
+                for k in range(B):
+                    slot = pool.slots[k]
+                    m = int(slot.roi_count.item())
+                    assert m == len(wants[k]) and int(slot.det_count.item()) > 0
+                    np.testing.assert_array_equal(h(slot.roi_idx[:m]), wants[k])
+                    assert float(slot.record[-1]) == float(int(slot.det_count.item()))
         finally:
             pool.close()
 

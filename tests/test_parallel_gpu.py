@@ -1,8 +1,13 @@
-"""Two ranks, one GPU: the image-parallel arrangement end to end on the HIP path -- every rank sends its shard of the
+"""Several ranks, one GPU: the image-parallel arrangement end to end on the HIP path -- every rank sends its shard of the
 images through the batched hot-path launches (FpnStreamPool) and the groups' records through parallel.GroupExchange
 (the exchange bench.py times), and must end with EVERY image's record, equal to the oracle's detections.  The ranks
 share cuda:0, so the backend is gloo (RCCL wants one device per rank; the driver's 8-GPU run uses "nccl"); they are
-fresh processes (spawn), never a re-exec of a process that touched the GPU."""
+fresh processes (spawn), never a re-exec of a process that touched the GPU.
+
+Cases: a small ragged one (2 ranks, 7 images of 200 x 320); BASELINE configs[3]'s workload at its size (8 images of
+800 x 1333: 267 069 anchors, 1000 proposals, P2..P5 x 256 channels; model/fpn/base_fpn_model.py:208-276) on 4 ranks x 2
+images -- a GPU box admits at most 6 processes on its card, so 8 ranks of one image cannot be rehearsed on it; and the
+RCCL ("nccl") call path itself with one rank (force_collective)."""
 import os
 import socket
 
@@ -11,8 +16,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-SHAPE, K, NCLS, CH, B, S = (200, 320), 200, 21, 16, 2, 2
-NUM_IMAGES = 7                          # 2 ranks x (2 groups x 2 images): rank 1's last group is ragged
+SMALL = dict(shape=(200, 320), K=200, ncls=21, ch=16, B=2, S=2, images=7, world=2, blind=3)   # rank 1's last group is ragged
+FULL = dict(shape=(800, 1333), K=1000, ncls=21, ch=256, B=2, S=1, images=8, world=4, blind=2)  # config 4's eight images
 
 
 def _free_port():
@@ -23,7 +28,8 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, q):
+def _rank(rank, cfg, port, q):
+    SHAPE, K, NCLS, CH, B, S, NUM_IMAGES, world = (cfg[k] for k in ('shape', 'K', 'ncls', 'ch', 'B', 'S', 'images', 'world'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -35,7 +41,7 @@ def _rank(rank, world, port, q):
         from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
         _lib.lib()
         mine = parallel.shard_images(NUM_IMAGES, rank, world)
-        pool = FpnStreamPool(S, SHAPE, NCLS, K, CH, batch=B, blind_chunks=3)
+        pool = FpnStreamPool(S, SHAPE, NCLS, K, CH, batch=B, blind_chunks=cfg['blind'])
         rec_len = pool.slots[0].record.numel()
         records = torch.zeros((pool.n, rec_len), dtype=torch.float32, device='cuda')
         keep = []
@@ -81,16 +87,17 @@ def _rank(rank, world, port, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_hip_path_and_group_exchange_every_rank_has_every_record():
+@pytest.mark.parametrize('cfg', [SMALL, FULL], ids=['2ranks-7x200x320', '4ranks-8x800x1333-config4'])
+def test_ranks_hip_path_and_group_exchange_every_rank_has_every_record(cfg):
     from oracle import c_oracle as co
-    from tf_eager_object_detection_amd import synthetic as syn
+    SHAPE, K, NCLS, NUM_IMAGES, world = (cfg[k] for k in ('shape', 'K', 'ncls', 'images', 'world'))
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, cfg, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in range(2)]
+    results = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -98,7 +105,7 @@ def test_two_ranks_hip_path_and_group_exchange_every_rank_has_every_record():
     anchors = co.fpn_anchors(SHAPE)
     want = {}
     for img in range(NUM_IMAGES):
-        host = _host_inputs(img)
+        host = _host_inputs(img, cfg)
         fg = co.rpn_fg_fpn(host['rpn_logits'])
         rois, _ = co.region_proposal(host['rpn_deltas'], anchors, fg, SHAPE, K, 0.7)
         lv, perm, _ = co.assign_levels(rois)
@@ -119,14 +126,16 @@ def test_two_ranks_hip_path_and_group_exchange_every_rank_has_every_record():
             np.testing.assert_array_equal(body[order, 5].astype(np.int32), wl[worder])
             np.testing.assert_array_equal(body[order, 4], ws[worder])
             assert np.max(np.abs(body[order, :4] - wb[worder])) <= 1e-4 * max(1.0, float(np.abs(wb).max()))
-    # both ranks hold identical copies
-    for img in range(NUM_IMAGES):
-        np.testing.assert_array_equal(results[0][1][img], results[1][1][img])
+    # all ranks hold identical copies
+    for other in results[1:]:
+        for img in range(NUM_IMAGES):
+            np.testing.assert_array_equal(results[0][1][img], other[1][img])
 
 
-def _host_inputs(img):
+def _host_inputs(img, cfg):
     """the numpy side of pipeline.synthetic_fpn_inputs for image `img` without touching the GPU in the parent"""
     from tf_eager_object_detection_amd import synthetic as syn
+    SHAPE, K, NCLS, CH = cfg['shape'], cfg['K'], cfg['ncls'], cfg['ch']
     rng = np.random.default_rng(1000 + img)
     shapes = syn.fpn_level_shapes(SHAPE)
     n = syn.num_fpn_anchors(SHAPE)
@@ -136,3 +145,64 @@ def _host_inputs(img):
     logits = syn.logits_from_prob(prob, rng)
     return dict(rpn_deltas=deltas, rpn_logits=logits, cls_scores=syn.class_scores(K, NCLS, rng),
                 cls_deltas=syn.class_deltas(K, NCLS, rng))
+
+
+def _rccl_rank(port, q):
+    """one rank, backend "nccl" (= RCCL): the collective bench.py issues with N > 1 GPUs, forced for a world of one"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        from tf_eager_object_detection_amd import _lib, parallel
+        from tf_eager_object_detection_amd.pipeline import FpnStreamPool, synthetic_fpn_inputs
+        _lib.lib()
+        cfg = SMALL
+        SHAPE, K, NCLS, CH, B, S = (cfg[k] for k in ('shape', 'K', 'ncls', 'ch', 'B', 'S'))
+        pool = FpnStreamPool(S, SHAPE, NCLS, K, CH, batch=B, blind_chunks=cfg['blind'])
+        rec_len = pool.slots[0].record.numel()
+        records = torch.zeros((pool.n, rec_len), dtype=torch.float32, device='cuda')
+        keep = []
+        for k in range(pool.n):
+            pool.slots[k].record = records[k]
+            _, dev = synthetic_fpn_inputs(SHAPE, NCLS, K, CH, seed=1000 + k)
+            keep.append(dev)
+            pool.bind(k, dev['rpn_logits'], dev['rpn_deltas'], dev['feats'], dev['cls_scores'], dev['cls_deltas'])
+        torch.cuda.synchronize()
+        calls = []
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda out, inp, **kw: calls.append((tuple(out.shape), tuple(inp.shape))) or real(out, inp, **kw)
+        ex = parallel.GroupExchange(S, B, rec_len, 'cuda', force_collective=True)
+        outs = []
+        for g in range(S):
+            pool.enqueue_group(g)
+            outs.append(ex.gather(g, records[g * B:(g + 1) * B], producer_stream=pool._group_streams[g]))
+        ex.synchronize()
+        pool.wait()
+        torch.cuda.synchronize()
+        dist.all_gather_into_tensor = real
+        same = all(bool(torch.equal(outs[g][0], records[g * B:(g + 1) * B])) for g in range(S))
+        counts = [float(records[k, -1]) for k in range(pool.n)]
+        q.put(dict(backend=dist.get_backend(), world=dist.get_world_size(), calls=calls, same=same, counts=counts,
+                   rec_len=rec_len))
+        pool.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_into_tensor_runs_with_one_rank():
+    """the "nccl" backend's call path of parallel.GroupExchange: one all_gather_into_tensor per stream group on the
+    communication stream, the gathered block equal to the group's records"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_rank, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    S, B = SMALL['S'], SMALL['B']
+    assert got['backend'] == 'nccl' and got['world'] == 1
+    assert got['calls'] == [((B, got['rec_len']), (B, got['rec_len']))] * S      # ONE collective per stream group
+    assert got['same'] and all(c > 0 for c in got['counts'])

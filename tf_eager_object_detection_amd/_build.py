@@ -17,8 +17,7 @@ HEADERS = [os.path.join(CSRC, 'odet_internal.h'), os.path.join(INCLUDE, 'odet.h'
 
 # -ffp-contract=off: the parity contract is "one IEEE float32 operation per reference
 # operation"; an FMA would change low bits of box coordinates and bilinear taps.
-EXTRA = os.environ.get('ODET_EXTRA_HIPCC_FLAGS', '').split()   # diagnostic builds only (tools/exp: the product sources carry no switches)
-HIPCC_FLAGS = EXTRA + ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
                '-fno-fast-math', '-Wall', '-Wno-unused-function', '-Wno-unused-variable']
 
 

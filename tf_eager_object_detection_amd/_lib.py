@@ -10,9 +10,8 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libodet_hip.so')
-if os.environ.get('ODET_LIB_PATH'):          # diagnostic builds of the same ABI (tools/): never a fallback
-    LIB_PATH = os.environ['ODET_LIB_PATH']
+LIB_PATH = os.path.join(_PKG, 'libodet_hip.so')     # (tools/_diag.py points it at a diagnostic build; no environment switch)
+ODET_VERSION = 101                                   # include/odet.h
 
 _lib = None
 
@@ -58,7 +57,7 @@ class OdetFpnStep(C.Structure):
         ('stream', C.c_void_p),
         ('roi_start_event', C.c_void_p), ('roi_stop_event', C.c_void_p),
         ('ws_rpn_clean', C.c_int32), ('single_level', C.c_int32), ('roi_pool_mode', C.c_int32),
-        ('reserved_flags', C.c_int32),
+        ('ws_post_clean', C.c_int32),
     ]
 
 
@@ -172,7 +171,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.odet_version() != 100:
+        if handle.odet_version() != ODET_VERSION:
             raise OdetError('libodet_hip.so version mismatch: %d' % handle.odet_version())
         if handle.odet_fpn_step_sizeof() != C.sizeof(OdetFpnStep):
             raise OdetError('odet_fpn_step_t layout mismatch: library %d bytes, binding %d'

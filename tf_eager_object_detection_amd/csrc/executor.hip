@@ -63,7 +63,7 @@ extern "C" int odet_fpn_step_enqueue(const odet_fpn_step_t* s, int stages) {
     rc = odet_post_ops_batch(&one, 1, s->num_proposals, s->ccls, s->num_classes,
                              PostOpsExtra{(float)(s->image_w - 1), (float)(s->image_h - 1), 1.0f, 0}, s->roi_means,
                              s->roi_stds, s->max_per_class, s->max_per_image, s->nms_iou, s->score_threshold,
-                             s->min_edge, (hipStream_t)s->stream, s->ws_rpn_clean);
+                             s->min_edge, (hipStream_t)s->stream, s->ws_post_clean);
   }
   return rc;
 }
@@ -154,6 +154,8 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
     if (rc != ODET_OK) return rc;
   }
   if (stages & ODET_STAGE_DETECT) {
+    bool post_clean = true;                    // (odet_fpn_step_t.ws_post_clean: its own promise since version 101)
+    for (int i = 0; i < count; ++i) post_clean = post_clean && steps[i]->ws_post_clean != 0;
     PostOpsImageIO io[ODET_MAX_BATCH];
     for (int i = 0; i < count; ++i) {
       const odet_fpn_step_t* t = steps[i];
@@ -163,7 +165,7 @@ extern "C" int odet_fpn_step_enqueue_batch(const odet_fpn_step_t* const* steps, 
     rc = odet_post_ops_batch(io, count, s->num_proposals, s->ccls, s->num_classes,
                              PostOpsExtra{(float)(s->image_w - 1), (float)(s->image_h - 1), 1.0f, 0}, s->roi_means,
                              s->roi_stds, s->max_per_class, s->max_per_image, s->nms_iou, s->score_threshold,
-                             s->min_edge, st, clean_all ? 1 : 0);
+                             s->min_edge, st, post_clean ? 1 : 0);
   }
   return rc;
 }

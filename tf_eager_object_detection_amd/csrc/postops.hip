@@ -465,6 +465,7 @@ int odet_post_ops_batch(const PostOpsImageIO* io, int B, int R, int Ccls, int nu
     float4* cb = ar.take<float4>((size_t)ncls1 * max_per_class);
     float* cs = ar.take<float>((size_t)ncls1 * max_per_class);
     uint32_t* tk = ar.take<uint32_t>(1);
+    ODET_REQUIRE(cc && cb && cs && tk, "odet_post_ops: workspace arena exhausted");
     p.scores_t.v[i] = a.scores; p.deltas_t.v[i] = a.deltas; p.rois_t.v[i] = (const float4*)a.rois;
     p.count_dev_t.v[i] = a.count_dev;
     p.cls_count_t.v[i] = cc; p.cls_boxes_t.v[i] = cb; p.cls_scores_t.v[i] = cs; p.ticket_t.v[i] = tk;

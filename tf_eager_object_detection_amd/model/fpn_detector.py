@@ -353,37 +353,73 @@ class _FinalLayer:
 class _NmsCompleteness:
     """The detectors run the proposal stage sync-free (no host check between kernels; graph-capturable) with a fixed
     number of NMS chunks.  If an image needs more than those, the hot path reports it EMPTY and flags it
-    (nms_done = 0, include/odet.h): `forward()` checks the flags after the last launch of the pass whenever it is not
-    being captured into a HIP graph and `check_nms` is on (default), and raises.  Throughput loops that do not want a
-    host sync per pass set `model.check_nms = False` and call `check_complete()` themselves (after a graph replay too)."""
+    (nms_done = 0, include/odet.h): `forward()` reads the flags after the last launch of the pass whenever it is not
+    being captured into a HIP graph and `check_nms` is on (default), and sends ONLY the flagged images through the pass
+    again from the RPN head's outputs with the exact proposal stage (host-checked chunks, as many as the image needs:
+    the reference's NMS is always exact, model/region_proposal.py:73-81) -- their outputs are overwritten in place, the
+    other images are not touched; `nms_reruns` counts them.  Throughput loops that do not want a host sync per pass set
+    `model.check_nms = False` and call `recover()` themselves (after a graph replay too); `check_complete()` raises instead."""
 
     check_nms = True
+    nms_reruns = 0
     _last_batch = 0
+    _last_pass = None            # (rpn scores, rpn deltas, maps, heads) of the last pass: what a re-run starts from
 
     def nms_done(self, batch=None):
         """device int32 flags (1 = complete) of the images of the last pass"""
         n = self._last_batch if batch is None else batch
         return [h.nms_done for h in self._hot[:n]]
 
-    def check_complete(self, batch=None):
+    def incomplete(self, batch=None):
+        """indices of the images of the last pass whose sync-free NMS did not complete (one device -> host copy)"""
         steps = getattr(self, '_steps', None)
         if steps is not None and hasattr(steps, 'nms_done_all'):
             n = self._last_batch if batch is None else batch
-            flags = steps.nms_done_all[:n].tolist()                       # one device -> host copy for the whole pass
+            flags = steps.nms_done_all[:n].tolist()
         else:
             flags = [int(t.item()) for t in self.nms_done(batch)]
-        bad = [b for b, f in enumerate(flags) if f != 1]
+        return [b for b, f in enumerate(flags) if f != 1]
+
+    def check_complete(self, batch=None):
+        bad = self.incomplete(batch)
         if bad:
             raise RuntimeError('the RPN NMS of image(s) %s did not complete inside blind_chunks = %d sync-free chunks: their '
-                               'results are reported EMPTY.  Build the detector with more chunks (blind_chunks=...) or a '
-                               'wider first chunk (nms_first_chunk=4096)' % (bad, self._hot[0].blind_chunks))
+                               'results are reported EMPTY (recover() re-runs them in the exact mode)'
+                               % (bad, self._hot[0].blind_chunks))
+
+    def recover(self, batch=None):
+        """re-runs the flagged images of the last pass in the exact mode; -> their indices"""
+        bad = self.incomplete(batch)
+        if bad and self._last_pass is None:
+            raise RuntimeError('image(s) %s incomplete and no pass to re-run them from' % bad)
+        for b in bad:
+            self._rerun_exact(b)
+        self.nms_reruns += len(bad)
+        return bad
+
+    def _rerun_exact(self, b):
+        """image b of the last pass again from the RPN head's outputs: exact proposals -> RoI features -> RoI head ->
+        post-ops, into the buffers the pass handed out"""
+        rpn_scores, rpn_deltas, maps, heads = self._last_pass
+        hot = self._hot[b]
+        hot.stage_proposals(rpn_scores[b], rpn_deltas[b], exact=True)
+        feats = hot.stage_roi(self._maps_of(maps, b))
+        logits, bbox = self.roi_head(feats)
+        cls, dlt = heads[b]
+        if cls.shape[0] == logits.shape[0] and cls.is_contiguous() and dlt.is_contiguous():
+            torch.softmax(logits.float(), dim=-1, out=cls)
+            dlt.view(dlt.shape[0], -1).copy_(bbox)
+        else:
+            cls, dlt = torch.softmax(logits.float(), dim=-1).contiguous(), bbox.float().contiguous()
+            heads[b] = (cls, dlt)
+        hot.stage_detect(cls, dlt)
 
     def _after_pass(self, batch, check):
         self._last_batch = batch
         if check is None:
             check = self.check_nms and not torch.cuda.is_current_stream_capturing()
         if check:
-            self.check_complete(batch)
+            self.recover(batch)
 
 
 class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
@@ -451,8 +487,8 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         return self
 
     # ---- dense parts ---------------------------------------------------------------------------
-    def features(self, images_nhwc):
-        """[B,H,W,3] -> (P2..P6), each [B,256,h,w] channels_last (= NHWC in memory)."""
+    def extractor(self, images_nhwc):
+        """[B,H,W,3] -> (C2, C3, C4, C5) channels_last (get_resnet_v1_extractor, resnet_fpn.py:262-289)."""
         # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 -- float16: one launch from the image; otherwise
         # the last three in one pass (x >= 0 after the ReLU, so skipping the window taps outside the map gives the same
         # maxima as the zero padding)
@@ -460,7 +496,15 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         c2 = self.conv2(x)
         c3 = self.conv3(c2)
         c4 = self.conv4(c3)
-        c5 = self.conv5(c4)
+        return c2, c3, c4, self.conv5(c4)
+
+    def features(self, images_nhwc):
+        """[B,H,W,3] -> (P2..P6), each [B,256,h,w] channels_last (= NHWC in memory)."""
+        return self.neck(self.extractor(images_nhwc))
+
+    def neck(self, c_list):
+        """(C2..C5) -> (P2..P6) (ResnetFpnNeck.call, resnet_fpn.py:378-407)."""
+        c2, c3, c4, c5 = c_list
         p5 = _conv_epi(self.p5, c5)
         p6 = p5[:, :, ::2, ::2]                                                  # MaxPooling2D(1x1, stride 2)
         p4 = self._lateral_merge(p5, self.l4, c4)
@@ -606,7 +650,14 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         B = images_nhwc.shape[0]
         if B > len(self._hot):
             raise ValueError('batch %d exceeds max_batch %d' % (B, len(self._hot)))
-        return self._hot_to_head(B, *self._dense(images_nhwc))
+        rpn_scores, rpn_deltas, maps = self._dense(images_nhwc)
+        heads = self._hot_to_head(B, rpn_scores, rpn_deltas, maps)
+        self._last_pass = (rpn_scores, rpn_deltas, maps, heads)
+        return heads
+
+    @staticmethod
+    def _maps_of(maps, b):
+        return [m[b:b + 1].contiguous() for m in maps]
 
     def _detect(self, heads):
         B = len(heads)
@@ -640,7 +691,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         heads = self._run_to_head(images_nhwc)
         B = len(heads)
         self._last_batch = B
-        self.check_complete(B)
+        self.recover(B)
         out = []
         for b, (cls, dlt) in enumerate(heads):
             hot = self._hot[b]

@@ -176,7 +176,9 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
             logits, bbox = self.roi_head(feats)
             torch.softmax(logits.float(), dim=-1, out=self._cls[:B].view(B * K, -1))
             self._dlt[:B].view(B * K, -1).copy_(bbox)
-            return [(self._cls[b], self._dlt[b]) for b in range(B)]
+            heads = [(self._cls[b], self._dlt[b]) for b in range(B)]
+            self._last_pass = (rpn_scores, rpn_deltas, maps, heads)
+            return heads
         def proposals_and_crops(b):
             hot = self._hot[b]
             hot.stage_proposals(rpn_scores[b], rpn_deltas[b])
@@ -186,7 +188,13 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         logits, bbox = self.roi_head(feats)                                      # one head pass for the whole batch
         cls = torch.softmax(logits.float(), dim=-1).reshape(B, K, -1).contiguous()
         bbox = bbox.float().reshape(B, K, -1).contiguous()
-        return [(cls[b], bbox[b]) for b in range(B)]
+        heads = [(cls[b], bbox[b]) for b in range(B)]
+        self._last_pass = (rpn_scores, rpn_deltas, maps, heads)
+        return heads
+
+    @staticmethod
+    def _maps_of(maps, b):
+        return maps[b:b + 1]
 
     @torch.no_grad()
     def forward(self, images_nhwc, check=None):
@@ -209,7 +217,7 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         heads = self._run_to_head(images_nhwc)
         B = len(heads)
         self._last_batch = B
-        self.check_complete(B)
+        self.recover(B)
         out = []
         for b, (cls, dlt) in enumerate(heads):
             hot = self._hot[b]

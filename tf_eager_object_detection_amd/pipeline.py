@@ -104,8 +104,20 @@ class FpnHotPath:
         return out
 
     # ---- stage 1: RPN outputs -> level-sorted proposals -------------------------------------
-    def stage_proposals(self, rpn_logits, rpn_deltas):
-        """rpn_logits [N,2] (bg,fg) as RpnHead emits them (base_fpn_model.py:429), rpn_deltas [N,4]."""
+    def stage_proposals(self, rpn_logits, rpn_deltas, exact=False):
+        """rpn_logits [N,2] (bg,fg) as RpnHead emits them (base_fpn_model.py:429), rpn_deltas [N,4].  exact: the library
+        checks the NMS state on the host after every chunk and runs as many chunks as the image needs (region_proposal.py:74
+        is always exact) -- the recovery of an image the sync-free plan reported incomplete; sets nms_done = 1."""
+        if exact:
+            ops.fpn_proposals(
+                rpn_logits, rpn_deltas, self.fh, self.fw, self.strides, self.wh, self.image_shape, self.K,
+                self.cfg['rpn_nms_iou'], self.cfg['rpn_means'], self.cfg['rpn_stds'],
+                min_level=self.min_level, max_level=self.max_level, workspace=self.ws_rpn, blind_chunks=1, done=None,
+                out=(self.rois, self.roi_idx, self.roi_count),
+                out_levels=(self.sorted_rois, self.roi_level, self.roi_perm, self.level_counts),
+                out_order=self.roi_order if self._fused_order else None)
+            self.nms_done.fill_(1)
+            return self.sorted_rois, self.roi_level, self.roi_count
         self._run('proposals', (rpn_logits, rpn_deltas), lambda: ops.fpn_proposals(
             rpn_logits, rpn_deltas, self.fh, self.fw, self.strides, self.wh, self.image_shape, self.K,
             self.cfg['rpn_nms_iou'], self.cfg['rpn_means'], self.cfg['rpn_stds'],
@@ -211,13 +223,16 @@ class FrcnnHotPath:
                                    dtype=torch.uint8, device=dev)
         self.record = torch.zeros(M * 6 + 1, dtype=torch.float32, device=dev)
 
-    def stage_proposals(self, rpn_logits, rpn_deltas):
-        """rpn_logits [fh*fw, 2A] as RpnHead emits them (:342-350), rpn_deltas [fh*fw*A, 4]."""
+    def stage_proposals(self, rpn_logits, rpn_deltas, exact=False):
+        """rpn_logits [fh*fw, 2A] as RpnHead emits them (:342-350), rpn_deltas [fh*fw*A, 4].  exact: host-checked chunks until
+        the NMS is complete (the recovery of an image the sync-free plan reported incomplete); sets nms_done = 1."""
         c = self.cfg
         ops.frcnn_proposals(rpn_logits, rpn_deltas, self.anchor_base, self.stride, self.fh, self.fw,
                             self.image_shape, self.K, c['rpn_nms_iou'], c['rpn_means'], c['rpn_stds'],
-                            workspace=self.ws_rpn, blind_chunks=self.blind_chunks, done=self.nms_done,
-                            out=(self.rois, self.roi_idx, self.roi_count))
+                            workspace=self.ws_rpn, blind_chunks=1 if exact else self.blind_chunks,
+                            done=None if exact else self.nms_done, out=(self.rois, self.roi_idx, self.roi_count))
+        if exact:
+            self.nms_done.fill_(1)
         return self.rois, self.roi_count
 
     def stage_roi(self, feat):
@@ -292,6 +307,7 @@ def _fill_step(st, h, stream_handle, rpn_logits, rpn_deltas, p_list, cls_softmax
     st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
     st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
     st.ws_rpn_clean = 1                              # (FpnHotPath zero-filled it at allocation and never exposes it)
+    st.ws_post_clean = 1
     st.ws_post, st.ws_post_bytes = h.ws_post.data_ptr(), h.ws_post.numel()
     st.stream = stream_handle
     return tensors
@@ -348,6 +364,7 @@ def _fill_frcnn_step(st, h, stream_handle, rpn_logits, rpn_deltas, feat, cls_sof
     st.det_scores, st.det_count, st.record = h.det_scores.data_ptr(), h.det_count.data_ptr(), h.record.data_ptr()
     st.ws_rpn, st.ws_rpn_bytes = h.ws_rpn.data_ptr(), h.ws_rpn.numel()
     st.ws_rpn_clean = 1
+    st.ws_post_clean = 1
     st.ws_post, st.ws_post_bytes = h.ws_post.data_ptr(), h.ws_post.numel()
     st.stream = stream_handle
     return [rpn_logits, rpn_deltas, cls_softmax, cls_deltas, feat]
@@ -463,6 +480,11 @@ class FpnStreamPool:
         self._single_worker = bool(sw) if sw is not None else self.batch >= 4
         self._group_streams = [torch.cuda.Stream() for _ in range(self.n_streams)]
         self.streams = [self._group_streams[k // self.batch] for k in range(self.n)]
+        # (the slots' NMS-completeness flags side by side: ONE device -> host copy checks every image in flight)
+        self.nms_done_all = torch.zeros(self.n, dtype=torch.int32, device=self.slots[0].device)
+        for k, h in enumerate(self.slots):
+            h.nms_done = self.nms_done_all[k:k + 1]
+        self.nms_reruns = 0
         self.steps = [ops.L.OdetFpnStep() for _ in range(self.n)]
         self._groups = []
         for g in range(self.n_streams):
@@ -516,6 +538,30 @@ class FpnStreamPool:
         rc = self._lib.odet_exec_wait(self._exec)
         if rc != 0:
             raise ops.L.OdetError('odet error %d: %s' % (rc, self._lib.odet_exec_last_error(self._exec).decode()))
+
+    def recover_incomplete(self):
+        """After wait(): the slots whose sync-free NMS did not complete inside their chunks (nms_done = 0: reported EMPTY)
+        go through the hot path again in the EXACT mode (nms_done = NULL: the library checks every chunk on the host and
+        runs as many as the image needs -- model/region_proposal.py:73-81 is always exact), each as a launch sequence of its
+        own on its stream, enqueued by the calling thread.  Returns the slots re-run (also counted in `nms_reruns`); their
+        outputs and records are complete once their streams have run (the exact mode synchronises them itself)."""
+        for st in self._group_streams:
+            st.synchronize()
+        bad = [k for k, f in enumerate(self.nms_done_all.tolist()) if f != 1]
+        for k in bad:
+            st = self.steps[k]
+            keep = st.nms_done
+            st.nms_done, st.ws_rpn_clean = None, 0     # (exact mode; the library zeroes the workspace header itself)
+            try:
+                ops.L.check(self._lib.odet_fpn_step_enqueue(self._C.byref(st), 7))
+            finally:
+                st.nms_done, st.ws_rpn_clean = keep, 1
+            with torch.cuda.stream(self.streams[k]):
+                self.nms_done_all[k:k + 1].fill_(1)
+        for k in bad:
+            self.streams[k].synchronize()
+        self.nms_reruns += len(bad)
+        return bad
 
     def close(self):
         if self._exec:

@@ -9,6 +9,7 @@ import ctypes as C, os, sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tools._diag            # (ODET_LIB_PATH selects a diagnostic build: tools only, the product reads no environment)
 from tf_eager_object_detection_amd import _lib, ops
 
 lib = _lib.lib()

@@ -4,6 +4,7 @@ with a diagnostic library whose output stores are dropped by the range check (OD
     python tools/r04/tail_phase2_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tools._diag            # (ODET_LIB_PATH selects a diagnostic build: tools only, the product reads no environment)
 import torch
 from tf_eager_object_detection_amd import ops
 B, H, W, cm, n3 = 30, 50, 84, 256, 1024

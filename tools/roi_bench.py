@@ -18,6 +18,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import tools._diag            # (ODET_LIB_PATH selects a diagnostic build: tools only, the product reads no environment)
 
 
 def main():

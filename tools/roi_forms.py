@@ -17,6 +17,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import tools._diag            # (ODET_LIB_PATH selects a diagnostic build: tools only, the product reads no environment)
 from tf_eager_object_detection_amd import _lib, ops
 from tf_eager_object_detection_amd import synthetic as syn
 from tf_eager_object_detection_amd.pipeline import (FpnStepBatch, FrcnnStepBatch, synthetic_fpn_inputs,
