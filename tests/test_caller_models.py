@@ -170,13 +170,14 @@ def test_resnet_v1_fpn_call_agrees_with_the_static_shape_detector_on_the_same_we
     detections = those of model/fpn_detector.ResNetFpnDetector (the sync-free arrangement) carrying the same weights."""
     from tf_eager_object_detection_amd.model.base_fpn_model import ResnetV1Fpn
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
-    torch.manual_seed(31)
+    torch.manual_seed(1)                 # (the weights and image of test_detector_hot_path_state_matches_oracle: detections exist)
     shape, K = (256, 352), 300
     m = ResnetV1Fpn(depth=50, rpn_proposal_num_post_nms_test=K, prediction_score_threshold=0.0)
     det = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32)
     det.load_state_dict(m.dense.state_dict())
     det.prepare()
-    img = _image(shape, 3)
+    rng = np.random.default_rng(1)
+    img = torch.from_numpy((rng.uniform(0, 255, (1,) + shape + (3,)) - 110).astype(np.float32)).cuda()
     boxes, labels, scores = m(img, training=False)
     db, dl, ds, dc = det(img)[0]
     n = int(dc.item())
