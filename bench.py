@@ -198,7 +198,7 @@ def load_traffic(workload_key, images_per_launch):
     return None, None
 
 
-def e2e_record(dtype_name, batch, budget_s=6.0, family='fpn', graph=False, eager=True):
+def e2e_record(dtype_name, batch, budget_s=6.0, family='fpn', graph=False, eager=True, f32_form='exact'):
     """An assembled detector end to end on synthetic images (random-init weights): backbone (+ neck) + RPN head + hot
     path + RoI head + post-ops; not the headline metric (that one is the hot path): a second, separately labelled
     record.  family = 'fpn': ResNet-101-FPN @ 800x1333 (BASELINE config 3); 'c4': ResNet-50 C4 Faster R-CNN @ 800x1333
@@ -211,7 +211,7 @@ def e2e_record(dtype_name, batch, budget_s=6.0, family='fpn', graph=False, eager
     image_shape = (600, 800) if family == 'vgg16' else IMAGE_SHAPE
     if family == 'fpn':
         model = ResNetFpnDetector(101, NUM_CLASSES, image_shape, NUM_PROPOSALS, dtype=dt, max_batch=batch,
-                                  blind_chunks=2, batched=True).prepare()
+                                  blind_chunks=2, batched=True, f32_form=f32_form).prepare()
     elif family == 'c4':
         model = ResNetC4Detector(50, NUM_CLASSES, image_shape, 300, dtype=dt, max_batch=batch, blind_chunks=4).prepare()
     else:
@@ -224,7 +224,7 @@ def e2e_record(dtype_name, batch, budget_s=6.0, family='fpn', graph=False, eager
         out = model(img)
     torch.cuda.synchronize()
     warm_s = time.perf_counter() - t0
-    rec = dict(unit='img/s', batch=batch, dtype=dtype_name,
+    rec = dict(unit='img/s', batch=batch, dtype=dtype_name if f32_form == 'exact' else dtype_name + ' split precision (x3)',
                model={'fpn': 'ResNet-101-FPN', 'c4': 'ResNet-50 C4 Faster R-CNN', 'vgg16': 'VGG16 Faster R-CNN'}[family],
                image=list(image_shape), weights='random init', data='synthetic', warmup_s=warm_s)
     if eager:
@@ -682,7 +682,7 @@ def main():
                    'roi_frac_B_roi': round(result['roofline']['frac'], 3),
                    'roi_frac_counter_bytes': (round(result['roofline']['hbm_frac_measured'], 3)
                                               if result['roofline']['hbm_frac_measured'] else None),
-                   'roi_frac_physical': 'roi_frac_counter_bytes (PMC HBM bytes); B_roi is reuse-blind',
+                   'roi_frac_physical': 'roi_frac_counter_bytes',
                    'roi_kernel_us': round(result['roofline']['kernel_ms'] * 1e3, 1),
                    'roi_vs_calibration': round(result['roofline']['calibration']['roi_kernel_vs_calibration'], 3)}
         if not args.no_config5 and world == 1:
@@ -726,11 +726,12 @@ def main():
             # float32: 30 images per pass for the same reason)
             legs = (('fp16', 'fp16', 60, 'fpn', False, True), ('fp16_b1', 'fp16', 1, 'fpn', True, True),
                     ('fp16_b4', 'fp16', 4, 'fpn', True, True), ('fp16_b8', 'fp16', 8, 'fpn', True, True),
-                    ('fp32', 'fp32', 30, 'fpn', False, True),
+                    ('fp32', 'fp32', 30, 'fpn', False, True), ('fp32_x3', 'fp32', 30, 'fpn', False, True),
                     ('fp16_resnet50_c4', 'fp16', 60, 'c4', False, True), ('fp16_vgg16_600x800', 'fp16', 64, 'vgg16', False, True))
             for name, dtn, b, fam, gr, eg in legs:
                 try:
-                    e2e[name] = e2e_record(dtn, b, budget_s=(6.0 if name in ('fp16', 'fp32') else 3.0), family=fam, graph=gr, eager=eg)
+                    e2e[name] = e2e_record(dtn, b, budget_s=(6.0 if name in ('fp16', 'fp32', 'fp32_x3') else 3.0), family=fam, graph=gr,
+                                           eager=eg, f32_form='x3' if name.endswith('_x3') else 'exact')
                 except Exception as ex:               # the headline record must not depend on the second one
                     e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
                 mark('e2e %s done' % name)
@@ -740,25 +741,33 @@ def main():
                 return round(v, 1) if isinstance(v, (int, float)) else None
             summary.update(e2e_fp16=[rate('fp16'), 60], e2e_fp16_b1_graph=rate('fp16_b1', 'value_hip_graph'),
                            e2e_fp16_b1_eager=rate('fp16_b1'), e2e_fp16_b4=[rate('fp16_b4'), rate('fp16_b4', 'value_hip_graph')],
-                           e2e_fp16_b8=[rate('fp16_b8'), rate('fp16_b8', 'value_hip_graph')], e2e_fp32=[rate('fp32'), 30],
+                           e2e_fp16_b8=[rate('fp16_b8'), rate('fp16_b8', 'value_hip_graph')], e2e_fp32=[rate('fp32'), 30], e2e_fp32_x3=[rate('fp32_x3'), 30],
                            c4_fp16=[rate('fp16_resnet50_c4'), 60], vgg16_fp16=[rate('fp16_vgg16_600x800'), 64])
             # the accuracy side of the throughput mode: float16 vs float32 detector, same weights, same annotated scenes,
             # the reference's evaluation loop (evaluation/precision_gate.py) -- for all three families
             from tf_eager_object_detection_amd.evaluation import precision_gate
-            for name, fam, n_img in (('fp16', 'fpn', args.gate_images), ('fp16_resnet50_c4', 'c4', max(256, args.gate_images // 4)),
-                                     ('fp16_vgg16_600x800', 'vgg16', max(256, args.gate_images // 4))):
+            # (all three families on the full number of scenes: 1024 left the C4 / VGG16 intervals wider than the bar; the
+            # float32 split-precision mode against the exact-float32 mode on a quarter of them: its differences are float32
+            # rounding, its interval is narrow at any size)
+            for name, fam, n_img, mode in (('fp16', 'fpn', args.gate_images, 'fp16'), ('fp16_resnet50_c4', 'c4', args.gate_images, 'fp16'),
+                                           ('fp16_vgg16_600x800', 'vgg16', args.gate_images, 'fp16'),
+                                           ('fp32_x3', 'fpn', max(256, args.gate_images // 4), 'x3')):
                 try:
-                    gate = precision_gate.fp16_vs_fp32(num_images=n_img, batch32=30, batch16=30, family=fam)
-                    gate.pop('protocol', None) if fam != 'fpn' else None
+                    gate = precision_gate.fp16_vs_fp32(num_images=n_img, batch32=30, batch16=30, family=fam, test_mode=mode)
+                    gate.pop('protocol', None) if name != 'fp16' else None
+                    gate.pop('fit', None) if name != 'fp16' else None
                     if isinstance(e2e.get(name), dict):
                         e2e[name]['map_delta_vs_fp32'] = gate
                     else:
                         e2e[name + '_map_delta_vs_fp32'] = gate
                     lo, hi = gate['map_delta_ci95_paired_bootstrap']
-                    summary['map_delta_' + fam] = [round(gate['map_delta'], 4), round(lo, 4), round(hi, 4), gate['images']]
+                    summary['map_delta_' + (fam if mode == 'fp16' else 'x3')] = [round(gate['map_delta'], 4), round(lo, 4), round(hi, 4),
+                                                                               gate['images']]
+                    if mode == 'x3':
+                        summary['x3_vs_exact'] = [round(gate['rpn_kept_index_agreement_mean'], 4), float('%.1e' % gate['p99_abs_dscore'])]
                 except Exception as ex:
                     e2e[name + '_map_delta_vs_fp32'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
-                mark('gate %s done' % fam)
+                mark('gate %s done' % name)
             if isinstance(e2e.get('fp16'), dict) and 'value' in e2e['fp16'] and 'map_delta_vs_fp32' in e2e['fp16']:
                 g = e2e['fp16']['map_delta_vs_fp32']
                 e2e['fp16']['target'] = ('%s the north star\'s >= 200 img/s on one MI355X (%.0f img/s); mAP delta vs the float32 mode on '
@@ -767,9 +776,17 @@ def main():
                                          % ('meets' if e2e['fp16']['value'] >= 200.0 else 'misses', e2e['fp16']['value'], g['map_delta'],
                                             g['map_delta_ci95_paired_bootstrap'][0], g['map_delta_ci95_paired_bootstrap'][1], g['images'],
                                             'inside' if g['within_bar'] else 'OUTSIDE', 'resolves it' if g['resolves_bar'] else 'wider than it'))
+            if isinstance(e2e.get('fp32_x3'), dict) and 'value' in e2e['fp32_x3']:
+                e2e['fp32_x3']['target'] = ('%s the north star\'s >= 200 img/s on one MI355X at the reference\'s (float32) accuracy: %.0f '
+                                            'img/s, float32 tensors in memory, float32 operands as three bfloat16 limbs on the matrix '
+                                            'cores (csrc/conv_x3.hip), float32 accumulation; the exact-float32 mode: %s img/s'
+                                            % ('meets' if e2e['fp32_x3']['value'] >= 200.0 else 'misses', e2e['fp32_x3']['value'],
+                                               rate('fp32')))
             e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
                            'mode (the reference computes in float32; exact-float32 matrix instructions, 157 TFLOP/s peak, 684 GFLOP '
-                           'per image), fp16 = throughput mode, narrower than the reference, gated by map_delta_vs_fp32')
+                           'per image), fp32_x3 = the same float32 tensors with every layer on the split-precision form (float32-class '
+                           'accuracy, 417 TFLOP/s-equivalent peak), fp16 = throughput mode, narrower than the reference, gated by '
+                           'map_delta_vs_fp32')
             result['e2e'] = e2e
         mr = result['multi_rank']
         summary['ranks'] = [mr['rccl_world'], round(mr['per_rank_img_s_min'], 1), round(mr['per_rank_img_s_max'], 1), mr['allgathers_in_timed_region']]

@@ -466,6 +466,26 @@ int odet_lateral_merge_f32(const void* x, const void* w, const void* bias, const
                            int batch, int H, int W, int cin, int cout, odet_stream_t stream);
 int odet_pointwise_dual_f32(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
                             const void* w, const void* bias, void* y, int batch, int cout, int relu, odet_stream_t stream);
+/* The SPLIT-PRECISION float32 forms (csrc/conv_x3.hip): the same layers, the same float32 x / bias / y / residual / top in
+ * memory and the same epilogues as the *_f32 entry points above, computed on the bfloat16 matrix instructions (16 x the
+ * float32 MFMA rate): every float32 operand is the exact sum of three bfloat16 limbs (round to nearest even), a product
+ * the six limb products down to 2^-16 of its size (the dropped ones are <= 2^-23 of it), float32 accumulation -- a float32
+ * evaluation of the reference's float32 convolution (resnet_fpn.py:154-289, 339-407; base_fpn_model.py:393-434) within
+ * float32 rounding of the float64 truth, like the fmaf chain of the *_f32 forms, not bit-identical to it.  `w3` = the
+ * weight's limb planes, bfloat16 [3][cout][K] (K = taps * cin (+ cin2) in the order of the float32 weight), written ONCE per
+ * weight tensor by odet_split_bf16x3 (n = cout * K float32 values -> planes [3][n]; n even).  cin % 32 == 0, cout % 64 == 0;
+ * pointwise: any cin >= 32. */
+int odet_split_bf16x3(const float* w, void* planes, long long n, odet_stream_t stream);
+int odet_conv3x3_x3(const void* x, const void* w3, const void* bias, void* y, int batch, int H, int W,
+                    int cin, int cout, int relu, odet_stream_t stream);
+int odet_conv3x3_x3_levels(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
+                           int batch, int cin, int cout, int relu, odet_stream_t stream);
+int odet_pointwise_x3(const void* x, const void* w3, const void* bias, const void* residual, void* y, int batch,
+                      int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream);
+int odet_lateral_merge_x3(const void* x, const void* w3, const void* bias, const void* top, int th, int tw, void* y,
+                          int batch, int H, int W, int cin, int cout, odet_stream_t stream);
+int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
+                           const void* w3, const void* bias, void* y, int batch, int cout, int relu, odet_stream_t stream);
 /* The stem's patch matrix in float32 mode: row (image, yo, xo) = the zero-padded 7 x 7 x 3 window of conv1_pad +
  * Conv2D(64, 7x7, strides 2, 'valid') (resnet_fpn.py:262-289) in (dy, dx, channel) order, padded from 147 to 160 floats;
  * images NHWC float32 [batch,H,W,3] -> patches [batch * Ho * Wo][160], Ho = (H - 1) / 2 + 1.  The convolution is then

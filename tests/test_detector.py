@@ -1335,14 +1335,16 @@ def test_detectors_have_no_library_or_cpu_route():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dt', [torch.float32, torch.float16])
-def test_detector_dense_parts_match_the_plain_torch_formulation(dt):
+@pytest.mark.parametrize('dt,form', [(torch.float32, 'exact'), (torch.float32, 'x3'), (torch.float16, 'exact')],
+                         ids=['float32-exact', 'float32-x3', 'float16'])
+def test_detector_dense_parts_match_the_plain_torch_formulation(dt, form):
     """features / rpn / roi_head of the ResNet-FPN detector (this repository's kernels) against the plain-torch formulation of
-    the same modules (library convolutions, float32 arithmetic on the same weights)"""
+    the same modules (library convolutions, float32 arithmetic on the same weights); float32 in both of its forms: the
+    exact-float32 matrix instructions and the split-precision form (three bfloat16 limbs) under the SAME tolerance"""
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
     torch.manual_seed(11)
     shape = (192, 256)
-    m = ResNetFpnDetector(50, 21, shape, 64, dtype=dt, max_batch=2).prepare()
+    m = ResNetFpnDetector(50, 21, shape, 64, dtype=dt, max_batch=2, f32_form=form).prepare()
     img = torch.randn((2,) + shape + (3,), device='cuda') * 40
     with torch.no_grad():
         ps = m.features(img)
@@ -1398,3 +1400,128 @@ def test_float32_patch_matrix_goes_through_in_groups_below_4_gib(monkeypatch, fa
     whole = whole if isinstance(whole, (list, tuple)) else [whole]
     parts = parts if isinstance(parts, (list, tuple)) else [parts]
     assert len(whole) == len(parts) and all(torch.equal(a, b) for a, b in zip(whole, parts))
+
+
+def _x3_and_exact(fn):
+    from tf_eager_object_detection_amd import ops
+    with ops.f32_form('exact'):
+        a = fn()
+    with ops.f32_form('x3'):
+        b = fn()
+    return a, b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,H,W,cin,cout', [(2, 25, 42, 256, 512), (1, 50, 84, 64, 64), (3, 13, 21, 512, 512), (1, 100, 167, 128, 128),
+                                             (2, 31, 45, 32, 192), (1, 7, 5, 96, 64), (1, 200, 334, 64, 64)])
+def test_conv3x3_split_precision_form(B, H, W, cin, cout):
+    """odet_conv3x3_x3 (csrc/conv_x3.hip: float32 operands as three bfloat16 limbs, six products per k, float32 accumulation):
+    EXACT on integer-valued data (every limb product and every partial sum is an integer below 2^24) and, on random data, as
+    close to the float64 convolution as the exact-float32 form is (within float32 rounding of the float64
+    truth) -- both forms share memory layout, tiling rules and epilogue"""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(H * 7 + cin)
+    xi = torch.randint(-3, 4, (B, H, W, cin), device='cuda', generator=g).float()
+    wi = torch.randint(-2, 3, (cout, cin, 3, 3), device='cuda', generator=g).float().contiguous(memory_format=torch.channels_last)
+    bi = torch.randint(-3, 4, (cout,), device='cuda', generator=g).float()
+    want = F.relu(F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double(), bi.double(), 1, 1)).permute(0, 2, 3, 1)
+    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(xi, wi, bi, relu=True))
+    assert torch.equal(ex.double(), want) and torch.equal(x3.double(), want)
+    x = torch.randn((B, H, W, cin), device='cuda', generator=g) * 5
+    w = (torch.randn((cout, cin, 3, 3), device='cuda', generator=g) * (9 * cin) ** -0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(cout, device='cuda', generator=g)
+    want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1).permute(0, 2, 3, 1)
+    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(x, w, b))
+    rms = float(want.pow(2).mean().sqrt())
+    e_ex, e_x3 = float((ex.double() - want).abs().max()) / rms, float((x3.double() - want).abs().max()) / rms
+    assert e_x3 <= max(2.0 * e_ex, 2e-6) and e_x3 < 2e-5, (e_ex, e_x3)
+    # huge and tiny magnitudes: the limbs keep float32's exponent range (bfloat16), nothing overflows or flushes
+    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(x * 1e18, w * 1e-20, None))
+    want = F.conv2d((x * 1e18).permute(0, 3, 1, 2).double(), (w * 1e-20).double(), None, 1, 1).permute(0, 2, 3, 1)
+    assert float((x3.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_pointwise_split_precision_forms():
+    """the 1x1 / dense / strided / two-source / lateral-merge / shortcut forms of the split-precision kernel against float64:
+    exact on integers, as close as the exact-float32 form on random data; multi-level launch of the 3x3 form"""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(9)
+
+    def close(fn, want, what):
+        ex, x3 = _x3_and_exact(fn)
+        rms = max(float(want.pow(2).mean().sqrt()), 1e-30)
+        e_ex, e_x3 = float((ex.double() - want).abs().max()) / rms, float((x3.double() - want).abs().max()) / rms
+        assert e_x3 <= max(2.0 * e_ex, 2e-6) and e_x3 < 3e-5, (what, e_ex, e_x3)
+    for B, H, W, cin, cout, stride in ((2, 25, 42, 1024, 256, 1), (1, 50, 84, 256, 512, 2), (3, 9, 7, 2048, 512, 1), (1, 33, 47, 64, 256, 1),
+                                       (1, 1, 1000, 12544, 1024, 1), (2, 40, 30, 160, 64, 1)):
+        x = torch.randn((B, H, W, cin), device='cuda', generator=g) * 3
+        w = torch.randn((cout, cin), device='cuda', generator=g) * cin ** -0.5
+        b = torch.randn(cout, device='cuda', generator=g)
+        Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        res = torch.randn((B, Ho, Wo, cout), device='cuda', generator=g)
+        want = torch.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), w.double()[:, :, None, None], b.double(), stride).permute(0, 2, 3, 1)
+                          + res.double())
+        close(lambda: ops.pointwise(x, w, b, res, True, stride), want, ('pointwise', B, H, W, cin, cout, stride))
+    # integers: exact
+    xi = torch.randint(-3, 4, (2, 13, 17, 256), device='cuda', generator=g).float()
+    wi = torch.randint(-2, 3, (128, 256), device='cuda', generator=g).float()
+    want = F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double()[:, :, None, None]).permute(0, 2, 3, 1)
+    ex, x3 = _x3_and_exact(lambda: ops.pointwise(xi, wi))
+    assert torch.equal(x3.double(), want) and torch.equal(ex, x3)
+    # two sources along K (a stage's first bottleneck: last 1x1 + strided convolutional shortcut as one contraction)
+    x1 = torch.randn((2, 13, 21, 128), device='cuda', generator=g)
+    x2 = torch.randn((2, 25, 42, 256), device='cuda', generator=g)
+    w = torch.randn((512, 128 + 256), device='cuda', generator=g) * 0.05
+    b = torch.randn(512, device='cuda', generator=g)
+    want = torch.relu(x1.double() @ w[:, :128].double().t() + x2[:, ::2, ::2].double() @ w[:, 128:].double().t() + b.double())
+    close(lambda: ops.pointwise_dual(x1, x2, w, b, 2, True), want, 'dual')
+    # the lateral convolution with the top-down merge in its epilogue: the merge arithmetic is the float32 kernel's
+    c = torch.randn((2, 26, 42, 512), device='cuda', generator=g)
+    top = torch.randn((2, 13, 21, 256), device='cuda', generator=g)
+    w = torch.randn((256, 512), device='cuda', generator=g) * 0.04
+    b = torch.randn(256, device='cuda', generator=g)
+    ex, x3 = _x3_and_exact(lambda: ops.lateral_merge(c, w, b, top))
+    lat = _x3_and_exact(lambda: ops.pointwise(c, w, b))[1]
+    assert torch.equal(x3, ops.fpn_topdown_merge(top, lat))                       # bit-identical to merge(conv_x3)
+    assert float((x3 - ex).abs().max()) <= 1e-5 * float(ex.abs().max())
+    # all pyramid levels in one launch == level by level
+    xs = [torch.randn((2, h, w_, 256), device='cuda', generator=g) for h, w_ in ((48, 64), (24, 32), (12, 16), (6, 8), (3, 4))]
+    w = (torch.randn((512, 256, 3, 3), device='cuda', generator=g) * 0.02).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(512, device='cuda', generator=g)
+    with ops.f32_form('x3'):
+        together = ops.conv3x3_f32_levels(xs, w, b, relu=True)
+        single = [ops.conv3x3_f32(x, w, b, relu=True) for x in xs]
+    assert all(torch.equal(a, s_) for a, s_ in zip(together, single))
+    # the limb planes: exact sum, cached per weight tensor
+    planes = ops.split_bf16x3(w.permute(0, 2, 3, 1).contiguous())
+    parts = (planes.view(torch.bfloat16).double()).sum(0)
+    assert torch.equal(parts, w.permute(0, 2, 3, 1).double())
+
+
+@pytest.mark.gpu
+def test_float32_x3_detector_agrees_with_the_exact_float32_detector():
+    """the split-precision float32 mode against the exact-float32 mode on the SAME weights and images:
+    class scores / boxes within 1e-4 (relative to the image scale for boxes), the RPN's kept anchor indices equal up to the
+    ties float32 rounding decides (reported; >= 99 % here), same number of detections"""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(1)
+    shape, K = (256, 352), 300
+    a = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=2, blind_chunks=3).prepare()
+    b = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=2, blind_chunks=3, f32_form='x3')
+    b.load_state_dict(a.state_dict())
+    b.prepare()
+    rng = np.random.default_rng(1)
+    img = torch.from_numpy((rng.uniform(0, 255, (2,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    oa, ob = a(img), b(img)
+    torch.cuda.synchronize()
+    sa, da, _, _ = a._last_pass
+    sb, db, _, _ = b._last_pass
+    assert float((sa - sb).abs().max()) <= 1e-4 * max(1.0, float(sa.abs().max()))
+    assert float((da - db).abs().max()) <= 1e-4 * max(1.0, float(da.abs().max()))
+    for i in range(2):
+        ka, kb = int(a._hot[i].roi_count.item()), int(b._hot[i].roi_count.item())
+        ia, ib = set(a._hot[i].roi_idx[:ka].tolist()), set(b._hot[i].roi_idx[:kb].tolist())
+        assert len(ia & ib) >= 0.99 * max(len(ia), 1), (len(ia & ib), len(ia))
+        na, nb = int(oa[i][3].item()), int(ob[i][3].item())
+        assert abs(na - nb) <= 1 and na > 0

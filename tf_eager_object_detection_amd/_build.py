@@ -11,9 +11,9 @@ CSRC = os.path.join(PKG, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(PKG), 'include')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libodet_hip.so')
-SOURCES = ['boxes.hip', 'sort.hip', 'nms.hip', 'roi.hip', 'roi_half.hip', 'postops.hip', 'neck.hip', 'epilogue.hip', 'conv1x1.hip', 'conv3x3.hip', 'conv_f32.hip', 'rpn_tail.hip',
+SOURCES = ['boxes.hip', 'sort.hip', 'nms.hip', 'roi.hip', 'roi_half.hip', 'postops.hip', 'neck.hip', 'epilogue.hip', 'conv1x1.hip', 'conv3x3.hip', 'conv_f32.hip', 'conv_x3.hip', 'rpn_tail.hip',
            'calib.hip', 'stem.hip', 'executor.hip']
-HEADERS = [os.path.join(CSRC, 'odet_internal.h'), os.path.join(INCLUDE, 'odet.h')]
+HEADERS = [os.path.join(CSRC, 'odet_internal.h'), os.path.join(CSRC, 'conv_f32_common.h'), os.path.join(INCLUDE, 'odet.h')]
 
 # -ffp-contract=off: the parity contract is "one IEEE float32 operation per reference
 # operation"; an FMA would change low bits of box coordinates and bilinear taps.

@@ -23,30 +23,13 @@
 #include <cstdlib>
 #include <mutex>
 
-#include "odet_internal.h"
+#include "conv_f32_common.h"
 
-typedef float c3f4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t f32_rsrc_t;
 typedef __attribute__((address_space(3))) void* f32_lds_ptr;
 
 #define F32_BK 32                 // input channels per K-step (128 bytes per row)
 #define F32_LDS_MAX (160 * 1024)
-
-struct ConvF32Params {
-  const float* x[ODET_MAX_LEVELS]; float* y[ODET_MAX_LEVELS];
-  const float* w; const float* bias;
-  long long M[ODET_MAX_LEVELS];
-  int H[ODET_MAX_LEVELS], W[ODET_MAX_LEVELS];
-  long long tile_start[ODET_MAX_LEVELS + 1];
-  int num_levels, cin, cout, relu;
-  int tiles_n;
-  // pointwise form (TAPS == 1, one map): output row m = (image, yo, xo) of a Ho x Wo map reads input pixel (yo, xo) * stride
-  int stride, Ho, Wo;
-  long long Min;
-  const float* res;               // + shortcut [M][cout]
-  const float* top; int th, tw; float tys, txs;   // or the FPN top-down merge: 0.5 * resize(top) + 0.5 * (conv + bias)
-  const float* x2; int cin2, k1steps; long long Min2;   // or two sources along K ([x | x2(::stride)], weights concatenated)
-};
 
 template <int MT, int WN, int TAPS>
 __device__ __forceinline__ void conv_tile_f32(const ConvF32Params& p) {
@@ -229,67 +212,7 @@ __device__ __forceinline__ void conv_tile_f32(const ConvF32Params& p) {
       compute(lds + stage);
     }
   }
-  // ---- epilogue: lane = pixel l15 of every pixel tile; tile t of the wave's 64-channel group: channels c0 + 16 t .. + 3
-  const int c0 = tn * TN + wn * 64 + lq * 4;
-  c3f4 bv[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    bv[t] = p.bias ? *reinterpret_cast<const c3f4*>(p.bias + c0 + 16 * t) : (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
-    if (m < M) {
-      float* dst = p.y[lv] + m * cout + c0;
-      if constexpr (TAPS == 1) {
-        if (p.top) {
-          // the FPN top-down merge (neck.hip's arithmetic and operation order, float32 throughout: bit-identical to
-          // odet_fpn_topdown_merge applied to the convolution's float32 result)
-          const long long opx = (long long)p.Ho * p.Wo;
-          const long long img = m / opx;
-          const int rem = (int)(m - img * opx);
-          const int yy = rem / p.Wo, xx = rem - yy * p.Wo;
-          const float fy = (float)yy * p.tys, fx = (float)xx * p.txs;
-          const float y0f = floorf(fy), x0f = floorf(fx);
-          const int y0 = (int)y0f, x0 = (int)x0f;
-          const int y1 = min(y0 + 1, p.th - 1), x1 = min(x0 + 1, p.tw - 1);
-          const float yl = fy - y0f, xl = fx - x0f;
-          const float* tb = p.top + (img * p.th * p.tw) * cout + c0;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const c3f4 a = *reinterpret_cast<const c3f4*>(tb + ((long long)y0 * p.tw + x0) * cout + 16 * t);
-            const c3f4 b = *reinterpret_cast<const c3f4*>(tb + ((long long)y0 * p.tw + x1) * cout + 16 * t);
-            const c3f4 c = *reinterpret_cast<const c3f4*>(tb + ((long long)y1 * p.tw + x0) * cout + 16 * t);
-            const c3f4 d = *reinterpret_cast<const c3f4*>(tb + ((long long)y1 * p.tw + x1) * cout + 16 * t);
-            c3f4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float lat = acc[mt][t][j] + bv[t][j];
-              const float tp = a[j] + (b[j] - a[j]) * xl;
-              const float bt = c[j] + (d[j] - c[j]) * xl;
-              const float up = tp + (bt - tp) * yl;
-              o[j] = up * 0.5f + lat * 0.5f;
-            }
-            *reinterpret_cast<c3f4*>(dst + 16 * t) = o;
-          }
-          continue;
-        }
-      }
-      const bool has_res = TAPS == 1 && p.res != nullptr;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        c3f4 o, r = (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
-        if (has_res) r = *reinterpret_cast<const c3f4*>(p.res + m * cout + c0 + 16 * t);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[mt][t][j] + bv[t][j];
-          if (has_res) v += r[j];
-          if (p.relu) v = v < 0.0f ? 0.0f : v;
-          o[j] = v;
-        }
-        *reinterpret_cast<c3f4*>(dst + 16 * t) = o;
-      }
-    }
-  }
+  conv_f32_epilogue<MT, TAPS>(p, acc, tile_m, TM, TN, wm, wn, tn, l15, lq, lv, M, cout);
 }
 
 template <int MT, int WN>

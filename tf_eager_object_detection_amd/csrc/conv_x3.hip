@@ -1,0 +1,528 @@
+// Split-precision float32 forms of the implicit-GEMM convolution kernel: the detectors' float32 mode at the reference's
+// accuracy on the bfloat16 matrix instructions (16 x the rate of the exact-float32 MFMA).  The reference computes its
+// convolutions / dense layers in float32 (resnet_fpn.py:154-289, 339-407; base_fpn_model.py:393-434); here every float32
+// operand is the EXACT sum of three bfloat16 limbs
+//
+//        a = a1 + a2 + a3,   a1 = bf16(a),  a2 = bf16(a - a1),  a3 = bf16(a - a1 - a2)        (round to nearest even; 3 x 8 = 24 bits)
+//
+// and a product is the six limb products down to 2^-16 of its size
+//
+//        a . b  ~  a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)         (dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-23 |a b|, random sign)
+//
+// each exact in float32 (8 x 8 bits), summed in the MFMA's float32 accumulator: the result is within float32 rounding of
+// the float64 truth, like the chain of float32 fused multiply-adds of v_mfma_f32_16x16x4_f32 (conv_f32.hip) -- a different,
+// equally valid float32 evaluation of the same sum -- at 6 bfloat16 MFMAs per 32 k instead of 8 float32 MFMAs per 32 k of 1/16 the
+// rate: 2.5 PFLOP/s / 6 = 417 "float32" TFLOP/s of peak against 157.
+//
+//  * WEIGHTS are split once on the host side (odet_split_bf16x3: three planes [3][cout][K] of bfloat16) and travel
+//    global -> LDS by LDS-DMA, 64-byte rows.
+//  * ACTIVATIONS stay float32 in memory (every layer reads and writes what conv_f32.hip does: a layer can run on either
+//    form).  A K-step (one tap x 32 channels = 128 bytes per pixel) is loaded into REGISTERS (buffer loads, the zero padding
+//    from the descriptor's range check), split there -- v_cvt_pk_bf16_f32 gives two limbs per instruction -- and written to
+//    LDS as three planes while the matrix pipe works on the previous K-step.
+//  * LDS image of a stage: [3 limbs][TM pixel rows][64 B] then [3 limbs][TN channel rows][64 B]; a fragment read takes 16
+//    consecutive rows x 64 B.  ds_read_b128 is served in groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...:
+//    MI355X guide, LDS table), and rows r and r + 4 of a 64-byte-row image share their banks: the 16-byte slot q of a row is
+//    therefore stored at q ^ 2 for rows 8..15 of every 16 -- each group then covers all 64 banks once (without it every
+//    fragment read is a 2-way conflict).
+//  * Workgroup = 8 waves, tile TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels, two stages; wave tile 16 MT pixels x 64
+//    channels: per K-step 3 x (4 + MT) fragment reads feed 24 MT MFMAs -- the loop is bound by the matrix pipe, not by LDS
+//    (the float16 kernel reads (4 + MT) fragments per 4 MT MFMAs).
+//  * Same transposed tiles, XCD-aware workgroup order, multi-level launches and epilogues (conv_f32_common.h) as the float32 kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+
+#include "conv_f32_common.h"
+
+typedef __bf16 x3b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 x3b2 __attribute__((ext_vector_type(2)));
+typedef float x3f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int x3u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int x3u2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t x3_rsrc_t;
+typedef __attribute__((address_space(3))) void* x3_lds_ptr;
+
+#define X3_BK 32                  // float32 input channels per K-step (128 bytes of a pixel's row; 64 bytes per limb)
+#define X3_LDS_MAX (160 * 1024)
+
+// two float32 -> their three bfloat16 limbs, packed (low half = first value)
+__device__ __forceinline__ void x3_split2(const x3f2 a, unsigned& h, unsigned& m, unsigned& l) {
+  const x3b2 hb = __builtin_convertvector(a, x3b2);
+  h = __builtin_bit_cast(unsigned, hb);
+  const x3f2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xFFFF0000u)};
+  const x3f2 r1 = a - hf;                                 // exact (the difference has at most 16 significant bits)
+  const x3b2 mb = __builtin_convertvector(r1, x3b2);
+  m = __builtin_bit_cast(unsigned, mb);
+  const x3f2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xFFFF0000u)};
+  const x3f2 r2 = r1 - mf;                                // exact (at most 8 significant bits are left)
+  const x3b2 lb = __builtin_convertvector(r2, x3b2);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
+// ---- weights: float32 [n] -> planes [3][n] of bfloat16 (once per weight tensor) ------------------------------------------------
+__global__ void __launch_bounds__(256) k_split_bf16x3(const float* __restrict__ w, unsigned* __restrict__ planes, long long n2) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
+    const x3f2 a = {w[2 * i], w[2 * i + 1]};
+    unsigned h, m, l;
+    x3_split2(a, h, m, l);
+    planes[i] = h; planes[n2 + i] = m; planes[2 * n2 + i] = l;
+  }
+}
+
+extern "C" int odet_split_bf16x3(const float* w, void* planes, long long n, odet_stream_t stream) {
+  ODET_REQUIRE(w && planes && n > 0 && n % 2 == 0, "odet_split_bf16x3: needs an even, positive element count");
+  const long long n2 = n / 2;
+  const int grid = (int)std::min<long long>((n2 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(k_split_bf16x3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)planes, n2);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+// ---- the tile ------------------------------------------------------------------------------------------------------------------
+// p.w = the weight PLANES (bfloat16 [3][cout][K], K = TAPS * cin (+ cin2)); everything else as in conv_f32.hip.
+template <int MT, int WN, int TAPS>
+__device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
+  constexpr int WM = 8 / WN;
+  constexpr int TM = WM * 16 * MT;
+  constexpr int TN = 64 * WN;
+  static_assert(TM % 64 == 0, "every wave loads whole 8-row pieces");
+  constexpr int XP = TM / 64;                            // pixel pieces (8 rows x 128 B of float32) per wave and K-step
+  constexpr int WPIECES = 3 * TN / 16;                   // weight pieces (16 rows x 64 B) per stage
+  constexpr int WPW = (WPIECES + 7) / 8;                 // per wave (the last ones only for the first waves)
+  constexpr uint32_t XLIMB = (uint32_t)TM * 64u;         // bytes of one limb plane of the pixel rows
+  constexpr uint32_t WLIMB = (uint32_t)TN * 64u;
+  constexpr uint32_t WBASE = 3u * XLIMB;
+  constexpr uint32_t STAGE = 3u * (XLIMB + WLIMB);
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WN, wn = wv % WN;
+  const long long blk = blockIdx.x;
+  const long long q8 = blk >> 3;
+  const long long slab = (blk & 7) + 8 * (q8 / p.tiles_n);
+  const int tn = (int)(q8 % p.tiles_n);
+  if (slab >= p.tile_start[p.num_levels]) return;
+  int lv = 0;
+#pragma unroll
+  for (int l = 1; l < ODET_MAX_LEVELS; ++l)
+    if (l < p.num_levels && slab >= p.tile_start[l]) lv = l;
+  const long long tile_m = slab - p.tile_start[lv];
+  const int H = p.H[lv], W = p.W[lv], cin = p.cin, cout = p.cout;
+  const uint32_t pixB = (uint32_t)cin * 4u;
+  const uint32_t PAD = TAPS == 9 ? (uint32_t)(W + 1) * pixB : 0u;
+  const uint32_t OOB = 0xFFFFFFF0u;
+  const long long M = p.M[lv];
+  const long long Min = TAPS == 9 ? M : p.Min;
+  const x3_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.x[lv])) - PAD, 0, (int)((uint32_t)Min * pixB + 2u * PAD), 0x00020000);
+  const bool dual = TAPS == 1 && p.x2 != nullptr;
+  const uint32_t pixB2 = dual ? (uint32_t)p.cin2 * 4u : 0u;
+  const x3_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(dual ? p.x2 : p.x[lv])), 0, (int)((uint32_t)(dual ? p.Min2 : 0) * pixB2), 0x00020000);
+  const uint32_t Ktot = (uint32_t)TAPS * (uint32_t)cin + (dual ? (uint32_t)p.cin2 : 0u);
+  const uint32_t wrowB = Ktot * 2u;                       // bytes of a weight row inside a limb plane
+  const uint32_t planeB = (uint32_t)cout * wrowB;
+  const x3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)(3u * planeB), 0x00020000);
+  // ---- what this thread loads per K-step: XP 16-byte slots of float32 pixel rows (row = piece * 8 + lane / 8, slot lane % 8)
+  const int sub = lane >> 3, sl = lane & 7;
+  uint32_t voffA[XP], voffA2[TAPS == 1 ? XP : 1], maskA[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int row = (wv + 8 * i) * 8 + sub;
+    const long long m = tile_m * TM + row;
+    uint32_t mk = 0;
+    if constexpr (TAPS == 9) {
+      if (m < M) {
+        const long long img = m / ((long long)H * W);
+        const int rem = (int)(m - img * H * W);
+        const int yy = rem / W, xx = rem - yy * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
+        }
+      }
+      voffA[i] = (uint32_t)m * pixB + (uint32_t)sl * 16u;
+    } else {
+      long long src = m;
+      if (p.stride != 1 && m < M) {
+        const long long opx = (long long)p.Ho * p.Wo;
+        const long long img = m / opx;
+        const int rem = (int)(m - img * opx);
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        src = (img * H + (long long)yo * p.stride) * W + (long long)xo * p.stride;
+      }
+      mk = m < M ? 1u : 0u;
+      voffA[i] = (uint32_t)(dual ? m : src) * pixB + (uint32_t)sl * 16u;
+      voffA2[i] = (uint32_t)src * pixB2 + (uint32_t)sl * 16u;
+    }
+    maskA[i] = mk;
+  }
+  // its weight pieces: piece pi = wv + 8 i -> limb pi / (TN / 16), rows 16 (pi % (TN / 16)) + lane / 4, 16-byte slot lane % 4
+  uint32_t voffW[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int pi = wv + 8 * i;
+    const int limb = pi / (TN / 16), rb = pi % (TN / 16);
+    const int ch = tn * TN + rb * 16 + (lane >> 2);
+    // (the DMA writes lane-linear: LDS slot lane % 4 of row lane / 4 receives the K slot (lane % 4) ^ 2 [rows 8..15])
+    voffW[i] = pi < WPIECES ? (uint32_t)limb * planeB + (uint32_t)ch * wrowB + (uint32_t)((lane & 3) ^ ((lane >> 5) << 1)) * 16u : OOB;
+  }
+  const int chunks = cin / X3_BK;
+  const int ksteps = TAPS * chunks + (dual ? p.cin2 / X3_BK : 0);
+  const int k1steps = dual ? p.k1steps : ksteps;
+  // the float32 slots of TWO K-steps in flight (buffer ks & 1): a load issued at the top of K-step ks is split and stored in
+  // the middle of K-step ks + 1 -- one and a half K-steps (~3 us) to arrive, whatever level of the memory system it comes from
+  x3u4 ra[2][XP];
+  auto load_a = [&](int ks, x3u4 (&r)[XP]) {
+    int tap = 0;
+    uint32_t soA;
+    if constexpr (TAPS == 9) {
+      tap = ks / chunks;
+      const int chunk = ks - tap * chunks;
+      soA = (uint32_t)((tap / 3) * W + tap % 3) * pixB + (uint32_t)chunk * 128u;
+    } else {
+      soA = (uint32_t)ks * 128u;
+    }
+#ifdef X3_DIAG_NOLOADA
+#pragma unroll
+    for (int i = 0; i < XP; ++i) r[i] = (x3u4){0x3f800000u + (unsigned)ks, 0x3f900000u, 0x3fa00000u, 0x3fb00000u};
+    return;
+#endif
+    if (TAPS == 1 && ks >= k1steps) {
+#pragma unroll
+      for (int i = 0; i < XP; ++i)
+        r[i] = __builtin_amdgcn_raw_buffer_load_b128(rx2, (int)((maskA[i] & 1u) ? voffA2[i] : OOB),
+                                                     (int)((uint32_t)(ks - k1steps) * 128u), 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < XP; ++i)
+        r[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(((maskA[i] >> tap) & 1u) ? voffA[i] : OOB), (int)soA, 0);
+    }
+  };
+  auto issue_w = [&](int ks, uint32_t stage) {
+#ifdef X3_DIAG_NOW
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < WPW; ++i)
+      if (WPIECES % 8 == 0 || wv + 8 * i < WPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (x3_lds_ptr)(lds + stage + WBASE + (uint32_t)(wv + 8 * i) * 1024u), 16,
+                                                 (int)voffW[i], (int)((uint32_t)ks * 64u), 0, 0);
+  };
+  // split a loaded slot and write its three limb planes: 4 channels = 8 bytes per limb
+  // (row = piece * 8 + sub, piece = wv + 8 i: rows 8..15 of a 16-row tile are the odd pieces = the odd waves)
+  const uint32_t sA = (uint32_t)sub * 64u + (uint32_t)(((sl >> 1) ^ ((wv & 1) << 1)) * 16 + (sl & 1) * 8);
+  auto store_piece = [&](const x3u4 v, int i, uint32_t stage) {
+#ifdef X3_DIAG_NOSPLIT
+    asm volatile("" :: "v"(v));
+    return;
+#endif
+#ifdef X3_DIAG_RAWSTORE
+    {
+      unsigned char* dst = lds + stage + (uint32_t)(wv + 8 * i) * 512u + sA;
+      *reinterpret_cast<x3u2*>(dst) = (x3u2){v[0], v[1]};
+      *reinterpret_cast<x3u2*>(dst + XLIMB) = (x3u2){v[2], v[3]};
+      *reinterpret_cast<x3u2*>(dst + 2u * XLIMB) = (x3u2){v[1], v[2]};
+      return;
+    }
+#endif
+    const c3f4 f = __builtin_bit_cast(c3f4, v);
+    unsigned h0, m0, l0, h1, m1, l1;
+    x3_split2((x3f2){f[0], f[1]}, h0, m0, l0);
+    x3_split2((x3f2){f[2], f[3]}, h1, m1, l1);
+    const x3u2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
+    unsigned char* dst = lds + stage + (uint32_t)(wv + 8 * i) * 512u + sA;
+    *reinterpret_cast<x3u2*>(dst) = h;
+    *reinterpret_cast<x3u2*>(dst + XLIMB) = m;
+    *reinterpret_cast<x3u2*>(dst + 2u * XLIMB) = l;
+  };
+  const int l15 = lane & 15, lq = lane >> 4;
+  const uint32_t fslot = (uint32_t)(lq ^ ((l15 >> 3) << 1)) * 16u;
+  const uint32_t xoff = (uint32_t)(wm * 16 * MT + l15) * 64u + fslot;                          // + mt * 1024 + limb * XLIMB
+  const uint32_t woff = WBASE + (uint32_t)(wn * 64 + l15) * 64u + fslot;                     // + t * 1024 + limb * WLIMB
+  c3f4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
+  constexpr int PPG = (XP + MT - 1) / MT;                // pixel pieces split and stored behind each group of MFMAs
+  // the MFMAs of stage `sb`; behind pixel tile mt's 24 MFMAs the pieces mt * PPG .. of the NEXT K-step (registers `r`) are
+  // split and stored into stage `nxt`: vector instructions and LDS stores issued in the shadow of the matrix pipe
+  auto compute = [&](const unsigned char* sb, const x3u4 (&r)[XP], uint32_t nxt, bool store, auto&& late_issue) {
+    x3b8 wf[3][4];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wf[l][t] = *reinterpret_cast<const x3b8*>(sb + woff + (uint32_t)l * WLIMB + (uint32_t)t * 1024u);
+    x3b8 xf[2][3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) xf[0][l] = *reinterpret_cast<const x3b8*>(sb + xoff + (uint32_t)l * XLIMB);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int c = mt & 1;
+      if (mt + 1 < MT) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+          xf[c ^ 1][l] = *reinterpret_cast<const x3b8*>(sb + xoff + (uint32_t)l * XLIMB + (uint32_t)(mt + 1) * 1024u);
+      }
+      // the six products, smallest first; four independent accumulators between two MFMAs on the same one
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][t], xf[c][0], acc[mt][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], xf[c][2], acc[mt][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], xf[c][1], acc[mt][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], xf[c][0], acc[mt][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], xf[c][1], acc[mt][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], xf[c][0], acc[mt][t], 0, 0, 0);
+      if (mt == (MT > 1 ? 1 : 0)) late_issue();
+      if (store) {
+#pragma unroll
+        for (int j = 0; j < PPG; ++j)
+          if (mt * PPG + j < XP) store_piece(r[mt * PPG + j], mt * PPG + j, nxt);
+      }
+    }
+  };
+  // ---- K loop.  Step ks: the weights of step ks + 1 travel into the other stage (LDS-DMA), the pixel slots of step ks + 2 into
+  // registers; the slots of step ks + 1 (loaded a step ago) are split and stored between the MFMAs of step ks.  The counted
+  // wait before the barrier leaves the newest XP loads (step ks + 2) in flight; a bare s_barrier, because __syncthreads() would
+  // drain them too.
+  auto step = [&](int ks, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {
+    const uint32_t cur = (uint32_t)(ks & 1) * STAGE, nxt = STAGE - cur;
+    const bool more = ks + 1 < ksteps, more2 = ks + 2 < ksteps;
+    // the two waves of a SIMD (w and w + 4) run the same program between the same barriers: waves 0-3 issue their copies
+    // right after the barrier, waves 4-7 behind their second group of MFMAs, so that one of the two always has matrix work
+    const bool early = wv < 4;
+    if (early) {
+      if (more) issue_w(ks + 1, nxt);
+      if (more2) load_a(ks + 2, rfree);
+    }
+    compute(lds + cur, rnext, nxt, more, [&] {
+      if (!early) {
+        if (more) issue_w(ks + 1, nxt);
+        if (more2) load_a(ks + 2, rfree);
+      }
+    });
+    if (more2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  issue_w(0, 0u);
+  load_a(0, ra[0]);
+  if (ksteps > 1) load_a(1, ra[1]);
+#pragma unroll
+  for (int i = 0; i < XP; ++i) store_piece(ra[0][i], i, 0u);
+  if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int ks = 0; ks < ksteps; ks += 2) {
+    step(ks, ra[0], ra[1]);                              // (step ks stores ra[1] = the slots of ks + 1, refills ra[0] with ks + 2)
+    if (ks + 1 < ksteps) step(ks + 1, ra[1], ra[0]);
+  }
+  conv_f32_epilogue<MT, TAPS>(p, acc, tile_m, TM, TN, wm, wn, tn, l15, lq, lv, M, cout);
+}
+
+template <int MT, int WN>
+__global__ void __launch_bounds__(512) k_conv3x3_x3(ConvF32Params p) {
+  conv_tile_x3<MT, WN, 9>(p);
+}
+
+template <int MT, int WN>
+__global__ void __launch_bounds__(512) k_pointwise_x3(ConvF32Params p) {
+  conv_tile_x3<MT, WN, 1>(p);
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------------
+// tiles (MT, WN): 256 x 128, 128 x 128 | 128 x 256 | 256 x 64, 128 x 64, 64 x 64 (pixels x channels)
+#define X3_FOR_TILES(F) F(4, 2) F(2, 2) F(4, 4) F(2, 1) F(1, 1)
+
+template <typename F>
+static void x3_for_each_kernel(F f) {
+#define X3_K(MT_, WN_) f((const void*)k_conv3x3_x3<MT_, WN_>); f((const void*)k_pointwise_x3<MT_, WN_>);
+  X3_FOR_TILES(X3_K)
+#undef X3_K
+}
+
+static hipError_t x3_prepare_kernels() {
+  static std::once_flag once;
+  static hipError_t once_rc = hipSuccess;
+  std::call_once(once, [] {
+    x3_for_each_kernel([](const void* k) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_MAX);
+      if (e != hipSuccess) once_rc = e;
+    });
+  });
+  return once_rc;
+}
+
+static unsigned x3_lds_bytes(int tm, int tn) { return (unsigned)(2 * 3 * (tm + tn) * 64); }
+
+// the tile with the least (rounds of 256 workgroups) x (matrix cycles per K-step + the per-step overhead a workgroup pays for
+// its barrier, its copies and the split of its pixel rows)
+static void x3_pick_tile(const long long* M, int num_levels, int cout, int* wn_out, int* mt_out) {
+  static const int cand[][2] = {{4, 2}, {2, 2}, {4, 4}, {2, 1}, {1, 1}};       // (mt, wn)
+  int wn_best = 0, mt_best = 0;
+  double best = 1e300;
+  for (const auto& c : cand) {
+    const int mt = c[0], wn = c[1];
+    if (cout % (64 * wn)) continue;
+    const int wm = 8 / wn, tm = wm * 16 * mt, tn = 64 * wn, tiles_n = cout / tn;
+    long long slabs = 0;
+    for (int l = 0; l < num_levels; ++l) slabs += (M[l] + tm - 1) / tm;
+    const long long blocks = (slabs + 7) / 8 * 8 * tiles_n;
+    const int occ = std::max(1, std::min(2, (int)(X3_LDS_MAX / x3_lds_bytes(tm, tn))));
+    // matrix cycles of a K-step for the CU: 6 MFMAs of 16 cycles per 16 x 16 tile on 4 SIMDs; + ~600 cycles of per-step overhead
+    const double per = (double)tm * tn / 256.0 * 6.0 * 16.0 / 4.0 + 600.0 / occ;
+    const double cost = (double)((blocks + 256 * occ - 1) / (256 * occ)) * per * occ;
+    if (cost < best * 0.98) { best = cost; wn_best = wn; mt_best = mt; }
+  }
+  *wn_out = wn_best; *mt_out = mt_best;
+}
+
+template <bool PW>
+static int x3_launch_tile(int wn, int mt, dim3 grid, unsigned lds_bytes, hipStream_t st, const ConvF32Params& p) {
+#define X3_L(MT_, WN_)                                                                                      \
+  if (mt == MT_ && wn == WN_) {                                                                             \
+    if (PW) hipLaunchKernelGGL((k_pointwise_x3<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);              \
+    else hipLaunchKernelGGL((k_conv3x3_x3<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);                   \
+    return ODET_OK;                                                                                         \
+  }
+  X3_FOR_TILES(X3_L)
+#undef X3_L
+  return odet_set_error(ODET_E_INVALID, "conv_x3: no kernel for the tile (mt %d, wn %d)", mt, wn);
+}
+
+static void x3_defaults(ConvF32Params* p) {
+  p->stride = 1; p->Ho = p->Wo = 0; p->Min = 0; p->res = nullptr; p->top = nullptr; p->th = p->tw = 0; p->tys = p->txs = 0.0f;
+  p->x2 = nullptr; p->cin2 = 0; p->k1steps = 0; p->Min2 = 0;
+}
+
+static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias, int batch,
+                             int cin, int cout, int relu, hipStream_t st) {
+  ODET_REQUIRE(levels && w3, "odet_conv3x3_x3: null pointer");
+  ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_x3: num_levels %d out of range", num_levels);
+  ODET_REQUIRE(batch > 0, "odet_conv3x3_x3: bad batch");
+  ODET_REQUIRE(cin > 0 && cin % X3_BK == 0, "odet_conv3x3_x3: cin %d must be a multiple of %d", cin, X3_BK);
+  ODET_REQUIRE(cout > 0 && cout % 64 == 0, "odet_conv3x3_x3: cout %d must be a multiple of 64", cout);
+  ODET_REQUIRE((unsigned long long)cout * 9ull * cin * 6ull < 0x7FFFFFFFull, "odet_conv3x3_x3: weights too large");
+  ODET_REQUIRE((uintptr_t)w3 % 16 == 0 && (uintptr_t)bias % 16 == 0, "odet_conv3x3_x3: pointers must be 16-byte aligned");
+  ODET_HIP(x3_prepare_kernels());
+  ConvF32Params p;
+  x3_defaults(&p);
+  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
+    const odet_conv_level_t& L = levels[l < num_levels ? l : 0];
+    ODET_REQUIRE(L.x && L.y && L.H > 0 && L.W > 0, "odet_conv3x3_x3: bad level %d", l);
+    ODET_REQUIRE(((uintptr_t)L.x | (uintptr_t)L.y) % 16 == 0, "odet_conv3x3_x3: maps must be 16-byte aligned");
+    const long long M = (long long)batch * L.H * L.W;
+    ODET_REQUIRE((unsigned long long)M * cin * 4ull + 2ull * (L.W + 1) * cin * 4ull < 0xFFFFFFF0ull,
+                 "odet_conv3x3_x3: level %d input larger than 4 GiB", l);
+    p.x[l] = (const float*)L.x; p.y[l] = (float*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
+  }
+  int wn, mt;
+  x3_pick_tile(p.M, num_levels, cout, &wn, &mt);
+  const int TMsel = (8 / wn) * 16 * mt;
+  long long total = 0;
+  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
+    p.tile_start[l] = total;
+    if (l < num_levels) total += (p.M[l] + TMsel - 1) / TMsel;
+  }
+  for (int l = num_levels; l <= ODET_MAX_LEVELS; ++l) p.tile_start[l] = total;
+  p.w = (const float*)w3; p.bias = (const float*)bias;
+  p.num_levels = num_levels; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
+  p.tiles_n = cout / (64 * wn);
+  const long long blocks = (total + 7) / 8 * 8 * p.tiles_n;
+  ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_x3: too many workgroups");
+  const int rc = x3_launch_tile<false>(wn, mt, dim3((unsigned)blocks), x3_lds_bytes(TMsel, 64 * wn), st, p);
+  if (rc != ODET_OK) return rc;
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+extern "C" int odet_conv3x3_x3(const void* x, const void* w3, const void* bias, void* y, int batch, int H, int W, int cin,
+                               int cout, int relu, odet_stream_t stream) {
+  ODET_REQUIRE(x && y, "odet_conv3x3_x3: null pointer");
+  const odet_conv_level_t one{x, y, H, W};
+  return conv3x3_x3_launch(&one, 1, w3, bias, batch, cin, cout, relu, (hipStream_t)stream);
+}
+
+extern "C" int odet_conv3x3_x3_levels(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
+                                      int batch, int cin, int cout, int relu, odet_stream_t stream) {
+  return conv3x3_x3_launch(levels, num_levels, w3, bias, batch, cin, cout, relu, (hipStream_t)stream);
+}
+
+struct PwX3Epilogue { const void* res; const void* top; int th, tw; const void* x2; int cin2; };
+
+static int pointwise_x3_launch(const char* who, const void* x, const void* w3, const void* bias, void* y, int batch, int H,
+                               int W, int stride, int cin, int cout, int relu, const PwX3Epilogue& epi, hipStream_t st) {
+  ODET_REQUIRE(x && w3 && y, "%s: null pointer", who);
+  ODET_REQUIRE(batch > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", who);
+  ODET_REQUIRE(cin % X3_BK == 0 && cin > 0, "%s: cin %d must be a positive multiple of %d", who, cin, X3_BK);
+  ODET_REQUIRE(cout > 0 && cout % 64 == 0, "%s: cout %d must be a multiple of 64", who, cout);
+  ODET_REQUIRE(((uintptr_t)x | (uintptr_t)w3 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)epi.res | (uintptr_t)epi.top |
+                (uintptr_t)epi.x2) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
+  ODET_REQUIRE(!(epi.res && epi.top), "%s: shortcut and top-down merge exclude each other", who);
+  ODET_REQUIRE(!epi.top || (stride == 1 && epi.th > 0 && epi.tw > 0 && !relu), "%s: bad merge arguments", who);
+  ODET_HIP(x3_prepare_kernels());
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const long long M = (long long)batch * Ho * Wo;
+  const long long Min = epi.x2 ? M : (long long)batch * H * W;
+  ODET_REQUIRE((unsigned long long)Min * cin * 4ull < 0xFFFFFFF0ull, "%s: input larger than 4 GiB", who);
+  ODET_REQUIRE(!epi.x2 || (epi.cin2 > 0 && epi.cin2 % X3_BK == 0 &&
+                           (unsigned long long)batch * H * W * epi.cin2 * 4ull < 0xFFFFFFF0ull), "%s: bad second source", who);
+  ODET_REQUIRE((unsigned long long)cout * (cin + (epi.x2 ? epi.cin2 : 0)) * 6ull < 0x7FFFFFFFull, "%s: weights too large", who);
+  ConvF32Params p;
+  x3_defaults(&p);
+  for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
+    p.x[l] = (const float*)x; p.y[l] = (float*)y; p.M[l] = M; p.H[l] = H; p.W[l] = W;
+  }
+  p.res = (const float*)epi.res;
+  p.top = (const float*)epi.top; p.th = epi.th; p.tw = epi.tw;
+  p.tys = epi.top ? (float)epi.th / (float)Ho : 0.0f;
+  p.txs = epi.top ? (float)epi.tw / (float)Wo : 0.0f;
+  p.stride = stride; p.Ho = Ho; p.Wo = Wo; p.Min = Min;
+  p.x2 = (const float*)epi.x2; p.cin2 = epi.x2 ? epi.cin2 : 0; p.k1steps = cin / X3_BK; p.Min2 = (long long)batch * H * W;
+  int wn, mt;
+  x3_pick_tile(&M, 1, cout, &wn, &mt);
+  const int TMsel = (8 / wn) * 16 * mt;
+  p.tiles_n = cout / (64 * wn);
+  const long long total = (M + TMsel - 1) / TMsel;
+  p.tile_start[0] = 0;
+  for (int l = 1; l <= ODET_MAX_LEVELS; ++l) p.tile_start[l] = total;
+  p.w = (const float*)w3; p.bias = (const float*)bias;
+  p.num_levels = 1; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
+  const long long blocks = (total + 7) / 8 * 8 * p.tiles_n;
+  ODET_REQUIRE(blocks < (1ll << 31), "%s: too many workgroups", who);
+  const int rc = x3_launch_tile<true>(wn, mt, dim3((unsigned)blocks), x3_lds_bytes(TMsel, 64 * wn), st, p);
+  if (rc != ODET_OK) return rc;
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
+extern "C" int odet_pointwise_x3(const void* x, const void* w3, const void* bias, const void* residual, void* y, int batch,
+                                 int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream) {
+  const PwX3Epilogue e{residual, nullptr, 0, 0, nullptr, 0};
+  return pointwise_x3_launch("odet_pointwise_x3", x, w3, bias, y, batch, H, W, stride, cin, cout, relu, e, (hipStream_t)stream);
+}
+
+extern "C" int odet_lateral_merge_x3(const void* x, const void* w3, const void* bias, const void* top, int th, int tw, void* y,
+                                     int batch, int H, int W, int cin, int cout, odet_stream_t stream) {
+  ODET_REQUIRE(top, "odet_lateral_merge_x3: null pointer");
+  const PwX3Epilogue e{nullptr, top, th, tw, nullptr, 0};
+  return pointwise_x3_launch("odet_lateral_merge_x3", x, w3, bias, y, batch, H, W, 1, cin, cout, 0, e, (hipStream_t)stream);
+}
+
+extern "C" int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
+                                      const void* w3, const void* bias, void* y, int batch, int cout, int relu,
+                                      odet_stream_t stream) {
+  ODET_REQUIRE(x2, "odet_pointwise_dual_x3: null pointer");
+  const PwX3Epilogue e{nullptr, nullptr, 0, 0, x2, cin2};
+  return pointwise_x3_launch("odet_pointwise_dual_x3", x1, w3, bias, y, batch, H2, W2, stride2, cin1, cout, relu, e,
+                             (hipStream_t)stream);
+}

@@ -312,6 +312,17 @@ def rpn_pair_padded(m, w):
     return c[1]
 
 
+def _in_f32_form(method):
+    """runs a detector's dense method with the float32 layers in the detector's `f32_form` ('exact' | 'x3': ops.f32_form)"""
+    import functools
+
+    @functools.wraps(method)
+    def run(self, *args, **kw):
+        with ops.f32_form(getattr(self, 'f32_form', 'exact')):
+            return method(self, *args, **kw)
+    return run
+
+
 class _FinalLayer:
     """The RoI heads' last layer of the three detectors: class logits and box regressions as ONE contraction with the
     concatenated [Ccls + 4 Ccls, K] weights (rows zero-padded to a multiple of 64) on the pointwise GEMM kernel, float32
@@ -428,10 +439,13 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
     per image, the padded detections of post_ops_prediction plus their count on the device."""
 
     def __init__(self, depth=101, num_classes=21, image_shape=(800, 1333), num_proposals=1000, dtype=torch.float32,
-                 max_batch=1, **hot_kwargs):
+                 max_batch=1, f32_form='exact', **hot_kwargs):
         super().__init__()
         b = _BLOCKS[depth]
         self.dtype = dtype
+        # float32 mode only: 'exact' = exact-float32 matrix instructions (the parity mode), 'x3' = split precision (three
+        # bfloat16 limbs per operand, six products per k, float32 accumulation: float32-class accuracy at 2.6 x the peak rate)
+        self.f32_form = f32_form
         self.image_shape = (int(image_shape[0]), int(image_shape[1]))
         self.num_classes = num_classes
         # extractor (resnet_fpn.py:228-259, 262-289)
@@ -487,6 +501,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         return self
 
     # ---- dense parts ---------------------------------------------------------------------------
+    @_in_f32_form
     def extractor(self, images_nhwc):
         """[B,H,W,3] -> (C2, C3, C4, C5) channels_last (get_resnet_v1_extractor, resnet_fpn.py:262-289)."""
         # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 -- float16: one launch from the image; otherwise
@@ -502,6 +517,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         """[B,H,W,3] -> (P2..P6), each [B,256,h,w] channels_last (= NHWC in memory)."""
         return self.neck(self.extractor(images_nhwc))
 
+    @_in_f32_form
     def neck(self, c_list):
         """(C2..C5) -> (P2..P6) (ResnetFpnNeck.call, resnet_fpn.py:378-407)."""
         c2, c3, c4, c5 = c_list
@@ -526,6 +542,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         float32 bit-identical to the TF1 restatement): for callers that already hold the lateral map."""
         return ops.fpn_topdown_merge(_nhwc(top), _nhwc(lateral)).permute(0, 3, 1, 2)
 
+    @_in_f32_form
     def rpn(self, p_list):
         """shared RpnHead on every level; outputs concatenated P2->P6 in (y, x, anchor) order
         (base_fpn_model.py:188-200, 427-432): scores [B, N, 2], deltas [B, N, 4] (float32)."""
@@ -570,6 +587,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         x = ops.dense(x if x.is_contiguous() else x.contiguous(), self.fc1.weight, self.fc1.bias, relu=True)
         return ops.dense(x, self.fc2.weight, self.fc2.bias, relu=True)
 
+    @_in_f32_form
     def roi_head(self, roi_features):
         """RoI features [R,7,7,256] -> (class logits [R,Ccls], box regressions [R,4 Ccls]), float32 (resnet_fpn.py:292-336)"""
         return self._final_outputs(self.head_activation(roi_features))

@@ -16,7 +16,7 @@ from .. import ops
 from ..pipeline import FrcnnHotPath, FrcnnStepBatch
 from . import fpn_detector as fpn
 from .fpn_detector import _BLOCKS, DEFAULT_BLIND_CHUNKS, ResNetFpnDetector, _NmsCompleteness, _FinalLayer, _conv, _conv_epi, _stem, \
-    _conv_relu_pool, _fold_frozen_bn, _nhwc, _no_kernel, _stack, rpn_pair_weights
+    _conv_relu_pool, _fold_frozen_bn, _in_f32_form, _nhwc, _no_kernel, _stack, rpn_pair_weights
 
 __all__ = ['ResNetC4Detector', 'Vgg16Detector']
 
@@ -26,10 +26,11 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
     (mean-subtracted) and returns, per image, the padded detections of post_ops_prediction + their count."""
 
     def __init__(self, depth=50, num_classes=21, image_shape=(800, 1333), num_proposals=300, dtype=torch.float32,
-                 max_batch=1, roi_chunk=0, **hot_kwargs):
+                 max_batch=1, roi_chunk=0, f32_form='exact', **hot_kwargs):
         super().__init__()
         b = _BLOCKS[depth]
         self.dtype = dtype
+        self.f32_form = f32_form             # float32 mode: 'exact' | 'x3' (model/fpn_detector.py)
         self.image_shape = (int(image_shape[0]), int(image_shape[1]))
         self.num_classes = num_classes
         # extractor (resnet_faster_rcnn.py:104-153): conv1 .. conv4, stride 16
@@ -109,12 +110,14 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         return out
 
     # ---- dense parts ---------------------------------------------------------------------------
+    @_in_f32_form
     def features(self, images_nhwc):
         """[B,H,W,3] -> C4 [B,1024,ceil(H/16),ceil(W/16)] channels_last (= NHWC in memory)."""
         # conv1_pad + valid 7x7/2, bias + ReLU, pool1_pad (zeros) + 3x3/2 (float16: one launch from the image)
         x = _stem(self.conv1, images_nhwc, self.dtype)
         return self.conv4(self.conv3(self.conv2(x)))
 
+    @_in_f32_form
     def rpn(self, c4):
         """RpnHead: scores [B, fh*fw, 2A] ([A bg | A fg] per location), deltas [B, fh*fw*A, 4] (float32)."""
         x = _conv_epi(self.rpn_conv, c4, relu=True)
@@ -142,6 +145,7 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         y = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
         return y.contiguous()
 
+    @_in_f32_form
     def roi_head(self, roi_features):
         """-> (score logits [R,C], box deltas [R,4C]), float32"""
         return self._final_outputs(self.head_activation(roi_features))
@@ -237,9 +241,10 @@ class Vgg16Detector(ResNetC4Detector):
     _CFG = ((64, 2), (128, 2), (256, 3), (512, 3), (512, 3))
 
     def __init__(self, num_classes=21, image_shape=(600, 800), num_proposals=300, dtype=torch.float32, max_batch=1,
-                 **hot_kwargs):
+                 f32_form='exact', **hot_kwargs):
         nn.Module.__init__(self)
         self.dtype = dtype
+        self.f32_form = f32_form
         self.image_shape = (int(image_shape[0]), int(image_shape[1]))
         self.num_classes = num_classes
         convs, cin = [], 3
@@ -266,6 +271,7 @@ class Vgg16Detector(ResNetC4Detector):
         self._max_batch = max_batch
         self._roi_chunk = 0
 
+    @_in_f32_form
     def features(self, images_nhwc):
         """[B,H,W,3] -> conv5_3 [B,512,ceil(H/16),ceil(W/16)] channels_last."""
         first = self.convs[0]

@@ -22,6 +22,66 @@ POSTOPS_MAX_ROIS = 4096
 POSTOPS_MAX_CANDIDATES = 8192
 MAX_LEVELS = 8
 
+# ---- the float32 layers' arithmetic form ------------------------------------------------------------------------------------
+# 'exact': v_mfma_f32_16x16x4_f32 (csrc/conv_f32.hip) -- every product and sum rounded to float32 once, a chain of fmaf.
+# 'x3':    split precision (csrc/conv_x3.hip) -- float32 operands as three bfloat16 limbs, six limb products per k on the
+#          bfloat16 matrix instructions, float32 accumulation: within float32 rounding of the float64 truth like 'exact',
+#          2.6 x its peak rate.  Same tensors in memory; only the weights get a cached companion (their limb planes).
+# A fixed choice of the caller (the detectors' `f32_form` argument), never a timing decision: the two forms round differently.
+_F32_FORM = ['exact']
+
+
+class f32_form:
+    """with ops.f32_form('x3'): ...  -- the form the float32 conv3x3 / pointwise / dense / lateral_merge / pointwise_dual calls
+    inside the block run on"""
+
+    def __init__(self, form):
+        if form not in ('exact', 'x3'):
+            raise ValueError("f32 form must be 'exact' or 'x3'")
+        self.form = form
+
+    def __enter__(self):
+        self.prev = _F32_FORM[0]
+        _F32_FORM[0] = self.form
+        return self
+
+    def __exit__(self, *exc):
+        _F32_FORM[0] = self.prev
+        return False
+
+
+_X3_PLANES = {}
+
+
+def split_bf16x3(w):
+    """float32 contiguous GPU tensor (even element count) -> its three bfloat16 limb planes, int16 [3, *w.shape]
+    (odet_split_bf16x3): w == plane0 + plane1 + plane2 exactly (round to nearest even at every limb)."""
+    if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous() or w.numel() % 2:
+        raise ValueError('split_bf16x3: needs a contiguous float32 GPU tensor with an even element count')
+    planes = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)
+    L.call('odet_split_bf16x3', L.dptr(w), C.c_void_p(planes.data_ptr()), w.numel(), L.stream())
+    return planes
+
+
+def _x3_planes(w):
+    """the limb planes of the (contiguous, float32) weight tensor `w`, cached until it is modified or freed: the entry keeps
+    `w` alive, so its address cannot be recycled under the key"""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _X3_PLANES.get(key)
+    if hit is None:
+        if len(_X3_PLANES) > 4096:
+            _X3_PLANES.clear()
+        hit = (w, split_bf16x3(w))
+        _X3_PLANES[key] = hit
+    return hit[1]
+
+
+def _f32_sym(sym, w):
+    """(entry point, weight pointer) of a float32 layer in the current form"""
+    if _F32_FORM[0] == 'x3':
+        return sym[:-3] + 'x3', C.c_void_p(_x3_planes(w).data_ptr())       # odet_*_f32 -> odet_*_x3
+    return sym, L.dptr(w)
+
 
 def _boxes(t, name):
     t = L.f32c(t, name)
@@ -453,7 +513,10 @@ def _conv3x3(dtype, x, weight, bias, relu, out):
         out = torch.empty(shape, dtype=dtype, device=x.device)
     elif out.dtype != dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous %s tensor [B,H,W,cout]' % name)
-    L.call(sym, L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
+    wp = L.dptr(w)
+    if dtype == torch.float32:
+        sym, wp = _f32_sym(sym, w)
+    L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
            cin, cout, 1 if relu else 0, L.stream())
     return out
 
@@ -477,7 +540,10 @@ def _conv3x3_levels(dtype, xs, weight, bias, relu, outs):
         if y.dtype != dtype or tuple(y.shape) != tuple(x.shape[:3]) + (cout,) or not y.is_contiguous():
             raise ValueError('outs must be contiguous %s tensors [B,H,W,cout]' % name)
         lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), y.data_ptr(), int(x.shape[1]), int(x.shape[2])
-    L.call(sym + '_levels', lv, len(xs), L.dptr(w), L.dptr(bias) if bias is not None else None, B, cin, cout,
+    wp = L.dptr(w)
+    if dtype == torch.float32:
+        sym, wp = _f32_sym(sym, w)
+    L.call(sym + '_levels', lv, len(xs), wp, L.dptr(bias) if bias is not None else None, B, cin, cout,
            1 if relu else 0, L.stream())
     return outs
 
@@ -735,7 +801,8 @@ def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=Non
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    L.call('odet_pointwise_' + sfx, L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None,
+    sym, wp = ('odet_pointwise_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_pointwise_f32', w)
+    L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None,
            L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, stride, cin, cout, 1 if relu else 0,
            L.stream())
     return out
@@ -764,7 +831,8 @@ def lateral_merge(x, weight, bias, top, out=None):
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    L.call('odet_lateral_merge_' + sfx, L.dptr(x), L.dptr(w), L.dptr(bias) if bias is not None else None, L.dptr(top),
+    sym, wp = ('odet_lateral_merge_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_lateral_merge_f32', w)
+    L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(top),
            int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, L.stream())
     return out
 
@@ -797,7 +865,8 @@ def pointwise_dual(x1, x2, weight, bias=None, stride=1, relu=True, out=None):
         out = torch.empty(shape, dtype=x1.dtype, device=x1.device)
     elif out.dtype != x1.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x1\'s dtype' % (shape,))
-    L.call('odet_pointwise_dual_' + sfx, L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, L.dptr(weight),
+    sym, wp = ('odet_pointwise_dual_' + sfx, L.dptr(weight)) if sfx != 'f32' else _f32_sym('odet_pointwise_dual_f32', weight)
+    L.call(sym, L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, wp,
            L.dptr(bias) if bias is not None else None, L.dptr(out), B, cout, 1 if relu else 0, L.stream())
     return out
 

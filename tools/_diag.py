@@ -22,9 +22,10 @@ def use_library(path):
     _lib.LIB_PATH = os.path.abspath(path)
 
 
-def build_variant(out_path, extra_flags=(), sources=None, patch=None):
+def build_variant(out_path, extra_flags=(), sources=None, patch=None, only=None):
     """libodet with `extra_flags` (e.g. -D switches a patch under tools/exp introduces) into `out_path`; `patch` is applied
-    with `git apply` to a temporary copy of csrc/ first and the build FAILS if it does not apply."""
+    with `git apply` to a temporary copy of csrc/ first and the build FAILS if it does not apply.  `only`: the sources to
+    recompile with the flags; the other objects are the product build's (csrc/_obj, built first if stale)."""
     import shutil
     import tempfile
     tmp = tempfile.mkdtemp(prefix='odet_variant_')
@@ -36,7 +37,12 @@ def build_variant(out_path, extra_flags=(), sources=None, patch=None):
         if patch:
             subprocess.check_call(['git', 'apply', '--verbose', os.path.abspath(patch)], cwd=tmp)
         objs = []
+        if only:
+            _build.build()
         for src in (sources or _build.SOURCES):
+            if only and src not in only:
+                objs.append(os.path.join(_build.OBJ_DIR, src + '.o'))
+                continue
             o = os.path.join(tmp, src + '.o')
             cmd = [_build._hipcc()] + list(extra_flags) + _build.HIPCC_FLAGS + _build.PER_SOURCE_FLAGS.get(src, []) + \
                   ['-I', os.path.join(tmp, 'include'), '-c', os.path.join(pkg, 'csrc', src), '-o', o]
