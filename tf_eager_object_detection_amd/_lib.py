@@ -131,6 +131,7 @@ SIGNATURES = {
     'odet_pointwise_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_lateral_merge_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'odet_debug_x3_tile': (_i, [_i, _i]),
     'odet_split_bf16x3': (_i, [_vp, _vp, _i64, _vp]),
     'odet_conv3x3_x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_conv3x3_x3_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

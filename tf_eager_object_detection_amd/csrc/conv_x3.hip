@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -189,11 +190,6 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
     } else {
       soA = (uint32_t)ks * 128u;
     }
-#ifdef X3_DIAG_NOLOADA
-#pragma unroll
-    for (int i = 0; i < XP; ++i) r[i] = (x3u4){0x3f800000u + (unsigned)ks, 0x3f900000u, 0x3fa00000u, 0x3fb00000u};
-    return;
-#endif
     if (TAPS == 1 && ks >= k1steps) {
 #pragma unroll
       for (int i = 0; i < XP; ++i)
@@ -206,9 +202,6 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
     }
   };
   auto issue_w = [&](int ks, uint32_t stage) {
-#ifdef X3_DIAG_NOW
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < WPW; ++i)
       if (WPIECES % 8 == 0 || wv + 8 * i < WPIECES)
@@ -219,19 +212,6 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   // (row = piece * 8 + sub, piece = wv + 8 i: rows 8..15 of a 16-row tile are the odd pieces = the odd waves)
   const uint32_t sA = (uint32_t)sub * 64u + (uint32_t)(((sl >> 1) ^ ((wv & 1) << 1)) * 16 + (sl & 1) * 8);
   auto store_piece = [&](const x3u4 v, int i, uint32_t stage) {
-#ifdef X3_DIAG_NOSPLIT
-    asm volatile("" :: "v"(v));
-    return;
-#endif
-#ifdef X3_DIAG_RAWSTORE
-    {
-      unsigned char* dst = lds + stage + (uint32_t)(wv + 8 * i) * 512u + sA;
-      *reinterpret_cast<x3u2*>(dst) = (x3u2){v[0], v[1]};
-      *reinterpret_cast<x3u2*>(dst + XLIMB) = (x3u2){v[2], v[3]};
-      *reinterpret_cast<x3u2*>(dst + 2u * XLIMB) = (x3u2){v[1], v[2]};
-      return;
-    }
-#endif
     const c3f4 f = __builtin_bit_cast(c3f4, v);
     unsigned h0, m0, l0, h1, m1, l1;
     x3_split2((x3f2){f[0], f[1]}, h0, m0, l0);
@@ -363,6 +343,15 @@ static hipError_t x3_prepare_kernels() {
 }
 
 static unsigned x3_lds_bytes(int tm, int tn) { return (unsigned)(2 * 3 * (tm + tn) * 64); }
+static int x3_tile_pixels(int mt, int wn) { return (8 / wn) * 16 * mt; }
+
+// Diagnostics (tools/r05): force the tile of this process's split-precision launches -- (mt, wn) of X3_FOR_TILES; mt = 0 clears.
+// Not part of the reference surface; the product never calls it.
+static std::atomic<unsigned> g_x3_override{0u};
+extern "C" int odet_debug_x3_tile(int mt, int wn) {
+  g_x3_override.store(mt > 0 ? ((unsigned)mt << 8 | (unsigned)wn) : 0u);
+  return ODET_OK;
+}
 
 // the tile with the least (rounds of 256 workgroups) x (matrix cycles per K-step + the per-step overhead a workgroup pays for
 // its barrier, its copies and the split of its pixel rows)
@@ -378,12 +367,18 @@ static void x3_pick_tile(const long long* M, int num_levels, int cout, int* wn_o
     for (int l = 0; l < num_levels; ++l) slabs += (M[l] + tm - 1) / tm;
     const long long blocks = (slabs + 7) / 8 * 8 * tiles_n;
     const int occ = std::max(1, std::min(2, (int)(X3_LDS_MAX / x3_lds_bytes(tm, tn))));
-    // matrix cycles of a K-step for the CU: 6 MFMAs of 16 cycles per 16 x 16 tile on 4 SIMDs; + ~600 cycles of per-step overhead
-    const double per = (double)tm * tn / 256.0 * 6.0 * 16.0 / 4.0 + 600.0 / occ;
+    // cycles of a K-step on a CU, fitted to the tiles' measured rates on the ResNet-101-FPN layers (tools/r05/x3_tiles.py): the
+    // matrix work (6 MFMAs of 16 cycles per 16 x 16 tile on 4 SIMDs) + what is not hidden behind it: ~3.5 cycles per pixel row
+    // (its float32 slots loaded, split and stored by the vector units), ~0.8 per weight row (LDS-DMA) and ~720 of barrier, waits
+    // and address arithmetic, which a second resident workgroup overlaps -- a pixel row costs four times a weight row, so the
+    // wide tile (128 pixels x 256 channels) wins wherever cout allows it
+    const double per = (double)tm * tn / 256.0 * 6.0 * 16.0 / 4.0 + 3.5 * tm + 0.8 * tn + 720.0 / occ;
     const double cost = (double)((blocks + 256 * occ - 1) / (256 * occ)) * per * occ;
     if (cost < best * 0.98) { best = cost; wn_best = wn; mt_best = mt; }
   }
   *wn_out = wn_best; *mt_out = mt_best;
+  const unsigned o = g_x3_override.load();
+  if (o && cout % (64 * (int)(o & 255)) == 0) { *mt_out = (int)(o >> 8); *wn_out = (int)(o & 255); }
 }
 
 template <bool PW>
@@ -427,7 +422,7 @@ static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, co
   }
   int wn, mt;
   x3_pick_tile(p.M, num_levels, cout, &wn, &mt);
-  const int TMsel = (8 / wn) * 16 * mt;
+  const int TMsel = x3_tile_pixels(mt, wn);
   long long total = 0;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     p.tile_start[l] = total;
@@ -490,7 +485,7 @@ static int pointwise_x3_launch(const char* who, const void* x, const void* w3, c
   p.x2 = (const float*)epi.x2; p.cin2 = epi.x2 ? epi.cin2 : 0; p.k1steps = cin / X3_BK; p.Min2 = (long long)batch * H * W;
   int wn, mt;
   x3_pick_tile(&M, 1, cout, &wn, &mt);
-  const int TMsel = (8 / wn) * 16 * mt;
+  const int TMsel = x3_tile_pixels(mt, wn);
   p.tiles_n = cout / (64 * wn);
   const long long total = (M + TMsel - 1) / TMsel;
   p.tile_start[0] = 0;
