@@ -62,6 +62,8 @@ struct RoiParams {
   int xcds_per_img;   // XCDs that serve one image (8 / batch)
   int slices;         // > 1: C / 256 workgroups per RoI, one 256-channel slice each
   int rois_per_xcd;   // slices > 1: an XCD walks its RoIs once per slice, SLICE-MAJOR (all of slice 0, then slice 1, ...)
+  int roi_groups;     // > 0 (slices > 1 and the image's XCDs are a multiple of the slices): an XCD serves ONE slice for one of
+                      // roi_groups contiguous parts of the processing order (rois_per_xcd RoIs each)
 };
 
 struct Axis {
@@ -500,8 +502,19 @@ __global__ void __launch_bounds__(1024) k_roi_pool(RoiParams p) {
     // SLICE-MAJOR -- the first rois_per_xcd slots are slice 0 of its RoIs, the next ones slice 1, ... -- so that what
     // its L2 has to hold at a time is one 256-channel slice of the map (50 x 84 x 1 KB = 4.3 MB of the C4 map, not 17 MB):
     // the L2-miss stream of the 8-image C4 launch fell from 750 to ~200 MB (tools/pmc_roi_forms.sh)
-    const int sl = slot / p.rois_per_xcd;
-    ri = sub * p.rois_per_xcd + (slot - sl * p.rois_per_xcd); py = w;
+    // With 8 or 4 XCDs for the image (launches of one or two images: the reference-surface layers) an XCD takes ONE slice
+    // for a contiguous part of the (spatially ordered) RoIs instead: the 8 L2s then fetch the map once between them, not
+    // once each -- big RoIs tap most of the map whatever their order (round 4: 1.84 x the distinct bytes from HBM).
+    int sl;
+    if (p.roi_groups > 0) {
+      sl = sub % p.slices;
+      ri = (sub / p.slices) * p.rois_per_xcd + slot;
+      if (slot >= p.rois_per_xcd) return;
+    } else {
+      sl = slot / p.rois_per_xcd;
+      ri = sub * p.rois_per_xcd + (slot - sl * p.rois_per_xcd);
+    }
+    py = w;
     ch0 = sl * 256; ch1 = ch0 + 256;
   } else if (p.waves == P) {
     ri = lb; py = w;
@@ -731,9 +744,16 @@ int odet_roi_pool_batch(const RoiImageIO* io, int B, int num_levels, int C, int 
   p.xcds_per_img = p.xcd_images ? 8 / B : 8;
   p.blocks_per_xcd = (p.nblocks + p.xcds_per_img - 1) / p.xcds_per_img;   // per XCD of an image
   p.rois_per_xcd = 0;
+  p.roi_groups = 0;
   if (p.slices > 1) {
-    p.rois_per_xcd = (n + p.xcds_per_img - 1) / p.xcds_per_img;
-    p.blocks_per_xcd = p.rois_per_xcd * p.slices;
+    if (p.xcds_per_img % p.slices == 0) {                 // an XCD = one slice of one part of the RoIs
+      p.roi_groups = p.xcds_per_img / p.slices;
+      p.rois_per_xcd = (n + p.roi_groups - 1) / p.roi_groups;
+      p.blocks_per_xcd = p.rois_per_xcd;
+    } else {                                              // an XCD = all slices of its RoIs, slice-major
+      p.rois_per_xcd = (n + p.xcds_per_img - 1) / p.xcds_per_img;
+      p.blocks_per_xcd = p.rois_per_xcd * p.slices;
+    }
     p.nblocks = p.blocks_per_xcd * p.xcds_per_img;        // (slots beyond the last RoI leave at `ri >= n`)
   }
   dim3 grid(p.blocks_per_xcd * 8, p.xcd_images ? 1 : B);
