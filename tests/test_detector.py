@@ -1525,3 +1525,38 @@ def test_float32_x3_detector_agrees_with_the_exact_float32_detector():
         assert len(ia & ib) >= 0.99 * max(len(ia), 1), (len(ia & ib), len(ia))
         na, nb = int(oa[i][3].item()), int(ob[i][3].item())
         assert abs(na - nb) <= 1 and na > 0
+
+
+@pytest.mark.gpu
+def test_float16_detections_of_one_image_do_not_depend_on_the_batch_beyond_rounding():
+    """the float16 bottleneck route depends on the batch (the fused 3x3 + 1x1 tail from 200 slabs on, two launches
+    below: another accumulation order before the one float16 rounding), so one image's low bits -- and NMS / top-k ties with
+    them -- may differ between batch 1 and batch 8.  Documented behaviour; the bound: the same image alone and as image 0 of a
+    batch of 8 gives RPN outputs within float16 rounding, >= 95 % of the same kept anchors, and the same detections up to
+    that (a labelled box within 2 px and 0.02 in score of a box of the other pass)."""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    torch.manual_seed(1)
+    shape, K = (256, 352), 300
+    m = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float16, max_batch=8, blind_chunks=3).prepare()
+    rng = np.random.default_rng(1)
+    img = torch.from_numpy((rng.uniform(0, 255, (8,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    out8 = m(img)
+    torch.cuda.synchronize()
+    s8, d8 = m._last_pass[0][0].clone(), m._last_pass[1][0].clone()
+    idx8 = set(m._hot[0].roi_idx[:int(m._hot[0].roi_count.item())].tolist())
+    b8, l8, c8, n8 = [t.clone() for t in out8[0]]
+    out1 = m(img[:1])
+    torch.cuda.synchronize()
+    s1, d1 = m._last_pass[0][0], m._last_pass[1][0]
+    idx1 = set(m._hot[0].roi_idx[:int(m._hot[0].roi_count.item())].tolist())
+    assert float((s1 - s8).abs().max()) <= 3e-2 * max(1.0, float(s8.abs().max()))
+    assert float((d1 - d8).abs().max()) <= 3e-2 * max(1.0, float(d8.abs().max()))
+    assert len(idx1 & idx8) >= 0.95 * max(len(idx8), 1), (len(idx1 & idx8), len(idx8))
+    b1, l1, c1, n1 = out1[0]
+    n1, n8 = int(n1.item()), int(n8.item())
+    assert n8 > 0 and abs(n1 - n8) <= max(2, n8 // 10)
+    matched = 0
+    for i in range(n1):
+        same = (l8[:n8] == l1[i]) & ((b8[:n8] - b1[i]).abs().max(dim=1).values <= 2.0) & ((c8[:n8] - c1[i]).abs() <= 0.02)
+        matched += int(bool(same.any()))
+    assert matched >= 0.9 * n1, (matched, n1)

@@ -109,6 +109,29 @@ def test_detect_image_matches_oracle_loop(raw_shape, R, mpc, mpi):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('R,mpc,mpi,decimals', [(300, 50, 20, 1), (1000, 50, 50, 2), (1500, 20, 30, 1), (300, 5, 3, 1)])
+def test_detect_image_eval_cap_keeps_every_tie_at_the_threshold(R, mpc, mpi, decimals):
+    """the evaluation loop's per-image cap (pascal_eval_files_utils.py:98-104: threshold = the max_per_image-th best score,
+    keep scores >= threshold) with QUANTISED scores: many detections share the threshold score and ALL of them stay -- the
+    merge's mode-1 branch (odet_eval_detect), R below and above 1024"""
+    import torch
+    rng = np.random.default_rng(R * 7 + mpi)
+    im = syn.eval_image(rng, raw_shape=(375, 500), num_rois=R)
+    sc = np.round(im['scores'], decimals).astype(np.float32)
+    g = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    kw = dict(score_threshold=0.05, iou_threshold=0.5, max_objects_per_class=mpc, max_objects_per_image=mpi, min_size=10)
+    got = pe.detect_image(g(sc), g(im['deltas']), g(im['rois']), im['img_scale'], im['raw_h'], im['raw_w'], **kw)
+    want = on.eval_detect_image(sc, im['deltas'], im['rois'], im['img_scale'], im['raw_h'], im['raw_w'], **kw)
+    total = sum(len(w) for w in want)
+    assert total > mpi                                   # (ties at the threshold: more than the cap survive)
+    for j in range(1, 21):
+        assert got[j].shape == want[j].shape, (j, got[j].shape, want[j].shape)
+        if len(want[j]):
+            np.testing.assert_array_equal(got[j][:, 4], want[j][:, 4])
+            assert np.max(np.abs(got[j][:, :4] - want[j][:, :4])) <= 1e-4 * max(1.0, float(np.abs(want[j]).max()))
+
+
+@pytest.mark.gpu
 def test_map_delta_on_synthetic_set_is_zero():
     """BASELINE metric 'mAP delta vs ref': identical weights-free inputs through the GPU loop and through
     the restated reference loop, scored by VOC AP (07 and area) -- the delta must be within 0.002

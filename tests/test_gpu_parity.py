@@ -533,12 +533,13 @@ def test_post_ops_edge_cases():
 
 @pytest.mark.parametrize('R,mpc,mpi,sthr,decimals', [(1000, 50, 50, 0.05, 2), (1000, 50, 50, 0.0, 1), (1000, 5, 5, 0.05, 2),
                                                       (1000, 50, 64, 0.05, 2), (200, 50, 50, 0.2, 2), (1000, 51, 64, 0.0, 2),
-                                                      (40, 50, 50, 0.0, 3), (1000, 50, 65, 0.05, 2)])
-def test_post_ops_ties_through_both_merge_forms(R, mpc, mpi, sthr, decimals):
+                                                      (40, 50, 50, 0.0, 3), (1000, 50, 65, 0.05, 2), (1500, 50, 50, 0.05, 2),
+                                                      (2500, 30, 100, 0.0, 1), (4096, 50, 50, 0.1, 2)])
+def test_post_ops_ties_through_the_merge(R, mpc, mpi, sthr, decimals):
     """Scores quantised to a few distinct values: the per-class order and the image's top-k are decided by the tie rule
-    (row / position order), and the max_per_image-th best score is shared by many entries.  20 classes x <= 51 per class
-    with max_per_image <= 64 goes through the one-wave merge, the others through the workgroup merge; the packed sort
-    of the rows that pass the filters covers 64 .. 1024 keys over the cases."""
+    (row / position order), and the max_per_image-th best score is shared by many entries.  One launch (k_postops): a class
+    workgroup sorts the rows that pass its filters (1024 keys, or the next power of two of R for R > 1024: the last three
+    cases), the last workgroup merges by a radix select of the max_per_image-th key with ties in position order."""
     from tf_eager_object_detection_amd.model.prediction import post_ops_prediction
     rng = np.random.default_rng(R + mpc + mpi)
     shape = (800, 1333)
