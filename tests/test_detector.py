@@ -1560,3 +1560,32 @@ def test_float16_detections_of_one_image_do_not_depend_on_the_batch_beyond_round
         same = (l8[:n8] == l1[i]) & ((b8[:n8] - b1[i]).abs().max(dim=1).values <= 2.0) & ((c8[:n8] - c1[i]).abs() <= 0.02)
         matched += int(bool(same.any()))
     assert matched >= 0.9 * n1, (matched, n1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['c4', 'vgg16'])
+def test_float32_x3_single_level_detectors_agree_with_the_exact_float32_detectors(kind):
+    """the split-precision float32 mode of the ResNet-C4 / VGG16 detectors (BASELINE configs 2 / 1) against their exact-float32
+    mode on the same weights: RPN outputs within 1e-4, >= 99 % of the same kept anchors, the same number of detections (+-1)"""
+    from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
+    torch.manual_seed(12)
+    shape, K = (256, 352), 100
+    mk = (lambda **kw: ResNetC4Detector(50, 21, shape, K, dtype=torch.float32, max_batch=2, **kw)) if kind == 'c4' else \
+         (lambda **kw: Vgg16Detector(21, shape, K, dtype=torch.float32, max_batch=2, **kw))
+    a = mk().prepare()
+    b = mk(f32_form='x3')
+    b.load_state_dict(a.state_dict())
+    b.prepare()
+    rng = np.random.default_rng(2)
+    img = torch.from_numpy((rng.uniform(0, 255, (2,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    oa, ob = a(img), b(img)
+    torch.cuda.synchronize()
+    sa, da = a._last_pass[0], a._last_pass[1]
+    sb, db = b._last_pass[0], b._last_pass[1]
+    assert float((sa - sb).abs().max()) <= 1e-4 * max(1.0, float(sa.abs().max()))
+    assert float((da - db).abs().max()) <= 1e-4 * max(1.0, float(da.abs().max()))
+    for i in range(2):
+        ka, kb = int(a._hot[i].roi_count.item()), int(b._hot[i].roi_count.item())
+        ia, ib = set(a._hot[i].roi_idx[:ka].tolist()), set(b._hot[i].roi_idx[:kb].tolist())
+        assert len(ia & ib) >= 0.99 * max(len(ia), 1), (len(ia & ib), len(ia))
+        assert abs(int(oa[i][3].item()) - int(ob[i][3].item())) <= 1

@@ -22,6 +22,8 @@ ap.add_argument('--model', default='fpn', choices=['fpn', 'c4', 'vgg16'],
 ap.add_argument('--h', type=int, default=800)
 ap.add_argument('--w', type=int, default=1333)
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True (no effect since round 4: the detectors launch no library convolution)')
+ap.add_argument('--f32-form', default='exact', choices=['exact', 'x3'], help='float32 mode: exact-float32 matrix instructions or the '
+                'split-precision form (csrc/conv_x3.hip)')
 ap.add_argument('--graph', action='store_true', help='replay the whole forward pass as one HIP graph')
 ap.add_argument('--blind-chunks', type=int, default=3, help='FPN: sync-free NMS chunks (3: the third one on the full order)')
 ap.add_argument('--per-image', action='store_true', help='FPN: every image through its own hot-path launches and RoI-head call '
@@ -34,11 +36,11 @@ if a.model == 'fpn':
     # chunk 0 + chunk 1 from the ranked selection + one per-image chunk on the full order: the float16 logits of the
     # random-init RPN tie in thousands, which the selection cannot split
     hot_kw = dict(blind_chunks=a.blind_chunks, batched=not a.per_image)
-    model = ResNetFpnDetector(a.depth, 21, (a.h, a.w), 1000, dtype=dt, max_batch=a.batch, **hot_kw).prepare()
+    model = ResNetFpnDetector(a.depth, 21, (a.h, a.w), 1000, dtype=dt, max_batch=a.batch, f32_form=a.f32_form, **hot_kw).prepare()
 elif a.model == 'c4':
-    model = ResNetC4Detector(a.depth, 21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4).prepare()
+    model = ResNetC4Detector(a.depth, 21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4, f32_form=a.f32_form).prepare()
 else:
-    model = Vgg16Detector(21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4).prepare()
+    model = Vgg16Detector(21, (a.h, a.w), 300, dtype=dt, max_batch=a.batch, blind_chunks=4, f32_form=a.f32_form).prepare()
 rng = np.random.default_rng(0)
 img = (rng.uniform(0, 255, (a.batch, a.h, a.w, 3)) - np.float32([103.939, 116.779, 123.68])).astype(np.float32)
 img = torch.from_numpy(img).cuda()

@@ -16,7 +16,7 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.
 python3 bench.py --streams 1 --batch 1 --rounds-per-step 768 --steps 10 --warmup 2 --no-cpu-baseline --no-e2e > $out/bench_s1b1.json 2> $out/bench_s1b1.err
 # 3. kernel stats of EXACTLY the driver's command (its roofline samples run under the kernel name k_roi_pool<.., 1>:
 #    that row's average is roofline.kernel_ms)
-timeout -s KILL 900 rocprofv3 --kernel-trace --stats -d $out/stats_driver --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/stats_driver.log 2>&1
+timeout -s KILL 1800 rocprofv3 --kernel-trace --stats -d $out/stats_driver --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/stats_driver.log 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/stats_s1b1 --output-format csv -- python3 bench.py --streams 1 --batch 1 --rounds-per-step 768 --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > $out/stats_s1b1.log 2>&1
 # 4. HBM-side traffic of the 8-image RoI launch (separate --pmc passes; FETCH_SIZE x 2 on gfx950)
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py --no-cpu-baseline --no-e2e --streams 1 --batch 8 --rounds-per-step 4 --steps 4 --warmup 1 > $out/pmc_fetch.log 2>&1
