@@ -50,9 +50,6 @@ class f32_form:
         return False
 
 
-_X3_PLANES = {}
-
-
 def split_bf16x3(w):
     """float32 contiguous GPU tensor (even element count) -> its three bfloat16 limb planes, int16 [3, *w.shape]
     (odet_split_bf16x3): w == plane0 + plane1 + plane2 exactly (round to nearest even at every limb)."""
@@ -63,23 +60,24 @@ def split_bf16x3(w):
     return planes
 
 
-def _x3_planes(w):
-    """the limb planes of the (contiguous, float32) weight tensor `w`, cached until it is modified or freed: the entry keeps
-    `w` alive, so its address cannot be recycled under the key"""
+def _x3_planes(holder, w):
+    """the limb planes of the (contiguous, float32) weight `w`, kept ON the tensor object the caller passed (`holder`: the
+    layer's parameter, or a module's cached concatenation) until that tensor is modified: the planes live exactly as long as
+    the weight they belong to -- no global cache that could outlive or be cleared under a captured HIP graph.  A caller that
+    passes a fresh temporary every time pays the split every time (correct, slow): keep weights in stable tensors."""
     key = (w.data_ptr(), w._version, tuple(w.shape))
-    hit = _X3_PLANES.get(key)
-    if hit is None:
-        if len(_X3_PLANES) > 4096:
-            _X3_PLANES.clear()
-        hit = (w, split_bf16x3(w))
-        _X3_PLANES[key] = hit
+    hit = holder.__dict__.get('_odet_x3')
+    if hit is None or hit[0] != key:
+        hit = (key, split_bf16x3(w), w)
+        holder.__dict__['_odet_x3'] = hit
     return hit[1]
 
 
-def _f32_sym(sym, w):
-    """(entry point, weight pointer) of a float32 layer in the current form"""
+def _f32_sym(sym, w, holder=None):
+    """(entry point, weight pointer) of a float32 layer in the current form; `holder` = the caller's weight tensor object"""
     if _F32_FORM[0] == 'x3':
-        return sym[:-3] + 'x3', C.c_void_p(_x3_planes(w).data_ptr())       # odet_*_f32 -> odet_*_x3
+        planes = _x3_planes(w if holder is None else holder, w)
+        return sym[:-3] + 'x3', C.c_void_p(planes.data_ptr())             # odet_*_f32 -> odet_*_x3
     return sym, L.dptr(w)
 
 
@@ -515,7 +513,7 @@ def _conv3x3(dtype, x, weight, bias, relu, out):
         raise ValueError('out must be a contiguous %s tensor [B,H,W,cout]' % name)
     wp = L.dptr(w)
     if dtype == torch.float32:
-        sym, wp = _f32_sym(sym, w)
+        sym, wp = _f32_sym(sym, w, weight)
     L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
            cin, cout, 1 if relu else 0, L.stream())
     return out
@@ -542,7 +540,7 @@ def _conv3x3_levels(dtype, xs, weight, bias, relu, outs):
         lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), y.data_ptr(), int(x.shape[1]), int(x.shape[2])
     wp = L.dptr(w)
     if dtype == torch.float32:
-        sym, wp = _f32_sym(sym, w)
+        sym, wp = _f32_sym(sym, w, weight)
     L.call(sym + '_levels', lv, len(xs), wp, L.dptr(bias) if bias is not None else None, B, cin, cout,
            1 if relu else 0, L.stream())
     return outs
@@ -801,7 +799,7 @@ def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=Non
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    sym, wp = ('odet_pointwise_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_pointwise_f32', w)
+    sym, wp = ('odet_pointwise_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_pointwise_f32', w, weight)
     L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None,
            L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, stride, cin, cout, 1 if relu else 0,
            L.stream())
@@ -831,7 +829,7 @@ def lateral_merge(x, weight, bias, top, out=None):
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    sym, wp = ('odet_lateral_merge_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_lateral_merge_f32', w)
+    sym, wp = ('odet_lateral_merge_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_lateral_merge_f32', w, weight)
     L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(top),
            int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, L.stream())
     return out

@@ -16,7 +16,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=210)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--f32-form', default='exact', choices=['exact', 'x3'], help='the form the float32 cases run on (x3: the '
+                    'split-precision kernel is exact on integer data too)')
     a = ap.parse_args()
+    ops._F32_FORM[0] = a.f32_form
     g = torch.Generator(device='cuda'); g.manual_seed(a.seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), device='cuda', generator=g).item())
     sparse = lambda shape, pct, lo, hi: ((torch.randint(0, 100, shape, device='cuda', generator=g) < pct).half()
