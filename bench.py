@@ -727,6 +727,7 @@ def main():
             legs = (('fp16', 'fp16', 60, 'fpn', False, True), ('fp16_b1', 'fp16', 1, 'fpn', True, True),
                     ('fp16_b4', 'fp16', 4, 'fpn', True, True), ('fp16_b8', 'fp16', 8, 'fpn', True, True),
                     ('fp32', 'fp32', 30, 'fpn', False, True), ('fp32_x3', 'fp32', 30, 'fpn', False, True),
+                    ('fp32_x3_b1', 'fp32', 1, 'fpn', True, False),
                     ('fp16_resnet50_c4', 'fp16', 60, 'c4', False, True), ('fp16_vgg16_600x800', 'fp16', 64, 'vgg16', False, True),
                     ('fp32_x3_resnet50_c4', 'fp32', 30, 'c4', False, True), ('fp32_x3_vgg16_600x800', 'fp32', 32, 'vgg16', False, True))
             for name, dtn, b, fam, gr, eg in legs:
@@ -743,6 +744,7 @@ def main():
             summary.update(e2e_fp16=[rate('fp16'), 60], e2e_fp16_b1_graph=rate('fp16_b1', 'value_hip_graph'),
                            e2e_fp16_b1_eager=rate('fp16_b1'), e2e_fp16_b4=[rate('fp16_b4'), rate('fp16_b4', 'value_hip_graph')],
                            e2e_fp16_b8=[rate('fp16_b8'), rate('fp16_b8', 'value_hip_graph')], e2e_fp32=[rate('fp32'), 30], e2e_fp32_x3=[rate('fp32_x3'), 30],
+                           e2e_fp32_x3_b1_graph=rate('fp32_x3_b1', 'value_hip_graph'),
                            c4_fp16=[rate('fp16_resnet50_c4'), 60], vgg16_fp16=[rate('fp16_vgg16_600x800'), 64],
                            c4_vgg16_fp32_x3=[rate('fp32_x3_resnet50_c4'), rate('fp32_x3_vgg16_600x800')])
             # the accuracy side of the throughput mode: float16 vs float32 detector, same weights, same annotated scenes,

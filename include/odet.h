@@ -474,18 +474,28 @@ int odet_pointwise_dual_f32(const void* x1, int cin1, const void* x2, int cin2, 
  * float32 rounding of the float64 truth, like the fmaf chain of the *_f32 forms, not bit-identical to it.  `w3` = the
  * weight's limb planes, bfloat16 [3][cout][K] (K = taps * cin (+ cin2) in the order of the float32 weight), written ONCE per
  * weight tensor by odet_split_bf16x3 (n = cout * K float32 values -> planes [3][n]; n even).  cin % 32 == 0, cout % 64 == 0;
- * pointwise: any cin >= 32. */
+ * pointwise: any cin >= 32.
+ * `workspace` (nullable; odet_x3_workspace_bytes() bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller and then only ever
+ * handed to these entry points, one workspace per stream that runs them): with it a launch that would leave CUs idle (few
+ * pixels, deep K: the small maps at batch 1 .. 8, the RoI head's dense layers) splits K over up to 8 workgroups per output
+ * tile; the last one to finish adds the float32 parts in their fixed order (deterministic; exact on integer data) and runs the
+ * epilogue.  Every launch leaves the workspace's ticket words zero again.  NULL: never split. */
+size_t odet_x3_workspace_bytes(void);
 int odet_split_bf16x3(const float* w, void* planes, long long n, odet_stream_t stream);
 int odet_conv3x3_x3(const void* x, const void* w3, const void* bias, void* y, int batch, int H, int W,
-                    int cin, int cout, int relu, odet_stream_t stream);
+                    int cin, int cout, int relu, void* workspace, size_t workspace_bytes, odet_stream_t stream);
 int odet_conv3x3_x3_levels(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
-                           int batch, int cin, int cout, int relu, odet_stream_t stream);
+                           int batch, int cin, int cout, int relu, void* workspace, size_t workspace_bytes,
+                           odet_stream_t stream);
 int odet_pointwise_x3(const void* x, const void* w3, const void* bias, const void* residual, void* y, int batch,
-                      int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream);
+                      int H, int W, int stride, int cin, int cout, int relu, void* workspace, size_t workspace_bytes,
+                      odet_stream_t stream);
 int odet_lateral_merge_x3(const void* x, const void* w3, const void* bias, const void* top, int th, int tw, void* y,
-                          int batch, int H, int W, int cin, int cout, odet_stream_t stream);
+                          int batch, int H, int W, int cin, int cout, void* workspace, size_t workspace_bytes,
+                          odet_stream_t stream);
 int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
-                           const void* w3, const void* bias, void* y, int batch, int cout, int relu, odet_stream_t stream);
+                           const void* w3, const void* bias, void* y, int batch, int cout, int relu,
+                           void* workspace, size_t workspace_bytes, odet_stream_t stream);
 /* The stem's patch matrix in float32 mode: row (image, yo, xo) = the zero-padded 7 x 7 x 3 window of conv1_pad +
  * Conv2D(64, 7x7, strides 2, 'valid') (resnet_fpn.py:262-289) in (dy, dx, channel) order, padded from 147 to 160 floats;
  * images NHWC float32 [batch,H,W,3] -> patches [batch * Ho * Wo][160], Ho = (H - 1) / 2 + 1.  The convolution is then
@@ -648,9 +658,9 @@ const char* odet_exec_last_error(odet_exec_t* ex);
  * {nw waves, wn waves along the channels, mt 16-pixel tiles per wave, ns LDS stages}: (nw / wn) * 16 * mt pixels x 64 * wn
  * channels; ns == 2 the half-step-pipelined loop, ns > 2 the ring forms for launches with few pixels.  nw = 0 clears. */
 int odet_debug_conv_tile(int form, int nw, int wn, int mt, int ns);
-/* the same for the split-precision float32 launches (csrc/conv_x3.hip): (mt, wn) of its tile list, (8, 2) = the wave-specialised
- * 256 x 128 tile of tools/exp/conv_x3_wave_specialised.patch; mt = 0 clears */
-int odet_debug_x3_tile(int mt, int wn);
+/* the same for the split-precision float32 launches (csrc/conv_x3.hip): (mt, wn) of its tile list ((8, 2) = the wave-specialised
+ * 256 x 128 tile of tools/exp/conv_x3_wave_specialised.patch) and the K split (workgroups per tile, 1 = none); mt = 0 clears */
+int odet_debug_x3_tile(int mt, int wn, int ksplit);
 
 #ifdef __cplusplus
 }

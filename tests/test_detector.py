@@ -1485,14 +1485,21 @@ def test_pointwise_split_precision_forms():
     lat = _x3_and_exact(lambda: ops.pointwise(c, w, b))[1]
     assert torch.equal(x3, ops.fpn_topdown_merge(top, lat))                       # bit-identical to merge(conv_x3)
     assert float((x3 - ex).abs().max()) <= 1e-5 * float(ex.abs().max())
-    # all pyramid levels in one launch == level by level
+    # all pyramid levels in one launch == level by level: the same bits without a workspace (no K split anywhere); with it a
+    # small level launched alone splits its K loop (another, equally valid summation order): float32 rounding apart
     xs = [torch.randn((2, h, w_, 256), device='cuda', generator=g) for h, w_ in ((48, 64), (24, 32), (12, 16), (6, 8), (3, 4))]
     w = (torch.randn((512, 256, 3, 3), device='cuda', generator=g) * 0.02).contiguous(memory_format=torch.channels_last)
     b = torch.randn(512, device='cuda', generator=g)
+    from tf_eager_object_detection_amd import _lib
     with ops.f32_form('x3'):
         together = ops.conv3x3_f32_levels(xs, w, b, relu=True)
         single = [ops.conv3x3_f32(x, w, b, relu=True) for x in xs]
-    assert all(torch.equal(a, s_) for a, s_ in zip(together, single))
+        _lib.call('odet_debug_x3_tile', 4, 4, 1)                                  # (one tile, no split: the launch grouping alone)
+        together_1 = ops.conv3x3_f32_levels(xs, w, b, relu=True)
+        single_1 = [ops.conv3x3_f32(x, w, b, relu=True) for x in xs]
+        _lib.call('odet_debug_x3_tile', 0, 0, 0)
+    assert all(torch.equal(a, s_) for a, s_ in zip(together_1, single_1))
+    assert all(float((a - s_).abs().max()) <= 2e-6 * float(s_.abs().max()) for a, s_ in zip(together, single))
     # the limb planes: exact sum, cached per weight tensor
     planes = ops.split_bf16x3(w.permute(0, 2, 3, 1).contiguous())
     parts = (planes.view(torch.bfloat16).double()).sum(0)
@@ -1589,3 +1596,41 @@ def test_float32_x3_single_level_detectors_agree_with_the_exact_float32_detector
         ia, ib = set(a._hot[i].roi_idx[:ka].tolist()), set(b._hot[i].roi_idx[:kb].tolist())
         assert len(ia & ib) >= 0.99 * max(len(ia), 1), (len(ia & ib), len(ia))
         assert abs(int(oa[i][3].item()) - int(ob[i][3].item())) <= 1
+
+
+@pytest.mark.gpu
+def test_split_precision_split_k_is_deterministic_exact_on_integers_and_leaves_its_workspace_clean():
+    """the K split of the split-precision kernel (launches with few pixels and deep K: conv5 / the dense layers at small batch):
+    S workgroups per tile, float32 parts added in fixed order by the last one.  Forced S = 2, 3, 5, 8 on integer data = the exact
+    result; on random data within float32 rounding of the unsplit launch and bit-identical from run to run; the ticket words of
+    the workspace are zero after every launch; the product's own pick splits these shapes"""
+    from tf_eager_object_detection_amd import ops, _lib
+    g = torch.Generator(device='cuda'); g.manual_seed(77)
+    with ops.f32_form('x3'):
+        for (B, H, W, cin, cout, k) in ((1, 25, 42, 512, 512, 3), (1, 1, 1000, 12544, 1024, 1), (2, 13, 21, 2048, 512, 1), (1, 50, 84, 256, 256, 3)):
+            xi = torch.randint(-2, 3, (B, H, W, cin), device='cuda', generator=g).float()
+            wi = ((torch.randint(0, 100, (cout, cin, k, k), device='cuda', generator=g) < 10).float()
+                  * torch.randint(-2, 3, (cout, cin, k, k), device='cuda', generator=g).float()).contiguous(memory_format=torch.channels_last)
+            x = torch.randn((B, H, W, cin), device='cuda', generator=g)
+            w = (torch.randn((cout, cin, k, k), device='cuda', generator=g) * (cin * k * k) ** -0.5).contiguous(memory_format=torch.channels_last)
+            b = torch.randint(-3, 4, (cout,), device='cuda', generator=g).float()
+            run = (lambda xx, ww: ops.conv3x3_f32(xx, ww, b, relu=True)) if k == 3 else \
+                  (lambda xx, ww: ops.pointwise(xx, ww.reshape(cout, cin).contiguous(), b, None, True))
+            want_i = torch.relu(F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double(), b.double(), 1, k // 2)).permute(0, 2, 3, 1)
+            _lib.call('odet_debug_x3_tile', 2, 2, 1)
+            base = run(x, w)
+            for S in (2, 3, 5, 8):
+                _lib.call('odet_debug_x3_tile', 2, 2, S)
+                got_i = run(xi, wi)
+                assert torch.equal(got_i.double(), want_i), (S, B, H, W, cin, cout, k)
+                a1, a2 = run(x, w), run(x, w)
+                assert torch.equal(a1, a2)                                            # deterministic
+                assert float((a1 - base).abs().max()) <= 2e-5 * float(base.abs().max())
+            _lib.call('odet_debug_x3_tile', 0, 0, 0)
+            auto = run(x, w)                                                          # the product's own pick
+            assert float((auto - base).abs().max()) <= 2e-5 * float(base.abs().max())
+        torch.cuda.synchronize()
+        assert ops._X3_WS, 'no split-K workspace was allocated'
+        for ws in ops._X3_WS.values():
+            assert int(ws[:16384].max().item()) == 0                                 # every ticket drawn back to zero
+    _lib.call('odet_debug_x3_tile', 0, 0, 0)

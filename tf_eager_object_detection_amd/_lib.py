@@ -131,13 +131,14 @@ SIGNATURES = {
     'odet_pointwise_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_lateral_merge_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    'odet_debug_x3_tile': (_i, [_i, _i]),
+    'odet_debug_x3_tile': (_i, [_i, _i, _i]),
+    'odet_x3_workspace_bytes': (_sz, []),
     'odet_split_bf16x3': (_i, [_vp, _vp, _i64, _vp]),
-    'odet_conv3x3_x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    'odet_conv3x3_x3_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'odet_pointwise_x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    'odet_lateral_merge_x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
-    'odet_pointwise_dual_x3': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'odet_conv3x3_x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_conv3x3_x3_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_pointwise_x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_lateral_merge_x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_pointwise_dual_x3': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     'odet_stem_patches_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'odet_rgb_patches3x3_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f16': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),

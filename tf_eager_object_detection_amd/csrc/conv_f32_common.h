@@ -24,6 +24,10 @@ struct ConvF32Params {
   const float* res;               // + shortcut [M][cout]
   const float* top; int th, tw; float tys, txs;   // or the FPN top-down merge: 0.5 * resize(top) + 0.5 * (conv + bias)
   const float* x2; int cin2, k1steps; long long Min2;   // or two sources along K ([x | x2(::stride)], weights concatenated)
+  // split-K (conv_x3.hip only; 0 / 1 = off): ksplit consecutive workgroups share an output tile, each takes a contiguous part
+  // of the K-steps and leaves its float32 partial tile in `part`; the one that draws the last of the tile's tickets adds the
+  // parts in their fixed order 0 .. ksplit - 1 and runs the epilogue (deterministic; exact on integers)
+  int ksplit; float* part; unsigned* ticket;
 };
 
 // bias (+ shortcut | FPN top-down merge) (+ ReLU) and the stores of a wave's MT x 4 accumulator tiles

@@ -103,7 +103,10 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv / WN, wn = wv % WN;
-  const long long blk = blockIdx.x;
+  // split-K: `S` consecutive workgroups per output tile (host: S <= ksteps / 8, launches that would leave CUs idle)
+  const int S = p.ksplit > 1 ? p.ksplit : 1;
+  const long long blk = S > 1 ? (long long)(blockIdx.x / (unsigned)S) : (long long)blockIdx.x;
+  const int z = S > 1 ? (int)(blockIdx.x - (unsigned)blk * (unsigned)S) : 0;
   const long long q8 = blk >> 3;
   const long long slab = (blk & 7) + 8 * (q8 / p.tiles_n);
   const int tn = (int)(q8 % p.tiles_n);
@@ -175,8 +178,10 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
     voffW[i] = pi < WPIECES ? (uint32_t)limb * planeB + (uint32_t)ch * wrowB + (uint32_t)((lane & 3) ^ ((lane >> 5) << 1)) * 16u : OOB;
   }
   const int chunks = cin / X3_BK;
-  const int ksteps = TAPS * chunks + (dual ? p.cin2 / X3_BK : 0);
-  const int k1steps = dual ? p.k1steps : ksteps;
+  const int ksteps_all = TAPS * chunks + (dual ? p.cin2 / X3_BK : 0);
+  const int k1steps = dual ? p.k1steps : ksteps_all;
+  const int ks_lo = (int)((long long)ksteps_all * z / S);               // this workgroup's part of the K-steps
+  const int ksteps = (int)((long long)ksteps_all * (z + 1) / S) - ks_lo;
   // the float32 slots of TWO K-steps in flight (buffer ks & 1): a load issued at the top of K-step ks is split and stored in
   // the middle of K-step ks + 1 -- one and a half K-steps (~3 us) to arrive, whatever level of the memory system it comes from
   x3u4 ra[2][XP];
@@ -276,9 +281,10 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   // registers; the slots of step ks + 1 (loaded a step ago) are split and stored between the MFMAs of step ks.  The counted
   // wait before the barrier leaves the newest XP loads (step ks + 2) in flight; a bare s_barrier, because __syncthreads() would
   // drain them too.
-  auto step = [&](int ks, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {
-    const uint32_t cur = (uint32_t)(ks & 1) * STAGE, nxt = STAGE - cur;
-    const bool more = ks + 1 < ksteps, more2 = ks + 2 < ksteps;
+  auto step = [&](int i, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {     // i = K-step of this workgroup's part
+    const int ks = ks_lo + i;
+    const uint32_t cur = (uint32_t)(i & 1) * STAGE, nxt = STAGE - cur;
+    const bool more = i + 1 < ksteps, more2 = i + 2 < ksteps;
     // the two waves of a SIMD (w and w + 4) run the same program between the same barriers: waves 0-3 issue their copies
     // right after the barrier, waves 4-7 behind their second group of MFMAs, so that one of the two always has matrix work
     const bool early = wv < 4;
@@ -295,16 +301,51 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
     if (more2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
-  issue_w(0, 0u);
-  load_a(0, ra[0]);
-  if (ksteps > 1) load_a(1, ra[1]);
+  issue_w(ks_lo, 0u);
+  load_a(ks_lo, ra[0]);
+  if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
 #pragma unroll
   for (int i = 0; i < XP; ++i) store_piece(ra[0][i], i, 0u);
   if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  for (int ks = 0; ks < ksteps; ks += 2) {
-    step(ks, ra[0], ra[1]);                              // (step ks stores ra[1] = the slots of ks + 1, refills ra[0] with ks + 2)
-    if (ks + 1 < ksteps) step(ks + 1, ra[1], ra[0]);
+  for (int i = 0; i < ksteps; i += 2) {
+    step(i, ra[0], ra[1]);                               // (step i stores ra[1] = the slots of i + 1, refills ra[0] with i + 2)
+    if (i + 1 < ksteps) step(i + 1, ra[1], ra[0]);
+  }
+  if (S > 1) {
+    // ---- split-K: leave this part's tile in the workspace, draw a ticket; the last of the tile's S workgroups adds the parts
+    // in their fixed order and goes on to the epilogue.  (MI355X guide, inter-workgroup visibility: every storing wave drains
+    // its stores, workgroup barrier, ONE lane releases at agent scope and only then signals; the consumer acquires at agent
+    // scope before its loads -- the parts were written through other XCDs' L2s.)
+    constexpr size_t PART = (size_t)8 * MT * 4 * 64;      // float4 values of one part: [wave][mt][t][lane]
+    c3f4* base = reinterpret_cast<c3f4*>(p.part) + (size_t)blk * S * PART + (size_t)wv * (MT * 4 * 64) + lane;
+    c3f4* mine = base + (size_t)z * PART;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mine[(mt * 4 + t) * 64] = acc[mt][t];
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // atomicInc wraps to 0 at S - 1: the ticket is clean again for the next launch on this workspace
+      s_last = atomicInc(p.ticket + blk, (unsigned)(S - 1)) == (unsigned)(S - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        c3f4 sum = __builtin_nontemporal_load(base + (mt * 4 + t) * 64);
+        for (int zz = 1; zz < S; ++zz) sum += __builtin_nontemporal_load(base + (size_t)zz * PART + (mt * 4 + t) * 64);
+        acc[mt][t] = sum;
+      }
   }
   conv_f32_epilogue<MT, TAPS>(p, acc, tile_m, TM, TN, wm, wn, tn, l15, lq, lv, M, cout);
 }
@@ -335,7 +376,8 @@ static hipError_t x3_prepare_kernels() {
   static hipError_t once_rc = hipSuccess;
   std::call_once(once, [] {
     x3_for_each_kernel([](const void* k) {
-      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_MAX);
+      // (the largest tile's two stages are 144 KB; the kernels also hold a few bytes of static LDS: the split-K flag)
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
       if (e != hipSuccess) once_rc = e;
     });
   });
@@ -345,19 +387,28 @@ static hipError_t x3_prepare_kernels() {
 static unsigned x3_lds_bytes(int tm, int tn) { return (unsigned)(2 * 3 * (tm + tn) * 64); }
 static int x3_tile_pixels(int mt, int wn) { return (8 / wn) * 16 * mt; }
 
-// Diagnostics (tools/r05): force the tile of this process's split-precision launches -- (mt, wn) of X3_FOR_TILES; mt = 0 clears.
+// Diagnostics (tools/r05): force the tile and the K split of this process's split-precision launches -- (mt, wn) of X3_FOR_TILES,
+// ksplit workgroups per tile (needs the workspace; not range-checked against the K-steps here); mt = 0 clears.
 // Not part of the reference surface; the product never calls it.
 static std::atomic<unsigned> g_x3_override{0u};
-extern "C" int odet_debug_x3_tile(int mt, int wn) {
-  g_x3_override.store(mt > 0 ? ((unsigned)mt << 8 | (unsigned)wn) : 0u);
+extern "C" int odet_debug_x3_tile(int mt, int wn, int ksplit) {
+  g_x3_override.store(mt > 0 ? ((unsigned)(ksplit > 1 ? ksplit : 1) << 16 | (unsigned)mt << 8 | (unsigned)wn) : 0u);
   return ODET_OK;
 }
 
-// the tile with the least (rounds of 256 workgroups) x (matrix cycles per K-step + the per-step overhead a workgroup pays for
-// its barrier, its copies and the split of its pixel rows)
-static void x3_pick_tile(const long long* M, int num_levels, int cout, int* wn_out, int* mt_out) {
+// ---- tile and split-K selection --------------------------------------------------------------------------------------------
+// Cycles of a K-step on a CU, fitted to the tiles' measured rates on the ResNet-101-FPN layers (tools/r05/x3_tiles.py): the
+// matrix work (6 MFMAs of 16 cycles per 16 x 16 tile on 4 SIMDs; two co-resident workgroups share the pipe) + what is not hidden
+// behind it: ~3.5 cycles per pixel row (its float32 slots loaded, split and stored by the vector units), ~0.8 per weight row
+// (LDS-DMA) and ~720 of barrier, waits and address arithmetic -- a pixel row costs four times a weight row, so the wide tile
+// (128 pixels x 256 channels) wins wherever cout allows it.  A launch that would leave CUs idle (few pixels: batch 1 .. 8 on the
+// 50 x 84 / 25 x 42 maps, the RoI head's dense layers) splits K over S workgroups per tile when every part keeps >= 8 K-steps:
+// a deep-K, few-row layer is a latency chain of its K-steps (conv5's 3 x 3 at batch 1: 144 steps of 1.5 us on 18 workgroups).
+#define X3_TICKETS 4096                                  // tiles of a split-K launch (the workspace's ticket words)
+struct X3Pick { int mt, wn, ksplit; };
+static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int ksteps, size_t part_bytes_max) {
   static const int cand[][2] = {{4, 2}, {2, 2}, {4, 4}, {2, 1}, {1, 1}};       // (mt, wn)
-  int wn_best = 0, mt_best = 0;
+  X3Pick best_pick{0, 0, 1};
   double best = 1e300;
   for (const auto& c : cand) {
     const int mt = c[0], wn = c[1];
@@ -365,20 +416,50 @@ static void x3_pick_tile(const long long* M, int num_levels, int cout, int* wn_o
     const int wm = 8 / wn, tm = wm * 16 * mt, tn = 64 * wn, tiles_n = cout / tn;
     long long slabs = 0;
     for (int l = 0; l < num_levels; ++l) slabs += (M[l] + tm - 1) / tm;
-    const long long blocks = (slabs + 7) / 8 * 8 * tiles_n;
+    const long long tiles = (slabs + 7) / 8 * 8 * tiles_n, real_tiles = slabs * tiles_n;
     const int occ = std::max(1, std::min(2, (int)(X3_LDS_MAX / x3_lds_bytes(tm, tn))));
-    // cycles of a K-step on a CU, fitted to the tiles' measured rates on the ResNet-101-FPN layers (tools/r05/x3_tiles.py): the
-    // matrix work (6 MFMAs of 16 cycles per 16 x 16 tile on 4 SIMDs) + what is not hidden behind it: ~3.5 cycles per pixel row
-    // (its float32 slots loaded, split and stored by the vector units), ~0.8 per weight row (LDS-DMA) and ~720 of barrier, waits
-    // and address arithmetic, which a second resident workgroup overlaps -- a pixel row costs four times a weight row, so the
-    // wide tile (128 pixels x 256 channels) wins wherever cout allows it
-    const double per = (double)tm * tn / 256.0 * 6.0 * 16.0 / 4.0 + 3.5 * tm + 0.8 * tn + 720.0 / occ;
-    const double cost = (double)((blocks + 256 * occ - 1) / (256 * occ)) * per * occ;
-    if (cost < best * 0.98) { best = cost; wn_best = wn; mt_best = mt; }
+    const double mfma = (double)tm * tn / 256.0 * 6.0 * 16.0 / 4.0, other = 3.5 * tm + 0.8 * tn + 720.0;
+    for (int S = 1; S <= 8; ++S) {
+      // a split only where the tiles leave CUs idle (the parts of a launch that fills the chip would be HBM traffic of their
+      // own: 1.1 GB for the RpnHead's P2 level at batch 1), every part at least 8 K-steps, tickets and parts inside the workspace
+      if (S > 1 && (real_tiles > 384 || ksteps / S < 8 || tiles > X3_TICKETS || (size_t)tiles * S * tm * tn * 4 > part_bytes_max)) break;
+      const long long blocks = real_tiles * S;
+      const long long conc = std::min<long long>(occ, (blocks + 255) / 256);          // workgroups that share a CU
+      const long long rounds = (blocks + 256 * conc - 1) / (256 * conc);
+      // per workgroup: ~6000 cycles of prologue (first loads) and epilogue; with a split, the last workgroup of a tile reads the
+      // S parts (~64 B / clock) behind a release / acquire hand-off (~2 us), and the parts are written and read once (~5 TB/s)
+      const double reduce = S > 1 ? 4000.0 + (double)S * tm * tn / 16.0 : 0.0;
+      const double traffic = S > 1 ? (double)real_tiles * S * tm * tn * 8.0 / 2400.0 : 0.0;
+      const double cost = (double)rounds * ((double)((ksteps + S - 1) / S) * ((double)conc * mfma + other + 400.0) + 6000.0 + reduce) + traffic;
+      if (cost < best * 0.97) { best = cost; best_pick = X3Pick{mt, wn, S}; }
+    }
   }
-  *wn_out = wn_best; *mt_out = mt_best;
   const unsigned o = g_x3_override.load();
-  if (o && cout % (64 * (int)(o & 255)) == 0) { *mt_out = (int)(o >> 8); *wn_out = (int)(o & 255); }
+  if (o && cout % (64 * (int)(o & 255)) == 0) {
+    best_pick = X3Pick{(int)(o >> 8 & 255), (int)(o & 255), std::max(1, (int)(o >> 16))};
+    const int tm = x3_tile_pixels(best_pick.mt, best_pick.wn), tn = 64 * best_pick.wn;
+    long long slabs = 0;
+    for (int l = 0; l < num_levels; ++l) slabs += (M[l] + tm - 1) / tm;
+    const long long tiles = (slabs + 7) / 8 * 8 * (cout / tn);
+    if (best_pick.ksplit > ksteps || tiles > X3_TICKETS || (size_t)tiles * best_pick.ksplit * tm * tn * 4 > part_bytes_max)
+      best_pick.ksplit = 1;                              // (a forced split that does not fit the workspace: none)
+  }
+  return best_pick;
+}
+
+// the workspace of the split-K launches: X3_TICKETS ticket words (zero-filled ONCE by the caller; every launch leaves them zero),
+// then the parts
+static int x3_apply_split(ConvF32Params* p, const X3Pick& pick, long long tiles, int TMsel, void* ws, size_t ws_bytes, const char* who) {
+  p->ksplit = pick.ksplit;
+  if (pick.ksplit <= 1) { p->ksplit = 0; return ODET_OK; }
+  ODET_REQUIRE(ws && tiles <= X3_TICKETS && ws_bytes >= (size_t)X3_TICKETS * 4 + (size_t)tiles * pick.ksplit * TMsel * 64 * pick.wn * 4,
+               "%s: split-K workspace too small", who);
+  p->ticket = (unsigned*)ws;
+  p->part = (float*)((char*)ws + (size_t)X3_TICKETS * 4);
+  return ODET_OK;
+}
+static size_t x3_part_bytes(const void* ws, size_t ws_bytes) {
+  return (ws && ws_bytes > (size_t)X3_TICKETS * 4 && (uintptr_t)ws % 16 == 0) ? ws_bytes - (size_t)X3_TICKETS * 4 : 0;
 }
 
 template <bool PW>
@@ -397,10 +478,11 @@ static int x3_launch_tile(int wn, int mt, dim3 grid, unsigned lds_bytes, hipStre
 static void x3_defaults(ConvF32Params* p) {
   p->stride = 1; p->Ho = p->Wo = 0; p->Min = 0; p->res = nullptr; p->top = nullptr; p->th = p->tw = 0; p->tys = p->txs = 0.0f;
   p->x2 = nullptr; p->cin2 = 0; p->k1steps = 0; p->Min2 = 0;
+  p->ksplit = 0; p->part = nullptr; p->ticket = nullptr;
 }
 
 static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias, int batch,
-                             int cin, int cout, int relu, hipStream_t st) {
+                             int cin, int cout, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
   ODET_REQUIRE(levels && w3, "odet_conv3x3_x3: null pointer");
   ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_x3: num_levels %d out of range", num_levels);
   ODET_REQUIRE(batch > 0, "odet_conv3x3_x3: bad batch");
@@ -420,8 +502,8 @@ static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, co
                  "odet_conv3x3_x3: level %d input larger than 4 GiB", l);
     p.x[l] = (const float*)L.x; p.y[l] = (float*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
   }
-  int wn, mt;
-  x3_pick_tile(p.M, num_levels, cout, &wn, &mt);
+  const X3Pick pick = x3_pick_tile(p.M, num_levels, cout, 9 * (cin / X3_BK), x3_part_bytes(ws, ws_bytes));
+  const int wn = pick.wn, mt = pick.mt;
   const int TMsel = x3_tile_pixels(mt, wn);
   long long total = 0;
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
@@ -433,29 +515,35 @@ static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, co
   p.num_levels = num_levels; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
   p.tiles_n = cout / (64 * wn);
   const long long blocks = (total + 7) / 8 * 8 * p.tiles_n;
-  ODET_REQUIRE(blocks < (1ll << 31), "odet_conv3x3_x3: too many workgroups");
-  const int rc = x3_launch_tile<false>(wn, mt, dim3((unsigned)blocks), x3_lds_bytes(TMsel, 64 * wn), st, p);
+  ODET_REQUIRE(blocks < (1ll << 28), "odet_conv3x3_x3: too many workgroups");
+  const int rs = x3_apply_split(&p, pick, blocks, TMsel, ws, ws_bytes, "odet_conv3x3_x3");
+  if (rs != ODET_OK) return rs;
+  const int rc = x3_launch_tile<false>(wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))), x3_lds_bytes(TMsel, 64 * wn), st, p);
   if (rc != ODET_OK) return rc;
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
 
+extern "C" size_t odet_x3_workspace_bytes(void) { return (size_t)X3_TICKETS * 4 + ((size_t)64 << 20); }
+
 extern "C" int odet_conv3x3_x3(const void* x, const void* w3, const void* bias, void* y, int batch, int H, int W, int cin,
-                               int cout, int relu, odet_stream_t stream) {
+                               int cout, int relu, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
   ODET_REQUIRE(x && y, "odet_conv3x3_x3: null pointer");
   const odet_conv_level_t one{x, y, H, W};
-  return conv3x3_x3_launch(&one, 1, w3, bias, batch, cin, cout, relu, (hipStream_t)stream);
+  return conv3x3_x3_launch(&one, 1, w3, bias, batch, cin, cout, relu, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int odet_conv3x3_x3_levels(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
-                                      int batch, int cin, int cout, int relu, odet_stream_t stream) {
-  return conv3x3_x3_launch(levels, num_levels, w3, bias, batch, cin, cout, relu, (hipStream_t)stream);
+                                      int batch, int cin, int cout, int relu, void* workspace, size_t workspace_bytes,
+                                      odet_stream_t stream) {
+  return conv3x3_x3_launch(levels, num_levels, w3, bias, batch, cin, cout, relu, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 struct PwX3Epilogue { const void* res; const void* top; int th, tw; const void* x2; int cin2; };
 
 static int pointwise_x3_launch(const char* who, const void* x, const void* w3, const void* bias, void* y, int batch, int H,
-                               int W, int stride, int cin, int cout, int relu, const PwX3Epilogue& epi, hipStream_t st) {
+                               int W, int stride, int cin, int cout, int relu, const PwX3Epilogue& epi, void* ws, size_t ws_bytes,
+                               hipStream_t st) {
   ODET_REQUIRE(x && w3 && y, "%s: null pointer", who);
   ODET_REQUIRE(batch > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", who);
   ODET_REQUIRE(cin % X3_BK == 0 && cin > 0, "%s: cin %d must be a positive multiple of %d", who, cin, X3_BK);
@@ -483,8 +571,8 @@ static int pointwise_x3_launch(const char* who, const void* x, const void* w3, c
   p.txs = epi.top ? (float)epi.tw / (float)Wo : 0.0f;
   p.stride = stride; p.Ho = Ho; p.Wo = Wo; p.Min = Min;
   p.x2 = (const float*)epi.x2; p.cin2 = epi.x2 ? epi.cin2 : 0; p.k1steps = cin / X3_BK; p.Min2 = (long long)batch * H * W;
-  int wn, mt;
-  x3_pick_tile(&M, 1, cout, &wn, &mt);
+  const X3Pick pick = x3_pick_tile(&M, 1, cout, (cin + (epi.x2 ? epi.cin2 : 0)) / X3_BK, x3_part_bytes(ws, ws_bytes));
+  const int wn = pick.wn, mt = pick.mt;
   const int TMsel = x3_tile_pixels(mt, wn);
   p.tiles_n = cout / (64 * wn);
   const long long total = (M + TMsel - 1) / TMsel;
@@ -493,31 +581,37 @@ static int pointwise_x3_launch(const char* who, const void* x, const void* w3, c
   p.w = (const float*)w3; p.bias = (const float*)bias;
   p.num_levels = 1; p.cin = cin; p.cout = cout; p.relu = relu ? 1 : 0;
   const long long blocks = (total + 7) / 8 * 8 * p.tiles_n;
-  ODET_REQUIRE(blocks < (1ll << 31), "%s: too many workgroups", who);
-  const int rc = x3_launch_tile<true>(wn, mt, dim3((unsigned)blocks), x3_lds_bytes(TMsel, 64 * wn), st, p);
+  ODET_REQUIRE(blocks < (1ll << 28), "%s: too many workgroups", who);
+  const int rs = x3_apply_split(&p, pick, blocks, TMsel, ws, ws_bytes, who);
+  if (rs != ODET_OK) return rs;
+  const int rc = x3_launch_tile<true>(wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))), x3_lds_bytes(TMsel, 64 * wn), st, p);
   if (rc != ODET_OK) return rc;
   ODET_LAUNCH_CHECK();
   return ODET_OK;
 }
 
 extern "C" int odet_pointwise_x3(const void* x, const void* w3, const void* bias, const void* residual, void* y, int batch,
-                                 int H, int W, int stride, int cin, int cout, int relu, odet_stream_t stream) {
+                                 int H, int W, int stride, int cin, int cout, int relu, void* workspace, size_t workspace_bytes,
+                                 odet_stream_t stream) {
   const PwX3Epilogue e{residual, nullptr, 0, 0, nullptr, 0};
-  return pointwise_x3_launch("odet_pointwise_x3", x, w3, bias, y, batch, H, W, stride, cin, cout, relu, e, (hipStream_t)stream);
+  return pointwise_x3_launch("odet_pointwise_x3", x, w3, bias, y, batch, H, W, stride, cin, cout, relu, e, workspace,
+                             workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int odet_lateral_merge_x3(const void* x, const void* w3, const void* bias, const void* top, int th, int tw, void* y,
-                                     int batch, int H, int W, int cin, int cout, odet_stream_t stream) {
+                                     int batch, int H, int W, int cin, int cout, void* workspace, size_t workspace_bytes,
+                                     odet_stream_t stream) {
   ODET_REQUIRE(top, "odet_lateral_merge_x3: null pointer");
   const PwX3Epilogue e{nullptr, top, th, tw, nullptr, 0};
-  return pointwise_x3_launch("odet_lateral_merge_x3", x, w3, bias, y, batch, H, W, 1, cin, cout, 0, e, (hipStream_t)stream);
+  return pointwise_x3_launch("odet_lateral_merge_x3", x, w3, bias, y, batch, H, W, 1, cin, cout, 0, e, workspace, workspace_bytes,
+                             (hipStream_t)stream);
 }
 
 extern "C" int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
                                       const void* w3, const void* bias, void* y, int batch, int cout, int relu,
-                                      odet_stream_t stream) {
+                                      void* workspace, size_t workspace_bytes, odet_stream_t stream) {
   ODET_REQUIRE(x2, "odet_pointwise_dual_x3: null pointer");
   const PwX3Epilogue e{nullptr, nullptr, 0, 0, x2, cin2};
-  return pointwise_x3_launch("odet_pointwise_dual_x3", x1, w3, bias, y, batch, H2, W2, stride2, cin1, cout, relu, e,
-                             (hipStream_t)stream);
+  return pointwise_x3_launch("odet_pointwise_dual_x3", x1, w3, bias, y, batch, H2, W2, stride2, cin1, cout, relu, e, workspace,
+                             workspace_bytes, (hipStream_t)stream);
 }

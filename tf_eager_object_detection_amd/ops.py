@@ -73,12 +73,29 @@ def _x3_planes(holder, w):
     return hit[1]
 
 
+_X3_WS = {}
+
+
+def _x3_workspace(device):
+    """the split-K workspace of the split-precision launches of the CURRENT stream on `device` (include/odet.h: zero-filled once,
+    one per stream, only ever handed to the odet_*_x3 entry points); allocated at the stream's first x3 launch -- a warm-up pass
+    before a HIP-graph capture, as the detectors' capture() makes"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _X3_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(int(L.lib().odet_x3_workspace_bytes()), dtype=torch.uint8, device=device)
+        _X3_WS[key] = ws
+    return ws
+
+
 def _f32_sym(sym, w, holder=None):
-    """(entry point, weight pointer) of a float32 layer in the current form; `holder` = the caller's weight tensor object"""
+    """(entry point, weight pointer, extra arguments before the stream) of a float32 layer in the current form; `holder` = the
+    caller's weight tensor object"""
     if _F32_FORM[0] == 'x3':
         planes = _x3_planes(w if holder is None else holder, w)
-        return sym[:-3] + 'x3', C.c_void_p(planes.data_ptr())             # odet_*_f32 -> odet_*_x3
-    return sym, L.dptr(w)
+        ws = _x3_workspace(w.device)
+        return sym[:-3] + 'x3', C.c_void_p(planes.data_ptr()), (C.c_void_p(ws.data_ptr()), ws.numel())   # odet_*_f32 -> odet_*_x3
+    return sym, L.dptr(w), ()
 
 
 def _boxes(t, name):
@@ -511,11 +528,11 @@ def _conv3x3(dtype, x, weight, bias, relu, out):
         out = torch.empty(shape, dtype=dtype, device=x.device)
     elif out.dtype != dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous %s tensor [B,H,W,cout]' % name)
-    wp = L.dptr(w)
+    wp, extra = L.dptr(w), ()
     if dtype == torch.float32:
-        sym, wp = _f32_sym(sym, w, weight)
+        sym, wp, extra = _f32_sym(sym, w, weight)
     L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
-           cin, cout, 1 if relu else 0, L.stream())
+           cin, cout, 1 if relu else 0, *extra, L.stream())
     return out
 
 
@@ -538,11 +555,11 @@ def _conv3x3_levels(dtype, xs, weight, bias, relu, outs):
         if y.dtype != dtype or tuple(y.shape) != tuple(x.shape[:3]) + (cout,) or not y.is_contiguous():
             raise ValueError('outs must be contiguous %s tensors [B,H,W,cout]' % name)
         lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), y.data_ptr(), int(x.shape[1]), int(x.shape[2])
-    wp = L.dptr(w)
+    wp, extra = L.dptr(w), ()
     if dtype == torch.float32:
-        sym, wp = _f32_sym(sym, w, weight)
+        sym, wp, extra = _f32_sym(sym, w, weight)
     L.call(sym + '_levels', lv, len(xs), wp, L.dptr(bias) if bias is not None else None, B, cin, cout,
-           1 if relu else 0, L.stream())
+           1 if relu else 0, *extra, L.stream())
     return outs
 
 
@@ -799,10 +816,10 @@ def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=Non
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    sym, wp = ('odet_pointwise_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_pointwise_f32', w, weight)
+    sym, wp, extra = ('odet_pointwise_' + sfx, L.dptr(w), ()) if sfx != 'f32' else _f32_sym('odet_pointwise_f32', w, weight)
     L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None,
            L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, stride, cin, cout, 1 if relu else 0,
-           L.stream())
+           *extra, L.stream())
     return out
 
 
@@ -829,9 +846,9 @@ def lateral_merge(x, weight, bias, top, out=None):
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    sym, wp = ('odet_lateral_merge_' + sfx, L.dptr(w)) if sfx != 'f32' else _f32_sym('odet_lateral_merge_f32', w, weight)
+    sym, wp, extra = ('odet_lateral_merge_' + sfx, L.dptr(w), ()) if sfx != 'f32' else _f32_sym('odet_lateral_merge_f32', w, weight)
     L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(top),
-           int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, L.stream())
+           int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, *extra, L.stream())
     return out
 
 
@@ -863,9 +880,9 @@ def pointwise_dual(x1, x2, weight, bias=None, stride=1, relu=True, out=None):
         out = torch.empty(shape, dtype=x1.dtype, device=x1.device)
     elif out.dtype != x1.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x1\'s dtype' % (shape,))
-    sym, wp = ('odet_pointwise_dual_' + sfx, L.dptr(weight)) if sfx != 'f32' else _f32_sym('odet_pointwise_dual_f32', weight)
+    sym, wp, extra = ('odet_pointwise_dual_' + sfx, L.dptr(weight), ()) if sfx != 'f32' else _f32_sym('odet_pointwise_dual_f32', weight)
     L.call(sym, L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, wp,
-           L.dptr(bias) if bias is not None else None, L.dptr(out), B, cout, 1 if relu else 0, L.stream())
+           L.dptr(bias) if bias is not None else None, L.dptr(out), B, cout, 1 if relu else 0, *extra, L.stream())
     return out
 
 

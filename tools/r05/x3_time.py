@@ -6,7 +6,7 @@ from tf_eager_object_detection_amd import ops
 torch.manual_seed(0)
 from tf_eager_object_detection_amd import _lib
 if len(sys.argv) > 2:
-    _lib.call('odet_debug_x3_tile', int(sys.argv[1]), int(sys.argv[2]))
+    _lib.call('odet_debug_x3_tile', int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 1)
 for (B, H, W, cin, cout, k) in ((15, 200, 334, 256, 512, 3), (15, 1, 1000, 12544, 1024, 1)):
     x = torch.randn(B, H, W, cin, device='cuda')
     w = torch.randn(cout, cin, k, k, device='cuda') * 0.02
