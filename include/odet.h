@@ -659,7 +659,7 @@ const char* odet_exec_last_error(odet_exec_t* ex);
  * channels; ns == 2 the half-step-pipelined loop, ns > 2 the ring forms for launches with few pixels.  nw = 0 clears. */
 int odet_debug_conv_tile(int form, int nw, int wn, int mt, int ns);
 /* the same for the split-precision float32 launches (csrc/conv_x3.hip): (mt, wn) of its tile list ((8, 2) = the wave-specialised
- * 256 x 128 tile of tools/exp/conv_x3_wave_specialised.patch) and the K split (workgroups per tile, 1 = none); mt = 0 clears */
+ * 256 x 128 tile of tools/exp/historical/conv_x3_wave_specialised.patch) and the K split (workgroups per tile, 1 = none); mt = 0 clears */
 int odet_debug_x3_tile(int mt, int wn, int ksplit);
 
 #ifdef __cplusplus
