@@ -537,7 +537,18 @@ class FpnStreamPool:
     def wait(self):
         rc = self._lib.odet_exec_wait(self._exec)
         if rc != 0:
-            raise ops.L.OdetError('odet error %d: %s' % (rc, self._lib.odet_exec_last_error(self._exec).decode()))
+            msg = self._lib.odet_exec_last_error(self._exec).decode()
+            # a failed launch sequence may have left a post-ops ticket or an NMS header half-way: the "clean workspace" promises
+            # of the step descriptors (ws_rpn_clean / ws_post_clean) hold again only after the workspaces are zero-filled
+            try:
+                torch.cuda.synchronize()
+                for h in self.slots:
+                    h.ws_post.zero_()
+                    h.ws_rpn.zero_()
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            raise ops.L.OdetError('odet error %d: %s' % (rc, msg))
 
     def recover_incomplete(self):
         """After wait(): the slots whose sync-free NMS did not complete inside their chunks (nms_done = 0: reported EMPTY)
