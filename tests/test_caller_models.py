@@ -34,6 +34,8 @@ def test_constructor_surface_matches_reference_names_cpu():
     assert _COMMON['scales'] == (8, 16, 32) and _COMMON['rpn_proposal_num_post_nms_test'] == 300
     for cls in (BaseFPN, BaseFasterRcnn):
         assert cls.call is cls.forward and hasattr(cls, 'im_detect')
+    assert all(hasattr(BaseFPN, n) for n in ('predict_rpns', 'predict_rois', '_assign_levels', '_get_anchors', '_get_roi_features'))
+    assert all(hasattr(BaseFasterRcnn, n) for n in ('predict_rpn', 'predict_roi', '_get_rpn_loss', '_get_roi_loss'))
 
 
 def _check_detections(got, want, tol=1e-4):
@@ -220,6 +222,12 @@ def test_faster_rcnn_models_call_agrees_with_the_static_shape_detectors(kind):
         assert got == (None, None, None)
         return
     boxes, labels, scores = got
+    # the debugging helpers of the reference's base class (base_faster_rcnn_model.py:226-266)
+    gt = torch.tensor([[30., 40., 200., 180.], [100., 60., 330., 250.]], device='cuda')
+    pos = m.predict_rpn(img, gt)
+    assert pos.dim() == 2 and pos.shape[1] == 4 and pos.shape[0] > 0
+    roi_out = m.predict_roi(img, gt, torch.tensor([3, 7], device='cuda'))
+    assert len(roi_out) == 5 and roi_out[0].shape[1] == 4 and roi_out[0].shape[0] == roi_out[1].shape[0]
     assert scores.shape[0] == n
     o1 = np.lexsort((labels.cpu().numpy(), -scores.cpu().numpy()))
     o2 = np.lexsort((dl[:n].cpu().numpy(), -ds[:n].cpu().numpy()))

@@ -166,6 +166,27 @@ class BaseFasterRcnn(torch.nn.Module):
                                       proposal_target_out_weights, sigma=self._roi_sigma)
         return roi_cls_loss, roi_reg_loss
 
+    def predict_rpn(self, image, gt_bboxes):
+        """:226-241 (a debugging helper): the anchors AnchorTarget labels positive for `gt_bboxes`.  The reference's body is
+        stale against its own AnchorTarget (it passes (anchors, gt_bboxes, image_shape) and unpacks an index list and a count,
+        model/anchor_target.py:37-107 takes (gt_bboxes, image_shape, anchors) and returns labels); this is its intent, written
+        like BaseFPN.predict_rpns (model/fpn/base_fpn_model.py:326-340)."""
+        image = _image_nhwc(image)
+        image_shape = [int(image.shape[1]), int(image.shape[2])]
+        anchors = self._anchor_generator(self._anchor_base, self._extractor_stride,
+                                         int(math.ceil(image_shape[0] / self._extractor_stride)),
+                                         int(math.ceil(image_shape[1] / self._extractor_stride)))
+        rpn_labels, _, _, _ = self._anchor_target((gt_bboxes, image_shape, anchors), True)
+        return anchors[torch.nonzero(rpn_labels > 0)[:, 0]]
+
+    @torch.no_grad()
+    def predict_roi(self, image, gt_bboxes, gt_labels):
+        """:243-266: (final_rois, final_labels, final_bbox_targets, bbox_inside_weights, bbox_outside_weights) of the
+        training-mode proposals"""
+        image = _image_nhwc(image)
+        rois = self._anchors_and_proposals(image, True)[5]
+        return self._proposal_target((rois, gt_bboxes, gt_labels), True)
+
     @torch.no_grad()
     def im_detect(self, preprocessed_image, img_scale):
         """:279-306"""
