@@ -309,18 +309,35 @@ class ResnetV1Fpn(BaseFPN):
                              % (roi_pool_size, roi_pool_size))
         if len(ratios) * len(scales) != 3:
             raise ValueError('ResnetV1Fpn: the RpnHead is built for 3 anchors per cell (ratios x scales)')
-        nn_module_init = torch.nn.Module.__init__
-        nn_module_init(self)                       # (the dense part must exist before BaseFPN.__init__ asks for the layers)
+        torch.nn.Module.__init__(self)             # (the dense part must exist before BaseFPN.__init__ asks for the layers)
         self._depth = depth
         self._roi_head_keep_dropout_rate = roi_head_keep_dropout_rate
         self._top_down_dims = top_down_dims
         dense = ResNetFpnDetector(depth, num_classes, (64, 64), 1, dtype=dtype)
         dense.to(device=device, dtype=dtype, memory_format=torch.channels_last).eval()
         self.__dict__['_dense_ref'] = dense
-        kw = {k: v for k, v in locals().items()
-              if k not in ('self', 'depth', 'roi_head_keep_dropout_rate', 'top_down_dims', 'dtype', 'device', 'dense',
-                           'ResNetFpnDetector', 'nn_module_init', '__class__')}
-        BaseFPN.__init__(self, **kw)
+        BaseFPN.__init__(
+            self, roi_feature_size=roi_feature_size, num_classes=num_classes, weight_decay=weight_decay,
+            level_name_list=level_name_list, min_level=min_level, max_level=max_level, anchor_stride_list=anchor_stride_list,
+            base_anchor_size_list=base_anchor_size_list, ratios=ratios, scales=scales, rpn_proposal_means=rpn_proposal_means,
+            rpn_proposal_stds=rpn_proposal_stds, rpn_proposal_num_pre_nms_train=rpn_proposal_num_pre_nms_train,
+            rpn_proposal_num_post_nms_train=rpn_proposal_num_post_nms_train,
+            rpn_proposal_num_pre_nms_test=rpn_proposal_num_pre_nms_test,
+            rpn_proposal_num_post_nms_test=rpn_proposal_num_post_nms_test,
+            rpn_proposal_nms_iou_threshold=rpn_proposal_nms_iou_threshold, rpn_sigma=rpn_sigma,
+            rpn_training_pos_iou_threshold=rpn_training_pos_iou_threshold,
+            rpn_training_neg_iou_threshold=rpn_training_neg_iou_threshold,
+            rpn_training_total_num_samples=rpn_training_total_num_samples,
+            rpn_training_max_pos_samples=rpn_training_max_pos_samples, roi_proposal_means=roi_proposal_means,
+            roi_proposal_stds=roi_proposal_stds, roi_pool_size=roi_pool_size,
+            roi_pooling_max_pooling_flag=roi_pooling_max_pooling_flag, roi_sigma=roi_sigma,
+            roi_training_pos_iou_threshold=roi_training_pos_iou_threshold,
+            roi_training_neg_iou_threshold=roi_training_neg_iou_threshold,
+            roi_training_total_num_samples=roi_training_total_num_samples,
+            roi_training_max_pos_samples=roi_training_max_pos_samples,
+            prediction_max_objects_per_image=prediction_max_objects_per_image,
+            prediction_max_objects_per_class=prediction_max_objects_per_class,
+            prediction_nms_iou_threshold=prediction_nms_iou_threshold, prediction_score_threshold=prediction_score_threshold)
         self.dense = dense
 
     def _get_roi_head(self):
