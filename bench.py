@@ -293,6 +293,7 @@ def self_launch(n, argv):
 
 
 def main():
+    t_main = time.perf_counter()
     # (before anything initialises HSA: dmabuf IPC is the only kind the host driver supports)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     ap = argparse.ArgumentParser()
@@ -323,6 +324,9 @@ def main():
     ap.add_argument('--roofline-samples', type=int, default=12, help='isolated RoI launches timed after the timed region')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; "
                     "'gloo' only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument('--time-budget', type=float, default=330.0,
+                    help='seconds the whole run aims to stay within: an accuracy gate that would not fit any more runs on fewer '
+                         'scenes (>= 1024; recorded as gate_scenes_reduced_to), nothing else is shortened')
     ap.add_argument('--trace', action='store_true', help='phase time stamps on stderr (synchronises at every mark)')
     ap.add_argument('--force-collective', action='store_true',
                     help='with ONE rank under torch.distributed.run: still issue the all-gather of every stream group (the RCCL '
@@ -758,7 +762,16 @@ def main():
                                            ('fp16_vgg16_600x800', 'vgg16', 2 * args.gate_images, 'fp16'),
                                            ('fp32_x3', 'fpn', max(256, args.gate_images // 8), 'x3')):
                 try:
+                    # (a slow or shared box: the gates are the long legs -- ~14 / 11 / 8 / 30 ms per scene for the four -- and
+                    # scale with the scene count; the headline legs above are never shortened)
+                    per_scene = {'fp16': 0.0140, 'fp16_resnet50_c4': 0.0115, 'fp16_vgg16_600x800': 0.0078, 'fp32_x3': 0.030}[name]
+                    left = args.time_budget - (time.perf_counter() - t_main) - 5.0
+                    wanted = n_img
+                    if per_scene * n_img > left:
+                        n_img = max(min(n_img, 1024), int(left / per_scene) // 256 * 256)
                     gate = precision_gate.fp16_vs_fp32(num_images=n_img, batch32=30, batch16=30, family=fam, test_mode=mode)
+                    if n_img != wanted:
+                        gate['gate_scenes_reduced_to'] = [n_img, wanted]
                     gate.pop('protocol', None) if name != 'fp16' else None
                     gate.pop('fit', None) if name != 'fp16' else None
                     if isinstance(e2e.get(name), dict):
