@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ODET_VERSION 101
+#define ODET_VERSION 102
 
 #define ODET_OK 0
 #define ODET_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -495,6 +495,31 @@ int odet_lateral_merge_x3(const void* x, const void* w3, const void* bias, const
                           odet_stream_t stream);
 int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
                            const void* w3, const void* bias, void* y, int batch, int cout, int relu,
+                           void* workspace, size_t workspace_bytes, odet_stream_t stream);
+/* The TWO-LIMB float16 forms of the same layers (csrc/conv_x3.hip, NL = 2): a float32 operand as h + l * 2^-11, h = f16(a),
+ * l = f16((a - h) * 2^11) (round to nearest even: 11 + 11 bits and l's sign = 23 of float32's 24 bits, every operand to
+ * within ONE float32 ulp), a product as h h + (h l + l h) * 2^-11 on v_mfma_f32_16x16x32_f16 (dropped: l l <= 2^-22 of it),
+ * two float32 accumulators joined at the end: HALF the matrix work of the three-limb form; against float64 its error on the
+ * detectors' layers is no larger than the exact-float32 form's (float32 accumulation dominates both) -- for data inside
+ * float16's RANGE.  |activation| > 65504 gives infinities / NaN in the result (never a wrong finite number); activations below 2^-14
+ * keep an absolute error <= 2^-36 instead of a relative one.  `w2` = float16 planes [2][cout][K] of w * 2^w_exp, written once
+ * per weight tensor by odet_split_f16x2; the caller picks w_exp (|w_exp| <= 100) so that the largest |w| * 2^w_exp lies in
+ * [512, 1024) -- every weight down to 2^-24 of the largest then keeps both limbs normal -- and passes the same w_exp to the
+ * layer, which scales the sums back (a power of two: exact).  Everything else as the *_x3 entry points. */
+int odet_split_f16x2(const float* w, void* planes, long long n, int w_exp, odet_stream_t stream);
+int odet_conv3x3_x2(const void* x, const void* w2, const void* bias, void* y, int batch, int H, int W,
+                    int cin, int cout, int relu, int w_exp, void* workspace, size_t workspace_bytes, odet_stream_t stream);
+int odet_conv3x3_x2_levels(const odet_conv_level_t* levels, int num_levels, const void* w2, const void* bias,
+                           int batch, int cin, int cout, int relu, int w_exp, void* workspace, size_t workspace_bytes,
+                           odet_stream_t stream);
+int odet_pointwise_x2(const void* x, const void* w2, const void* bias, const void* residual, void* y, int batch,
+                      int H, int W, int stride, int cin, int cout, int relu, int w_exp, void* workspace,
+                      size_t workspace_bytes, odet_stream_t stream);
+int odet_lateral_merge_x2(const void* x, const void* w2, const void* bias, const void* top, int th, int tw, void* y,
+                          int batch, int H, int W, int cin, int cout, int w_exp, void* workspace, size_t workspace_bytes,
+                          odet_stream_t stream);
+int odet_pointwise_dual_x2(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
+                           const void* w2, const void* bias, void* y, int batch, int cout, int relu, int w_exp,
                            void* workspace, size_t workspace_bytes, odet_stream_t stream);
 /* The stem's patch matrix in float32 mode: row (image, yo, xo) = the zero-padded 7 x 7 x 3 window of conv1_pad +
  * Conv2D(64, 7x7, strides 2, 'valid') (resnet_fpn.py:262-289) in (dy, dx, channel) order, padded from 147 to 160 floats;

@@ -83,7 +83,7 @@ def test_bench_e2e_summary_keys():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][-1])
     e = d['e2e']
-    for leg in ('fp16', 'fp16_b1', 'fp16_b4', 'fp16_b8', 'fp32', 'fp32_x3', 'fp16_resnet50_c4', 'fp16_vgg16_600x800'):
+    for leg in ('fp16', 'fp16_b1', 'fp16_b4', 'fp16_b8', 'fp32', 'fp32_x3', 'fp32_x2', 'fp16_resnet50_c4', 'fp16_vgg16_600x800'):
         assert 'error' not in e[leg], (leg, e[leg])
         assert e[leg]['value'] > 0 and e[leg]['nms_done'] == 1
     assert e['fp16_b1']['batch'] == 1 and e['fp16_b1']['value_hip_graph'] > e['fp16_b1']['value'] * 0.9
@@ -94,8 +94,13 @@ def test_bench_e2e_summary_keys():
     gx = e['fp32_x3']['map_delta_vs_fp32']
     assert e['fp32_x3']['value'] > 1.2 * e['fp32']['value'] and abs(gx['map_delta']) < 1e-3
     assert gx['rpn_kept_index_agreement_mean'] > 0.995 and gx['p99_abs_dscore'] < 1e-3
+    # the two-limb float16 form of the same mode: faster again, the same detector up to float32 rounding
+    g2 = e['fp32_x2']['map_delta_vs_fp32']
+    assert e['fp32_x2']['value'] > 1.1 * e['fp32_x3']['value'] and abs(g2['map_delta']) < 1e-3
+    assert g2['rpn_kept_index_agreement_mean'] > 0.995 and g2['p99_abs_dscore'] < 1e-3
     sm = d['summary']
     assert list(d.keys())[-1] == 'summary' and len(json.dumps(sm)) <= 1024
+    assert sm['fp32_x2'][0] == round(e['fp32_x2']['value'], 1) and len(sm['fp32_x2']) == 4
     assert sm['e2e_fp32_x3'][0] == round(e['fp32_x3']['value'], 1) and len(sm['map_delta_x3']) == 4
     assert sm['e2e_fp16_b1_graph'] == round(e['fp16_b1']['value_hip_graph'], 1) and sm['e2e_fp16'][0] == round(e['fp16']['value'], 1)
     assert sm['map_delta_fpn'][3] == 256 and len(sm['map_delta_c4']) == 4 and len(sm['map_delta_vgg16']) == 4

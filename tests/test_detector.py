@@ -1335,8 +1335,8 @@ def test_detectors_have_no_library_or_cpu_route():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dt,form', [(torch.float32, 'exact'), (torch.float32, 'x3'), (torch.float16, 'exact')],
-                         ids=['float32-exact', 'float32-x3', 'float16'])
+@pytest.mark.parametrize('dt,form', [(torch.float32, 'exact'), (torch.float32, 'x3'), (torch.float32, 'x2'), (torch.float16, 'exact')],
+                         ids=['float32-exact', 'float32-x3', 'float32-x2', 'float16'])
 def test_detector_dense_parts_match_the_plain_torch_formulation(dt, form):
     """features / rpn / roi_head of the ResNet-FPN detector (this repository's kernels) against the plain-torch formulation of
     the same modules (library convolutions, float32 arithmetic on the same weights); float32 in both of its forms: the
@@ -1402,54 +1402,76 @@ def test_float32_patch_matrix_goes_through_in_groups_below_4_gib(monkeypatch, fa
     assert len(whole) == len(parts) and all(torch.equal(a, b) for a, b in zip(whole, parts))
 
 
-def _x3_and_exact(fn):
+def _x3_and_exact(fn, form='x3'):
     from tf_eager_object_detection_amd import ops
     with ops.f32_form('exact'):
         a = fn()
-    with ops.f32_form('x3'):
+    with ops.f32_form(form):
         b = fn()
     return a, b
 
 
+SPLIT_FORMS = ['x3', 'x2']          # three bfloat16 limbs / two float16 limbs (csrc/conv_x3.hip, NL = 3 / 2)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize('form', SPLIT_FORMS)
 @pytest.mark.parametrize('B,H,W,cin,cout', [(2, 25, 42, 256, 512), (1, 50, 84, 64, 64), (3, 13, 21, 512, 512), (1, 100, 167, 128, 128),
                                              (2, 31, 45, 32, 192), (1, 7, 5, 96, 64), (1, 200, 334, 64, 64)])
-def test_conv3x3_split_precision_form(B, H, W, cin, cout):
-    """odet_conv3x3_x3 (csrc/conv_x3.hip: float32 operands as three bfloat16 limbs, six products per k, float32 accumulation):
+def test_conv3x3_split_precision_form(B, H, W, cin, cout, form):
+    """odet_conv3x3_x3 / _x2 (csrc/conv_x3.hip: float32 operands as three bfloat16 limbs, six products per k -- or two float16
+    limbs h + l * 2^-11, three products per k -- float32 accumulation):
     EXACT on integer-valued data (every limb product and every partial sum is an integer below 2^24) and, on random data, as
     close to the float64 convolution as the exact-float32 form is (within float32 rounding of the float64
-    truth) -- both forms share memory layout, tiling rules and epilogue"""
+    truth) -- all forms share memory layout, tiling rules and epilogue"""
     from tf_eager_object_detection_amd import ops
     g = torch.Generator(device='cuda'); g.manual_seed(H * 7 + cin)
     xi = torch.randint(-3, 4, (B, H, W, cin), device='cuda', generator=g).float()
     wi = torch.randint(-2, 3, (cout, cin, 3, 3), device='cuda', generator=g).float().contiguous(memory_format=torch.channels_last)
     bi = torch.randint(-3, 4, (cout,), device='cuda', generator=g).float()
     want = F.relu(F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double(), bi.double(), 1, 1)).permute(0, 2, 3, 1)
-    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(xi, wi, bi, relu=True))
+    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(xi, wi, bi, relu=True), form)
     assert torch.equal(ex.double(), want) and torch.equal(x3.double(), want)
     x = torch.randn((B, H, W, cin), device='cuda', generator=g) * 5
     w = (torch.randn((cout, cin, 3, 3), device='cuda', generator=g) * (9 * cin) ** -0.5).contiguous(memory_format=torch.channels_last)
     b = torch.randn(cout, device='cuda', generator=g)
     want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1).permute(0, 2, 3, 1)
-    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(x, w, b))
+    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(x, w, b), form)
     rms = float(want.pow(2).mean().sqrt())
     e_ex, e_x3 = float((ex.double() - want).abs().max()) / rms, float((x3.double() - want).abs().max()) / rms
     assert e_x3 <= max(2.0 * e_ex, 2e-6) and e_x3 < 2e-5, (e_ex, e_x3)
-    # huge and tiny magnitudes: the limbs keep float32's exponent range (bfloat16), nothing overflows or flushes
-    ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(x * 1e18, w * 1e-20, None))
-    want = F.conv2d((x * 1e18).permute(0, 3, 1, 2).double(), (w * 1e-20).double(), None, 1, 1).permute(0, 2, 3, 1)
-    assert float((x3.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    if form == 'x3':
+        # huge and tiny magnitudes: the limbs keep float32's exponent range (bfloat16), nothing overflows or flushes
+        ex, x3 = _x3_and_exact(lambda: ops.conv3x3_f32(x * 1e18, w * 1e-20, None))
+        want = F.conv2d((x * 1e18).permute(0, 3, 1, 2).double(), (w * 1e-20).double(), None, 1, 1).permute(0, 2, 3, 1)
+        assert float((x3.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    else:
+        # float16 limbs: the WEIGHTS' scale is free (the planes hold w * 2^w_exp), the activations must lie inside float16's
+        # range -- up to 65504 at full accuracy, beyond it infinities / NaN, not a wrong finite number
+        xs = x * (6.0e4 / float(x.abs().max()))
+        ex, x2 = _x3_and_exact(lambda: ops.conv3x3_f32(xs, w * 1e-20, None), form)
+        want = F.conv2d(xs.permute(0, 3, 1, 2).double(), (w * 1e-20).double(), None, 1, 1).permute(0, 2, 3, 1)
+        assert float((x2.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+        ex, x2 = _x3_and_exact(lambda: ops.conv3x3_f32(x * 1e-3, w * 1e12, None), form)
+        want = F.conv2d((x * 1e-3).permute(0, 3, 1, 2).double(), (w * 1e12).double(), None, 1, 1).permute(0, 2, 3, 1)
+        assert float((x2.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+        xo = x.clone()
+        xo[0, H // 2, W // 2, 3] = 7.0e4
+        _, x2 = _x3_and_exact(lambda: ops.conv3x3_f32(xo, w, None), form)
+        hit = x2[0, max(H // 2 - 1, 0):H // 2 + 2, max(W // 2 - 1, 0):W // 2 + 2]
+        assert not torch.isfinite(hit).any() and torch.isfinite(x2).sum() == x2.numel() - hit.numel()
 
 
 @pytest.mark.gpu
-def test_pointwise_split_precision_forms():
+@pytest.mark.parametrize('form', SPLIT_FORMS)
+def test_pointwise_split_precision_forms(form):
     """the 1x1 / dense / strided / two-source / lateral-merge / shortcut forms of the split-precision kernel against float64:
     exact on integers, as close as the exact-float32 form on random data; multi-level launch of the 3x3 form"""
     from tf_eager_object_detection_amd import ops
     g = torch.Generator(device='cuda'); g.manual_seed(9)
 
     def close(fn, want, what):
-        ex, x3 = _x3_and_exact(fn)
+        ex, x3 = _x3_and_exact(fn, form)
         rms = max(float(want.pow(2).mean().sqrt()), 1e-30)
         e_ex, e_x3 = float((ex.double() - want).abs().max()) / rms, float((x3.double() - want).abs().max()) / rms
         assert e_x3 <= max(2.0 * e_ex, 2e-6) and e_x3 < 3e-5, (what, e_ex, e_x3)
@@ -1467,7 +1489,7 @@ def test_pointwise_split_precision_forms():
     xi = torch.randint(-3, 4, (2, 13, 17, 256), device='cuda', generator=g).float()
     wi = torch.randint(-2, 3, (128, 256), device='cuda', generator=g).float()
     want = F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double()[:, :, None, None]).permute(0, 2, 3, 1)
-    ex, x3 = _x3_and_exact(lambda: ops.pointwise(xi, wi))
+    ex, x3 = _x3_and_exact(lambda: ops.pointwise(xi, wi), form)
     assert torch.equal(x3.double(), want) and torch.equal(ex, x3)
     # two sources along K (a stage's first bottleneck: last 1x1 + strided convolutional shortcut as one contraction)
     x1 = torch.randn((2, 13, 21, 128), device='cuda', generator=g)
@@ -1481,8 +1503,8 @@ def test_pointwise_split_precision_forms():
     top = torch.randn((2, 13, 21, 256), device='cuda', generator=g)
     w = torch.randn((256, 512), device='cuda', generator=g) * 0.04
     b = torch.randn(256, device='cuda', generator=g)
-    ex, x3 = _x3_and_exact(lambda: ops.lateral_merge(c, w, b, top))
-    lat = _x3_and_exact(lambda: ops.pointwise(c, w, b))[1]
+    ex, x3 = _x3_and_exact(lambda: ops.lateral_merge(c, w, b, top), form)
+    lat = _x3_and_exact(lambda: ops.pointwise(c, w, b), form)[1]
     assert torch.equal(x3, ops.fpn_topdown_merge(top, lat))                       # bit-identical to merge(conv_x3)
     assert float((x3 - ex).abs().max()) <= 1e-5 * float(ex.abs().max())
     # all pyramid levels in one launch == level by level: the same bits without a workspace (no K split anywhere); with it a
@@ -1491,7 +1513,7 @@ def test_pointwise_split_precision_forms():
     w = (torch.randn((512, 256, 3, 3), device='cuda', generator=g) * 0.02).contiguous(memory_format=torch.channels_last)
     b = torch.randn(512, device='cuda', generator=g)
     from tf_eager_object_detection_amd import _lib
-    with ops.f32_form('x3'):
+    with ops.f32_form(form):
         together = ops.conv3x3_f32_levels(xs, w, b, relu=True)
         single = [ops.conv3x3_f32(x, w, b, relu=True) for x in xs]
         _lib.call('odet_debug_x3_tile', 4, 4, 1)                                  # (one tile, no split: the launch grouping alone)
@@ -1500,14 +1522,22 @@ def test_pointwise_split_precision_forms():
         _lib.call('odet_debug_x3_tile', 0, 0, 0)
     assert all(torch.equal(a, s_) for a, s_ in zip(together_1, single_1))
     assert all(float((a - s_).abs().max()) <= 2e-6 * float(s_.abs().max()) for a, s_ in zip(together, single))
-    # the limb planes: exact sum, cached per weight tensor
-    planes = ops.split_bf16x3(w.permute(0, 2, 3, 1).contiguous())
-    parts = (planes.view(torch.bfloat16).double()).sum(0)
-    assert torch.equal(parts, w.permute(0, 2, 3, 1).double())
+    # the limb planes: exact sum (three bfloat16 limbs) / the scaled weight to within one float32 ulp (two float16 limbs: 23 bits)
+    wk = w.permute(0, 2, 3, 1).contiguous()
+    if form == 'x3':
+        planes = ops.split_bf16x3(wk)
+        assert torch.equal(planes.view(torch.bfloat16).double().sum(0), wk.double())
+    else:
+        planes, w_exp = ops.split_f16x2(wk)
+        assert 512.0 <= float(wk.abs().max()) * 2.0 ** w_exp < 1024.0
+        pl = planes.view(torch.float16).double()
+        scaled = wk.double() * 2.0 ** w_exp
+        assert bool(((pl[0] + pl[1] * 2.0 ** -11 - scaled).abs() <= 2.0 ** -23 * scaled.abs()).all())     # one float32 ulp
 
 
 @pytest.mark.gpu
-def test_float32_x3_detector_agrees_with_the_exact_float32_detector():
+@pytest.mark.parametrize('form', SPLIT_FORMS)
+def test_float32_x3_detector_agrees_with_the_exact_float32_detector(form):
     """the split-precision float32 mode against the exact-float32 mode on the SAME weights and images:
     class scores / boxes within 1e-4 (relative to the image scale for boxes), the RPN's kept anchor indices equal up to the
     ties float32 rounding decides (reported; >= 99 % here), same number of detections"""
@@ -1515,7 +1545,7 @@ def test_float32_x3_detector_agrees_with_the_exact_float32_detector():
     torch.manual_seed(1)
     shape, K = (256, 352), 300
     a = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=2, blind_chunks=3).prepare()
-    b = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=2, blind_chunks=3, f32_form='x3')
+    b = ResNetFpnDetector(50, 21, shape, K, dtype=torch.float32, max_batch=2, blind_chunks=3, f32_form=form)
     b.load_state_dict(a.state_dict())
     b.prepare()
     rng = np.random.default_rng(1)
@@ -1570,8 +1600,9 @@ def test_float16_detections_of_one_image_do_not_depend_on_the_batch_beyond_round
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('form', SPLIT_FORMS)
 @pytest.mark.parametrize('kind', ['c4', 'vgg16'])
-def test_float32_x3_single_level_detectors_agree_with_the_exact_float32_detectors(kind):
+def test_float32_x3_single_level_detectors_agree_with_the_exact_float32_detectors(kind, form):
     """the split-precision float32 mode of the ResNet-C4 / VGG16 detectors (BASELINE configs 2 / 1) against their exact-float32
     mode on the same weights: RPN outputs within 1e-4, >= 99 % of the same kept anchors, the same number of detections (+-1)"""
     from tf_eager_object_detection_amd.model.frcnn_detector import ResNetC4Detector, Vgg16Detector
@@ -1580,7 +1611,7 @@ def test_float32_x3_single_level_detectors_agree_with_the_exact_float32_detector
     mk = (lambda **kw: ResNetC4Detector(50, 21, shape, K, dtype=torch.float32, max_batch=2, **kw)) if kind == 'c4' else \
          (lambda **kw: Vgg16Detector(21, shape, K, dtype=torch.float32, max_batch=2, **kw))
     a = mk().prepare()
-    b = mk(f32_form='x3')
+    b = mk(f32_form=form)
     b.load_state_dict(a.state_dict())
     b.prepare()
     rng = np.random.default_rng(2)
@@ -1599,14 +1630,15 @@ def test_float32_x3_single_level_detectors_agree_with_the_exact_float32_detector
 
 
 @pytest.mark.gpu
-def test_split_precision_split_k_is_deterministic_exact_on_integers_and_leaves_its_workspace_clean():
+@pytest.mark.parametrize('form', SPLIT_FORMS)
+def test_split_precision_split_k_is_deterministic_exact_on_integers_and_leaves_its_workspace_clean(form):
     """the K split of the split-precision kernel (launches with few pixels and deep K: conv5 / the dense layers at small batch):
     S workgroups per tile, float32 parts added in fixed order by the last one.  Forced S = 2, 3, 5, 8 on integer data = the exact
     result; on random data within float32 rounding of the unsplit launch and bit-identical from run to run; the ticket words of
     the workspace are zero after every launch; the product's own pick splits these shapes"""
     from tf_eager_object_detection_amd import ops, _lib
     g = torch.Generator(device='cuda'); g.manual_seed(77)
-    with ops.f32_form('x3'):
+    with ops.f32_form(form):
         for (B, H, W, cin, cout, k) in ((1, 25, 42, 512, 512, 3), (1, 1, 1000, 12544, 1024, 1), (2, 13, 21, 2048, 512, 1), (1, 50, 84, 256, 256, 3)):
             xi = torch.randint(-2, 3, (B, H, W, cin), device='cuda', generator=g).float()
             wi = ((torch.randint(0, 100, (cout, cin, k, k), device='cuda', generator=g) < 10).float()

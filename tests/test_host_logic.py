@@ -53,7 +53,7 @@ def test_library_loads_and_exports_every_header_symbol():
     assert len(syms) >= 20
     for name in syms:
         assert hasattr(handle, name), 'libodet_hip.so does not export %s' % name
-    assert handle.odet_version() == 101
+    assert handle.odet_version() == 102
 
 
 def test_ctypes_table_matches_header():

@@ -11,7 +11,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libodet_hip.so')     # (tools/_diag.py points it at a diagnostic build; no environment switch)
-ODET_VERSION = 101                                   # include/odet.h
+ODET_VERSION = 102                                   # include/odet.h
 
 _lib = None
 
@@ -139,6 +139,12 @@ SIGNATURES = {
     'odet_pointwise_x3': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'odet_lateral_merge_x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'odet_pointwise_dual_x3': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_split_f16x2': (_i, [_vp, _vp, _i64, _i, _vp]),
+    'odet_conv3x3_x2': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_conv3x3_x2_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_pointwise_x2': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_lateral_merge_x2': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'odet_pointwise_dual_x2': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     'odet_stem_patches_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'odet_rgb_patches3x3_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f16': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -28,6 +28,7 @@ struct ConvF32Params {
   // of the K-steps and leaves its float32 partial tile in `part`; the one that draws the last of the tile's tickets adds the
   // parts in their fixed order 0 .. ksplit - 1 and runs the epilogue (deterministic; exact on integers)
   int ksplit; float* part; unsigned* ticket;
+  float acc_scale;                // conv_x3.hip's two-limb float16 form: 2^-w_exp (the weight planes hold w * 2^w_exp); else unused
 };
 
 // bias (+ shortcut | FPN top-down merge) (+ ReLU) and the stores of a wave's MT x 4 accumulator tiles

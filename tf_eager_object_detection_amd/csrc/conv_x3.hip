@@ -36,11 +36,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "conv_f32_common.h"
 
 typedef __bf16 x3b8 __attribute__((ext_vector_type(8)));
 typedef __bf16 x3b2 __attribute__((ext_vector_type(2)));
+typedef _Float16 x2h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x2h2 __attribute__((ext_vector_type(2)));
 typedef float x3f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int x3u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int x3u2 __attribute__((ext_vector_type(2)));
@@ -64,6 +67,17 @@ __device__ __forceinline__ void x3_split2(const x3f2 a, unsigned& h, unsigned& m
   l = __builtin_bit_cast(unsigned, lb);
 }
 
+// two float32 -> their two float16 limbs, packed: a ~ h + l * 2^-11, h = f16(a), l = f16((a - h) * 2^11) (the low limb scaled
+// into float16's normal range; |a| > 65504 gives infinities -- and a NaN result -- never a wrong finite number)
+__device__ __forceinline__ void x2_split2(const x3f2 a, unsigned& h, unsigned& l) {
+  const x2h2 hb = __builtin_convertvector(a, x2h2);
+  h = __builtin_bit_cast(unsigned, hb);
+  const x3f2 hf = __builtin_convertvector(hb, x3f2);
+  const x3f2 r = (a - hf) * 2048.0f;                      // exact (the difference has at most 13 significant bits)
+  const x2h2 lb = __builtin_convertvector(r, x2h2);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
 // ---- weights: float32 [n] -> planes [3][n] of bfloat16 (once per weight tensor) ------------------------------------------------
 __global__ void __launch_bounds__(256) k_split_bf16x3(const float* __restrict__ w, unsigned* __restrict__ planes, long long n2) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
@@ -83,21 +97,53 @@ extern "C" int odet_split_bf16x3(const float* w, void* planes, long long n, odet
   return ODET_OK;
 }
 
+// float32 [n] -> planes [2][n] of float16 of w * 2^w_exp (the caller picks w_exp so that the largest |w| lands in [512, 1024):
+// every weight down to 2^-24 of the largest keeps both limbs in float16's normal range; the kernels scale the sums back)
+__global__ void __launch_bounds__(256) k_split_f16x2(const float* __restrict__ w, unsigned* __restrict__ planes, long long n2, int w_exp) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) {
+    const x3f2 a = {ldexpf(w[2 * i], w_exp), ldexpf(w[2 * i + 1], w_exp)};
+    unsigned h, l;
+    x2_split2(a, h, l);
+    planes[i] = h; planes[n2 + i] = l;
+  }
+}
+
+extern "C" int odet_split_f16x2(const float* w, void* planes, long long n, int w_exp, odet_stream_t stream) {
+  ODET_REQUIRE(w && planes && n > 0 && n % 2 == 0, "odet_split_f16x2: needs an even, positive element count");
+  ODET_REQUIRE(w_exp >= -100 && w_exp <= 100, "odet_split_f16x2: w_exp %d out of range", w_exp);
+  const long long n2 = n / 2;
+  const int grid = (int)std::min<long long>((n2 + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(k_split_f16x2, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (unsigned*)planes, n2, w_exp);
+  ODET_LAUNCH_CHECK();
+  return ODET_OK;
+}
+
 // ---- the tile ------------------------------------------------------------------------------------------------------------------
-// p.w = the weight PLANES (bfloat16 [3][cout][K], K = TAPS * cin (+ cin2)); everything else as in conv_f32.hip.
-template <int MT, int WN, int TAPS>
+// p.w = the weight PLANES ([NL][cout][K] of 2-byte limbs, K = TAPS * cin (+ cin2)); everything else as in conv_f32.hip.
+// NL = 3: bfloat16 limbs, six products (above).  NL = 2: float16 limbs h + l * 2^-11 (11 + 11 bits and the sign of l: 23 of
+// float32's 24 bits -- every operand to within ONE float32 ulp, 2^-23), three products -- h h into one accumulator, h l + l h
+// into a second one that joins it times 2^-11 at the end (dropped: l l <= 2^-22 |a b|): half the matrix work, for data inside
+// float16's RANGE.  Against float64 on the network's layers its error is no larger than the exact-float32 form's
+// (tools/r05/x3_layers.py --check: the accumulation's float32 rounding dominates both).
+template <int MT, int WN, int TAPS, int NL>
 __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
+  static_assert(NL == 2 || NL == 3, "two float16 or three bfloat16 limbs");
+  using frag_t = std::conditional_t<NL == 3, x3b8, x2h8>;
   constexpr int WM = 8 / WN;
   constexpr int TM = WM * 16 * MT;
   constexpr int TN = 64 * WN;
   static_assert(TM % 64 == 0, "every wave loads whole 8-row pieces");
   constexpr int XP = TM / 64;                            // pixel pieces (8 rows x 128 B of float32) per wave and K-step
-  constexpr int WPIECES = 3 * TN / 16;                   // weight pieces (16 rows x 64 B) per stage
+  constexpr int WPIECES = NL * TN / 16;                  // weight pieces (16 rows x 64 B) per stage
   constexpr int WPW = (WPIECES + 7) / 8;                 // per wave (the last ones only for the first waves)
   constexpr uint32_t XLIMB = (uint32_t)TM * 64u;         // bytes of one limb plane of the pixel rows
   constexpr uint32_t WLIMB = (uint32_t)TN * 64u;
-  constexpr uint32_t WBASE = 3u * XLIMB;
-  constexpr uint32_t STAGE = 3u * (XLIMB + WLIMB);
+  constexpr uint32_t WBASE = (uint32_t)NL * XLIMB;
+  constexpr uint32_t STAGE = (uint32_t)NL * (XLIMB + WLIMB);
+  // stages: the weights of K-step ks + NS - 1 travel while ks is computed.  Two limbs: three stages -- a K-step is 12 MFMAs per
+  // pixel tile, shorter than an LDS-DMA's way through the memory system, so the copy gets two K-steps.
+  constexpr int NS = NL == 2 ? 3 : 2;
+  static_assert(NS == 2 || WPIECES % 8 == 0, "the counted wait needs the same number of copies from every wave");
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -131,7 +177,7 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   const uint32_t Ktot = (uint32_t)TAPS * (uint32_t)cin + (dual ? (uint32_t)p.cin2 : 0u);
   const uint32_t wrowB = Ktot * 2u;                       // bytes of a weight row inside a limb plane
   const uint32_t planeB = (uint32_t)cout * wrowB;
-  const x3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)(3u * planeB), 0x00020000);
+  const x3_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((uint32_t)NL * planeB), 0x00020000);
   // ---- what this thread loads per K-step: XP 16-byte slots of float32 pixel rows (row = piece * 8 + lane / 8, slot lane % 8)
   const int sub = lane >> 3, sl = lane & 7;
   uint32_t voffA[XP], voffA2[TAPS == 1 ? XP : 1], maskA[XP];
@@ -184,7 +230,7 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   const int ksteps = (int)((long long)ksteps_all * (z + 1) / S) - ks_lo;
   // the float32 slots of TWO K-steps in flight (buffer ks & 1): a load issued at the top of K-step ks is split and stored in
   // the middle of K-step ks + 1 -- one and a half K-steps (~3 us) to arrive, whatever level of the memory system it comes from
-  x3u4 ra[2][XP];
+  x3u4 ra[NS][XP];
   auto load_a = [&](int ks, x3u4 (&r)[XP]) {
     int tap = 0;
     uint32_t soA;
@@ -218,14 +264,23 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   const uint32_t sA = (uint32_t)sub * 64u + (uint32_t)(((sl >> 1) ^ ((wv & 1) << 1)) * 16 + (sl & 1) * 8);
   auto store_piece = [&](const x3u4 v, int i, uint32_t stage) {
     const c3f4 f = __builtin_bit_cast(c3f4, v);
-    unsigned h0, m0, l0, h1, m1, l1;
-    x3_split2((x3f2){f[0], f[1]}, h0, m0, l0);
-    x3_split2((x3f2){f[2], f[3]}, h1, m1, l1);
-    const x3u2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
     unsigned char* dst = lds + stage + (uint32_t)(wv + 8 * i) * 512u + sA;
-    *reinterpret_cast<x3u2*>(dst) = h;
-    *reinterpret_cast<x3u2*>(dst + XLIMB) = m;
-    *reinterpret_cast<x3u2*>(dst + 2u * XLIMB) = l;
+    if constexpr (NL == 3) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      x3_split2((x3f2){f[0], f[1]}, h0, m0, l0);
+      x3_split2((x3f2){f[2], f[3]}, h1, m1, l1);
+      const x3u2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
+      *reinterpret_cast<x3u2*>(dst) = h;
+      *reinterpret_cast<x3u2*>(dst + XLIMB) = m;
+      *reinterpret_cast<x3u2*>(dst + 2u * XLIMB) = l;
+    } else {
+      unsigned h0, l0, h1, l1;
+      x2_split2((x3f2){f[0], f[1]}, h0, l0);
+      x2_split2((x3f2){f[2], f[3]}, h1, l1);
+      const x3u2 h = {h0, h1}, l = {l0, l1};
+      *reinterpret_cast<x3u2*>(dst) = h;
+      *reinterpret_cast<x3u2*>(dst + XLIMB) = l;
+    }
   };
   const int l15 = lane & 15, lq = lane >> 4;
   const uint32_t fslot = (uint32_t)(lq ^ ((l15 >> 3) << 1)) * 16u;
@@ -236,39 +291,58 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mt][t] = (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
+  c3f4 acc2[NL == 2 ? MT : 1][4];                        // NL = 2: the h l + l h products (scaled by 2^11)
+#pragma unroll
+  for (int mt = 0; mt < (NL == 2 ? MT : 1); ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[mt][t] = (c3f4){0.0f, 0.0f, 0.0f, 0.0f};
+  auto mma = [](const frag_t& a, const frag_t& b, const c3f4& c) {
+    if constexpr (NL == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  };
   constexpr int PPG = (XP + MT - 1) / MT;                // pixel pieces split and stored behind each group of MFMAs
   // the MFMAs of stage `sb`; behind pixel tile mt's 24 MFMAs the pieces mt * PPG .. of the NEXT K-step (registers `r`) are
   // split and stored into stage `nxt`: vector instructions and LDS stores issued in the shadow of the matrix pipe
   auto compute = [&](const unsigned char* sb, const x3u4 (&r)[XP], uint32_t nxt, bool store, auto&& late_issue) {
-    x3b8 wf[3][4];
+    frag_t wf[NL][4];
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < NL; ++l)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) wf[l][t] = *reinterpret_cast<const x3b8*>(sb + woff + (uint32_t)l * WLIMB + (uint32_t)t * 1024u);
-    x3b8 xf[2][3];
+      for (int t = 0; t < 4; ++t) wf[l][t] = *reinterpret_cast<const frag_t*>(sb + woff + (uint32_t)l * WLIMB + (uint32_t)t * 1024u);
+    frag_t xf[2][NL];
 #pragma unroll
-    for (int l = 0; l < 3; ++l) xf[0][l] = *reinterpret_cast<const x3b8*>(sb + xoff + (uint32_t)l * XLIMB);
+    for (int l = 0; l < NL; ++l) xf[0][l] = *reinterpret_cast<const frag_t*>(sb + xoff + (uint32_t)l * XLIMB);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int c = mt & 1;
       if (mt + 1 < MT) {
 #pragma unroll
-        for (int l = 0; l < 3; ++l)
-          xf[c ^ 1][l] = *reinterpret_cast<const x3b8*>(sb + xoff + (uint32_t)l * XLIMB + (uint32_t)(mt + 1) * 1024u);
+        for (int l = 0; l < NL; ++l)
+          xf[c ^ 1][l] = *reinterpret_cast<const frag_t*>(sb + xoff + (uint32_t)l * XLIMB + (uint32_t)(mt + 1) * 1024u);
       }
-      // the six products, smallest first; four independent accumulators between two MFMAs on the same one
+      // the products, smallest first; four independent accumulators between two MFMAs on the same one
+      if constexpr (NL == 3) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][t], xf[c][0], acc[mt][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mma(wf[2][t], xf[c][0], acc[mt][t]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], xf[c][2], acc[mt][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mma(wf[0][t], xf[c][2], acc[mt][t]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], xf[c][1], acc[mt][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mma(wf[1][t], xf[c][1], acc[mt][t]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][t], xf[c][0], acc[mt][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mma(wf[1][t], xf[c][0], acc[mt][t]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], xf[c][1], acc[mt][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mma(wf[0][t], xf[c][1], acc[mt][t]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][t], xf[c][0], acc[mt][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mma(wf[0][t], xf[c][0], acc[mt][t]);
+      } else {
+        const int m2 = NL == 2 ? mt : 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc2[m2][t] = mma(wf[1][t], xf[c][0], acc2[m2][t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = mma(wf[0][t], xf[c][0], acc[mt][t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc2[m2][t] = mma(wf[0][t], xf[c][1], acc2[m2][t]);
+      }
       if (mt == (MT > 1 ? 1 : 0)) late_issue();
       if (store) {
 #pragma unroll
@@ -277,40 +351,74 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
       }
     }
   };
-  // ---- K loop.  Step ks: the weights of step ks + 1 travel into the other stage (LDS-DMA), the pixel slots of step ks + 2 into
-  // registers; the slots of step ks + 1 (loaded a step ago) are split and stored between the MFMAs of step ks.  The counted
-  // wait before the barrier leaves the newest XP loads (step ks + 2) in flight; a bare s_barrier, because __syncthreads() would
-  // drain them too.
+  // ---- K loop.  Step i: the weights of step i + NS - 1 travel into their stage (LDS-DMA), the pixel slots of step i + NS into
+  // registers (buffer (i + NS) % NS = the one step i - 1 emptied); the slots of step i + 1 are split and stored between the MFMAs
+  // of step i.  The counted wait before the barrier leaves everything younger than the weights of step i + 1 in flight; a bare
+  // s_barrier, because __syncthreads() would drain it all.
   auto step = [&](int i, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {     // i = K-step of this workgroup's part
     const int ks = ks_lo + i;
-    const uint32_t cur = (uint32_t)(i & 1) * STAGE, nxt = STAGE - cur;
-    const bool more = i + 1 < ksteps, more2 = i + 2 < ksteps;
+    const uint32_t si = (uint32_t)i % (uint32_t)NS;
+    const uint32_t cur = si * STAGE, nxt = (si + 1 == NS ? 0u : si + 1) * STAGE;
+    const uint32_t wst = NS == 2 ? nxt : (si == 0 ? 2u : si - 1) * STAGE;           // stage of K-step i + NS - 1
+    const bool more = i + 1 < ksteps, morew = i + NS - 1 < ksteps, morea = i + NS < ksteps;
     // the two waves of a SIMD (w and w + 4) run the same program between the same barriers: waves 0-3 issue their copies
     // right after the barrier, waves 4-7 behind their second group of MFMAs, so that one of the two always has matrix work
     const bool early = wv < 4;
     if (early) {
-      if (more) issue_w(ks + 1, nxt);
-      if (more2) load_a(ks + 2, rfree);
+      if (morew) issue_w(ks + NS - 1, wst);
+      if (morea) load_a(ks + NS, rfree);
     }
     compute(lds + cur, rnext, nxt, more, [&] {
       if (!early) {
-        if (more) issue_w(ks + 1, nxt);
-        if (more2) load_a(ks + 2, rfree);
+        if (morew) issue_w(ks + NS - 1, wst);
+        if (morea) load_a(ks + NS, rfree);
       }
     });
-    if (more2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (NS == 2) {
+      if (morea) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      // younger than the weights of i + 1: the slots of i + 2 (issued a step ago), the weights of i + 2 and the slots of i + 3
+      if (morea) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * XP + WPW) : "memory");
+      else if (morew) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
   };
-  issue_w(ks_lo, 0u);
-  load_a(ks_lo, ra[0]);
-  if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
+  if constexpr (NS == 2) {
+    issue_w(ks_lo, 0u);
+    load_a(ks_lo, ra[0]);
+    if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
 #pragma unroll
-  for (int i = 0; i < XP; ++i) store_piece(ra[0][i], i, 0u);
-  if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  for (int i = 0; i < ksteps; i += 2) {
-    step(i, ra[0], ra[1]);                               // (step i stores ra[1] = the slots of i + 1, refills ra[0] with i + 2)
-    if (i + 1 < ksteps) step(i + 1, ra[1], ra[0]);
+    for (int i = 0; i < XP; ++i) store_piece(ra[0][i], i, 0u);
+    if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = 0; i < ksteps; i += 2) {
+      step(i, ra[0], ra[1]);                             // (step i stores ra[1] = the slots of i + 1, refills ra[0] with i + 2)
+      if (i + 1 < ksteps) step(i + 1, ra[1], ra[0]);
+    }
+  } else {
+    load_a(ks_lo, ra[0]);
+    issue_w(ks_lo, 0u);
+    if (ksteps > 1) { load_a(ks_lo + 1, ra[1]); issue_w(ks_lo + 1, STAGE); }
+    if (ksteps > 2) load_a(ks_lo + 2, ra[2]);
+#pragma unroll
+    for (int i = 0; i < XP; ++i) store_piece(ra[0][i], i, 0u);
+    if (ksteps > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * XP + WPW) : "memory");
+    else if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = 0; i < ksteps; i += 3) {
+      step(i, ra[0], ra[1]);
+      if (i + 1 < ksteps) step(i + 1, ra[1], ra[2]);
+      if (i + 2 < ksteps) step(i + 2, ra[2], ra[0]);
+    }
+  }
+  if constexpr (NL == 2) {
+    // the two accumulators joined, the weights' scale (a power of two) taken back out
+    const float s2 = p.acc_scale * 0x1p-11f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = acc[mt][t] * p.acc_scale + acc2[mt][t] * s2;
   }
   if (S > 1) {
     // ---- split-K: leave this part's tile in the workspace, draw a ticket; the last of the tile's S workgroups adds the parts
@@ -352,23 +460,38 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
 
 template <int MT, int WN>
 __global__ void __launch_bounds__(512) k_conv3x3_x3(ConvF32Params p) {
-  conv_tile_x3<MT, WN, 9>(p);
+  conv_tile_x3<MT, WN, 9, 3>(p);
 }
 
 template <int MT, int WN>
 __global__ void __launch_bounds__(512) k_pointwise_x3(ConvF32Params p) {
-  conv_tile_x3<MT, WN, 1>(p);
+  conv_tile_x3<MT, WN, 1, 3>(p);
+}
+
+template <int MT, int WN>
+__global__ void __launch_bounds__(512) k_conv3x3_x2(ConvF32Params p) {
+  conv_tile_x3<MT, WN, 9, 2>(p);
+}
+
+template <int MT, int WN>
+__global__ void __launch_bounds__(512) k_pointwise_x2(ConvF32Params p) {
+  conv_tile_x3<MT, WN, 1, 2>(p);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------------
 // tiles (MT, WN): 256 x 128, 128 x 128 | 128 x 256 | 256 x 64, 128 x 64, 64 x 64 (pixels x channels)
+// (the two-limb form keeps two accumulator sets: 256 x 128 would not fit the register file)
 #define X3_FOR_TILES(F) F(4, 2) F(2, 2) F(4, 4) F(2, 1) F(1, 1)
+#define X2_FOR_TILES(F) F(2, 2) F(4, 4) F(2, 1) F(1, 1)
 
 template <typename F>
 static void x3_for_each_kernel(F f) {
 #define X3_K(MT_, WN_) f((const void*)k_conv3x3_x3<MT_, WN_>); f((const void*)k_pointwise_x3<MT_, WN_>);
+#define X2_K(MT_, WN_) f((const void*)k_conv3x3_x2<MT_, WN_>); f((const void*)k_pointwise_x2<MT_, WN_>);
   X3_FOR_TILES(X3_K)
+  X2_FOR_TILES(X2_K)
 #undef X3_K
+#undef X2_K
 }
 
 static hipError_t x3_prepare_kernels() {
@@ -384,7 +507,7 @@ static hipError_t x3_prepare_kernels() {
   return once_rc;
 }
 
-static unsigned x3_lds_bytes(int tm, int tn) { return (unsigned)(2 * 3 * (tm + tn) * 64); }
+static unsigned x3_lds_bytes(int tm, int tn, int nl) { return (unsigned)((nl == 2 ? 3 : 2) * nl * (tm + tn) * 64); }
 static int x3_tile_pixels(int mt, int wn) { return (8 / wn) * 16 * mt; }
 
 // Diagnostics (tools/r05): force the tile and the K split of this process's split-precision launches -- (mt, wn) of X3_FOR_TILES,
@@ -406,19 +529,21 @@ extern "C" int odet_debug_x3_tile(int mt, int wn, int ksplit) {
 // a deep-K, few-row layer is a latency chain of its K-steps (conv5's 3 x 3 at batch 1: 144 steps of 1.5 us on 18 workgroups).
 #define X3_TICKETS 4096                                  // tiles of a split-K launch (the workspace's ticket words)
 struct X3Pick { int mt, wn, ksplit; };
-static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int ksteps, size_t part_bytes_max) {
+static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int ksteps, size_t part_bytes_max, int nl) {
   static const int cand[][2] = {{4, 2}, {2, 2}, {4, 4}, {2, 1}, {1, 1}};       // (mt, wn)
   X3Pick best_pick{0, 0, 1};
   double best = 1e300;
   for (const auto& c : cand) {
     const int mt = c[0], wn = c[1];
-    if (cout % (64 * wn)) continue;
+    if (cout % (64 * wn) || (nl == 2 && mt == 4 && wn == 2)) continue;
     const int wm = 8 / wn, tm = wm * 16 * mt, tn = 64 * wn, tiles_n = cout / tn;
     long long slabs = 0;
     for (int l = 0; l < num_levels; ++l) slabs += (M[l] + tm - 1) / tm;
     const long long tiles = (slabs + 7) / 8 * 8 * tiles_n, real_tiles = slabs * tiles_n;
-    const int occ = std::max(1, std::min(2, (int)(X3_LDS_MAX / x3_lds_bytes(tm, tn))));
-    const double mfma = (double)tm * tn / 256.0 * 6.0 * 16.0 / 4.0, other = 3.5 * tm + 0.8 * tn + 720.0;
+    const int occ = std::max(1, std::min(2, (int)(X3_LDS_MAX / x3_lds_bytes(tm, tn, nl))));
+    // (two limbs: 3 products, two thirds of the weight rows' bytes, a shorter split)
+    const double mfma = (double)tm * tn / 256.0 * (nl == 3 ? 6.0 : 3.0) * 16.0 / 4.0;
+    const double other = (nl == 3 ? 3.5 : 3.0) * tm + (nl == 3 ? 0.8 : 0.55) * tn + 720.0;
     for (int S = 1; S <= 8; ++S) {
       // a split only where the tiles leave CUs idle (the parts of a launch that fills the chip would be HBM traffic of their
       // own: 1.1 GB for the RpnHead's P2 level at batch 1), every part at least 8 K-steps, tickets and parts inside the workspace
@@ -435,7 +560,7 @@ static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int kst
     }
   }
   const unsigned o = g_x3_override.load();
-  if (o && cout % (64 * (int)(o & 255)) == 0) {
+  if (o && cout % (64 * (int)(o & 255)) == 0 && !(nl == 2 && (o >> 8 & 255) == 4 && (o & 255) == 2)) {
     best_pick = X3Pick{(int)(o >> 8 & 255), (int)(o & 255), std::max(1, (int)(o >> 16))};
     const int tm = x3_tile_pixels(best_pick.mt, best_pick.wn), tn = 64 * best_pick.wn;
     long long slabs = 0;
@@ -463,27 +588,40 @@ static size_t x3_part_bytes(const void* ws, size_t ws_bytes) {
 }
 
 template <bool PW>
-static int x3_launch_tile(int wn, int mt, dim3 grid, unsigned lds_bytes, hipStream_t st, const ConvF32Params& p) {
+static int x3_launch_tile(int nl, int wn, int mt, dim3 grid, unsigned lds_bytes, hipStream_t st, const ConvF32Params& p) {
 #define X3_L(MT_, WN_)                                                                                      \
-  if (mt == MT_ && wn == WN_) {                                                                             \
+  if (nl == 3 && mt == MT_ && wn == WN_) {                                                                  \
     if (PW) hipLaunchKernelGGL((k_pointwise_x3<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);              \
     else hipLaunchKernelGGL((k_conv3x3_x3<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);                   \
     return ODET_OK;                                                                                         \
   }
+#define X2_L(MT_, WN_)                                                                                      \
+  if (nl == 2 && mt == MT_ && wn == WN_) {                                                                  \
+    if (PW) hipLaunchKernelGGL((k_pointwise_x2<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);              \
+    else hipLaunchKernelGGL((k_conv3x3_x2<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);                   \
+    return ODET_OK;                                                                                         \
+  }
   X3_FOR_TILES(X3_L)
+  X2_FOR_TILES(X2_L)
 #undef X3_L
+#undef X2_L
   return odet_set_error(ODET_E_INVALID, "conv_x3: no kernel for the tile (mt %d, wn %d)", mt, wn);
 }
 
 static void x3_defaults(ConvF32Params* p) {
   p->stride = 1; p->Ho = p->Wo = 0; p->Min = 0; p->res = nullptr; p->top = nullptr; p->th = p->tw = 0; p->tys = p->txs = 0.0f;
   p->x2 = nullptr; p->cin2 = 0; p->k1steps = 0; p->Min2 = 0;
-  p->ksplit = 0; p->part = nullptr; p->ticket = nullptr;
+  p->ksplit = 0; p->part = nullptr; p->ticket = nullptr; p->acc_scale = 1.0f;
 }
 
-static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias, int batch,
-                             int cin, int cout, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
+// the limb form of a launch: 3 bfloat16 planes, or 2 float16 planes of w * 2^w_exp
+struct X3Form { int nl, w_exp; };
+static bool x3_form_ok(const X3Form& f) { return f.nl == 3 || (f.nl == 2 && f.w_exp >= -100 && f.w_exp <= 100); }
+
+static int conv3x3_x3_launch(const X3Form& form, const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
+                             int batch, int cin, int cout, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
   ODET_REQUIRE(levels && w3, "odet_conv3x3_x3: null pointer");
+  ODET_REQUIRE(x3_form_ok(form), "odet_conv3x3_x2: w_exp %d out of range", form.w_exp);
   ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_x3: num_levels %d out of range", num_levels);
   ODET_REQUIRE(batch > 0, "odet_conv3x3_x3: bad batch");
   ODET_REQUIRE(cin > 0 && cin % X3_BK == 0, "odet_conv3x3_x3: cin %d must be a multiple of %d", cin, X3_BK);
@@ -502,7 +640,8 @@ static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, co
                  "odet_conv3x3_x3: level %d input larger than 4 GiB", l);
     p.x[l] = (const float*)L.x; p.y[l] = (float*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
   }
-  const X3Pick pick = x3_pick_tile(p.M, num_levels, cout, 9 * (cin / X3_BK), x3_part_bytes(ws, ws_bytes));
+  const X3Pick pick = x3_pick_tile(p.M, num_levels, cout, 9 * (cin / X3_BK), x3_part_bytes(ws, ws_bytes), form.nl);
+  p.acc_scale = form.nl == 2 ? ldexpf(1.0f, -form.w_exp) : 1.0f;
   const int wn = pick.wn, mt = pick.mt;
   const int TMsel = x3_tile_pixels(mt, wn);
   long long total = 0;
@@ -518,7 +657,8 @@ static int conv3x3_x3_launch(const odet_conv_level_t* levels, int num_levels, co
   ODET_REQUIRE(blocks < (1ll << 28), "odet_conv3x3_x3: too many workgroups");
   const int rs = x3_apply_split(&p, pick, blocks, TMsel, ws, ws_bytes, "odet_conv3x3_x3");
   if (rs != ODET_OK) return rs;
-  const int rc = x3_launch_tile<false>(wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))), x3_lds_bytes(TMsel, 64 * wn), st, p);
+  const int rc = x3_launch_tile<false>(form.nl, wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))),
+                                       x3_lds_bytes(TMsel, 64 * wn, form.nl), st, p);
   if (rc != ODET_OK) return rc;
   ODET_LAUNCH_CHECK();
   return ODET_OK;
@@ -530,21 +670,37 @@ extern "C" int odet_conv3x3_x3(const void* x, const void* w3, const void* bias, 
                                int cout, int relu, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
   ODET_REQUIRE(x && y, "odet_conv3x3_x3: null pointer");
   const odet_conv_level_t one{x, y, H, W};
-  return conv3x3_x3_launch(&one, 1, w3, bias, batch, cin, cout, relu, workspace, workspace_bytes, (hipStream_t)stream);
+  return conv3x3_x3_launch(X3Form{3, 0}, &one, 1, w3, bias, batch, cin, cout, relu, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int odet_conv3x3_x2(const void* x, const void* w2, const void* bias, void* y, int batch, int H, int W, int cin,
+                               int cout, int relu, int w_exp, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(x && y, "odet_conv3x3_x2: null pointer");
+  const odet_conv_level_t one{x, y, H, W};
+  return conv3x3_x3_launch(X3Form{2, w_exp}, &one, 1, w2, bias, batch, cin, cout, relu, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int odet_conv3x3_x2_levels(const odet_conv_level_t* levels, int num_levels, const void* w2, const void* bias,
+                                      int batch, int cin, int cout, int relu, int w_exp, void* workspace, size_t workspace_bytes,
+                                      odet_stream_t stream) {
+  return conv3x3_x3_launch(X3Form{2, w_exp}, levels, num_levels, w2, bias, batch, cin, cout, relu, workspace, workspace_bytes,
+                           (hipStream_t)stream);
 }
 
 extern "C" int odet_conv3x3_x3_levels(const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
                                       int batch, int cin, int cout, int relu, void* workspace, size_t workspace_bytes,
                                       odet_stream_t stream) {
-  return conv3x3_x3_launch(levels, num_levels, w3, bias, batch, cin, cout, relu, workspace, workspace_bytes, (hipStream_t)stream);
+  return conv3x3_x3_launch(X3Form{3, 0}, levels, num_levels, w3, bias, batch, cin, cout, relu, workspace, workspace_bytes,
+                           (hipStream_t)stream);
 }
 
 struct PwX3Epilogue { const void* res; const void* top; int th, tw; const void* x2; int cin2; };
 
-static int pointwise_x3_launch(const char* who, const void* x, const void* w3, const void* bias, void* y, int batch, int H,
-                               int W, int stride, int cin, int cout, int relu, const PwX3Epilogue& epi, void* ws, size_t ws_bytes,
-                               hipStream_t st) {
+static int pointwise_x3_launch(const char* who, const X3Form& form, const void* x, const void* w3, const void* bias, void* y,
+                               int batch, int H, int W, int stride, int cin, int cout, int relu, const PwX3Epilogue& epi, void* ws,
+                               size_t ws_bytes, hipStream_t st) {
   ODET_REQUIRE(x && w3 && y, "%s: null pointer", who);
+  ODET_REQUIRE(x3_form_ok(form), "%s: w_exp %d out of range", who, form.w_exp);
   ODET_REQUIRE(batch > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "%s: bad shape", who);
   ODET_REQUIRE(cin % X3_BK == 0 && cin > 0, "%s: cin %d must be a positive multiple of %d", who, cin, X3_BK);
   ODET_REQUIRE(cout > 0 && cout % 64 == 0, "%s: cout %d must be a multiple of 64", who, cout);
@@ -571,7 +727,8 @@ static int pointwise_x3_launch(const char* who, const void* x, const void* w3, c
   p.txs = epi.top ? (float)epi.tw / (float)Wo : 0.0f;
   p.stride = stride; p.Ho = Ho; p.Wo = Wo; p.Min = Min;
   p.x2 = (const float*)epi.x2; p.cin2 = epi.x2 ? epi.cin2 : 0; p.k1steps = cin / X3_BK; p.Min2 = (long long)batch * H * W;
-  const X3Pick pick = x3_pick_tile(&M, 1, cout, (cin + (epi.x2 ? epi.cin2 : 0)) / X3_BK, x3_part_bytes(ws, ws_bytes));
+  const X3Pick pick = x3_pick_tile(&M, 1, cout, (cin + (epi.x2 ? epi.cin2 : 0)) / X3_BK, x3_part_bytes(ws, ws_bytes), form.nl);
+  p.acc_scale = form.nl == 2 ? ldexpf(1.0f, -form.w_exp) : 1.0f;
   const int wn = pick.wn, mt = pick.mt;
   const int TMsel = x3_tile_pixels(mt, wn);
   p.tiles_n = cout / (64 * wn);
@@ -584,7 +741,8 @@ static int pointwise_x3_launch(const char* who, const void* x, const void* w3, c
   ODET_REQUIRE(blocks < (1ll << 28), "%s: too many workgroups", who);
   const int rs = x3_apply_split(&p, pick, blocks, TMsel, ws, ws_bytes, who);
   if (rs != ODET_OK) return rs;
-  const int rc = x3_launch_tile<true>(wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))), x3_lds_bytes(TMsel, 64 * wn), st, p);
+  const int rc = x3_launch_tile<true>(form.nl, wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))),
+                                      x3_lds_bytes(TMsel, 64 * wn, form.nl), st, p);
   if (rc != ODET_OK) return rc;
   ODET_LAUNCH_CHECK();
   return ODET_OK;
@@ -594,7 +752,7 @@ extern "C" int odet_pointwise_x3(const void* x, const void* w3, const void* bias
                                  int H, int W, int stride, int cin, int cout, int relu, void* workspace, size_t workspace_bytes,
                                  odet_stream_t stream) {
   const PwX3Epilogue e{residual, nullptr, 0, 0, nullptr, 0};
-  return pointwise_x3_launch("odet_pointwise_x3", x, w3, bias, y, batch, H, W, stride, cin, cout, relu, e, workspace,
+  return pointwise_x3_launch("odet_pointwise_x3", X3Form{3, 0}, x, w3, bias, y, batch, H, W, stride, cin, cout, relu, e, workspace,
                              workspace_bytes, (hipStream_t)stream);
 }
 
@@ -603,8 +761,8 @@ extern "C" int odet_lateral_merge_x3(const void* x, const void* w3, const void* 
                                      odet_stream_t stream) {
   ODET_REQUIRE(top, "odet_lateral_merge_x3: null pointer");
   const PwX3Epilogue e{nullptr, top, th, tw, nullptr, 0};
-  return pointwise_x3_launch("odet_lateral_merge_x3", x, w3, bias, y, batch, H, W, 1, cin, cout, 0, e, workspace, workspace_bytes,
-                             (hipStream_t)stream);
+  return pointwise_x3_launch("odet_lateral_merge_x3", X3Form{3, 0}, x, w3, bias, y, batch, H, W, 1, cin, cout, 0, e, workspace,
+                             workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
@@ -612,6 +770,33 @@ extern "C" int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, 
                                       void* workspace, size_t workspace_bytes, odet_stream_t stream) {
   ODET_REQUIRE(x2, "odet_pointwise_dual_x3: null pointer");
   const PwX3Epilogue e{nullptr, nullptr, 0, 0, x2, cin2};
-  return pointwise_x3_launch("odet_pointwise_dual_x3", x1, w3, bias, y, batch, H2, W2, stride2, cin1, cout, relu, e, workspace,
+  return pointwise_x3_launch("odet_pointwise_dual_x3", X3Form{3, 0}, x1, w3, bias, y, batch, H2, W2, stride2, cin1, cout, relu, e,
+                             workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- the two-limb float16 forms: the same layers, `w2` = odet_split_f16x2's planes of w * 2^w_exp --------------------------
+extern "C" int odet_pointwise_x2(const void* x, const void* w2, const void* bias, const void* residual, void* y, int batch,
+                                 int H, int W, int stride, int cin, int cout, int relu, int w_exp, void* workspace,
+                                 size_t workspace_bytes, odet_stream_t stream) {
+  const PwX3Epilogue e{residual, nullptr, 0, 0, nullptr, 0};
+  return pointwise_x3_launch("odet_pointwise_x2", X3Form{2, w_exp}, x, w2, bias, y, batch, H, W, stride, cin, cout, relu, e,
+                             workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int odet_lateral_merge_x2(const void* x, const void* w2, const void* bias, const void* top, int th, int tw, void* y,
+                                     int batch, int H, int W, int cin, int cout, int w_exp, void* workspace, size_t workspace_bytes,
+                                     odet_stream_t stream) {
+  ODET_REQUIRE(top, "odet_lateral_merge_x2: null pointer");
+  const PwX3Epilogue e{nullptr, top, th, tw, nullptr, 0};
+  return pointwise_x3_launch("odet_lateral_merge_x2", X3Form{2, w_exp}, x, w2, bias, y, batch, H, W, 1, cin, cout, 0, e, workspace,
                              workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int odet_pointwise_dual_x2(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
+                                      const void* w2, const void* bias, void* y, int batch, int cout, int relu, int w_exp,
+                                      void* workspace, size_t workspace_bytes, odet_stream_t stream) {
+  ODET_REQUIRE(x2, "odet_pointwise_dual_x2: null pointer");
+  const PwX3Epilogue e{nullptr, nullptr, 0, 0, x2, cin2};
+  return pointwise_x3_launch("odet_pointwise_dual_x2", X3Form{2, w_exp}, x1, w2, bias, y, batch, H2, W2, stride2, cin1, cout, relu,
+                             e, workspace, workspace_bytes, (hipStream_t)stream);
 }

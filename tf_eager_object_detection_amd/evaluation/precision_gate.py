@@ -446,7 +446,7 @@ def fp16_vs_fp32(num_images=256, image_shape=None, depth=None, num_classes=21, n
     VGG16 @ 600x800 -- BASELINE configs 3 / 2 / 1).  -> dict for bench.py's `e2e.*.map_delta_vs_fp32` and the GPU tests;
     `within_bar` = the point estimate is inside the north star's +-0.002, `resolves_bar` = the paired-bootstrap 95 % interval
     is narrower than the bar on both sides (the gate can tell +-0.002 from noise at this number of scenes).
-    test_mode: 'fp16' (the float16 throughput mode) or 'x3' (the float32 split-precision mode, csrc/conv_x3.hip) as the
+    test_mode: 'fp16' (the float16 throughput mode) or 'x3' / 'x2' (the float32 split-precision modes, csrc/conv_x3.hip) as the
     detector under test; the reference detector is always the exact-float32 mode (the `*_fp16` keys then hold the x3 figures)."""
     name, shape0, prop0 = _FAMILIES[family]
     image_shape = tuple(shape0 if image_shape is None else image_shape)
@@ -458,8 +458,8 @@ def fp16_vs_fp32(num_images=256, image_shape=None, depth=None, num_classes=21, n
                                                          batch=batch32), ridge=ridge)
     fit['ridge'] = ridge
     state = {k: v.detach().clone() for k, v in m32.state_dict().items()}
-    if test_mode == 'x3':
-        m16 = _build(family, depth, num_classes, image_shape, num_proposals, torch.float32, batch16, dict(hot_kwargs, f32_form='x3'))
+    if test_mode in ('x3', 'x2'):
+        m16 = _build(family, depth, num_classes, image_shape, num_proposals, torch.float32, batch16, dict(hot_kwargs, f32_form=test_mode))
     else:
         m16 = _build(family, depth, num_classes, image_shape, num_proposals, torch.float16, batch16, hot_kwargs)
     m16.load_state_dict(state)
@@ -483,7 +483,9 @@ def fp16_vs_fp32(num_images=256, image_shape=None, depth=None, num_classes=21, n
     rec = dict(images=num_images, image=list(image_shape), model=(name % depth) if '%d' in name else name, family=family,
                metric='VOC07 11-point mAP',
                test_mode={'fp16': 'float16 throughput mode', 'x3': 'float32 split-precision mode (three bfloat16 limbs, six products '
-                          'per k, float32 accumulation); the *_fp16 keys hold ITS figures'}[test_mode],
+                          'per k, float32 accumulation); the *_fp16 keys hold ITS figures',
+                          'x2': 'float32 split-precision mode, two float16 limbs (three products per k, float32 accumulation, '
+                          'float16 range); the *_fp16 keys hold ITS figures'}[test_mode],
                protocol='annotated synthetic scenes (coloured rectangles / ellipses, class = colour); float32 (parity mode) '
                         'and float16 detector with the SAME weights on the SAME images: im_detect -> detect_image (score >= '
                         '0.05, per-class NMS 0.3, 50 per image; evaluation/pascal_eval_files_utils.py:76-106) -> VOC07 mAP '

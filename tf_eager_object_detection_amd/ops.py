@@ -7,6 +7,7 @@ reference itself does at region_proposal.py:78 / prediction.py:147); ``pipeline.
 everything padded and sync-free.
 """
 import ctypes as C
+import math
 
 import numpy as np
 import torch
@@ -27,6 +28,8 @@ MAX_LEVELS = 8
 # 'x3':    split precision (csrc/conv_x3.hip) -- float32 operands as three bfloat16 limbs, six limb products per k on the
 #          bfloat16 matrix instructions, float32 accumulation: within float32 rounding of the float64 truth like 'exact',
 #          2.6 x its peak rate.  Same tensors in memory; only the weights get a cached companion (their limb planes).
+# 'x2':    the two-limb float16 form of the same kernel -- h + l * 2^-11 (operands to one float32 ulp), three products, half the
+#          matrix work of 'x3'; for data inside float16's RANGE (|activation| <= 65504, else infinities / NaN; include/odet.h).
 # A fixed choice of the caller (the detectors' `f32_form` argument), never a timing decision: the two forms round differently.
 _F32_FORM = ['exact']
 
@@ -36,8 +39,8 @@ class f32_form:
     inside the block run on"""
 
     def __init__(self, form):
-        if form not in ('exact', 'x3'):
-            raise ValueError("f32 form must be 'exact' or 'x3'")
+        if form not in ('exact', 'x3', 'x2'):
+            raise ValueError("f32 form must be 'exact', 'x3' or 'x2'")
         self.form = form
 
     def __enter__(self):
@@ -60,6 +63,26 @@ def split_bf16x3(w):
     return planes
 
 
+def f16x2_exponent(w):
+    """the power of two the two-limb planes of `w` are scaled by: the largest |w| * 2^e lies in [512, 1024)"""
+    top = float(w.abs().max())
+    if not math.isfinite(top):
+        raise ValueError('split_f16x2: the weights must be finite')
+    return 0 if top == 0.0 else max(-100, min(100, 9 - math.frexp(top)[1] + 1))
+
+
+def split_f16x2(w, w_exp=None):
+    """float32 contiguous GPU tensor (even element count) -> (its two float16 limb planes of w * 2^w_exp, int16 [2, *w.shape];
+    w_exp) (odet_split_f16x2): w * 2^w_exp = plane0 + plane1 * 2^-11 to within one float32 ulp."""
+    if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous() or w.numel() % 2:
+        raise ValueError('split_f16x2: needs a contiguous float32 GPU tensor with an even element count')
+    if w_exp is None:
+        w_exp = f16x2_exponent(w)
+    planes = torch.empty((2,) + tuple(w.shape), dtype=torch.int16, device=w.device)
+    L.call('odet_split_f16x2', L.dptr(w), C.c_void_p(planes.data_ptr()), w.numel(), int(w_exp), L.stream())
+    return planes, int(w_exp)
+
+
 def _x3_planes(holder, w):
     """the limb planes of the (contiguous, float32) weight `w`, kept ON the tensor object the caller passed (`holder`: the
     layer's parameter, or a module's cached concatenation) until that tensor is modified: the planes live exactly as long as
@@ -70,6 +93,17 @@ def _x3_planes(holder, w):
     if hit is None or hit[0] != key:
         hit = (key, split_bf16x3(w), w)
         holder.__dict__['_odet_x3'] = hit
+    return hit[1]
+
+
+def _x2_planes(holder, w):
+    """the same for the two-limb form: (planes, w_exp) (the exponent is read from the weights -- one host synchronisation per
+    weight tensor, at its first use: a warm-up pass before a HIP-graph capture, as for the workspace)"""
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = holder.__dict__.get('_odet_x2')
+    if hit is None or hit[0] != key:
+        hit = (key, split_f16x2(w), w)
+        holder.__dict__['_odet_x2'] = hit
     return hit[1]
 
 
@@ -95,6 +129,10 @@ def _f32_sym(sym, w, holder=None):
         planes = _x3_planes(w if holder is None else holder, w)
         ws = _x3_workspace(w.device)
         return sym[:-3] + 'x3', C.c_void_p(planes.data_ptr()), (C.c_void_p(ws.data_ptr()), ws.numel())   # odet_*_f32 -> odet_*_x3
+    if _F32_FORM[0] == 'x2':
+        planes, w_exp = _x2_planes(w if holder is None else holder, w)
+        ws = _x3_workspace(w.device)
+        return sym[:-3] + 'x2', C.c_void_p(planes.data_ptr()), (w_exp, C.c_void_p(ws.data_ptr()), ws.numel())
     return sym, L.dptr(w), ()
 
 

@@ -22,7 +22,7 @@ ap.add_argument('--model', default='fpn', choices=['fpn', 'c4', 'vgg16'],
 ap.add_argument('--h', type=int, default=800)
 ap.add_argument('--w', type=int, default=1333)
 ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True (no effect since round 4: the detectors launch no library convolution)')
-ap.add_argument('--f32-form', default='exact', choices=['exact', 'x3'], help='float32 mode: exact-float32 matrix instructions or the '
+ap.add_argument('--f32-form', default='exact', choices=['exact', 'x3', 'x2'], help='float32 mode: exact-float32 matrix instructions or the '
                 'split-precision form (csrc/conv_x3.hip)')
 ap.add_argument('--graph', action='store_true', help='replay the whole forward pass as one HIP graph')
 ap.add_argument('--blind-chunks', type=int, default=3, help='FPN: sync-free NMS chunks (3: the third one on the full order)')

@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=210)
     ap.add_argument('--seed', type=int, default=0)
-    ap.add_argument('--f32-form', default='exact', choices=['exact', 'x3'], help='the form the float32 cases run on (x3: the '
+    ap.add_argument('--f32-form', default='exact', choices=['exact', 'x3', 'x2'], help='the form the float32 cases run on (x3: the '
                     'split-precision kernel is exact on integer data too)')
     a = ap.parse_args()
     ops._F32_FORM[0] = a.f32_form

@@ -12,7 +12,9 @@ ap.add_argument('--batch', type=int, default=15)
 ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--check', action='store_true', help='errors against float64 on small maps')
 ap.add_argument('--out', default='')
+ap.add_argument('--forms', default='exact,x3,x2')
 args = ap.parse_args()
+FORMS = tuple(args.forms.split(','))
 torch.manual_seed(0)
 dev = 'cuda'
 
@@ -37,12 +39,12 @@ if args.check:
         wl = w.contiguous(memory_format=torch.channels_last)
         ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
         outs = {}
-        for form in ('exact', 'x3'):
+        for form in FORMS:
             with ops.f32_form(form):
                 outs[form] = (ops.conv3x3_f32(x, wl, b) if k == 3 else ops.pointwise(x, w.reshape(cout, cin).contiguous(), b)).double()
         rms = float(ref.pow(2).mean().sqrt())
         rec = {'shape': [B, H, W, cin, cout, k], 'rms': rms}
-        for form in ('exact', 'x3'):
+        for form in FORMS:
             d = (outs[form] - ref).abs()
             rec[form] = {'max_rel_rms': float(d.max()) / rms, 'mean_rel_rms': float(d.mean()) / rms}
         th = F.conv2d(x.permute(0, 3, 1, 2), w, b, padding=k // 2).permute(0, 2, 3, 1).double()
@@ -66,15 +68,13 @@ else:
         wl = w.contiguous(memory_format=torch.channels_last)
         w2 = w.reshape(cout, cin).contiguous() if k == 1 else None
         rec = {'layer': name, 'shape': [B, H, W, cin, cout, k], 'GFLOP': 2.0 * B * H * W * cin * cout * k * k / 1e9}
-        for form in ('exact', 'x3'):
+        for form in FORMS:
             with ops.f32_form(form):
                 fn = (lambda: ops.conv3x3_f32(x, wl, b, relu=True)) if k == 3 else (lambda: ops.pointwise(x, w2, b, None, True))
                 us = timed(fn, args.reps)
             rec[form + '_us'] = us
             rec[form + '_TFLOPs'] = rec['GFLOP'] / us * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 if False else rec['GFLOP'] * 1e9 / (us * 1e-6) / 1e12
-        rec['speedup'] = rec['exact_us'] / rec['x3_us']
-        print('%-18s exact %8.1f us %6.1f TF | x3 %8.1f us %6.1f TF | x%.2f' % (name, rec['exact_us'], rec['exact_TFLOPs'], rec['x3_us'],
-                                                                              rec['x3_TFLOPs'], rec['speedup']), flush=True)
+        print('%-18s ' % name + ' | '.join('%s %8.1f us %6.1f TF' % (f, rec[f + '_us'], rec[f + '_TFLOPs']) for f in FORMS), flush=True)
         res['layers'].append(rec)
 if args.out:
     json.dump(res, open(args.out, 'w'), indent=1)

@@ -9,6 +9,7 @@ from tf_eager_object_detection_amd import ops, _lib
 torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 SPLITS = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1]       # K splits to try per tile
+FORM = sys.argv[3] if len(sys.argv) > 3 else 'x3'
 layers = [('rpn P2', B, 200, 334, 256, 512, 3), ('conv4 3x3', B, 50, 84, 256, 256, 3), ('conv3 3x3', B, 100, 167, 128, 128, 3),
           ('conv5 3x3', B, 25, 42, 512, 512, 3), ('conv4 first', B, 50, 84, 1024, 256, 1), ('conv4 last', B, 50, 84, 256, 1024, 1),
           ('conv5 first', B, 25, 42, 2048, 512, 1), ('conv3 last', B, 100, 167, 128, 512, 1), ('fc1', 1, 1, 1000 * B, 12544, 1024, 1),
@@ -22,10 +23,10 @@ for name, b, H, W, cin, cout, k in layers:
     gf = 2.0 * b * H * W * cin * cout * k * k
     line = '%-12s' % name
     ref = None
-    with ops.f32_form('x3'):
+    with ops.f32_form(FORM):
         fn = (lambda: ops.conv3x3_f32(x, wl, bias, relu=True)) if k == 3 else (lambda: ops.pointwise(x, w2, bias, None, True))
         for mt, wn, ks in [(0, 0, 0)] + [(m_, w_, s_) for (m_, w_) in ((4, 2), (2, 2), (4, 4), (2, 1), (1, 1)) for s_ in SPLITS]:
-            if mt and (cout % (64 * wn) or (ks > 1 and (cin * k * k // 32) // ks < 4)):
+            if mt and (cout % (64 * wn) or (FORM == 'x2' and (mt, wn) == (4, 2)) or (ks > 1 and (cin * k * k // 32) // ks < 4)):
                 continue
             _lib.call('odet_debug_x3_tile', mt, wn, ks)
             y = fn(); torch.cuda.synchronize()
