@@ -303,7 +303,7 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   constexpr int PPG = (XP + MT - 1) / MT;                // pixel pieces split and stored behind each group of MFMAs
   // the MFMAs of stage `sb`; behind pixel tile mt's 24 MFMAs the pieces mt * PPG .. of the NEXT K-step (registers `r`) are
   // split and stored into stage `nxt`: vector instructions and LDS stores issued in the shadow of the matrix pipe
-  auto compute = [&](const unsigned char* sb, const x3u4 (&r)[XP], uint32_t nxt, bool store, auto&& late_issue) {
+  auto compute = [&](const unsigned char* sb, const x3u4 (&r)[XP], uint32_t nxt, bool store, auto&& early_issue, auto&& late_issue) {
     frag_t wf[NL][4];
 #pragma unroll
     for (int l = 0; l < NL; ++l)
@@ -320,6 +320,7 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
         for (int l = 0; l < NL; ++l)
           xf[c ^ 1][l] = *reinterpret_cast<const frag_t*>(sb + xoff + (uint32_t)l * XLIMB + (uint32_t)(mt + 1) * 1024u);
       }
+      if (mt == 0) early_issue();                        // (behind the step's first fragment reads)
       // the products, smallest first; four independent accumulators between two MFMAs on the same one
       if constexpr (NL == 3) {
 #pragma unroll
@@ -355,25 +356,30 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   // registers (buffer (i + NS) % NS = the one step i - 1 emptied); the slots of step i + 1 are split and stored between the MFMAs
   // of step i.  The counted wait before the barrier leaves everything younger than the weights of step i + 1 in flight; a bare
   // s_barrier, because __syncthreads() would drain it all.
-  auto step = [&](int i, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {     // i = K-step of this workgroup's part
+  // The two waves of a SIMD (w and w + 4) run between the same barriers: waves 0-3 issue their copies right after the barrier,
+  // waves 4-7 behind their second group of MFMAs, so that one of the two always has matrix work.  The two kinds run SEPARATE
+  // copies of the loop (EARLY a compile-time constant), and the loop proper -- every step with all its copies to issue -- has
+  // no condition in it: the compiler's wait-count insertion merges the pending loads of all paths it cannot tell apart, and
+  // with both kinds in one body (or the end-of-K tests inside it) it drained EVERY outstanding copy (s_waitcnt vmcnt(0)) before
+  // each refill of a slot buffer -- the prefetch depth was one step in name only (diagnostic build without the slot loads:
+  // + 25 % three limbs, + 37 % two; tools/r05/x2_diag.sh).  The last 2 NS - 1 steps run the guarded form.
+  auto step = [&](auto early_c, auto steady_c, auto pos_c, int i, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {
+    constexpr bool EARLY = decltype(early_c)::value, STEADY = decltype(steady_c)::value;
+    constexpr uint32_t si = (uint32_t)decltype(pos_c)::value;           // i % NS
     const int ks = ks_lo + i;
-    const uint32_t si = (uint32_t)i % (uint32_t)NS;
-    const uint32_t cur = si * STAGE, nxt = (si + 1 == NS ? 0u : si + 1) * STAGE;
-    const uint32_t wst = NS == 2 ? nxt : (si == 0 ? 2u : si - 1) * STAGE;           // stage of K-step i + NS - 1
-    const bool more = i + 1 < ksteps, morew = i + NS - 1 < ksteps, morea = i + NS < ksteps;
-    // the two waves of a SIMD (w and w + 4) run the same program between the same barriers: waves 0-3 issue their copies
-    // right after the barrier, waves 4-7 behind their second group of MFMAs, so that one of the two always has matrix work
-    const bool early = wv < 4;
-    if (early) {
+    constexpr uint32_t cur = si * STAGE, nxt = (si + 1 == NS ? 0u : si + 1) * STAGE;
+    constexpr uint32_t wst = NS == 2 ? nxt : (si == 0 ? 2u : si - 1) * STAGE;      // stage of K-step i + NS - 1
+    const bool more = STEADY || i + 1 < ksteps, morew = STEADY || i + NS - 1 < ksteps, morea = STEADY || i + NS < ksteps;
+    // (the counted waits below count copies in ISSUE order: the slot loads are plain loads the compiler may move across the
+    // LDS-DMA copies -- it did, once the loop was restructured --, so the order is pinned)
+    auto issue = [&] {
+      asm volatile("" ::: "memory");
       if (morew) issue_w(ks + NS - 1, wst);
+      asm volatile("" ::: "memory");
       if (morea) load_a(ks + NS, rfree);
-    }
-    compute(lds + cur, rnext, nxt, more, [&] {
-      if (!early) {
-        if (morew) issue_w(ks + NS - 1, wst);
-        if (morea) load_a(ks + NS, rfree);
-      }
-    });
+      asm volatile("" ::: "memory");
+    };
+    compute(lds + cur, rnext, nxt, more, [&] { if constexpr (EARLY) issue(); }, [&] { if constexpr (!EARLY) issue(); });
     if constexpr (NS == 2) {
       if (morea) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -384,34 +390,62 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   };
-  if constexpr (NS == 2) {
-    issue_w(ks_lo, 0u);
-    load_a(ks_lo, ra[0]);
-    if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
+  using c0_t = std::integral_constant<int, 0>;
+  using c1_t = std::integral_constant<int, 1>;
+  using c2_t = std::integral_constant<int, 2>;
+  auto kloop = [&](auto early_c) {
+    constexpr std::true_type steady{};
+    constexpr std::false_type guarded{};
+    int i = 0;
+    if constexpr (NS == 2) {
+      issue_w(ks_lo, 0u);
+      asm volatile("" ::: "memory");
+      load_a(ks_lo, ra[0]);
+      asm volatile("" ::: "memory");
+      if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < XP; ++i) store_piece(ra[0][i], i, 0u);
-    if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int i = 0; i < ksteps; i += 2) {
-      step(i, ra[0], ra[1]);                             // (step i stores ra[1] = the slots of i + 1, refills ra[0] with i + 2)
-      if (i + 1 < ksteps) step(i + 1, ra[1], ra[0]);
-    }
-  } else {
-    load_a(ks_lo, ra[0]);
-    issue_w(ks_lo, 0u);
-    if (ksteps > 1) { load_a(ks_lo + 1, ra[1]); issue_w(ks_lo + 1, STAGE); }
-    if (ksteps > 2) load_a(ks_lo + 2, ra[2]);
+      for (int j = 0; j < XP; ++j) store_piece(ra[0][j], j, 0u);
+      if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      for (; i + 3 < ksteps; i += 2) {                   // (both steps have their slots of i + 2 / i + 3 to load)
+        step(early_c, steady, c0_t{}, i, ra[0], ra[1]);  // (step i stores ra[1] = the slots of i + 1, refills ra[0] with i + 2)
+        step(early_c, steady, c1_t{}, i + 1, ra[1], ra[0]);
+      }
+      for (; i < ksteps; i += 2) {
+        step(early_c, guarded, c0_t{}, i, ra[0], ra[1]);
+        if (i + 1 < ksteps) step(early_c, guarded, c1_t{}, i + 1, ra[1], ra[0]);
+      }
+    } else {
+      load_a(ks_lo, ra[0]);
+      asm volatile("" ::: "memory");
+      issue_w(ks_lo, 0u);
+      asm volatile("" ::: "memory");
+      if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
+      asm volatile("" ::: "memory");
+      if (ksteps > 1) issue_w(ks_lo + 1, STAGE);
+      asm volatile("" ::: "memory");
+      if (ksteps > 2) load_a(ks_lo + 2, ra[2]);
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < XP; ++i) store_piece(ra[0][i], i, 0u);
-    if (ksteps > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * XP + WPW) : "memory");
-    else if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int i = 0; i < ksteps; i += 3) {
-      step(i, ra[0], ra[1]);
-      if (i + 1 < ksteps) step(i + 1, ra[1], ra[2]);
-      if (i + 2 < ksteps) step(i + 2, ra[2], ra[0]);
+      for (int j = 0; j < XP; ++j) store_piece(ra[0][j], j, 0u);
+      if (ksteps > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * XP + WPW) : "memory");
+      else if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      for (; i + 5 < ksteps; i += 3) {
+        step(early_c, steady, c0_t{}, i, ra[0], ra[1]);
+        step(early_c, steady, c1_t{}, i + 1, ra[1], ra[2]);
+        step(early_c, steady, c2_t{}, i + 2, ra[2], ra[0]);
+      }
+      for (; i < ksteps; i += 3) {
+        step(early_c, guarded, c0_t{}, i, ra[0], ra[1]);
+        if (i + 1 < ksteps) step(early_c, guarded, c1_t{}, i + 1, ra[1], ra[2]);
+        if (i + 2 < ksteps) step(early_c, guarded, c2_t{}, i + 2, ra[2], ra[0]);
+      }
     }
-  }
+  };
+  if (wv < 4) kloop(std::true_type{});
+  else kloop(std::false_type{});
   if constexpr (NL == 2) {
     // the two accumulators joined, the weights' scale (a power of two) taken back out
     const float s2 = p.acc_scale * 0x1p-11f;

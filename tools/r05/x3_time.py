@@ -5,6 +5,7 @@ import torch
 from tf_eager_object_detection_amd import ops
 torch.manual_seed(0)
 from tf_eager_object_detection_amd import _lib
+FORM = sys.argv[4] if len(sys.argv) > 4 else 'x3'
 if len(sys.argv) > 2:
     _lib.call('odet_debug_x3_tile', int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 1)
 for (B, H, W, cin, cout, k) in ((15, 200, 334, 256, 512, 3), (15, 1, 1000, 12544, 1024, 1)):
@@ -12,7 +13,7 @@ for (B, H, W, cin, cout, k) in ((15, 200, 334, 256, 512, 3), (15, 1, 1000, 12544
     w = torch.randn(cout, cin, k, k, device='cuda') * 0.02
     wl = w.contiguous(memory_format=torch.channels_last)
     w2 = w.reshape(cout, cin).contiguous() if k == 1 else None
-    with ops.f32_form('x3'):
+    with ops.f32_form(FORM):
         fn = (lambda: ops.conv3x3_f32(x, wl, None, relu=True)) if k == 3 else (lambda: ops.pointwise(x, w2, None, None, True))
         fn(); torch.cuda.synchronize()
         ts = []
