@@ -52,6 +52,11 @@ typedef __attribute__((address_space(3))) void* x3_lds_ptr;
 
 #define X3_BK 32                  // float32 input channels per K-step (128 bytes of a pixel's row; 64 bytes per limb)
 #define X3_LDS_MAX (160 * 1024)
+// K-steps the pixel slots are loaded ahead of their use, as a function of the LDS stages (register buffers; measured NS + 1 and
+// NS + 2 on both forms: no gain -- what the slot path costs is its instructions, not its latency)
+#ifndef X3_NA
+#define X3_NA(NS) (NS)
+#endif
 
 // two float32 -> their three bfloat16 limbs, packed (low half = first value)
 __device__ __forceinline__ void x3_split2(const x3f2 a, unsigned& h, unsigned& m, unsigned& l) {
@@ -143,6 +148,7 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   // stages: the weights of K-step ks + NS - 1 travel while ks is computed.  Two limbs: three stages -- a K-step is 12 MFMAs per
   // pixel tile, shorter than an LDS-DMA's way through the memory system, so the copy gets two K-steps.
   constexpr int NS = NL == 2 ? 3 : 2;
+  constexpr int NA = X3_NA(NS);                          // K-steps the pixel slots are loaded ahead (register buffers)
   static_assert(NS == 2 || WPIECES % 8 == 0, "the counted wait needs the same number of copies from every wave");
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -230,7 +236,7 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   const int ksteps = (int)((long long)ksteps_all * (z + 1) / S) - ks_lo;
   // the float32 slots of TWO K-steps in flight (buffer ks & 1): a load issued at the top of K-step ks is split and stored in
   // the middle of K-step ks + 1 -- one and a half K-steps (~3 us) to arrive, whatever level of the memory system it comes from
-  x3u4 ra[NS][XP];
+  x3u4 ra[NA][XP];
   auto load_a = [&](int ks, x3u4 (&r)[XP]) {
     int tap = 0;
     uint32_t soA;
@@ -363,86 +369,74 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   // with both kinds in one body (or the end-of-K tests inside it) it drained EVERY outstanding copy (s_waitcnt vmcnt(0)) before
   // each refill of a slot buffer -- the prefetch depth was one step in name only (diagnostic build without the slot loads:
   // + 25 % three limbs, + 37 % two; tools/r05/x2_diag.sh).  The last 2 NS - 1 steps run the guarded form.
-  auto step = [&](auto early_c, auto steady_c, auto pos_c, int i, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {
+  // Slot buffers: NA = X3_NA(NS) register sets, the slots of step i + NA are loaded during step i (buffer i % NA, emptied by step
+  // i - 1); the loop is unrolled NA steps (the buffers are registers: compile-time indices), the LDS stage of a step is a scalar.
+  auto step = [&](auto early_c, auto steady_c, int i, uint32_t si, x3u4 (&rfree)[XP], const x3u4 (&rnext)[XP]) {
     constexpr bool EARLY = decltype(early_c)::value, STEADY = decltype(steady_c)::value;
-    constexpr uint32_t si = (uint32_t)decltype(pos_c)::value;           // i % NS
     const int ks = ks_lo + i;
-    constexpr uint32_t cur = si * STAGE, nxt = (si + 1 == NS ? 0u : si + 1) * STAGE;
-    constexpr uint32_t wst = NS == 2 ? nxt : (si == 0 ? 2u : si - 1) * STAGE;      // stage of K-step i + NS - 1
-    const bool more = STEADY || i + 1 < ksteps, morew = STEADY || i + NS - 1 < ksteps, morea = STEADY || i + NS < ksteps;
+    const uint32_t cur = si * STAGE, nxt = (si + 1 == NS ? 0u : si + 1) * STAGE;
+    const uint32_t wst = NS == 2 ? nxt : (si == 0 ? 2u : si - 1) * STAGE;          // stage of K-step i + NS - 1
+    const bool more = STEADY || i + 1 < ksteps, morew = STEADY || i + NS - 1 < ksteps, morea = STEADY || i + NA < ksteps;
     // (the counted waits below count copies in ISSUE order: the slot loads are plain loads the compiler may move across the
     // LDS-DMA copies -- it did, once the loop was restructured --, so the order is pinned)
     auto issue = [&] {
       asm volatile("" ::: "memory");
       if (morew) issue_w(ks + NS - 1, wst);
       asm volatile("" ::: "memory");
-      if (morea) load_a(ks + NS, rfree);
+      if (morea) load_a(ks + NA, rfree);
       asm volatile("" ::: "memory");
     };
     compute(lds + cur, rnext, nxt, more, [&] { if constexpr (EARLY) issue(); }, [&] { if constexpr (!EARLY) issue(); });
+    // all but what was issued after the weights of step i + 1: the slots of that step (i - NS + 2) and, with three stages, the
+    // weights and slots of step i
     if constexpr (NS == 2) {
       if (morea) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
-      // younger than the weights of i + 1: the slots of i + 2 (issued a step ago), the weights of i + 2 and the slots of i + 3
+      const bool aprev = STEADY || i - 1 + NA < ksteps;
       if (morea) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * XP + WPW) : "memory");
-      else if (morew) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
+      else if (morew && aprev) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
+      else if (morew) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   };
-  using c0_t = std::integral_constant<int, 0>;
-  using c1_t = std::integral_constant<int, 1>;
-  using c2_t = std::integral_constant<int, 2>;
   auto kloop = [&](auto early_c) {
     constexpr std::true_type steady{};
     constexpr std::false_type guarded{};
-    int i = 0;
-    if constexpr (NS == 2) {
-      issue_w(ks_lo, 0u);
-      asm volatile("" ::: "memory");
-      load_a(ks_lo, ra[0]);
-      asm volatile("" ::: "memory");
-      if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
-      asm volatile("" ::: "memory");
+    // ---- prologue, in the order the steps -NA .. -1 would have issued: step j the weights of j + NS - 1, then the slots of j + NA
 #pragma unroll
-      for (int j = 0; j < XP; ++j) store_piece(ra[0][j], j, 0u);
-      if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      for (; i + 3 < ksteps; i += 2) {                   // (both steps have their slots of i + 2 / i + 3 to load)
-        step(early_c, steady, c0_t{}, i, ra[0], ra[1]);  // (step i stores ra[1] = the slots of i + 1, refills ra[0] with i + 2)
-        step(early_c, steady, c1_t{}, i + 1, ra[1], ra[0]);
-      }
-      for (; i < ksteps; i += 2) {
-        step(early_c, guarded, c0_t{}, i, ra[0], ra[1]);
-        if (i + 1 < ksteps) step(early_c, guarded, c1_t{}, i + 1, ra[1], ra[0]);
-      }
-    } else {
-      load_a(ks_lo, ra[0]);
+    for (int j = -NA; j < 0; ++j) {
       asm volatile("" ::: "memory");
-      issue_w(ks_lo, 0u);
+      if (j + NS - 1 >= 0 && j + NS - 1 < ksteps) issue_w(ks_lo + j + NS - 1, (uint32_t)(j + NS - 1) * STAGE);
       asm volatile("" ::: "memory");
-      if (ksteps > 1) load_a(ks_lo + 1, ra[1]);
-      asm volatile("" ::: "memory");
-      if (ksteps > 1) issue_w(ks_lo + 1, STAGE);
-      asm volatile("" ::: "memory");
-      if (ksteps > 2) load_a(ks_lo + 2, ra[2]);
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < XP; ++j) store_piece(ra[0][j], j, 0u);
-      if (ksteps > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * XP + WPW) : "memory");
-      else if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      for (; i + 5 < ksteps; i += 3) {
-        step(early_c, steady, c0_t{}, i, ra[0], ra[1]);
-        step(early_c, steady, c1_t{}, i + 1, ra[1], ra[2]);
-        step(early_c, steady, c2_t{}, i + 2, ra[2], ra[0]);
-      }
-      for (; i < ksteps; i += 3) {
-        step(early_c, guarded, c0_t{}, i, ra[0], ra[1]);
-        if (i + 1 < ksteps) step(early_c, guarded, c1_t{}, i + 1, ra[1], ra[2]);
-        if (i + 2 < ksteps) step(early_c, guarded, c2_t{}, i + 2, ra[2], ra[0]);
-      }
+      if (j + NA < ksteps) load_a(ks_lo + j + NA, ra[j + NA]);
     }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < XP; ++j) store_piece(ra[0][j], j, 0u);
+    // (the weights of step 0 were issued by "step" 1 - NS: younger are its slots and everything of the later "steps")
+    if constexpr (NS == 2) {
+      if (ksteps > NA - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      if (ksteps > NA - 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * XP + WPW) : "memory");
+      else if (ksteps > NA - 2 && ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(XP + WPW) : "memory");
+      else if (ksteps > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    int i = 0;
+    uint32_t si = 0;                                     // i % NS
+    auto round = [&](auto steady_c) {                    // NA steps; buffers: step i + u refills u, splits and stores u + 1
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        if (decltype(steady_c)::value || i + u < ksteps) {
+          step(early_c, steady_c, i + u, si, ra[u], ra[u + 1 == NA ? 0 : u + 1]);
+          si = si + 1 == NS ? 0u : si + 1;
+        }
+      }
+    };
+    for (; i + 2 * NA - 1 < ksteps; i += NA) round(steady);     // (the round's last step still has its slots of i + 2 NA - 1 to load)
+    for (; i < ksteps; i += NA) round(guarded);
   };
   if (wv < 4) kloop(std::true_type{});
   else kloop(std::false_type{});
