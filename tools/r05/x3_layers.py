@@ -32,7 +32,7 @@ def timed(fn, reps):
 res = {'batch': args.batch, 'layers': []}
 if args.check:
     for (B, H, W, cin, cout, k) in [(2, 25, 42, 256, 512, 3), (1, 50, 84, 64, 64, 3), (3, 13, 21, 512, 512, 3), (2, 50, 84, 256, 64, 1),
-                                    (2, 25, 42, 1024, 256, 1), (1, 100, 167, 64, 256, 1), (1, 7, 9, 2048, 512, 1), (4, 31, 45, 32, 128, 1)]:
+                                    (2, 25, 42, 1024, 256, 1), (1, 100, 167, 64, 256, 1), (1, 7, 9, 2048, 512, 1), (4, 31, 45, 96, 128, 1)]:
         x = (torch.randn(B, H, W, cin, device=dev) * 3.0).contiguous()
         w = torch.randn(cout, cin, k, k, device=dev) * (2.0 / (cin * k * k)) ** 0.5
         b = torch.randn(cout, device=dev) * 0.1
