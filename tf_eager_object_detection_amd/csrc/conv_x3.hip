@@ -25,10 +25,11 @@
 //    MI355X guide, LDS table), and rows r and r + 4 of a 64-byte-row image share their banks: the 16-byte slot q of a row is
 //    therefore stored at q ^ 2 for rows 8..15 of every 16 -- each group then covers all 64 banks once (without it every
 //    fragment read is a 2-way conflict).
-//  * Workgroup = 8 waves, tile TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels, two stages; wave tile 16 MT pixels x 64
-//    channels: per K-step 3 x (4 + MT) fragment reads feed 24 MT MFMAs -- the loop is bound by the matrix pipe, not by LDS
-//    (the float16 kernel reads (4 + MT) fragments per 4 MT MFMAs).
+//  * Workgroup = 8 waves, tile TM = (8 / WN) * 16 * MT pixels x TN = 64 * WN channels, two stages (three limbs) / three (two limbs);
+//    wave tile 16 MT pixels x 64 channels: per K-step NL x (4 + MT) fragment reads feed 24 MT / 12 MT MFMAs.
 //  * Same transposed tiles, XCD-aware workgroup order, multi-level launches and epilogues (conv_f32_common.h) as the float32 kernel.
+//  * The TWO-LIMB form (conv_tile_x3<.., NL = 2>, the odet_*_x2 entry points): float16 limbs h + l * 2^-11, three products per k;
+//    see the template's header.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
