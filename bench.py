@@ -241,6 +241,8 @@ def e2e_record(dtype_name, batch, budget_s=6.0, family='fpn', graph=False, eager
         rec.update(value=steps * batch / el, steps=steps, ms_per_image=el / (steps * batch) * 1e3)
     rec['nms_done'] = int(all(int(v) == 1 for v in model._steps.nms_done_all[:batch].tolist()))
     rec['detections_image0'] = int(out[0][3].item())
+    if f32_form == 'x2':                                # (passes whose activations left float16's range and were repeated on three limbs)
+        rec['range_reruns'] = int(model.range_reruns)
     if graph:
         try:
             run = model.capture(batch)

@@ -1565,6 +1565,43 @@ def test_float32_x3_detector_agrees_with_the_exact_float32_detector(form):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('family', ['fpn', 'vgg16'])
+def test_two_limb_pass_out_of_float16_range_is_detected_and_repeated_on_three_limbs(family):
+    """f32_form = 'x2' computes on float16 limbs: an activation beyond 65504 makes that layer's output non-finite (include/odet.h).
+    The detectors read that off the pass's own outputs where they read the NMS flags (range_ok) and repeat the pass on the
+    three-limb form (float32's range): images a hundred times brighter than any real input give EXACTLY the three-limb detector's
+    results, `range_reruns` counts the pass; ordinary images are not re-run"""
+    from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
+    from tf_eager_object_detection_amd.model.frcnn_detector import Vgg16Detector
+    torch.manual_seed(1)
+    shape = (256, 352)
+    mk = (lambda form: ResNetFpnDetector(50, 21, shape, 300, dtype=torch.float32, max_batch=2, blind_chunks=3, f32_form=form)) \
+        if family == 'fpn' else (lambda form: Vgg16Detector(21, shape, 100, dtype=torch.float32, max_batch=2, f32_form=form))
+    a = mk('x3').prepare()
+    b = mk('x2')
+    b.load_state_dict(a.state_dict())
+    b.prepare()
+    rng = np.random.default_rng(1)
+    img = torch.from_numpy((rng.uniform(0, 255, (2,) + shape + (3,)) - 110).astype(np.float32)).cuda()
+    ob = b(img)
+    torch.cuda.synchronize()
+    assert b.range_reruns == 0 and b.range_ok() and b.f32_form == 'x2'
+    n_ok = [int(o[3].item()) for o in ob]
+    big = img * 3000.0                                   # (activations of the first layers ~ 1e5 .. 1e6)
+    oa = [tuple(t.clone() for t in o) for o in a(big)]
+    ob = b(big)
+    torch.cuda.synchronize()
+    assert b.range_reruns == 1 and b.f32_form == 'x2'
+    for x, y in zip(oa, ob):
+        n = int(x[3].item())
+        assert n == int(y[3].item())
+        assert torch.equal(x[0][:n], y[0][:n]) and torch.equal(x[1][:n], y[1][:n]) and torch.equal(x[2][:n], y[2][:n])
+    ob = b(img)                                          # back on two limbs
+    torch.cuda.synchronize()
+    assert b.range_reruns == 1 and [int(o[3].item()) for o in ob] == n_ok
+
+
+@pytest.mark.gpu
 def test_float16_detections_of_one_image_do_not_depend_on_the_batch_beyond_rounding():
     """the float16 bottleneck route depends on the batch (the fused 3x3 + 1x1 tail from 200 slabs on, two launches
     below: another accumulation order before the one float16 rounding), so one image's low bits -- and NMS / top-k ties with

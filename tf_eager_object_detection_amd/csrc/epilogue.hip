@@ -136,7 +136,12 @@ __global__ void __launch_bounds__(256) k_bias_relu_maxpool(PoolEpiParams p) {
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], __uint_as_float(xw[q]));
+          for (int q = 0; q < 4; ++q) {
+            // (float32: a NaN stays -- the two-limb convolutions mark an operand beyond float16's range that way and the
+            // detectors look for it at the end of the pass, model/fpn_detector.py range_ok; fmaxf would drop it)
+            const float f = __uint_as_float(xw[q]);
+            m[q] = (f > m[q] || f != f) ? f : m[q];
+          }
         }
       }
     }

@@ -313,7 +313,7 @@ def rpn_pair_padded(m, w):
 
 
 def _in_f32_form(method):
-    """runs a detector's dense method with the float32 layers in the detector's `f32_form` ('exact' | 'x3': ops.f32_form)"""
+    """runs a detector's dense method with the float32 layers in the detector's `f32_form` ('exact' | 'x3' | 'x2': ops.f32_form)"""
     import functools
 
     @functools.wraps(method)
@@ -426,11 +426,44 @@ class _NmsCompleteness:
         hot.stage_detect(cls, dlt)
 
     def _after_pass(self, batch, check):
+        """-> False if the pass has to be repeated on the three-limb form (range_ok), else True"""
         self._last_batch = batch
         if check is None:
             check = self.check_nms and not torch.cuda.is_current_stream_capturing()
         if check:
+            if getattr(self, 'f32_form', 'exact') == 'x2' and not self.range_ok(batch):
+                return False
             self.recover(batch)
+        return True
+
+    # ---- the two-limb float32 form's RANGE (f32_form = 'x2': float16 limbs; an activation beyond 65504 gives inf / NaN in that
+    # layer's output, include/odet.h) -- checked where the NMS flags are read, on the pass's own outputs: every later layer
+    # propagates a non-finite value (the convolutions' ReLU is `v < 0 ? 0 : v`), so a pass whose RPN outputs and head outputs
+    # are all finite had no overflow upstream of them.  A pass that fails is run again on the three-limb form (bfloat16 limbs:
+    # float32's range), counted in `range_reruns`.
+    range_reruns = 0
+
+    def range_ok(self, batch=None):
+        """True iff the RPN scores / deltas and the RoI head's outputs of the last pass are all finite (one host sync)"""
+        n = self._last_batch if batch is None else batch
+        rpn_scores, rpn_deltas, _, heads = self._last_pass
+        t = rpn_scores[:n].sum() + rpn_deltas[:n].sum()
+        for cls, dlt in heads[:n]:
+            t = t + cls.sum() + dlt.sum()
+        return bool(torch.isfinite(t).item())
+
+    def _forward_checked(self, images_nhwc, check, run):
+        """run(images) -> outputs, then the after-pass checks; a two-limb pass out of range is repeated on three limbs"""
+        outs = run(images_nhwc)
+        if not self._after_pass(len(outs), check):
+            self.range_reruns += 1
+            self.f32_form = 'x3'
+            try:
+                outs = run(images_nhwc)
+                self._after_pass(len(outs), check)
+            finally:
+                self.f32_form = 'x2'
+        return outs
 
 
 class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
@@ -693,11 +726,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
     def forward(self, images_nhwc, check=None):
         """-> per image (boxes [M,4], labels [M], scores [M], count) padded to max_per_image, count on the device
         (post_ops_prediction, base_fpn_model.py:267-275).  check: see _NmsCompleteness."""
-        heads = self._run_to_head(images_nhwc)
-        B = len(heads)
-        outs = self._detect(heads)
-        self._after_pass(B, check)
-        return outs
+        return self._forward_checked(images_nhwc, check, lambda im: self._detect(self._run_to_head(im)))
 
     @torch.no_grad()
     def im_detect(self, images_nhwc, img_scale):

@@ -202,16 +202,15 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
 
     @torch.no_grad()
     def forward(self, images_nhwc, check=None):
-        heads = self._run_to_head(images_nhwc)
-        B = len(heads)
-        if self._steps is not None:
-            sb = self._steps
-            sb.enqueue(sb.STAGE_DETECT, B)
-            outs = [(h.det_boxes, h.det_labels, h.det_scores, h.det_count) for h in sb.slots[:B]]
-        else:
-            outs = self._per_image(B, lambda b: self._hot[b].stage_detect(heads[b][0], heads[b][1]))
-        self._after_pass(B, check)
-        return outs
+        def run(im):
+            heads = self._run_to_head(im)
+            B = len(heads)
+            if self._steps is not None:
+                sb = self._steps
+                sb.enqueue(sb.STAGE_DETECT, B)
+                return [(h.det_boxes, h.det_labels, h.det_scores, h.det_count) for h in sb.slots[:B]]
+            return self._per_image(B, lambda b: self._hot[b].stage_detect(heads[b][0], heads[b][1]))
+        return self._forward_checked(images_nhwc, check, run)
 
     @torch.no_grad()
     def im_detect(self, images_nhwc, img_scale):
