@@ -501,7 +501,8 @@ int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, i
  * within ONE float32 ulp), a product as h h + (h l + l h) * 2^-11 on v_mfma_f32_16x16x32_f16 (dropped: l l <= 2^-22 of it),
  * two float32 accumulators joined at the end: HALF the matrix work of the three-limb form; against float64 its error on the
  * detectors' layers is no larger than the exact-float32 form's (float32 accumulation dominates both) -- for data inside
- * float16's RANGE.  |activation| > 65504 gives infinities / NaN in the result (never a wrong finite number); activations below 2^-14
+ * float16's RANGE.  |activation| > 65504 gives infinities / NaN in the result (never a wrong finite number; the layers' ReLU and
+ * the float32 odet_bias_relu_maxpool keep a NaN, so a caller can test the END of a chain of layers); activations below 2^-14
  * keep an absolute error <= 2^-36 instead of a relative one.  `w2` = float16 planes [2][cout][K] of w * 2^w_exp, written once
  * per weight tensor by odet_split_f16x2; the caller picks w_exp (|w_exp| <= 100) so that the largest |w| * 2^w_exp lies in
  * [512, 1024) -- every weight down to 2^-24 of the largest then keeps both limbs normal -- and passes the same w_exp to the
