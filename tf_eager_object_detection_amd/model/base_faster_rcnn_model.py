@@ -249,8 +249,10 @@ class ResNetFasterRcnn(_FrcnnFromDense):
     pooling + score / box layers.  Keyword arguments and defaults as there (`_COMMON`; model_factory.py:117 passes
     roi_pooling_max_pooling_flag=False from the config)."""
 
-    def __init__(self, depth=50, roi_feature_size=(7, 7, 1024), dtype=torch.float32, device='cuda', **kwargs):
+    def __init__(self, depth=50, roi_feature_size=(7, 7, 1024), dtype=torch.float32, device='cuda', f32_form='exact', **kwargs):
         from .frcnn_detector import ResNetC4Detector
+        from .fpn_detector import check_caller_f32_form
+        check_caller_f32_form(f32_form)
         if depth not in [50, 101, 152]:
             raise ValueError('unknown resnet layers number {}'.format(depth))
         kw = dict(_COMMON)
@@ -262,7 +264,7 @@ class ResNetFasterRcnn(_FrcnnFromDense):
         self._roi_feature_size = roi_feature_size
         if len(kw['ratios']) * len(kw['scales']) != 9 or kw['extractor_stride'] != 16:
             raise ValueError('ResNetFasterRcnn: the dense kernels are built for 9 anchors per cell at stride 16')
-        self._init_with_dense(ResNetC4Detector(depth, kw['num_classes'], (64, 64), 1, dtype=dtype), dtype, device, kw)
+        self._init_with_dense(ResNetC4Detector(depth, kw['num_classes'], (64, 64), 1, dtype=dtype, f32_form=f32_form), dtype, device, kw)
 
 
 class Vgg16FasterRcnn(_FrcnnFromDense):
@@ -270,8 +272,10 @@ class Vgg16FasterRcnn(_FrcnnFromDense):
     inference).  `slim_ckpt_file_path` must be None: no checkpoint exists offline (random initialisation)."""
 
     def __init__(self, slim_ckpt_file_path=None, roi_head_keep_dropout_rate=0.5, roi_feature_size=(7, 7, 512),
-                 dtype=torch.float32, device='cuda', **kwargs):
+                 dtype=torch.float32, device='cuda', f32_form='exact', **kwargs):
         from .frcnn_detector import Vgg16Detector
+        from .fpn_detector import check_caller_f32_form
+        check_caller_f32_form(f32_form)
         if slim_ckpt_file_path is not None:
             raise ValueError('Vgg16FasterRcnn: checkpoint import is out of scope (SURVEY section 2); weights are random')
         kw = dict(_COMMON)
@@ -283,4 +287,4 @@ class Vgg16FasterRcnn(_FrcnnFromDense):
         self._roi_feature_size = roi_feature_size
         if len(kw['ratios']) * len(kw['scales']) != 9 or kw['extractor_stride'] != 16:
             raise ValueError('Vgg16FasterRcnn: the dense kernels are built for 9 anchors per cell at stride 16')
-        self._init_with_dense(Vgg16Detector(kw['num_classes'], (64, 64), 1, dtype=dtype), dtype, device, kw)
+        self._init_with_dense(Vgg16Detector(kw['num_classes'], (64, 64), 1, dtype=dtype, f32_form=f32_form), dtype, device, kw)

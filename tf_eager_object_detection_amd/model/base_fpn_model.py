@@ -287,7 +287,8 @@ class ResnetV1Fpn(BaseFPN):
     (get_resnet_v1_extractor :262-289), ResnetFpnNeck (:339-407), the RpnHead's convolutions and ResnetRoiHead (:292-336;
     dropout is inference-only identity) -- are the hand-written kernels of model/fpn_detector.ResNetFpnDetector, which this
     class owns as `dense`; weights are randomly initialised with the reference's initialisers (no checkpoints offline).
-    `dtype`: torch.float32 (the reference's precision) or torch.float16 (throughput mode)."""
+    `dtype`: torch.float32 (the reference's precision) or torch.float16 (throughput mode); `f32_form`: the float32 layers'
+    arithmetic, 'exact' (float32 matrix instructions) or 'x3' (split precision, three bfloat16 limbs: ops.f32_form)."""
 
     def __init__(self, depth=50, roi_head_keep_dropout_rate=0.5, roi_feature_size=(7, 7, 256), num_classes=21,
                  weight_decay=0.0001, level_name_list=('p2', 'p3', 'p4', 'p5', 'p6'), min_level=2, max_level=5,
@@ -302,8 +303,10 @@ class ResnetV1Fpn(BaseFPN):
                  roi_training_pos_iou_threshold=0.5, roi_training_neg_iou_threshold=0.1,
                  roi_training_total_num_samples=256, roi_training_max_pos_samples=64,
                  prediction_max_objects_per_image=50, prediction_max_objects_per_class=50,
-                 prediction_nms_iou_threshold=0.3, prediction_score_threshold=0.3, dtype=torch.float32, device='cuda'):
-        from .fpn_detector import ResNetFpnDetector
+                 prediction_nms_iou_threshold=0.3, prediction_score_threshold=0.3, dtype=torch.float32, device='cuda',
+                 f32_form='exact'):
+        from .fpn_detector import ResNetFpnDetector, check_caller_f32_form
+        check_caller_f32_form(f32_form)
         if top_down_dims != 256 or tuple(roi_feature_size) != (roi_pool_size, roi_pool_size, top_down_dims):
             raise ValueError('ResnetV1Fpn: the dense kernels are built for 256 top-down channels and %dx%dx256 RoI features'
                              % (roi_pool_size, roi_pool_size))
@@ -313,7 +316,7 @@ class ResnetV1Fpn(BaseFPN):
         self._depth = depth
         self._roi_head_keep_dropout_rate = roi_head_keep_dropout_rate
         self._top_down_dims = top_down_dims
-        dense = ResNetFpnDetector(depth, num_classes, (64, 64), 1, dtype=dtype)
+        dense = ResNetFpnDetector(depth, num_classes, (64, 64), 1, dtype=dtype, f32_form=f32_form)
         dense.to(device=device, dtype=dtype, memory_format=torch.channels_last).eval()
         self.__dict__['_dense_ref'] = dense
         BaseFPN.__init__(

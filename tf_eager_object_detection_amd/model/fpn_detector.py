@@ -312,6 +312,14 @@ def rpn_pair_padded(m, w):
     return c[1]
 
 
+def check_caller_f32_form(form):
+    """the reference-surface caller objects (base_fpn_model.py, base_faster_rcnn_model.py) compose the layers themselves and
+    have no after-pass range check: they take the full-range float32 forms only"""
+    if form not in ('exact', 'x3'):
+        raise ValueError("f32_form must be 'exact' or 'x3' here (the two-limb form 'x2' needs the detectors' range check: "
+                         "model.fpn_detector / frcnn_detector)")
+
+
 def _in_f32_form(method):
     """runs a detector's dense method with the float32 layers in the detector's `f32_form` ('exact' | 'x3' | 'x2': ops.f32_form)"""
     import functools
