@@ -31,6 +31,9 @@
 extern "C" {
 #endif
 
+/* 100: round 4.  101: odet_fpn_step_t.ws_post_clean, the odet_*_x3 entry points (three bfloat16 limbs) with their split-K
+ * workspace.  102: the odet_*_x2 entry points (two float16 limbs) and odet_split_f16x2; odet_bias_relu_maxpool keeps a NaN
+ * in float32. */
 #define ODET_VERSION 102
 
 #define ODET_OK 0
