@@ -21,7 +21,7 @@ thread of the library) carry `--batch` images each whose kernels share their lau
 step); with N > 1 every round of streams x batch images ends with ONE RCCL all-gather of the fixed-size
 detection records.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus
+Prints ONE JSON line (rank 0), <= 8 KB (LINE_LIMIT; asserted in tests/test_bench_contract.py), with the driver's contract plus
   `roofline`     dominant kernel = the fused RoI crop+pool kernel (HBM bound), the 8-image launch of one stream
                  group: >= 10 launches in a short phase AFTER the timed region, each alone on the GPU with cold
                  maps, HIP events attached to the dispatch.  Those launches run under their own kernel name
@@ -35,17 +35,25 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
                  (`value`) and one thread (`value_1thread`); it also carries the mAP delta of the evaluation loop.
   `value_clustered` the same path, same protocol, on trained-like (clustered) RPN scores: a second timed region; the
                  sync-free NMS plan is widened by itself, rung by rung, when a distribution needs it (`config.replanned`).
-  `config5`      (N = 1) BASELINE configs[4] as a measured record: the same hot path at 1333x1333 (446 118 anchors, 1000
-                 proposals), 81 classes, caps 100 per class / 300 per image (config/faster_rcnn_config.py:93-113's COCO caps),
-                 float16 feature maps into the RoI kernel -- throughput, its RoI launch alone, its roofline fractions.
   `multi_rank`   what a 2 / 4 / 8-GPU run needs to validate itself: the backend's world size (RCCL), per-rank img/s min / max,
                  the number of all-gathers issued and their record bytes.
-  `summary`      LAST key, <= 1 KB, values only: every headline figure of this line (the driver keeps the tail of stdout).
-  `e2e`          (N = 1) a second, separately labelled record: the assembled detectors end to end (hand-written
-                 convolutions around the hot path, no library convolution or GEMM): ResNet-101-FPN fp32 = the reference's precision,
-                 fp16 = throughput mode (narrower than the reference; eager and as one HIP graph) with its accuracy gate
-                 `map_delta_vs_fp32` (float16 vs float32 detector on identical weights and annotated synthetic scenes,
-                 the reference's evaluation loop), ResNet-50 C4 and VGG16 (BASELINE configs 2 and 1) in fp16.
+  `detail`       (N = 1) where the secondary records are and how their process ended (below).
+  `summary`      LAST key, <= 1 KB, values only: every headline figure of this line AND of the side file.
+
+Everything that is not the headline -- (N = 1 only) -- runs AFTER the line's own measurements in a fresh CHILD process
+(`bench.py --detail-child`, started with subprocess, own session, hard timeout; never an exec of the process that holds the
+GPU) and writes `bench_detail.json` next to this file, rewritten after every leg (progress on stderr).  A hang or GPU fault in
+any of those legs costs that leg: the parent prints its line regardless.  The side file holds
+  `config5`      BASELINE configs[4] as a measured record: the same hot path at 1333x1333 (446 118 anchors, 1000
+                 proposals), 81 classes, caps 100 per class / 300 per image (config/faster_rcnn_config.py:93-113's COCO caps),
+                 float16 feature maps into the RoI kernel -- throughput, its RoI launch alone, its roofline fractions.
+  `e2e`          a second, separately labelled record: the assembled detectors end to end (hand-written
+                 convolutions around the hot path, no library convolution or GEMM): ResNet-101-FPN fp32 = the reference's
+                 precision (exact / three-limb / two-limb forms), fp16 = throughput mode (narrower than the reference; eager and
+                 as one HIP graph), ResNet-50 C4 and VGG16 (BASELINE configs 2 and 1), and the accuracy gates
+                 `map_delta_vs_fp32` (a mode vs the exact-float32 detector on identical weights and annotated synthetic
+                 scenes, the reference's evaluation loop; `ci_inside_bar` = both ends of the paired-bootstrap CI95 within +-0.002).
+The whole default run aims at `--time-budget` (190 s): the gates run on as many scenes as fit.
 """
 import argparse
 import ctypes
@@ -276,6 +284,138 @@ E2E_CONV_PATH = ('hand-written HIP kernels only, at every batch size (float16: 3
                  'no library convolution / GEMM route (model/fpn_detector.py)')
 
 
+HARD_LIMIT_EXTRA_S = 25.0   # the child plans inside its budget; this much later a hang is assumed
+LINE_LIMIT = 8192          # bytes of the ONE stdout line (the driver's parser lost a 22 KB line in round 5; 15 KB parsed)
+
+_RENDEZVOUS_ENV = ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK',
+                   'ROLE_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID')
+
+
+class _Terminated(Exception):
+    pass
+
+
+def run_detail_child(args, t_main):
+    """Start `bench.py --detail-child <side file>` as a fresh CHILD process (own session; stdout -> this process's stderr),
+    wait for it under a hard limit, and return what it left in the side file (+ how it ended).  The child plans its legs
+    inside the budget it is given; the hard limit (budget + HARD_LIMIT_EXTRA_S) and SIGTERM to this process only catch a hang: the child's
+    process group -- the one started here, by pid -- is killed, and the side file still holds every finished leg."""
+    import signal
+    import subprocess
+    path = os.path.abspath(args.detail_out)
+    for q in (path, path + '.tmp'):
+        try:
+            os.remove(q)
+        except OSError:
+            pass
+    budget = max(args.time_budget - (time.perf_counter() - t_main) - 5.0, 1.0)
+    cmd = [sys.executable, os.path.abspath(__file__), '--detail-child', path, '--time-budget', '%.1f' % budget,
+           '--steps', str(args.steps), '--warmup', str(args.warmup), '--rounds-per-step', str(args.rounds_per_step),
+           '--streams', str(args.streams), '--batch', str(args.batch), '--blind-chunks', str(args.blind_chunks),
+           '--nms-first-chunk', str(args.nms_first_chunk), '--roofline-samples', str(args.roofline_samples),
+           '--gate-images', str(args.gate_images)]
+    cmd += ['--no-e2e'] if args.no_e2e else []
+    cmd += ['--no-config5'] if args.no_config5 else []
+    cmd += ['--trace'] if args.trace else []
+    env = {k: v for k, v in os.environ.items() if k not in _RENDEZVOUS_ENV}
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, stdout=sys.stderr, stderr=sys.stderr, env=env, start_new_session=True)
+
+    def on_term(signum, frame):
+        raise _Terminated()
+    old = signal.signal(signal.SIGTERM, on_term)
+    try:
+        rc = proc.wait(timeout=budget + HARD_LIMIT_EXTRA_S)
+    except (subprocess.TimeoutExpired, _Terminated, KeyboardInterrupt) as ex:
+        rc = 'killed (%s)' % type(ex).__name__
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # exactly the group started above
+        except OSError:
+            pass
+        try:
+            proc.wait(timeout=10.0)
+        except Exception:
+            pass
+    finally:
+        signal.signal(signal.SIGTERM, old)
+    detail = {}
+    try:
+        detail = json.load(open(path))
+    except Exception as ex:
+        detail = {'error': 'no side file: %s: %s' % (type(ex).__name__, ex)}
+    detail.update(file=os.path.relpath(path, ROOT) if path.startswith(ROOT) else path, child_rc=rc,
+                  child_s=round(time.perf_counter() - t0, 1), legs_done_n=len(detail.get('legs_done', [])))
+    detail.setdefault('complete', False)
+    try:                                                  # (the side file also says how its writer ended)
+        with open(path + '.tmp', 'w') as f:
+            json.dump(detail, f)
+        os.replace(path + '.tmp', path)
+    except OSError:
+        pass
+    return detail
+
+
+def summarise_detail(summary, detail):
+    """the headline figures of the side file's records -> `summary` (values only; the records themselves stay in the file)"""
+    e2e = detail.get('e2e') or {}
+    c5 = detail.get('config5')
+
+    def rate(name, key='value'):
+        v = (e2e.get(name) or {}).get(key)
+        return round(v, 1) if isinstance(v, (int, float)) else None
+    if isinstance(c5, dict) and 'value' in c5:
+        # [img/s, us of the 8-image RoI launch, its fraction of 8 TB/s on B_min]
+        summary['cfg5_hot_path'] = [round(c5['value'], 1), round(c5['roofline']['kernel_ms'] * 1e3, 1), round(c5['roofline']['frac_on_B_min'], 3)]
+    elif c5 is not None:
+        summary['cfg5_hot_path'] = 'error'
+    if len(e2e) > 1:
+        summary.update(e2e_fp16=[rate('fp16'), 60], e2e_fp16_b1_graph=rate('fp16_b1', 'value_hip_graph'),
+                       e2e_fp16_b1_eager=rate('fp16_b1'), e2e_fp16_b4=[rate('fp16_b4'), rate('fp16_b4', 'value_hip_graph')],
+                       e2e_fp16_b8=[rate('fp16_b8'), rate('fp16_b8', 'value_hip_graph')], e2e_fp32=[rate('fp32'), 30],
+                       e2e_fp32_x3=[rate('fp32_x3'), 30], e2e_fp32_x3_b1_graph=rate('fp32_x3_b1', 'value_hip_graph'),
+                       fp32_x2=[rate('fp32_x2'), rate('fp32_x2_b1', 'value_hip_graph')],   # (+ mAP delta, kept-anchor agreement)
+                       c4_fp16=[rate('fp16_resnet50_c4'), 60], vgg16_fp16=[rate('fp16_vgg16_600x800'), 64],
+                       c4_vgg16_fp32_x3=[rate('fp32_x3_resnet50_c4'), rate('fp32_x3_vgg16_600x800')])
+        for name, key in (('fp16', 'fpn'), ('fp16_resnet50_c4', 'c4'), ('fp16_vgg16_600x800', 'vgg16'), ('fp32_x3', 'x3'), ('fp32_x2', 'x2')):
+            g = (e2e.get(name) or {}).get('map_delta_vs_fp32') or e2e.get(name + '_map_delta_vs_fp32')
+            if not isinstance(g, dict) or 'map_delta' not in g:
+                continue
+            lo, hi = g['map_delta_ci95_paired_bootstrap']
+            if key == 'x2':         # (one compact entry: img/s at 30, batch-1 graph img/s, mAP delta, kept-anchor agreement)
+                summary['fp32_x2'] = summary['fp32_x2'][:2] + [round(g['map_delta'], 4), round(g['rpn_kept_index_agreement_mean'], 4)]
+                continue
+            # [mAP delta, CI95 low, CI95 high, scenes, both ends of the interval within +-0.002 (1 / 0)]
+            summary['map_delta_' + key] = [round(g['map_delta'], 4), round(lo, 4), round(hi, 4), g['images'], int(bool(g['ci_inside_bar']))]
+            if key == 'x3':
+                summary['x3_vs_exact'] = [round(g['rpn_kept_index_agreement_mean'], 4), float('%.1e' % g['p99_abs_dscore'])]
+    summary['detail'] = [detail.get('file'), int(bool(detail.get('complete'))), detail.get('legs_done_n')]
+
+
+def compact_line(result):
+    """json.dumps(result) kept <= LINE_LIMIT bytes: the contract keys, `config`, `roofline`, `cpu_baseline`, `multi_rank`,
+    `summary` stay; should the line ever outgrow the limit, its explanatory strings go first (recorded in `dropped`)."""
+    line = json.dumps(result)
+    dropped = []
+    for path_ in (('cpu_baseline', 'sample_detail'), ('roofline', 'calibration', 'kernel'), ('roofline', 'traffic_source'),
+                  ('config', 'second_distribution'), ('cpu_baseline', 'map_delta', 'data'), ('roofline', 'kernel'),
+                  ('multi_rank', 'collective'), ('config', 'step')):
+        if len(line) <= LINE_LIMIT:
+            break
+        d = result
+        for k in path_[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+        if isinstance(d, dict) and path_[-1] in d:
+            del d[path_[-1]]
+            dropped.append('.'.join(path_))
+            summ = result.pop('summary', None)
+            result['dropped'] = dropped
+            if summ is not None:
+                result['summary'] = summ                  # (stays the LAST key)
+            line = json.dumps(result)
+    return line
+
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher's environment: start `python -m torch.distributed.run --nnodes=1
     --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process (never an
@@ -326,9 +466,14 @@ def main():
     ap.add_argument('--roofline-samples', type=int, default=12, help='isolated RoI launches timed after the timed region')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; "
                     "'gloo' only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument('--time-budget', type=float, default=330.0,
-                    help='seconds the whole run aims to stay within: an accuracy gate that would not fit any more runs on fewer '
-                         'scenes (>= 1024; recorded as gate_scenes_reduced_to), nothing else is shortened')
+    ap.add_argument('--time-budget', type=float, default=190.0,
+                    help='seconds the whole run aims to stay within: the accuracy gates of the detail process run on as many '
+                         'scenes as fit (recorded as gate_scenes_reduced_to; --time-budget 900 runs them at full size); the '
+                         'headline legs are never shortened')
+    ap.add_argument('--detail-out', default=os.path.join(ROOT, 'bench_detail.json'),
+                    help='side file of the N = 1 run: config 5, every end-to-end leg and every gate record (the stdout line keeps '
+                         'their headline figures in `summary`)')
+    ap.add_argument('--detail-child', default=None, help=argparse.SUPPRESS)    # (internal: this process IS the detail child)
     ap.add_argument('--trace', action='store_true', help='phase time stamps on stderr (synchronises at every mark)')
     ap.add_argument('--force-collective', action='store_true',
                     help='with ONE rank under torch.distributed.run: still issue the all-gather of every stream group (the RCCL '
@@ -613,8 +758,127 @@ def main():
                              'roi_kernel_vs_calibration': cal_ms / roi_ms}
         return rf
 
-    # ---- the headline: SURVEY 8(d)'s distribution (or --scores), then the OTHER distribution beside it
     cfg3 = dict(image_shape=IMAGE_SHAPE, num_classes=NUM_CLASSES, max_per_class=50, max_per_image=50, maps=args.maps)
+
+    def run_detail(path):
+        """(the CHILD process of an N = 1 run) BASELINE configs[4], the assembled detectors end to end and their accuracy gates
+        -> the side file `path`, rewritten (atomically) after every leg, so that whatever was finished when this process ends
+        -- normally, by the parent's timeout, or in a GPU fault -- is on disk.  Nothing here can touch the headline: the parent
+        measured it before it started this process."""
+        detail = {'complete': False, 'legs_done': [], 'config5': None, 'e2e': {'conv_path': E2E_CONV_PATH}}
+        e2e = detail['e2e']
+
+        def flush(leg=None):
+            if leg is not None:
+                detail['legs_done'].append([leg, round(time.perf_counter() - t_main, 1)])
+            with open(path + '.tmp', 'w') as f:
+                json.dump(detail, f)
+            os.replace(path + '.tmp', path)
+            if leg is not None:
+                print('[bench detail %.1f s] %s' % (time.perf_counter() - t_main, leg), file=sys.stderr, flush=True)
+
+        def left():
+            return args.time_budget - (time.perf_counter() - t_main)
+
+        flush()
+        if not args.no_config5:
+            # ---- BASELINE configs[4]: 1333 x 1333, 446 118 anchors, 1000 proposals, 81 classes, caps 100 / 300 (the COCO
+            # configuration's per-class / per-image caps: config/faster_rcnn_config.py:112-113), float16 feature maps
+            try:
+                cfg5 = dict(image_shape=(1333, 1333), num_classes=81, max_per_class=100, max_per_image=300, maps='f16')
+                w5 = Workload(cfg5, 'distinct', args.nms_first_chunk, args.blind_chunks)
+                steps5 = max(2, args.steps // 4)
+                el5, rp5 = w5.measure(steps5, max(1, args.warmup // 2))
+                rf5 = roofline_phase(w5, max(6, args.roofline_samples // 2),
+                                     'k_roi_pool<MAX2, NORM_IMAGE, __half> (float16 maps: float32 lerps, float16 in / out)',
+                                     'fpn_hot_path_1333x1333_r101fpn_81cls_f16maps')
+                detail['config5'] = {
+                    'workload': 'BASELINE configs[4]: ResNet-101-FPN hot path @ 1333x1333 (446118 anchors -> 1000 proposals), 81 '
+                                'classes, max 100 per class / 300 per image, float16 feature maps into the RoI kernel',
+                    'value': steps5 * images_per_step / el5, 'unit': 'img/s', 'steps': steps5, 'timed_images': steps5 * images_per_step,
+                    'timed_region_s': el5, 'ms_per_image': el5 / (steps5 * images_per_step) * 1e3, 'dtype': 'f16',
+                    'anchors': syn.num_fpn_anchors((1333, 1333)), 'num_classes': 81, 'max_per_class': 100, 'max_per_image': 300,
+                    'nms_first_chunk': w5.nms_first_chunk, 'blind_chunks': w5.blind_chunks, 'replanned': rp5,
+                    'proposals_kept': int(w5.pool.slots[0].roi_count.item()),
+                    'detections_image0': int(w5.pool.slots[0].det_count.item()), 'roofline': rf5}
+                w5.close()
+                del w5
+            except Exception as ex:
+                detail['config5'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+            torch.cuda.empty_cache()
+            flush('config5')
+        if not args.no_e2e:
+            # (float16: 60 images per pass -- conv4's 50 x 84 maps then cut into four full rounds of 256-pixel workgroup tiles:
+            # +2 % over 30, +5 % over 15; 8 / 16 images leave a fifth of a round empty; batch 1 -- the BASELINE configs' own
+            # batch -- replayed as ONE HIP graph, batch 4 / 8 eager and as a graph; float32: 30 images per pass for the same
+            # reason).  (name, dtype, batch, family, graph, eager, timed seconds)
+            legs = (('fp16', 'fp16', 60, 'fpn', False, True, 3.0), ('fp16_b1', 'fp16', 1, 'fpn', True, True, 1.5),
+                    ('fp32_x3', 'fp32', 30, 'fpn', False, True, 3.0), ('fp32_x3_b1', 'fp32', 1, 'fpn', True, False, 1.5),
+                    ('fp32_x2', 'fp32', 30, 'fpn', False, True, 3.0), ('fp32_x2_b1', 'fp32', 1, 'fpn', True, False, 1.5),
+                    ('fp32', 'fp32', 30, 'fpn', False, True, 3.0),
+                    ('fp16_b4', 'fp16', 4, 'fpn', True, True, 1.0), ('fp16_b8', 'fp16', 8, 'fpn', True, True, 1.0),
+                    ('fp16_resnet50_c4', 'fp16', 60, 'c4', False, True, 1.5), ('fp16_vgg16_600x800', 'fp16', 64, 'vgg16', False, True, 1.5),
+                    ('fp32_x3_resnet50_c4', 'fp32', 30, 'c4', False, True, 1.5), ('fp32_x3_vgg16_600x800', 'fp32', 32, 'vgg16', False, True, 1.5))
+            for name, dtn, b, fam, gr, eg, budget in legs:
+                if left() < 3.0 * budget + 6.0:           # (the parent's clock: a leg that cannot finish is not started)
+                    e2e[name] = {'skipped': 'time budget (%.0f s left)' % left()}
+                    continue
+                try:
+                    e2e[name] = e2e_record(dtn, b, budget_s=budget, family=fam, graph=gr, eager=eg,
+                                           f32_form='x3' if 'fp32_x3' in name else 'x2' if 'fp32_x2' in name else 'exact')
+                except Exception as ex:
+                    e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+                flush('e2e ' + name)
+            e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
+                           'mode (the reference computes in float32; exact-float32 matrix instructions, 157 TFLOP/s peak, 684 GFLOP '
+                           'per image), fp32_x3 / fp32_x2 = the same float32 tensors with every layer on the split-precision forms '
+                           '(float32-class accuracy; three bfloat16 limbs: 417 TFLOP/s-equivalent peak, two float16 limbs: 833, '
+                           'float16 range), fp16 = throughput mode, narrower than the reference, gated by map_delta_vs_fp32')
+            # the accuracy side of the modes: a detector mode vs the exact-float32 detector, same weights, same annotated scenes,
+            # the reference's evaluation loop (evaluation/precision_gate.py) -- for all three families.  Scenes a family needs
+            # for a paired-bootstrap 95 % interval INSIDE +-0.002 (both ends; `ci_inside_bar`): ~4096 (FPN), ~6144 (C4), ~8192
+            # (VGG16; the single-level detectors keep 300 proposals and fewer detections per scene); the split-precision modes
+            # differ from the exact mode by float32 rounding: 512.  `--gate-images` scales all of them; the default run gives
+            # the gates what is left of --time-budget (scene counts cut in proportion, recorded in gate_scenes_reduced_to), the
+            # full-size gates are a longer --time-budget away (profiles/: the committed full run).
+            from tf_eager_object_detection_amd.evaluation import precision_gate
+            g_ = args.gate_images
+            gates = [('fp16', 'fpn', g_, 'fp16', 0.0140), ('fp16_resnet50_c4', 'c4', g_ * 3 // 2, 'fp16', 0.0115),
+                     ('fp16_vgg16_600x800', 'vgg16', 2 * g_, 'fp16', 0.0078),
+                     ('fp32_x3', 'fpn', max(128, g_ // 8), 'x3', 0.030), ('fp32_x2', 'fpn', max(128, g_ // 8), 'x2', 0.028)]
+            fixed = 2.5                                   # (two detectors built + the heads fitted, per gate)
+            need = sum(n * c + fixed for _, _, n, _, c in gates)
+            have = left() - 8.0
+            scale = min(1.0, max(0.0, (have - fixed * len(gates)) / max(need - fixed * len(gates), 1e-9)))
+            for name, fam, wanted, mode, per_scene in gates:
+                n_img = wanted if scale >= 1.0 else max(128, int(wanted * scale) // 128 * 128)
+                if left() < n_img * per_scene + fixed + 4.0:
+                    n_img = int((left() - fixed - 4.0) / per_scene) // 128 * 128
+                if n_img < 128:
+                    e2e[name + '_map_delta_vs_fp32'] = {'skipped': 'time budget (%.0f s left)' % left()}
+                    flush('gate %s skipped' % name)
+                    continue
+                try:
+                    gate = precision_gate.fp16_vs_fp32(num_images=n_img, batch32=30, batch16=30, family=fam, test_mode=mode)
+                    if n_img != wanted:
+                        gate['gate_scenes_reduced_to'] = [n_img, wanted]
+                    gate.pop('protocol', None) if name != 'fp16' else None
+                    gate.pop('fit', None) if name != 'fp16' else None
+                    if isinstance(e2e.get(name), dict):
+                        e2e[name]['map_delta_vs_fp32'] = gate
+                    else:
+                        e2e[name + '_map_delta_vs_fp32'] = gate
+                except Exception as ex:
+                    e2e[name + '_map_delta_vs_fp32'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+                flush('gate %s (%d scenes)' % (name, n_img))
+        detail['complete'] = True
+        flush('done')
+
+    if args.detail_child:
+        run_detail(args.detail_child)
+        return
+
+    # ---- the headline: SURVEY 8(d)'s distribution (or --scores), then the OTHER distribution beside it
     wl = Workload(cfg3, args.scores, args.nms_first_chunk, args.blind_chunks)
     elapsed, replans = wl.measure(args.steps, args.warmup)
     per_rank_s, allgathers, nms_reruns = wl.per_rank_s, wl.allgathers, wl.nms_reruns
@@ -640,7 +904,6 @@ def main():
         del wl2
         torch.cuda.empty_cache()
 
-    result = None
     if rank == 0:
         k = k_kept
         result = {
@@ -683,7 +946,6 @@ def main():
             'per_rank_spread': (max(rates) - min(rates)) / max(rates),
             'images_per_rank': args.steps * images_per_step,
         }
-    if rank == 0:
         summary = {'hot_path_img_s': round(result['value'], 1), 'hot_path_clustered_img_s': round(other['value'], 1) if other else None,
                    'roi_frac_B_roi': round(result['roofline']['frac'], 3),
                    'roi_frac_counter_bytes': (round(result['roofline']['hbm_frac_measured'], 3)
@@ -691,141 +953,23 @@ def main():
                    'roi_frac_physical': 'roi_frac_counter_bytes',
                    'roi_kernel_us': round(result['roofline']['kernel_ms'] * 1e3, 1),
                    'roi_vs_calibration': round(result['roofline']['calibration']['roi_kernel_vs_calibration'], 3)}
-        if not args.no_config5 and world == 1:
-            # ---- BASELINE configs[4]: 1333 x 1333, 446 118 anchors, 1000 proposals, 81 classes, caps 100 / 300 (the COCO
-            # configuration's per-class / per-image caps: config/faster_rcnn_config.py:112-113), float16 feature maps
-            try:
-                cfg5 = dict(image_shape=(1333, 1333), num_classes=81, max_per_class=100, max_per_image=300, maps='f16')
-                w5 = Workload(cfg5, 'distinct', args.nms_first_chunk, args.blind_chunks)
-                steps5 = max(2, args.steps // 4)
-                el5, rp5 = w5.measure(steps5, max(1, args.warmup // 2))
-                rf5 = roofline_phase(w5, max(6, args.roofline_samples // 2),
-                                     'k_roi_pool<MAX2, NORM_IMAGE, __half> (float16 maps: float32 lerps, float16 in / out)',
-                                     'fpn_hot_path_1333x1333_r101fpn_81cls_f16maps')
-                result['config5'] = {
-                    'workload': 'BASELINE configs[4]: ResNet-101-FPN hot path @ 1333x1333 (446118 anchors -> 1000 proposals), 81 '
-                                'classes, max 100 per class / 300 per image, float16 feature maps into the RoI kernel',
-                    'value': steps5 * images_per_step / el5, 'unit': 'img/s', 'steps': steps5, 'timed_images': steps5 * images_per_step,
-                    'timed_region_s': el5, 'ms_per_image': el5 / (steps5 * images_per_step) * 1e3, 'dtype': 'f16',
-                    'anchors': syn.num_fpn_anchors((1333, 1333)), 'num_classes': 81, 'max_per_class': 100, 'max_per_image': 300,
-                    'nms_first_chunk': w5.nms_first_chunk, 'blind_chunks': w5.blind_chunks, 'replanned': rp5,
-                    'proposals_kept': int(w5.pool.slots[0].roi_count.item()),
-                    'detections_image0': int(w5.pool.slots[0].det_count.item()), 'roofline': rf5}
-                # [img/s, us of the 8-image RoI launch, its fraction of 8 TB/s on B_min]
-                summary['cfg5_hot_path'] = [round(result['config5']['value'], 1), round(rf5['kernel_ms'] * 1e3, 1), round(rf5['frac_on_B_min'], 3)]
-                w5.close()
-                del w5
-            except Exception as ex:                   # the headline record must not depend on this one
-                result['config5'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
-            torch.cuda.empty_cache()
-            mark('config 5 done')
         if not args.no_cpu_baseline and world == 1:
             result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
             cb = result['cpu_baseline']
             summary['cpu_port_img_s'] = [round(cb['value'], 1), cb['cores']]
             mark('cpu baseline done')
-        if not args.no_e2e and world == 1:
-            e2e = {'conv_path': E2E_CONV_PATH}
-            # (float16: 60 images per pass -- conv4's 50 x 84 maps then cut into four full rounds of 256-pixel workgroup tiles:
-            # +2 % over 30, +5 % over 15; 8 / 16 images leave a fifth of a round empty; batch 1 -- the BASELINE configs' own
-            # batch -- replayed as ONE HIP graph (a pass is ~140 launches), batch 4 / 8 eager and as a graph;
-            # float32: 30 images per pass for the same reason)
-            legs = (('fp16', 'fp16', 60, 'fpn', False, True), ('fp16_b1', 'fp16', 1, 'fpn', True, True),
-                    ('fp16_b4', 'fp16', 4, 'fpn', True, True), ('fp16_b8', 'fp16', 8, 'fpn', True, True),
-                    ('fp32', 'fp32', 30, 'fpn', False, True), ('fp32_x3', 'fp32', 30, 'fpn', False, True),
-                    ('fp32_x3_b1', 'fp32', 1, 'fpn', True, False),
-                    ('fp32_x2', 'fp32', 30, 'fpn', False, True), ('fp32_x2_b1', 'fp32', 1, 'fpn', True, False),
-                    ('fp16_resnet50_c4', 'fp16', 60, 'c4', False, True), ('fp16_vgg16_600x800', 'fp16', 64, 'vgg16', False, True),
-                    ('fp32_x3_resnet50_c4', 'fp32', 30, 'c4', False, True), ('fp32_x3_vgg16_600x800', 'fp32', 32, 'vgg16', False, True))
-            for name, dtn, b, fam, gr, eg in legs:
-                try:
-                    e2e[name] = e2e_record(dtn, b, budget_s=(5.0 if name in ('fp16', 'fp32', 'fp32_x3') else 4.0 if name == 'fp32_x2' else 2.0),
-                                           family=fam, graph=gr, eager=eg,
-                                           f32_form='x3' if 'fp32_x3' in name else 'x2' if 'fp32_x2' in name else 'exact')
-                except Exception as ex:               # the headline record must not depend on the second one
-                    e2e[name] = {'error': '%s: %s' % (type(ex).__name__, ex)}
-                mark('e2e %s done' % name)
-
-            def rate(name, key='value'):
-                v = e2e.get(name, {}).get(key)
-                return round(v, 1) if isinstance(v, (int, float)) else None
-            summary.update(e2e_fp16=[rate('fp16'), 60], e2e_fp16_b1_graph=rate('fp16_b1', 'value_hip_graph'),
-                           e2e_fp16_b1_eager=rate('fp16_b1'), e2e_fp16_b4=[rate('fp16_b4'), rate('fp16_b4', 'value_hip_graph')],
-                           e2e_fp16_b8=[rate('fp16_b8'), rate('fp16_b8', 'value_hip_graph')], e2e_fp32=[rate('fp32'), 30], e2e_fp32_x3=[rate('fp32_x3'), 30],
-                           e2e_fp32_x3_b1_graph=rate('fp32_x3_b1', 'value_hip_graph'),
-                           fp32_x2=[rate('fp32_x2'), rate('fp32_x2_b1', 'value_hip_graph')],   # (+ mAP delta, kept-anchor agreement)
-                           c4_fp16=[rate('fp16_resnet50_c4'), 60], vgg16_fp16=[rate('fp16_vgg16_600x800'), 64],
-                           c4_vgg16_fp32_x3=[rate('fp32_x3_resnet50_c4'), rate('fp32_x3_vgg16_600x800')])
-            # the accuracy side of the throughput mode: float16 vs float32 detector, same weights, same annotated scenes,
-            # the reference's evaluation loop (evaluation/precision_gate.py) -- for all three families
-            from tf_eager_object_detection_amd.evaluation import precision_gate
-            # (the number of scenes each family needs for a paired-bootstrap 95 % interval inside +-0.002: 4096 for the FPN
-            # detector; the single-level detectors keep 300 proposals and fewer detections per scene, their intervals at 4096
-            # scenes were +-0.0026 (C4) / +-0.0020 (VGG16), at 8192 / 6144 +-0.0012 / +-0.0019: one and a half times / twice as many.  The float32 split-precision
-            # mode against the exact-float32 mode on an eighth: its differences are float32 rounding)
-            for name, fam, n_img, mode in (('fp16', 'fpn', args.gate_images, 'fp16'), ('fp16_resnet50_c4', 'c4', args.gate_images * 3 // 2, 'fp16'),
-                                           ('fp16_vgg16_600x800', 'vgg16', 2 * args.gate_images, 'fp16'),
-                                           ('fp32_x3', 'fpn', max(256, args.gate_images // 8), 'x3'),
-                                           ('fp32_x2', 'fpn', max(256, args.gate_images // 8), 'x2')):
-                try:
-                    # (a slow or shared box: the gates are the long legs -- ~14 / 11 / 8 / 30 / 28 ms per scene for the five -- and
-                    # scale with the scene count; the headline legs above are never shortened)
-                    per_scene = {'fp16': 0.0140, 'fp16_resnet50_c4': 0.0115, 'fp16_vgg16_600x800': 0.0078, 'fp32_x3': 0.030,
-                                 'fp32_x2': 0.028}[name]
-                    left = args.time_budget - (time.perf_counter() - t_main) - 5.0
-                    wanted = n_img
-                    if per_scene * n_img > left:
-                        n_img = max(min(n_img, 1024), int(left / per_scene) // 256 * 256)
-                    gate = precision_gate.fp16_vs_fp32(num_images=n_img, batch32=30, batch16=30, family=fam, test_mode=mode)
-                    if n_img != wanted:
-                        gate['gate_scenes_reduced_to'] = [n_img, wanted]
-                    gate.pop('protocol', None) if name != 'fp16' else None
-                    gate.pop('fit', None) if name != 'fp16' else None
-                    if isinstance(e2e.get(name), dict):
-                        e2e[name]['map_delta_vs_fp32'] = gate
-                    else:
-                        e2e[name + '_map_delta_vs_fp32'] = gate
-                    lo, hi = gate['map_delta_ci95_paired_bootstrap']
-                    if mode == 'x2':                  # (one compact entry: img/s at 30, batch-1 graph img/s, mAP delta, kept-anchor agreement)
-                        summary['fp32_x2'] = summary['fp32_x2'][:2] + [round(gate['map_delta'], 4), round(gate['rpn_kept_index_agreement_mean'], 4)]
-                        mark('gate %s done' % name)
-                        continue
-                    summary['map_delta_' + (fam if mode == 'fp16' else mode)] = [round(gate['map_delta'], 4), round(lo, 4), round(hi, 4),
-                                                                               gate['images']]
-                    if mode == 'x3':
-                        summary[mode + '_vs_exact'] = [round(gate['rpn_kept_index_agreement_mean'], 4), float('%.1e' % gate['p99_abs_dscore'])]
-                except Exception as ex:
-                    e2e[name + '_map_delta_vs_fp32'] = {'error': '%s: %s' % (type(ex).__name__, ex)}
-                mark('gate %s done' % name)
-            if isinstance(e2e.get('fp16'), dict) and 'value' in e2e['fp16'] and 'map_delta_vs_fp32' in e2e['fp16']:
-                g = e2e['fp16']['map_delta_vs_fp32']
-                e2e['fp16']['target'] = ('%s the north star\'s >= 200 img/s on one MI355X (%.0f img/s); mAP delta vs the float32 mode on '
-                                         'identical weights and images = %+.4f, paired-bootstrap CI95 [%+.4f, %+.4f] on %d held-out '
-                                         'scenes (bar +-0.002: point estimate %s, interval %s)'
-                                         % ('meets' if e2e['fp16']['value'] >= 200.0 else 'misses', e2e['fp16']['value'], g['map_delta'],
-                                            g['map_delta_ci95_paired_bootstrap'][0], g['map_delta_ci95_paired_bootstrap'][1], g['images'],
-                                            'inside' if g['within_bar'] else 'OUTSIDE', 'resolves it' if g['resolves_bar'] else 'wider than it'))
-            if isinstance(e2e.get('fp32_x3'), dict) and 'value' in e2e['fp32_x3']:
-                e2e['fp32_x3']['target'] = ('%s the north star\'s >= 200 img/s on one MI355X at the reference\'s (float32) accuracy: %.0f '
-                                            'img/s, float32 tensors in memory, float32 operands as three bfloat16 limbs on the matrix '
-                                            'cores (csrc/conv_x3.hip), float32 accumulation; the exact-float32 mode: %s img/s'
-                                            % ('meets' if e2e['fp32_x3']['value'] >= 200.0 else 'misses', e2e['fp32_x3']['value'],
-                                               rate('fp32')))
-            if isinstance(e2e.get('fp32_x2'), dict) and 'value' in e2e['fp32_x2']:
-                e2e['fp32_x2']['target'] = ('the same float32 tensors with every layer on the TWO-limb form: float32 operands as h + l * 2^-11 '
-                                            'in float16, three products per k, float32 accumulation -- float32-class accuracy for data '
-                                            'inside float16\'s RANGE (|activation| <= 65504; beyond it a layer yields inf / NaN), half the '
-                                            'matrix work of the three-limb form: %.0f img/s' % e2e['fp32_x2']['value'])
-            e2e['note'] = ('second record, not the headline metric: the assembled detector end to end; fp32 = parity '
-                           'mode (the reference computes in float32; exact-float32 matrix instructions, 157 TFLOP/s peak, 684 GFLOP '
-                           'per image), fp32_x3 = the same float32 tensors with every layer on the split-precision form (float32-class '
-                           'accuracy, 417 TFLOP/s-equivalent peak), fp16 = throughput mode, narrower than the reference, gated by '
-                           'map_delta_vs_fp32')
-            result['e2e'] = e2e
+        if world == 1 and not (args.no_e2e and args.no_config5):
+            # ---- everything that is not the headline runs in a FRESH CHILD PROCESS (never an exec of this one, which holds the
+            # GPU) under a timeout: a hang or a GPU fault in any of its legs costs that leg, not the line.  Its records go to
+            # the side file (and its progress to stderr); this line keeps their headline figures in `summary`.
+            detail = run_detail_child(args, t_main)
+            result['detail'] = {k_: detail.get(k_) for k_ in ('file', 'complete', 'child_rc', 'child_s', 'legs_done_n')}
+            summarise_detail(summary, detail)
         mr = result['multi_rank']
         summary['ranks'] = [mr['rccl_world'], round(mr['per_rank_img_s_min'], 1), round(mr['per_rank_img_s_max'], 1), mr['allgathers_in_timed_region']]
+        summary['run_s'] = round(time.perf_counter() - t_main, 1)
         result['summary'] = summary                   # LAST key: the tail of the line carries every headline figure
-        print(json.dumps(result))
+        print(compact_line(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

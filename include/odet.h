@@ -33,8 +33,10 @@ extern "C" {
 
 /* 100: round 4.  101: odet_fpn_step_t.ws_post_clean, the odet_*_x3 entry points (three bfloat16 limbs) with their split-K
  * workspace.  102: the odet_*_x2 entry points (two float16 limbs) and odet_split_f16x2; odet_bias_relu_maxpool keeps a NaN
- * in float32. */
-#define ODET_VERSION 102
+ * in float32.  103: the two-limb launches report an out-of-range activation in a status word of their workspace
+ * (odet_x2_status_offset); the tile-forcing diagnostics left this header and the shipped library (include/odet_diag.h, a
+ * separate -DODET_DIAG build). */
+#define ODET_VERSION 103
 
 #define ODET_OK 0
 #define ODET_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -476,8 +478,8 @@ int odet_pointwise_dual_f32(const void* x1, int cin1, const void* x2, int cin2, 
  * evaluation of the reference's float32 convolution (resnet_fpn.py:154-289, 339-407; base_fpn_model.py:393-434) within
  * float32 rounding of the float64 truth, like the fmaf chain of the *_f32 forms, not bit-identical to it.  `w3` = the
  * weight's limb planes, bfloat16 [3][cout][K] (K = taps * cin (+ cin2) in the order of the float32 weight), written ONCE per
- * weight tensor by odet_split_bf16x3 (n = cout * K float32 values -> planes [3][n]; n even).  cin % 32 == 0, cout % 64 == 0;
- * pointwise: any cin >= 32.
+ * weight tensor by odet_split_bf16x3 (n = cout * K float32 values -> planes [3][n]; n even).  cin (and cin2) a positive
+ * multiple of 32 (the kernel's 128-byte K-steps), cout % 64 == 0.
  * `workspace` (nullable; odet_x3_workspace_bytes() bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller and then only ever
  * handed to these entry points, one workspace per stream that runs them): with it a launch that would leave CUs idle (few
  * pixels, deep K: the small maps at batch 1 .. 8, the RoI head's dense layers) splits K over up to 8 workgroups per output
@@ -504,13 +506,18 @@ int odet_pointwise_dual_x3(const void* x1, int cin1, const void* x2, int cin2, i
  * within ONE float32 ulp), a product as h h + (h l + l h) * 2^-11 on v_mfma_f32_16x16x32_f16 (dropped: l l <= 2^-22 of it),
  * two float32 accumulators joined at the end: HALF the matrix work of the three-limb form; against float64 its error on the
  * detectors' layers is no larger than the exact-float32 form's (float32 accumulation dominates both) -- for data inside
- * float16's RANGE.  |activation| > 65504 gives infinities / NaN in the result (never a wrong finite number; the layers' ReLU and
- * the float32 odet_bias_relu_maxpool keep a NaN, so a caller can test the END of a chain of layers); activations below 2^-14
+ * float16's RANGE.  |activation| >= 65520 becomes an infinite limb: every product with it is infinite or NaN, so every sum it
+ * enters is non-finite BEFORE bias / shortcut / ReLU whatever the weights' signs (never a wrong finite number), and the launch
+ * REPORTS it: with a workspace, the epilogue ORs 1 into the uint32 RANGE STATUS word at byte odet_x2_status_offset() of the
+ * workspace whenever a raw sum is not finite (sticky: launches only OR into it; the caller reads it after a chain of layers
+ * and clears it -- it is part of the region the caller zero-fills once).  A ReLU (`v < 0 ? 0 : v` maps -inf to 0) can hide
+ * the value downstream, never the flag.  Without a workspace a launch cannot report.  Activations below 2^-14
  * keep an absolute error <= 2^-36 instead of a relative one.  `w2` = float16 planes [2][cout][K] of w * 2^w_exp, written once
  * per weight tensor by odet_split_f16x2; the caller picks w_exp (|w_exp| <= 100) so that the largest |w| * 2^w_exp lies in
  * [512, 1024) -- every weight down to 2^-24 of the largest then keeps both limbs normal -- and passes the same w_exp to the
  * layer, which scales the sums back (a power of two: exact).  Everything else as the *_x3 entry points. */
 int odet_split_f16x2(const float* w, void* planes, long long n, int w_exp, odet_stream_t stream);
+size_t odet_x2_status_offset(void);
 int odet_conv3x3_x2(const void* x, const void* w2, const void* bias, void* y, int batch, int H, int W,
                     int cin, int cout, int relu, int w_exp, void* workspace, size_t workspace_bytes, odet_stream_t stream);
 int odet_conv3x3_x2_levels(const odet_conv_level_t* levels, int num_levels, const void* w2, const void* bias,
@@ -681,15 +688,6 @@ int odet_exec_submit_batch(odet_exec_t* ex, int worker, const odet_fpn_step_t* c
  * text through odet_exec_last_error) and clears it */
 int odet_exec_wait(odet_exec_t* ex);
 const char* odet_exec_last_error(odet_exec_t* ex);
-
-/* Diagnostics only (tools/exp, tools/r04; the product never calls it; no reference counterpart): forces the workgroup
- * tile of this process's next float16 3x3 (form 0; the fused bottleneck tail included) / pointwise (form 1) launches --
- * {nw waves, wn waves along the channels, mt 16-pixel tiles per wave, ns LDS stages}: (nw / wn) * 16 * mt pixels x 64 * wn
- * channels; ns == 2 the half-step-pipelined loop, ns > 2 the ring forms for launches with few pixels.  nw = 0 clears. */
-int odet_debug_conv_tile(int form, int nw, int wn, int mt, int ns);
-/* the same for the split-precision float32 launches (csrc/conv_x3.hip): (mt, wn) of its tile list ((8, 2) = the wave-specialised
- * 256 x 128 tile of tools/exp/historical/conv_x3_wave_specialised.patch) and the K split (workgroups per tile, 1 = none); mt = 0 clears */
-int odet_debug_x3_tile(int mt, int wn, int ksplit);
 
 #ifdef __cplusplus
 }

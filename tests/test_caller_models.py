@@ -36,12 +36,14 @@ def test_constructor_surface_matches_reference_names_cpu():
         assert cls.call is cls.forward and hasattr(cls, 'im_detect')
     assert all(hasattr(BaseFPN, n) for n in ('predict_rpns', 'predict_rois', '_assign_levels', '_get_anchors', '_get_roi_features'))
     assert all(hasattr(BaseFasterRcnn, n) for n in ('predict_rpn', 'predict_roi', '_get_rpn_loss', '_get_roi_loss'))
-    # the float32 layers' form: full-range forms only here (the two-limb form needs the detectors' after-pass range check)
+    # the float32 layers' form: 'exact' | 'x3' | 'x2' (with 'x2' the composed passes carry the range check: caller_range_checked)
     from tf_eager_object_detection_amd.model.base_faster_rcnn_model import ResNetFasterRcnn, Vgg16FasterRcnn
     for ctor in (ResnetV1Fpn, ResNetFasterRcnn, Vgg16FasterRcnn):
         assert inspect.signature(ctor.__init__).parameters['f32_form'].default == 'exact'
-        with pytest.raises(ValueError, match='x2'):
-            ctor(f32_form='x2', device='cpu')
+        with pytest.raises(ValueError, match='f32_form'):
+            ctor(f32_form='x4', device='cpu')
+    for cls in (BaseFPN, BaseFasterRcnn):
+        assert hasattr(cls.forward, '__wrapped__') and hasattr(cls.im_detect, '__wrapped__')
 
 
 def _check_detections(got, want, tol=1e-4):

@@ -1513,13 +1513,14 @@ def test_pointwise_split_precision_forms(form):
     w = (torch.randn((512, 256, 3, 3), device='cuda', generator=g) * 0.02).contiguous(memory_format=torch.channels_last)
     b = torch.randn(512, device='cuda', generator=g)
     from tf_eager_object_detection_amd import _lib
+    from tools._diag import diag_library
     with ops.f32_form(form):
         together = ops.conv3x3_f32_levels(xs, w, b, relu=True)
         single = [ops.conv3x3_f32(x, w, b, relu=True) for x in xs]
-        _lib.call('odet_debug_x3_tile', 4, 4, 1)                                  # (one tile, no split: the launch grouping alone)
-        together_1 = ops.conv3x3_f32_levels(xs, w, b, relu=True)
-        single_1 = [ops.conv3x3_f32(x, w, b, relu=True) for x in xs]
-        _lib.call('odet_debug_x3_tile', 0, 0, 0)
+        with diag_library():                              # (the -DODET_DIAG build: the shipped library has no tile override)
+            _lib.call('odet_debug_x3_tile', 4, 4, 1)                              # (one tile, no split: the launch grouping alone)
+            together_1 = ops.conv3x3_f32_levels(xs, w, b, relu=True)
+            single_1 = [ops.conv3x3_f32(x, w, b, relu=True) for x in xs]
     assert all(torch.equal(a, s_) for a, s_ in zip(together_1, single_1))
     assert all(float((a - s_).abs().max()) <= 2e-6 * float(s_.abs().max()) for a, s_ in zip(together, single))
     # the limb planes: exact sum (three bfloat16 limbs) / the scaled weight to within one float32 ulp (two float16 limbs: 23 bits)
@@ -1567,10 +1568,11 @@ def test_float32_x3_detector_agrees_with_the_exact_float32_detector(form):
 @pytest.mark.gpu
 @pytest.mark.parametrize('family', ['fpn', 'vgg16'])
 def test_two_limb_pass_out_of_float16_range_is_detected_and_repeated_on_three_limbs(family):
-    """f32_form = 'x2' computes on float16 limbs: an activation beyond 65504 makes that layer's output non-finite (include/odet.h).
-    The detectors read that off the pass's own outputs where they read the NMS flags (range_ok) and repeat the pass on the
-    three-limb form (float32's range): images a hundred times brighter than any real input give EXACTLY the three-limb detector's
-    results, `range_reruns` counts the pass; ordinary images are not re-run"""
+    """f32_form = 'x2' computes on float16 limbs: an activation beyond float16's range makes every sum it enters non-finite and the
+    launch's epilogue sets the RANGE STATUS word of the instance's workspace (include/odet.h).  The detectors read that word where
+    they read the NMS flags (range_ok) and repeat the pass on the three-limb form (float32's range): images 3000 times brighter than
+    any real input give EXACTLY the three-limb detector's results, `range_reruns` counts the pass; ordinary images are not
+    re-run.  im_detect (the evaluation entry: ADVICE r5) goes through the same check."""
     from tf_eager_object_detection_amd.model.fpn_detector import ResNetFpnDetector
     from tf_eager_object_detection_amd.model.frcnn_detector import Vgg16Detector
     torch.manual_seed(1)
@@ -1599,6 +1601,71 @@ def test_two_limb_pass_out_of_float16_range_is_detected_and_repeated_on_three_li
     ob = b(img)                                          # back on two limbs
     torch.cuda.synchronize()
     assert b.range_reruns == 1 and [int(o[3].item()) for o in ob] == n_ok
+    # the evaluation entry: the same check, the three-limb detector's scores / deltas / rois bit for bit
+    ia, ib = a.im_detect(big, 1.0), b.im_detect(big, 1.0)
+    assert b.range_reruns == 2 and b.f32_form == 'x2'
+    for x, y in zip(ia, ib):
+        assert all(torch.equal(u, v) for u, v in zip(x, y)) and bool(torch.isfinite(y[0]).all())
+    b.im_detect(img, 1.0)
+    assert b.range_reruns == 2
+
+
+@pytest.mark.gpu
+def test_two_limb_overflow_that_a_relu_would_hide_still_sets_the_status_word():
+    """ONE activation outside float16's range, all-negative weights, a ReLU behind the layer: the sums it enters
+    are -inf, the ReLU maps them to 0, every output is finite -- propagation cannot see it, the status word does.  Then a
+    detector whose first layers are made negative the same way: the pass is repeated on three limbs."""
+    from tf_eager_object_detection_amd import ops
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    for k in (3, 1):
+        x = torch.rand((1, 24, 32, 64), device='cuda', generator=g)
+        x[0, 11, 17, 5] = 70000.0                         # the only value beyond 65504
+        w = (-torch.rand((128, 64, k, k), device='cuda', generator=g) - 0.01).contiguous(memory_format=torch.channels_last)
+        b = torch.zeros(128, device='cuda')
+        ws = ops.X3Workspace(x.device)
+        run = (lambda: ops.conv3x3_f32(x, w, b, relu=True)) if k == 3 else \
+              (lambda: ops.pointwise(x, w.reshape(128, 64).contiguous(), b, None, True))
+        with ops.f32_form('x2', workspace=ws):
+            y = run()
+        assert bool(torch.isfinite(y).all()) and float(y.abs().max()) == 0.0      # nothing to propagate
+        assert int(ws.range_flag().item()) == 1 and not ws.range_ok() and ws.range_ok()   # reported; reading clears it
+        x[0, 11, 17, 5] = 60000.0                                                 # inside the range: no report
+        with ops.f32_form('x2', workspace=ws):
+            run()
+        assert ws.range_ok()
+        with ops.f32_form('x3', workspace=ws):                                    # the three-limb form never reports
+            x[0, 11, 17, 5] = 70000.0
+            run()
+        assert ws.range_ok()
+    # a workspace is what carries the word: the default one of the stream when the block names none
+    w3 = (-torch.rand((128, 64, 3, 3), device='cuda', generator=g) - 0.01).contiguous(memory_format=torch.channels_last)
+    ops._x3_workspace(x.device).range_ok()
+    with ops.f32_form('x2'):
+        ops.conv3x3_f32(x, w3, b, relu=True)
+    assert not ops._x3_workspace(x.device).range_ok()
+
+
+@pytest.mark.gpu
+def test_caller_object_on_two_limbs_repeats_an_out_of_range_pass():
+    """the reference-surface models take f32_form = 'x2' (VERDICT r5 #8): call() / im_detect on an image 3000 times brighter than
+    real ones equal the 'x3' model's results bit for bit, the dense part counts the repeated pass"""
+    from tf_eager_object_detection_amd.model.base_fpn_model import ResnetV1Fpn
+    torch.manual_seed(3)
+    kw = dict(depth=50, rpn_proposal_num_post_nms_test=64, prediction_score_threshold=0.0)
+    a = ResnetV1Fpn(f32_form='x3', **kw)
+    b = ResnetV1Fpn(f32_form='x2', **kw)
+    b._dense_ref.load_state_dict(a._dense_ref.state_dict())
+    rng = np.random.default_rng(4)
+    img = torch.from_numpy((rng.uniform(0, 255, (1, 192, 256, 3)) - 110).astype(np.float32)).cuda()
+    b(img, training=False)
+    assert b._dense_ref.range_reruns == 0
+    big = img * 3000.0
+    oa, ob = a(big, training=False), b(big, training=False)
+    assert b._dense_ref.range_reruns == 1 and b._dense_ref.f32_form == 'x2'
+    for u, v in zip(oa, ob):
+        assert (u is None and v is None) or torch.equal(u, v)
+    ia, ib = a.im_detect(big, 1.0), b.im_detect(big, 1.0)
+    assert b._dense_ref.range_reruns == 2 and all(torch.equal(u, v) for u, v in zip(ia, ib))
 
 
 @pytest.mark.gpu
@@ -1674,6 +1741,7 @@ def test_split_precision_split_k_is_deterministic_exact_on_integers_and_leaves_i
     result; on random data within float32 rounding of the unsplit launch and bit-identical from run to run; the ticket words of
     the workspace are zero after every launch; the product's own pick splits these shapes"""
     from tf_eager_object_detection_amd import ops, _lib
+    from tools._diag import diag_library
     g = torch.Generator(device='cuda'); g.manual_seed(77)
     with ops.f32_form(form):
         for (B, H, W, cin, cout, k) in ((1, 25, 42, 512, 512, 3), (1, 1, 1000, 12544, 1024, 1), (2, 13, 21, 2048, 512, 1), (1, 50, 84, 256, 256, 3)):
@@ -1686,20 +1754,20 @@ def test_split_precision_split_k_is_deterministic_exact_on_integers_and_leaves_i
             run = (lambda xx, ww: ops.conv3x3_f32(xx, ww, b, relu=True)) if k == 3 else \
                   (lambda xx, ww: ops.pointwise(xx, ww.reshape(cout, cin).contiguous(), b, None, True))
             want_i = torch.relu(F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double(), b.double(), 1, k // 2)).permute(0, 2, 3, 1)
-            _lib.call('odet_debug_x3_tile', 2, 2, 1)
-            base = run(x, w)
-            for S in (2, 3, 5, 8):
-                _lib.call('odet_debug_x3_tile', 2, 2, S)
-                got_i = run(xi, wi)
-                assert torch.equal(got_i.double(), want_i), (S, B, H, W, cin, cout, k)
-                a1, a2 = run(x, w), run(x, w)
-                assert torch.equal(a1, a2)                                            # deterministic
-                assert float((a1 - base).abs().max()) <= 2e-5 * float(base.abs().max())
-            _lib.call('odet_debug_x3_tile', 0, 0, 0)
-            auto = run(x, w)                                                          # the product's own pick
+            with diag_library():                          # (the -DODET_DIAG build: the shipped library has no tile override)
+                _lib.call('odet_debug_x3_tile', 2, 2, 1)
+                base = run(x, w)
+                for S in (2, 3, 5, 8):
+                    _lib.call('odet_debug_x3_tile', 2, 2, S)
+                    got_i = run(xi, wi)
+                    assert torch.equal(got_i.double(), want_i), (S, B, H, W, cin, cout, k)
+                    a1, a2 = run(x, w), run(x, w)
+                    assert torch.equal(a1, a2)                                        # deterministic
+                    assert float((a1 - base).abs().max()) <= 2e-5 * float(base.abs().max())
+            auto = run(x, w)                                                          # the product's own pick (shipped library)
             assert float((auto - base).abs().max()) <= 2e-5 * float(base.abs().max())
         torch.cuda.synchronize()
         assert ops._X3_WS, 'no split-K workspace was allocated'
         for ws in ops._X3_WS.values():
-            assert int(ws[:16384].max().item()) == 0                                 # every ticket drawn back to zero
-    _lib.call('odet_debug_x3_tile', 0, 0, 0)
+            assert int(ws.buf[:16384].max().item()) == 0                             # every ticket drawn back to zero
+            assert ws.range_ok()                                                     # and nothing reported out of range

@@ -4,6 +4,7 @@ table in sync with the header) and the fail-loudly rule (no CPU path)."""
 import ctypes
 import os
 import re
+import subprocess
 import sys
 
 import numpy as np
@@ -53,7 +54,55 @@ def test_library_loads_and_exports_every_header_symbol():
     assert len(syms) >= 20
     for name in syms:
         assert hasattr(handle, name), 'libodet_hip.so does not export %s' % name
-    assert handle.odet_version() == 102
+    assert handle.odet_version() == 103
+
+
+def test_shipped_library_has_no_debug_hooks():
+    """the tile-forcing diagnostics are not in the product ABI -- not in include/odet.h, not exported by
+    libodet_hip.so, not in the ctypes table; they live in include/odet_diag.h and the separate -DODET_DIAG build"""
+    from tf_eager_object_detection_amd import _build, _lib
+    assert not [n for n in _header_symbols() if 'debug' in n]
+    assert not [n for n in _lib.SIGNATURES if 'debug' in n]
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert 'debug' not in out
+    exported = sorted(set(re.findall(r'\b(odet_[a-z0-9_]+)\b', out)))
+    assert exported == _header_symbols()                  # the library exports exactly what the header declares
+    diag = open(os.path.join(ROOT, 'include', 'odet_diag.h')).read()
+    assert 'odet_debug_conv_tile' in diag and 'odet_debug_x3_tile' in diag
+    lib = _build.build_diag()
+    out = subprocess.run(['nm', '-D', '--defined-only', lib], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert 'odet_debug_conv_tile' in out and 'odet_debug_x3_tile' in out
+
+
+def test_f32_form_is_per_thread_context():
+    """the float32 form is ambient state of the calling CONTEXT (contextvars), not a process global: two threads
+    entering and leaving f32_form blocks in the interleaving A-enter, B-enter, A-exit, B-exit each keep their own form, and
+    nothing is left switched afterwards"""
+    import threading
+    from tf_eager_object_detection_amd import ops
+    seen, steps = {}, [threading.Event() for _ in range(4)]
+
+    def a():
+        with ops.f32_form('x3'):
+            steps[0].set(); steps[1].wait(5)
+            seen['a_inside'] = ops.current_f32_form()
+        steps[2].set()
+        seen['a_after'] = ops.current_f32_form()
+
+    def b():
+        steps[0].wait(5)
+        with ops.f32_form('x2'):
+            steps[1].set(); steps[2].wait(5)
+            seen['b_inside'] = ops.current_f32_form()
+        seen['b_after'] = ops.current_f32_form()
+
+    ts = [threading.Thread(target=a), threading.Thread(target=b)]
+    [t.start() for t in ts]
+    [t.join(10) for t in ts]
+    assert seen == {'a_inside': 'x3', 'a_after': 'exact', 'b_inside': 'x2', 'b_after': 'exact'}
+    assert ops.current_f32_form() == 'exact'
+    with pytest.raises(ValueError):
+        ops.f32_form('x4')
 
 
 def test_ctypes_table_matches_header():

@@ -70,5 +70,41 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# ---- the DIAGNOSTIC build: the same sources, the two files with tile-forcing hooks compiled with -DODET_DIAG (include/odet_diag.h).
+# Test / tool infrastructure (tools/_diag.py loads it explicitly); the product never loads it and the shipped library has no hook.
+DIAG_LIB = os.path.join(os.path.dirname(PKG), 'tools', 'libodet_hip_diag.so')
+DIAG_SOURCES = ['conv3x3.hip', 'conv_x3.hip']
+
+
+def build_diag(force=False, verbose=False):
+    build(force=False, verbose=verbose)               # (the other objects are the product's)
+    hipcc = _hipcc()
+    objs, procs = [], []
+    for src in SOURCES:
+        if src not in DIAG_SOURCES:
+            objs.append(os.path.join(OBJ_DIR, src + '.o'))
+            continue
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, src + '.diag.o')
+        objs.append(o)
+        if force or _stale(o, [s] + HEADERS + [os.path.join(INCLUDE, 'odet_diag.h'), os.path.abspath(__file__)]):
+            cmd = [hipcc, '-DODET_DIAG'] + HIPCC_FLAGS + PER_SOURCE_FLAGS.get(src, []) + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed on %s (diagnostic build)' % src)
+    if force or procs or _stale(DIAG_LIB, objs):
+        tmp = DIAG_LIB + '.tmp.%d' % os.getpid()
+        # -Bsymbolic: the library's own calls bind to its own definitions even when the product library (same symbol names,
+        # RTLD_GLOBAL) is loaded in the same process
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,-Bsymbolic'] + objs + ['-lpthread', '-o', tmp])
+        os.replace(tmp, DIAG_LIB)
+    return DIAG_LIB
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    if '--diag' in sys.argv:
+        print(build_diag(force='--force' in sys.argv, verbose=True))

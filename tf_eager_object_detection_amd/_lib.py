@@ -11,7 +11,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libodet_hip.so')     # (tools/_diag.py points it at a diagnostic build; no environment switch)
-ODET_VERSION = 102                                   # include/odet.h
+ODET_VERSION = 103                                   # include/odet.h
 
 _lib = None
 
@@ -131,8 +131,8 @@ SIGNATURES = {
     'odet_pointwise_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'odet_lateral_merge_f32': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f32': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    'odet_debug_x3_tile': (_i, [_i, _i, _i]),
     'odet_x3_workspace_bytes': (_sz, []),
+    'odet_x2_status_offset': (_sz, []),
     'odet_split_bf16x3': (_i, [_vp, _vp, _i64, _vp]),
     'odet_conv3x3_x3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'odet_conv3x3_x3_levels': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -161,7 +161,6 @@ SIGNATURES = {
     'odet_exec_submit_batch': (_i, [_vp, _i, _vp, _i, _i]),
     'odet_exec_wait': (_i, [_vp]),
     'odet_exec_last_error': (C.c_char_p, [_vp]),
-    'odet_debug_conv_tile': (_i, [_i, _i, _i, _i, _i]),
 }
 
 

@@ -805,10 +805,10 @@ static inline int tile_tm(const ConvTile& t) { return (t.nw / t.wn) * 16 * t.mt;
 static inline unsigned tile_lds(const ConvTile& t) { return (unsigned)t.ns * (unsigned)(tile_tm(t) + 64 * t.wn) * 128u; }
 
 static hipError_t tiles_init() {                // (more than the default 64 KB of dynamic LDS)
-  static std::once_flag once;
-  static hipError_t rc = hipSuccess;
-  std::call_once(once, [] {
-    auto set = [](const void* k_) {
+  static OdetPerDeviceOnce once;
+  return once.run([] {
+    hipError_t rc = hipSuccess;
+    auto set = [&rc](const void* k_) {
       const hipError_t e_ = hipFuncSetAttribute(k_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e_ != hipSuccess) rc = e_;
     };
@@ -819,8 +819,8 @@ static hipError_t tiles_init() {                // (more than the default 64 KB 
     set((const void*)k_conv3x3_f16<4, 4, true>); set((const void*)k_conv3x3_f16<5, 4, true>);
     set((const void*)k_conv3x3_f16<6, 4, true>); set((const void*)k_conv3x3_f16<7, 4, true>);
     set((const void*)k_conv3x3_f16<8, 4, true>);
+    return rc;
   });
-  return rc;
 }
 
 static int launch_tile(conv_kernel_t k, const ConvTile& t, unsigned blocks, unsigned lds_bytes, Conv3x3Params& p, hipStream_t st) {
@@ -879,8 +879,10 @@ static ConvTile pick_small(const long long* level_px, int num_levels, int cout, 
   return pick;
 }
 
-// Diagnostics (tools/exp, tools/r04): force the tile of the 3x3 (form 0; the fused tail included) / pointwise (form 1)
-// launches of this process; nw = 0 clears.  Not part of the reference surface; the product never calls it.
+#ifdef ODET_DIAG
+// Diagnostic build only (-DODET_DIAG: tools/libodet_hip_diag.so, include/odet_diag.h; the shipped library has neither the entry
+// point nor the override): force the tile of the 3x3 (form 0; the fused tail included) / pointwise (form 1) launches of this
+// process; nw = 0 clears.
 static std::atomic<unsigned> g_tile_override[2] = {{0u}, {0u}};
 extern "C" int odet_debug_conv_tile(int form, int nw, int wn, int mt, int ns) {
   ODET_REQUIRE(form == 0 || form == 1, "odet_debug_conv_tile: form 0 (3x3) or 1 (pointwise)");
@@ -898,6 +900,9 @@ static bool tile_override(int form, int cout, int need_wn, ConvTile* t) {
   *t = o;
   return true;
 }
+#else
+static inline bool tile_override(int, int, int, ConvTile*) { return false; }   // (the shipped library: no process-global override)
+#endif
 
 struct Conv3x3Tail {             // the fused RpnHead tail (nullable in conv3x3_launch)
   const void* w; const void* b; int A; float* scores; long long s_stride; float* deltas; long long d_stride;

@@ -239,15 +239,15 @@ static void f32_for_each_kernel(F f) {
 }
 
 static hipError_t f32_prepare_kernels() {
-  static std::once_flag once;
-  static hipError_t once_rc = hipSuccess;
-  std::call_once(once, [] {
-    f32_for_each_kernel([](const void* k) {
+  static OdetPerDeviceOnce once;
+  return once.run([] {
+    hipError_t rc = hipSuccess;
+    f32_for_each_kernel([&rc](const void* k) {
       const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_MAX);
-      if (e != hipSuccess) once_rc = e;
+      if (e != hipSuccess) rc = e;
     });
+    return rc;
   });
-  return once_rc;
 }
 
 static unsigned f32_lds_bytes(int tm, int tn) {          // (the kernel's NSTAGE rule)
@@ -306,7 +306,7 @@ static void f32_launch_tile(int wn, int mt, dim3 grid, unsigned lds_bytes, hipSt
 static void f32_defaults(ConvF32Params* p) {
   p->stride = 1; p->Ho = p->Wo = 0; p->Min = 0; p->res = nullptr; p->top = nullptr; p->th = p->tw = 0; p->tys = p->txs = 0.0f;
   p->x2 = nullptr; p->cin2 = 0; p->k1steps = 0; p->Min2 = 0;
-  p->ksplit = 0; p->part = nullptr; p->ticket = nullptr; p->acc_scale = 1.0f;
+  p->ksplit = 0; p->part = nullptr; p->ticket = nullptr; p->acc_scale = 1.0f; p->status = nullptr;
 }
 
 static int conv3x3_f32_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,

@@ -29,6 +29,10 @@ struct ConvF32Params {
   // parts in their fixed order 0 .. ksplit - 1 and runs the epilogue (deterministic; exact on integers)
   int ksplit; float* part; unsigned* ticket;
   float acc_scale;                // conv_x3.hip's two-limb float16 form: 2^-w_exp (the weight planes hold w * 2^w_exp); else unused
+  // conv_x3.hip's two-limb form: the RANGE status word (nullable).  An activation beyond float16's range becomes an infinite
+  // limb, and every product with it is infinite or NaN: every sum it enters is non-finite BEFORE bias / shortcut / ReLU, whatever
+  // the weights' signs -- the epilogue ORs 1 into the word when it sees one (a wave ballot, then at most one atomic per wave)
+  unsigned* status;
 };
 
 // bias (+ shortcut | FPN top-down merge) (+ ReLU) and the stores of a wave's MT x 4 accumulator tiles
@@ -37,6 +41,18 @@ __device__ __forceinline__ void conv_f32_epilogue(const ConvF32Params& p, c3f4 (
                                                   int wm, int wn, int tn, int l15, int lq, int lv, long long M, int cout) {
   // lane = pixel l15 of every pixel tile; tile t of the wave's 64-channel group: channels c0 + 16 t .. + 3
   const int c0 = tn * TN + wn * 64 + lq * 4;
+  if (p.status) {
+    // the raw sums, before anything can hide a non-finite one (ReLU maps -inf to 0): rows past M were computed from zeros
+    bool bad = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= !(__builtin_fabsf(acc[mt][t][j]) <= 3.4028234663852886e38f);
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(bad);
+    if (any != 0ull && (int)(threadIdx.x & 63) == (int)__builtin_ctzll(any)) atomicOr(p.status, 1u);
+  }
   c3f4 bv[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)

@@ -524,29 +524,31 @@ static void x3_for_each_kernel(F f) {
 }
 
 static hipError_t x3_prepare_kernels() {
-  static std::once_flag once;
-  static hipError_t once_rc = hipSuccess;
-  std::call_once(once, [] {
-    x3_for_each_kernel([](const void* k) {
+  static OdetPerDeviceOnce once;
+  return once.run([] {
+    hipError_t rc = hipSuccess;
+    x3_for_each_kernel([&rc](const void* k) {
       // (the largest tile's two stages are 144 KB; the kernels also hold a few bytes of static LDS: the split-K flag)
       const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-      if (e != hipSuccess) once_rc = e;
+      if (e != hipSuccess) rc = e;
     });
+    return rc;
   });
-  return once_rc;
 }
 
 static unsigned x3_lds_bytes(int tm, int tn, int nl) { return (unsigned)((nl == 2 ? 3 : 2) * nl * (tm + tn) * 64); }
 static int x3_tile_pixels(int mt, int wn) { return (8 / wn) * 16 * mt; }
 
-// Diagnostics (tools/r05): force the tile and the K split of this process's split-precision launches -- (mt, wn) of X3_FOR_TILES,
-// ksplit workgroups per tile (needs the workspace; not range-checked against the K-steps here); mt = 0 clears.
-// Not part of the reference surface; the product never calls it.
+#ifdef ODET_DIAG
+// Diagnostic build only (-DODET_DIAG: tools/libodet_hip_diag.so, include/odet_diag.h; the shipped library has neither the entry
+// point nor the override): force the tile and the K split of this process's split-precision launches -- (mt, wn) of
+// X3_FOR_TILES, ksplit workgroups per tile (needs the workspace; not range-checked against the K-steps here); mt = 0 clears.
 static std::atomic<unsigned> g_x3_override{0u};
 extern "C" int odet_debug_x3_tile(int mt, int wn, int ksplit) {
   g_x3_override.store(mt > 0 ? ((unsigned)(ksplit > 1 ? ksplit : 1) << 16 | (unsigned)mt << 8 | (unsigned)wn) : 0u);
   return ODET_OK;
 }
+#endif
 
 // ---- tile and split-K selection --------------------------------------------------------------------------------------------
 // Cycles of a K-step on a CU, fitted to the tiles' measured rates on the ResNet-101-FPN layers (tools/r05/x3_tiles.py): the
@@ -588,6 +590,7 @@ static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int kst
       if (cost < best * 0.97) { best = cost; best_pick = X3Pick{mt, wn, S}; }
     }
   }
+#ifdef ODET_DIAG
   const unsigned o = g_x3_override.load();
   if (o && cout % (64 * (int)(o & 255)) == 0 && !(nl == 2 && (o >> 8 & 255) == 4 && (o & 255) == 2)) {
     best_pick = X3Pick{(int)(o >> 8 & 255), (int)(o & 255), std::max(1, (int)(o >> 16))};
@@ -598,23 +601,28 @@ static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int kst
     if (best_pick.ksplit > ksteps || tiles > X3_TICKETS || (size_t)tiles * best_pick.ksplit * tm * tn * 4 > part_bytes_max)
       best_pick.ksplit = 1;                              // (a forced split that does not fit the workspace: none)
   }
+#endif
   return best_pick;
 }
 
-// the workspace of the split-K launches: X3_TICKETS ticket words (zero-filled ONCE by the caller; every launch leaves them zero),
-// then the parts
+// the workspace of the split-precision launches: X3_TICKETS ticket words (zero-filled ONCE by the caller; every launch leaves them
+// zero), the two-limb form's RANGE status word (X3_STATUS_BYTES reserved; sticky: launches only ever OR into it, the caller
+// reads and clears it), then the split-K parts
+#define X3_STATUS_BYTES 64
+#define X3_HEAD_BYTES ((size_t)X3_TICKETS * 4 + X3_STATUS_BYTES)
 static int x3_apply_split(ConvF32Params* p, const X3Pick& pick, long long tiles, int TMsel, void* ws, size_t ws_bytes, const char* who) {
   p->ksplit = pick.ksplit;
   if (pick.ksplit <= 1) { p->ksplit = 0; return ODET_OK; }
-  ODET_REQUIRE(ws && tiles <= X3_TICKETS && ws_bytes >= (size_t)X3_TICKETS * 4 + (size_t)tiles * pick.ksplit * TMsel * 64 * pick.wn * 4,
+  ODET_REQUIRE(ws && tiles <= X3_TICKETS && ws_bytes >= X3_HEAD_BYTES + (size_t)tiles * pick.ksplit * TMsel * 64 * pick.wn * 4,
                "%s: split-K workspace too small", who);
   p->ticket = (unsigned*)ws;
-  p->part = (float*)((char*)ws + (size_t)X3_TICKETS * 4);
+  p->part = (float*)((char*)ws + X3_HEAD_BYTES);
   return ODET_OK;
 }
 static size_t x3_part_bytes(const void* ws, size_t ws_bytes) {
-  return (ws && ws_bytes > (size_t)X3_TICKETS * 4 && (uintptr_t)ws % 16 == 0) ? ws_bytes - (size_t)X3_TICKETS * 4 : 0;
+  return (ws && ws_bytes > X3_HEAD_BYTES && (uintptr_t)ws % 16 == 0) ? ws_bytes - X3_HEAD_BYTES : 0;
 }
+
 
 template <bool PW>
 static int x3_launch_tile(int nl, int wn, int mt, dim3 grid, unsigned lds_bytes, hipStream_t st, const ConvF32Params& p) {
@@ -640,12 +648,15 @@ static int x3_launch_tile(int nl, int wn, int mt, dim3 grid, unsigned lds_bytes,
 static void x3_defaults(ConvF32Params* p) {
   p->stride = 1; p->Ho = p->Wo = 0; p->Min = 0; p->res = nullptr; p->top = nullptr; p->th = p->tw = 0; p->tys = p->txs = 0.0f;
   p->x2 = nullptr; p->cin2 = 0; p->k1steps = 0; p->Min2 = 0;
-  p->ksplit = 0; p->part = nullptr; p->ticket = nullptr; p->acc_scale = 1.0f;
+  p->ksplit = 0; p->part = nullptr; p->ticket = nullptr; p->acc_scale = 1.0f; p->status = nullptr;
 }
 
 // the limb form of a launch: 3 bfloat16 planes, or 2 float16 planes of w * 2^w_exp
 struct X3Form { int nl, w_exp; };
 static bool x3_form_ok(const X3Form& f) { return f.nl == 3 || (f.nl == 2 && f.w_exp >= -100 && f.w_exp <= 100); }
+static unsigned* x3_status_word(const X3Form& form, void* ws, size_t ws_bytes) {
+  return (form.nl == 2 && ws && ws_bytes >= X3_HEAD_BYTES && (uintptr_t)ws % 16 == 0) ? (unsigned*)((char*)ws + (size_t)X3_TICKETS * 4) : nullptr;
+}
 
 static int conv3x3_x3_launch(const X3Form& form, const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
                              int batch, int cin, int cout, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -671,6 +682,7 @@ static int conv3x3_x3_launch(const X3Form& form, const odet_conv_level_t* levels
   }
   const X3Pick pick = x3_pick_tile(p.M, num_levels, cout, 9 * (cin / X3_BK), x3_part_bytes(ws, ws_bytes), form.nl);
   p.acc_scale = form.nl == 2 ? ldexpf(1.0f, -form.w_exp) : 1.0f;
+  p.status = x3_status_word(form, ws, ws_bytes);
   const int wn = pick.wn, mt = pick.mt;
   const int TMsel = x3_tile_pixels(mt, wn);
   long long total = 0;
@@ -693,7 +705,8 @@ static int conv3x3_x3_launch(const X3Form& form, const odet_conv_level_t* levels
   return ODET_OK;
 }
 
-extern "C" size_t odet_x3_workspace_bytes(void) { return (size_t)X3_TICKETS * 4 + ((size_t)64 << 20); }
+extern "C" size_t odet_x3_workspace_bytes(void) { return X3_HEAD_BYTES + ((size_t)64 << 20); }
+extern "C" size_t odet_x2_status_offset(void) { return (size_t)X3_TICKETS * 4; }
 
 extern "C" int odet_conv3x3_x3(const void* x, const void* w3, const void* bias, void* y, int batch, int H, int W, int cin,
                                int cout, int relu, void* workspace, size_t workspace_bytes, odet_stream_t stream) {
@@ -758,6 +771,7 @@ static int pointwise_x3_launch(const char* who, const X3Form& form, const void* 
   p.x2 = (const float*)epi.x2; p.cin2 = epi.x2 ? epi.cin2 : 0; p.k1steps = cin / X3_BK; p.Min2 = (long long)batch * H * W;
   const X3Pick pick = x3_pick_tile(&M, 1, cout, (cin + (epi.x2 ? epi.cin2 : 0)) / X3_BK, x3_part_bytes(ws, ws_bytes), form.nl);
   p.acc_scale = form.nl == 2 ? ldexpf(1.0f, -form.w_exp) : 1.0f;
+  p.status = x3_status_word(form, ws, ws_bytes);
   const int wn = pick.wn, mt = pick.mt;
   const int TMsel = x3_tile_pixels(mt, wn);
   p.tiles_n = cout / (64 * wn);

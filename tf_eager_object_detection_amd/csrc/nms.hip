@@ -1213,13 +1213,10 @@ static int nms_run(NmsJob& J, hipStream_t st) {
       if (!J.img[i].out_done)
         return odet_set_error(ODET_E_INVALID, "odet_nms: batches need the sync-free mode (out_done)");
   }
-  static std::once_flag once;       // (executor threads may arrive here together)
-  static hipError_t once_rc = hipSuccess;
-  std::call_once(once, [] {
-    once_rc = hipFuncSetAttribute((const void*)k_nms_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  SCAN_DYN_LDS);
-  });
-  ODET_HIP(once_rc);
+  static OdetPerDeviceOnce once;    // (executor threads may arrive here together)
+  ODET_HIP(once.run([] {
+    return hipFuncSetAttribute((const void*)k_nms_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAN_DYN_LDS);
+  }));
   const PerImg<NmsHeader*> hdrs = per_img<NmsHeader*>(J, [&](int i) { return w[i].hdr; });
   const PerImg<const uint32_t*> keys = per_img<const uint32_t*>(J, [&](int i) { return (const uint32_t*)w[i].keys_a; });
   if (!J.ws_clean) {

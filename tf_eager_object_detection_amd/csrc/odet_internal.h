@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/odet.h"
 
 #define ODET_WAVE 64
@@ -26,6 +28,24 @@ int odet_set_error(int code, const char* fmt, ...);
   } while (0)
 
 #define ODET_LAUNCH_CHECK() ODET_HIP(hipGetLastError())
+
+// Runs `fn() -> hipError_t` once per DEVICE of this process (keyed by the current device's ordinal) and returns its result every
+// time: a kernel attribute (hipFuncSetAttribute: more than 64 KB of dynamic LDS) belongs to ONE device's copy of the kernel, so
+// a process that drives a second GPU has to set it there too.  Thread-safe (executor threads may arrive together).
+struct OdetPerDeviceOnce {
+  static constexpr int MAXDEV = 64;
+  std::once_flag once[MAXDEV];
+  hipError_t rc[MAXDEV];
+  template <typename F>
+  hipError_t run(F fn) {
+    int dev = 0;
+    const hipError_t eg = hipGetDevice(&dev);
+    if (eg != hipSuccess) return eg;
+    if (dev < 0 || dev >= MAXDEV) return hipErrorInvalidDevice;
+    std::call_once(once[dev], [&] { rc[dev] = fn(); });
+    return rc[dev];
+  }
+};
 
 static inline size_t odet_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -485,12 +485,8 @@ int odet_post_ops_batch(const PostOpsImageIO* io, int B, int R, int Ccls, int nu
   const size_t lds1 = lds_class > lds_merge ? lds_class : lds_merge;
   if (lds1 > 150 * 1024)
     return odet_set_error(ODET_E_LIMIT, "odet_post_ops: R/max_per_class need %zu B of LDS (> 150 KiB)", lds1);
-  static std::once_flag once;       // (executor threads may arrive here together)
-  static hipError_t once_rc = hipSuccess;
-  std::call_once(once, [] {
-    once_rc = hipFuncSetAttribute((const void*)k_postops, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  });
-  ODET_HIP(once_rc);
+  static OdetPerDeviceOnce once;    // (executor threads may arrive here together)
+  ODET_HIP(once.run([] { return hipFuncSetAttribute((const void*)k_postops, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }));
   hipLaunchKernelGGL(k_postops, dim3(ncls1, B), dim3(PO_THREADS), lds1, st, p);
   ODET_LAUNCH_CHECK();
   return ODET_OK;

@@ -14,6 +14,7 @@ import torch
 from .. import ops
 from ..utils.anchor_generator import generate_anchor_base, generate_by_anchor_base_tf
 from .anchor_target import AnchorTarget
+from .fpn_detector import caller_range_checked
 from .base_fpn_model import _Part, _image_nhwc
 from .losses import cls_loss, smooth_l1_loss
 from .prediction import post_ops_prediction
@@ -112,6 +113,7 @@ class BaseFasterRcnn(torch.nn.Module):
         rois = self._rpn_proposal((rpn_bbox_txtytwth, anchors, scores, image_shape), training=training)
         return image_shape, shared_features, anchors, rpn_score, rpn_bbox_txtytwth, rois
 
+    @caller_range_checked
     def forward(self, inputs, training=None, mask=None):
         if training:
             image, gt_bboxes, gt_labels = inputs
@@ -187,6 +189,7 @@ class BaseFasterRcnn(torch.nn.Module):
         rois = self._anchors_and_proposals(image, True)[5]
         return self._proposal_target((rois, gt_bboxes, gt_labels), True)
 
+    @caller_range_checked
     @torch.no_grad()
     def im_detect(self, preprocessed_image, img_scale):
         """:279-306"""

@@ -16,6 +16,7 @@ import torch
 from .. import ops
 from ..utils.anchor_generator import make_anchors
 from .anchor_target import AnchorTarget
+from .fpn_detector import caller_range_checked
 from .losses import cls_loss, smooth_l1_loss
 from .prediction import post_ops_prediction
 from .proposal_target import ProposalTarget
@@ -161,6 +162,7 @@ class BaseFPN(torch.nn.Module):
         return ops.rpn_fg_softmax(all_fpn_scores, 1, ops.RPN_LAYOUT_FPN)
 
     # ---- :202-276 ------------------------------------------------------------------------------
+    @caller_range_checked
     def forward(self, inputs, training=None, mask=None):
         if training:
             image, gt_bboxes, gt_labels = inputs
@@ -240,6 +242,7 @@ class BaseFPN(torch.nn.Module):
         rpn_labels, _, _, _ = self._anchor_target((gt_bboxes, image_shape, all_anchors), True)
         return all_anchors[torch.nonzero(rpn_labels > 0)[:, 0]]
 
+    @caller_range_checked
     @torch.no_grad()
     def predict_rois(self, preprocessed_img, gt_bboxes, gt_labels, training=True):
         image = _image_nhwc(preprocessed_img)
@@ -251,6 +254,7 @@ class BaseFPN(torch.nn.Module):
                                   training=training)
         return self._proposal_target((rois, gt_bboxes, gt_labels), True)[0]
 
+    @caller_range_checked
     @torch.no_grad()
     def im_detect(self, preprocessed_img, img_scale):
         image = _image_nhwc(preprocessed_img)
@@ -288,7 +292,8 @@ class ResnetV1Fpn(BaseFPN):
     dropout is inference-only identity) -- are the hand-written kernels of model/fpn_detector.ResNetFpnDetector, which this
     class owns as `dense`; weights are randomly initialised with the reference's initialisers (no checkpoints offline).
     `dtype`: torch.float32 (the reference's precision) or torch.float16 (throughput mode); `f32_form`: the float32 layers'
-    arithmetic, 'exact' (float32 matrix instructions) or 'x3' (split precision, three bfloat16 limbs: ops.f32_form)."""
+    arithmetic, 'exact' (float32 matrix instructions), 'x3' (split precision, three bfloat16 limbs) or 'x2' (two float16 limbs; a
+    pass that leaves float16's range is repeated on three limbs: fpn_detector.caller_range_checked) -- ops.f32_form."""
 
     def __init__(self, depth=50, roi_head_keep_dropout_rate=0.5, roi_feature_size=(7, 7, 256), num_classes=21,
                  weight_decay=0.0001, level_name_list=('p2', 'p3', 'p4', 'p5', 'p6'), min_level=2, max_level=5,

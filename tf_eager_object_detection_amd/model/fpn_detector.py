@@ -313,11 +313,25 @@ def rpn_pair_padded(m, w):
 
 
 def check_caller_f32_form(form):
-    """the reference-surface caller objects (base_fpn_model.py, base_faster_rcnn_model.py) compose the layers themselves and
-    have no after-pass range check: they take the full-range float32 forms only"""
-    if form not in ('exact', 'x3'):
-        raise ValueError("f32_form must be 'exact' or 'x3' here (the two-limb form 'x2' needs the detectors' range check: "
-                         "model.fpn_detector / frcnn_detector)")
+    """the reference-surface caller objects (base_fpn_model.py, base_faster_rcnn_model.py) take every float32 form; with 'x2'
+    their call / im_detect / predict_rois read the dense part's range status word after the pass and repeat an out-of-range
+    pass on three limbs (run_range_checked below), as the detectors do"""
+    if form not in ('exact', 'x3', 'x2'):
+        raise ValueError("f32_form must be 'exact', 'x3' or 'x2'")
+
+
+def caller_range_checked(method):
+    """decorator for the caller objects' composed passes (call / im_detect / predict_rois): with the dense part on the two-limb
+    form, a pass that reported an out-of-range activation is repeated on three limbs (run_range_checked)"""
+    import functools
+
+    @functools.wraps(method)
+    def run(self, *args, **kw):
+        dense = self.__dict__.get('_dense_ref')
+        if dense is None or getattr(dense, 'f32_form', 'exact') != 'x2':
+            return method(self, *args, **kw)
+        return dense.run_range_checked(lambda: method(self, *args, **kw))
+    return run
 
 
 def _in_f32_form(method):
@@ -326,9 +340,25 @@ def _in_f32_form(method):
 
     @functools.wraps(method)
     def run(self, *args, **kw):
-        with ops.f32_form(getattr(self, 'f32_form', 'exact')):
+        form = getattr(self, 'f32_form', 'exact')
+        with ops.f32_form(form, workspace=_x3_workspace_of(self) if form != 'exact' else None):
             return method(self, *args, **kw)
     return run
+
+
+def _x3_workspace_of(model):
+    """the split-precision workspace (split-K tickets / parts, the two-limb form's range status word) a detector instance OWNS:
+    every launch of the instance -- eager on any stream, or replayed from a graph captured on a side stream -- uses this one, so
+    a graph never shares tickets with another instance's graph and range_ok() always reads the word its own launches set.
+    One instance's passes must not run concurrently with each other (they share every activation buffer anyway)."""
+    ws = model.__dict__.get('_x3_ws')
+    if ws is None:
+        dev = next(model.parameters()).device
+        if dev.type != 'cuda':
+            return None
+        ws = ops.X3Workspace(dev)
+        model.__dict__['_x3_ws'] = ws
+    return ws
 
 
 class _FinalLayer:
@@ -444,21 +474,32 @@ class _NmsCompleteness:
             self.recover(batch)
         return True
 
-    # ---- the two-limb float32 form's RANGE (f32_form = 'x2': float16 limbs; an activation beyond 65504 gives inf / NaN in that
-    # layer's output, include/odet.h) -- checked where the NMS flags are read, on the pass's own outputs: every later layer
-    # propagates a non-finite value (the convolutions' ReLU is `v < 0 ? 0 : v`), so a pass whose RPN outputs and head outputs
-    # are all finite had no overflow upstream of them.  A pass that fails is run again on the three-limb form (bfloat16 limbs:
-    # float32's range), counted in `range_reruns`.
+    # ---- the two-limb float32 form's RANGE (f32_form = 'x2': float16 limbs).  An activation beyond float16's range becomes an
+    # infinite limb and every sum it enters is non-finite before bias / shortcut / ReLU, whatever the weights' signs: the
+    # launch's epilogue ORs 1 into the RANGE STATUS word of the instance's workspace (include/odet.h; csrc/conv_f32_common.h) --
+    # a flag, not a propagated value: a -inf that a ReLU maps to 0 is still reported.  The word is read where the NMS flags
+    # are read; a pass that set it is run again on the three-limb form (bfloat16 limbs: float32's range), counted in
+    # `range_reruns`.
     range_reruns = 0
 
     def range_ok(self, batch=None):
-        """True iff the RPN scores / deltas and the RoI head's outputs of the last pass are all finite (one host sync)"""
-        n = self._last_batch if batch is None else batch
-        rpn_scores, rpn_deltas, _, heads = self._last_pass
-        t = rpn_scores[:n].sum() + rpn_deltas[:n].sum()
-        for cls, dlt in heads[:n]:
-            t = t + cls.sum() + dlt.sum()
-        return bool(torch.isfinite(t).item())
+        """True iff no two-limb launch of this instance since the last call met an activation outside float16's range (reads
+        and clears the status word: one host sync).  After replays of a capture()d graph the caller calls this itself."""
+        ws = self.__dict__.get('_x3_ws')
+        return True if ws is None else ws.range_ok()
+
+    def run_range_checked(self, fn):
+        """fn() -> result on this instance's float32 form; a two-limb pass that reported an out-of-range activation is repeated
+        on three limbs (`range_reruns`).  For composed passes (im_detect, the caller objects' call)."""
+        out = fn()
+        if getattr(self, 'f32_form', 'exact') == 'x2' and not self.range_ok():
+            self.range_reruns += 1
+            self.f32_form = 'x3'
+            try:
+                out = fn()
+            finally:
+                self.f32_form = 'x2'
+        return out
 
     def _forward_checked(self, images_nhwc, check, run):
         """run(images) -> outputs, then the after-pass checks; a two-limb pass out of range is repeated on three limbs"""
@@ -525,6 +566,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         `blind_chunks` chunks: the first one shared by the batch, the others per image); `batched=False` in
         the hot-path keywords selects the per-image path (FpnHotPath per image)."""
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
+        ops.invalidate_planes(self)                   # (cached limb planes of weights that may have been rewritten through .data)
         fd = torch.float16 if self.dtype == torch.float16 else torch.float32
         self._rpn_pair = None
         self._steps = None
@@ -639,7 +681,10 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         convolutions, neck merges, the sync-free hot path, the RoI head) and
         returns `run(images_nhwc) -> outputs`: the images are copied into the graph's static input and the
         graph is replayed -- a few hundred launches cost one host call, which is what a batch-1 latency
-        step is bound by.  Needs the sync-free proposal stage (blind_chunks >= 1: no host check inside)."""
+        step is bound by.  Needs the sync-free proposal stage (blind_chunks >= 1: no host check inside).
+        A replay makes NO after-pass check (no host sync): `run.recover()` re-runs images whose sync-free NMS did not complete,
+        and with f32_form = 'x2' the caller reads `run.range_ok()` (the instance's status word: False = some replay since the
+        last call met an activation outside float16's range -- run those images through forward() again)."""
         if not self._hot:
             raise RuntimeError('prepare() first')
         dev = next(self.parameters()).device
@@ -661,6 +706,8 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
             return static_out
 
         run.graph = graph
+        run.range_ok = self.range_ok
+        run.recover = lambda: self.recover(batch)
         return run
 
     # ---- the model ----------------------------------------------------------------------------------
@@ -743,7 +790,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         in level-sorted order with empty levels dropped (:384-388) -- what evaluation.pascal_eval.detect_image
         (pascal_eval_files_utils.py:76-106) consumes with img_scale = 1.  img_scale: one number or one per image.
         Host-syncs once (R is data dependent, as in the reference)."""
-        heads = self._run_to_head(images_nhwc)
+        heads = self.run_range_checked(lambda: self._run_to_head(images_nhwc))     # ('x2': out of range -> again on three limbs)
         B = len(heads)
         self._last_batch = B
         self.recover(B)

@@ -30,7 +30,7 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         super().__init__()
         b = _BLOCKS[depth]
         self.dtype = dtype
-        self.f32_form = f32_form             # float32 mode: 'exact' | 'x3' (model/fpn_detector.py)
+        self.f32_form = f32_form             # float32 mode: 'exact' | 'x3' | 'x2' (model/fpn_detector.py)
         self.image_shape = (int(image_shape[0]), int(image_shape[1]))
         self.num_classes = num_classes
         # extractor (resnet_faster_rcnn.py:104-153): conv1 .. conv4, stride 16
@@ -64,6 +64,7 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         kernel launches (FrcnnStepBatch: odet_fpn_step_t.single_level) and through the RoI head as one batch;
         `batched=False` in the hot-path keywords selects one FrcnnHotPath per image on a stream of its own."""
         self.to(device=device, dtype=self.dtype, memory_format=torch.channels_last).eval()
+        ops.invalidate_planes(self)                   # (cached limb planes of weights that may have been rewritten through .data)
         # float16 maps go straight into the RoI kernel (pooled 14x14 + max and un-pooled 7x7 crop alike)
         feat_dtype = torch.float16 if self.dtype == torch.float16 else torch.float32
         self._feature_dtype = feat_dtype
@@ -217,7 +218,7 @@ class ResNetC4Detector(_NmsCompleteness, _FinalLayer, nn.Module):
         """The evaluation entry of the reference models (base_faster_rcnn_model.py:279-306): per image
         (softmax scores [R,Ccls], raw deltas [R,4*Ccls], rois / img_scale [R,4]) for the R proposals the image kept
         (NMS order); consumed by evaluation.pascal_eval.detect_image with img_scale = 1.  Host-syncs once."""
-        heads = self._run_to_head(images_nhwc)
+        heads = self.run_range_checked(lambda: self._run_to_head(images_nhwc))     # ('x2': out of range -> again on three limbs)
         B = len(heads)
         self._last_batch = B
         self.recover(B)

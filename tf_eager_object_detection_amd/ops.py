@@ -31,25 +31,36 @@ MAX_LEVELS = 8
 # 'x2':    the two-limb float16 form of the same kernel -- h + l * 2^-11 (operands to one float32 ulp), three products, half the
 #          matrix work of 'x3'; for data inside float16's RANGE (|activation| <= 65504, else infinities / NaN; include/odet.h).
 # A fixed choice of the caller (the detectors' `f32_form` argument), never a timing decision: the two forms round differently.
-_F32_FORM = ['exact']
+# The form (and, optionally, the split-K / status workspace the launches of the block use) is AMBIENT state of the calling
+# context, held in a contextvars.ContextVar: two Python threads (or asyncio tasks) that enter and leave `f32_form` blocks in any
+# interleaving each see their own value -- a form switch is never implicit and can never leak into another thread's layers.
+import contextvars
+
+_F32_CTX = contextvars.ContextVar('odet_f32_form', default=('exact', None))
+
+
+def current_f32_form():
+    return _F32_CTX.get()[0]
 
 
 class f32_form:
     """with ops.f32_form('x3'): ...  -- the form the float32 conv3x3 / pointwise / dense / lateral_merge / pointwise_dual calls
-    inside the block run on"""
+    inside the block run on.  `workspace`: an ops.X3Workspace the block's split-precision launches use (the detectors own one
+    per instance); None = the calling stream's default workspace."""
 
-    def __init__(self, form):
+    def __init__(self, form, workspace=None):
         if form not in ('exact', 'x3', 'x2'):
             raise ValueError("f32 form must be 'exact', 'x3' or 'x2'")
-        self.form = form
+        if workspace is not None and not isinstance(workspace, X3Workspace):
+            raise TypeError('workspace must be an ops.X3Workspace')
+        self.form, self.workspace = form, workspace
 
     def __enter__(self):
-        self.prev = _F32_FORM[0]
-        _F32_FORM[0] = self.form
+        self._token = _F32_CTX.set((self.form, self.workspace))
         return self
 
     def __exit__(self, *exc):
-        _F32_FORM[0] = self.prev
+        _F32_CTX.reset(self._token)
         return False
 
 
@@ -83,13 +94,22 @@ def split_f16x2(w, w_exp=None):
     return planes, int(w_exp)
 
 
+def _plane_key(w):
+    """cache key of a weight's limb planes; None (= split again, every time) for tensors without a version counter (inference
+    tensors: torch raises on ._version)"""
+    try:
+        return (w.data_ptr(), w._version, tuple(w.shape))
+    except RuntimeError:
+        return None
+
+
 def _x3_planes(holder, w):
     """the limb planes of the (contiguous, float32) weight `w`, kept ON the tensor object the caller passed (`holder`: the
     layer's parameter, or a module's cached concatenation) until that tensor is modified: the planes live exactly as long as
     the weight they belong to -- no global cache that could outlive or be cleared under a captured HIP graph.  A caller that
     passes a fresh temporary every time pays the split every time (correct, slow): keep weights in stable tensors."""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    hit = holder.__dict__.get('_odet_x3')
+    key = _plane_key(w)
+    hit = holder.__dict__.get('_odet_x3') if key is not None else None
     if hit is None or hit[0] != key:
         hit = (key, split_bf16x3(w), w)
         holder.__dict__['_odet_x3'] = hit
@@ -99,41 +119,104 @@ def _x3_planes(holder, w):
 def _x2_planes(holder, w):
     """the same for the two-limb form: (planes, w_exp) (the exponent is read from the weights -- one host synchronisation per
     weight tensor, at its first use: a warm-up pass before a HIP-graph capture, as for the workspace)"""
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    hit = holder.__dict__.get('_odet_x2')
+    key = _plane_key(w)
+    hit = holder.__dict__.get('_odet_x2') if key is not None else None
     if hit is None or hit[0] != key:
         hit = (key, split_f16x2(w), w)
         holder.__dict__['_odet_x2'] = hit
     return hit[1]
 
 
+class X3Workspace:
+    """The caller-owned workspace of the split-precision launches (include/odet.h): split-K ticket words (zero-filled once; every
+    launch leaves them zero), the two-limb form's RANGE STATUS word, the split-K parts.  One workspace serves launches that are
+    ordered on the device (one stream, or one captured graph replayed by one stream at a time): two launches that run
+    CONCURRENTLY must not share one -- the detectors own one per instance for that reason (a captured graph keeps using the
+    instance's, whatever stream replays it), bare `ops` calls get one per (device, stream)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(int(L.lib().odet_x3_workspace_bytes()), dtype=torch.uint8, device=device)
+        off = int(L.lib().odet_x2_status_offset())
+        self._head = self.buf[:off + 64]
+        self._status = self.buf[off:off + 4].view(torch.int32)
+
+    def args(self):
+        return C.c_void_p(self.buf.data_ptr()), self.buf.numel()
+
+    def range_flag(self):
+        """the status word as a device tensor (int32 [1]; non-zero: a two-limb launch since the last clear saw a non-finite sum)"""
+        return self._status
+
+    def range_ok(self, clear=True):
+        """True iff no two-limb launch on this workspace since the last clear met an activation outside float16's range (one host
+        sync); clears the word when it was set"""
+        bad = int(self._status.item()) != 0
+        if bad and clear:
+            self._status.zero_()
+        return not bad
+
+    def reset(self):
+        """tickets and status back to zero (after a failed or aborted launch the tickets may be left non-zero)"""
+        self._head.zero_()
+
+
 _X3_WS = {}
 
 
 def _x3_workspace(device):
-    """the split-K workspace of the split-precision launches of the CURRENT stream on `device` (include/odet.h: zero-filled once,
-    one per stream, only ever handed to the odet_*_x3 entry points); allocated at the stream's first x3 launch -- a warm-up pass
-    before a HIP-graph capture, as the detectors' capture() makes"""
+    """the workspace of the current context: the one the enclosing f32_form block names, else the CURRENT stream's on `device`
+    (allocated at the stream's first split-precision launch -- a warm-up pass before a HIP-graph capture)"""
+    ws = _F32_CTX.get()[1]
+    if ws is not None:
+        return ws
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _X3_WS.get(key)
     if ws is None:
-        ws = torch.zeros(int(L.lib().odet_x3_workspace_bytes()), dtype=torch.uint8, device=device)
+        ws = X3Workspace(device)
         _X3_WS[key] = ws
     return ws
+
+
+def invalidate_planes(module_or_tensor):
+    """drops the cached limb planes of a weight tensor / of every parameter and cached concatenation of a module: call after
+    writing weights in a way that does not bump the tensor version (`.data` writes, set_()); load_state_dict() and the
+    detectors' prepare() do.  (In-place ops through the tensor itself bump the version and need nothing.)"""
+    import torch.nn as nn
+    objs = [module_or_tensor]
+    if isinstance(module_or_tensor, nn.Module):
+        objs = list(module_or_tensor.parameters()) + list(module_or_tensor.buffers())
+        for m in module_or_tensor.modules():
+            for v in list(m.__dict__.values()):
+                if isinstance(v, torch.Tensor):
+                    objs.append(v)
+                elif isinstance(v, (tuple, list)):
+                    objs += [t for t in v if isinstance(t, torch.Tensor)]
+    for t in objs:
+        t.__dict__.pop('_odet_x3', None)
+        t.__dict__.pop('_odet_x2', None)
 
 
 def _f32_sym(sym, w, holder=None):
     """(entry point, weight pointer, extra arguments before the stream) of a float32 layer in the current form; `holder` = the
     caller's weight tensor object"""
-    if _F32_FORM[0] == 'x3':
+    form = _F32_CTX.get()[0]
+    if form == 'x3':
         planes = _x3_planes(w if holder is None else holder, w)
-        ws = _x3_workspace(w.device)
-        return sym[:-3] + 'x3', C.c_void_p(planes.data_ptr()), (C.c_void_p(ws.data_ptr()), ws.numel())   # odet_*_f32 -> odet_*_x3
-    if _F32_FORM[0] == 'x2':
+        return sym[:-3] + 'x3', C.c_void_p(planes.data_ptr()), _x3_workspace(w.device).args()   # odet_*_f32 -> odet_*_x3
+    if form == 'x2':
         planes, w_exp = _x2_planes(w if holder is None else holder, w)
-        ws = _x3_workspace(w.device)
-        return sym[:-3] + 'x2', C.c_void_p(planes.data_ptr()), (w_exp, C.c_void_p(ws.data_ptr()), ws.numel())
+        return sym[:-3] + 'x2', C.c_void_p(planes.data_ptr()), (w_exp,) + _x3_workspace(w.device).args()
     return sym, L.dptr(w), ()
+
+
+def _f32_call(sym, *args):
+    """L.call for a float32 layer; a split-precision launch that FAILS may leave its workspace's tickets non-zero: reset them"""
+    try:
+        L.call(sym, *args)
+    except L.OdetError:
+        if sym.endswith(('_x3', '_x2', '_x3_levels', '_x2_levels')):
+            _x3_workspace(torch.device('cuda', torch.cuda.current_device())).reset()
+        raise
 
 
 def _boxes(t, name):
@@ -569,7 +652,7 @@ def _conv3x3(dtype, x, weight, bias, relu, out):
     wp, extra = L.dptr(w), ()
     if dtype == torch.float32:
         sym, wp, extra = _f32_sym(sym, w, weight)
-    L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
+    _f32_call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(out), B, H, W,
            cin, cout, 1 if relu else 0, *extra, L.stream())
     return out
 
@@ -596,7 +679,7 @@ def _conv3x3_levels(dtype, xs, weight, bias, relu, outs):
     wp, extra = L.dptr(w), ()
     if dtype == torch.float32:
         sym, wp, extra = _f32_sym(sym, w, weight)
-    L.call(sym + '_levels', lv, len(xs), wp, L.dptr(bias) if bias is not None else None, B, cin, cout,
+    _f32_call(sym + '_levels', lv, len(xs), wp, L.dptr(bias) if bias is not None else None, B, cin, cout,
            1 if relu else 0, *extra, L.stream())
     return outs
 
@@ -855,7 +938,7 @@ def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=Non
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
     sym, wp, extra = ('odet_pointwise_' + sfx, L.dptr(w), ()) if sfx != 'f32' else _f32_sym('odet_pointwise_f32', w, weight)
-    L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None,
+    _f32_call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None,
            L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, stride, cin, cout, 1 if relu else 0,
            *extra, L.stream())
     return out
@@ -885,7 +968,7 @@ def lateral_merge(x, weight, bias, top, out=None):
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
     sym, wp, extra = ('odet_lateral_merge_' + sfx, L.dptr(w), ()) if sfx != 'f32' else _f32_sym('odet_lateral_merge_f32', w, weight)
-    L.call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(top),
+    _f32_call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(top),
            int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, *extra, L.stream())
     return out
 
@@ -919,7 +1002,7 @@ def pointwise_dual(x1, x2, weight, bias=None, stride=1, relu=True, out=None):
     elif out.dtype != x1.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x1\'s dtype' % (shape,))
     sym, wp, extra = ('odet_pointwise_dual_' + sfx, L.dptr(weight), ()) if sfx != 'f32' else _f32_sym('odet_pointwise_dual_f32', weight)
-    L.call(sym, L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, wp,
+    _f32_call(sym, L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, wp,
            L.dptr(bias) if bias is not None else None, L.dptr(out), B, cout, 1 if relu else 0, *extra, L.stream())
     return out
 

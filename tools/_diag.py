@@ -25,7 +25,8 @@ def use_library(path):
 def build_variant(out_path, extra_flags=(), sources=None, patch=None, only=None):
     """libodet with `extra_flags` (e.g. -D switches a patch under tools/exp introduces) into `out_path`; `patch` is applied
     with `git apply` to a temporary copy of csrc/ first and the build FAILS if it does not apply.  `only`: the sources to
-    recompile with the flags; the other objects are the product build's (csrc/_obj, built first if stale)."""
+    recompile with the flags; the other objects are the product build's (csrc/_obj, built first if stale).  Variants that
+    force tiles (odet_debug_*) pass '-DODET_DIAG' in `extra_flags` and are loaded with ODET_LIB_PATH + DIAG_SIGNATURES."""
     import shutil
     import tempfile
     tmp = tempfile.mkdtemp(prefix='odet_variant_')
@@ -52,6 +53,61 @@ def build_variant(out_path, extra_flags=(), sources=None, patch=None, only=None)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out_path
+
+
+# ---- the diagnostic build of the library (tools/libodet_hip_diag.so: _build.build_diag(), include/odet_diag.h) ----------------
+DIAG_SIGNATURES = {
+    'odet_debug_conv_tile': (_lib._i, [_lib._i] * 5),
+    'odet_debug_x3_tile': (_lib._i, [_lib._i] * 3),
+}
+_diag_handle = None
+
+
+def diag_handle():
+    """ctypes handle of the diagnostic library (every product signature + the odet_debug_* hooks); built on demand where hipcc
+    exists, otherwise it must have travelled with the snapshot (__graft_entry__.build() builds it)"""
+    global _diag_handle
+    if _diag_handle is None:
+        import ctypes as C
+        import torch  # noqa: F401  (its HIP runtime first, as _lib.lib() does)
+        path = _build.DIAG_LIB
+        if not os.path.exists(path):
+            _build.build_diag()
+        h = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in list(_lib.SIGNATURES.items()) + list(DIAG_SIGNATURES.items()):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        if h.odet_version() != _lib.ODET_VERSION:
+            raise _lib.OdetError('libodet_hip_diag.so version mismatch: %d' % h.odet_version())
+        _diag_handle = h
+    return _diag_handle
+
+
+class diag_library:
+    """with tools._diag.diag_library() as lib:  -- every C-ABI call of the block (ops.*, _lib.call) goes to the DIAGNOSTIC build,
+    which alone has odet_debug_conv_tile / odet_debug_x3_tile; any forced tile is cleared on the way out and the product
+    library is back afterwards.  Both libraries are stateless apart from that override, so buffers made by one work with the other."""
+
+    def __enter__(self):
+        _lib.lib()                                    # (the product library first: it stays the process's RTLD_GLOBAL one)
+        self.prev = _lib._lib
+        _lib._lib = diag_handle()
+        return _lib._lib
+
+    def __exit__(self, *exc):
+        try:
+            _lib._lib.odet_debug_conv_tile(0, 0, 0, 0, 0)
+            _lib._lib.odet_debug_conv_tile(1, 0, 0, 0, 0)
+            _lib._lib.odet_debug_x3_tile(0, 0, 0)
+        finally:
+            _lib._lib = self.prev
+        return False
+
+
+def use_diag_build():
+    """(scripts) the diagnostic build for the WHOLE process: call before the first _lib.lib()"""
+    use_library(_build.build_diag() if not os.path.exists(_build.DIAG_LIB) else _build.DIAG_LIB)
+    _lib.SIGNATURES.update(DIAG_SIGNATURES)
 
 
 if os.environ.get('ODET_LIB_PATH'):

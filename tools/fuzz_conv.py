@@ -19,7 +19,7 @@ def main():
     ap.add_argument('--f32-form', default='exact', choices=['exact', 'x3', 'x2'], help='the form the float32 cases run on (x3: the '
                     'split-precision kernel is exact on integer data too)')
     a = ap.parse_args()
-    ops._F32_FORM[0] = a.f32_form
+    ops.f32_form(a.f32_form).__enter__()          # (for the rest of the process)
     g = torch.Generator(device='cuda'); g.manual_seed(a.seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), device='cuda', generator=g).item())
     sparse = lambda shape, pct, lo, hi: ((torch.randint(0, 100, shape, device='cuda', generator=g) < pct).half()

@@ -4,6 +4,9 @@ a launch is prologue + epilogue: which tile serves it best at 30 images?  Also t
     python tools/r04/dual_tiles.py [batch, default 30]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tools._diag
+if not os.environ.get('ODET_LIB_PATH'):
+    tools._diag.use_diag_build()      # (odet_debug_* exist only in the -DODET_DIAG build: include/odet_diag.h)
 import torch
 from tf_eager_object_detection_amd import ops, _lib
 

@@ -6,6 +6,9 @@ picks by itself; every result checked for exactness on integer data first.
     python tools/r04/small_tiles.py [batches, default 1,2,4] [--json out]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tools._diag
+if not os.environ.get('ODET_LIB_PATH'):
+    tools._diag.use_diag_build()      # (odet_debug_* exist only in the -DODET_DIAG build: include/odet_diag.h)
 import torch, torch.nn.functional as F
 from tf_eager_object_detection_amd import ops, _lib
 

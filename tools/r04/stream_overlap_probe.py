@@ -6,6 +6,9 @@ ResNet-101-FPN, 800x1333; S detector instances of B images on S streams, passes 
     python tools/r04/stream_overlap_probe.py"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tools._diag
+if not os.environ.get('ODET_LIB_PATH'):
+    tools._diag.use_diag_build()      # (odet_debug_* exist only in the -DODET_DIAG build: include/odet_diag.h)
 import numpy as np, torch
 from tf_eager_object_detection_amd import _lib
 from tf_eager_object_detection_amd.model import fpn_detector as fpn

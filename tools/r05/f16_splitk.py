@@ -18,6 +18,8 @@ CU; larger tiles + split-K trade half the operand bytes for the parts' traffic a
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tools._diag
+if not os.environ.get('ODET_LIB_PATH'):
+    tools._diag.use_diag_build()      # (odet_debug_* exist only in the -DODET_DIAG build: include/odet_diag.h)
 import torch
 from tf_eager_object_detection_amd import ops, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

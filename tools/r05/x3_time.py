@@ -1,6 +1,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tools._diag
+if not os.environ.get('ODET_LIB_PATH'):
+    tools._diag.use_diag_build()      # (odet_debug_* exist only in the -DODET_DIAG build: include/odet_diag.h)
 import torch
 from tf_eager_object_detection_amd import ops
 torch.manual_seed(0)
