@@ -35,9 +35,8 @@ extern "C" {
  * workspace.  102: the odet_*_x2 entry points (two float16 limbs) and odet_split_f16x2; odet_bias_relu_maxpool keeps a NaN
  * in float32.  103: the two-limb launches report an out-of-range activation in a status word of their workspace
  * (odet_x2_status_offset); the tile-forcing diagnostics left this header and the shipped library (include/odet_diag.h, a
- * separate -DODET_DIAG build).  104: limb planes of ACTIVATIONS (odet_*_xl: a layer leaves its result as limb planes too, the
- * 3x3 form reads its input from them by LDS-DMA; odet_split_activation). */
-#define ODET_VERSION 104
+ * separate -DODET_DIAG build). */
+#define ODET_VERSION 103
 
 #define ODET_OK 0
 #define ODET_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -533,30 +532,6 @@ int odet_lateral_merge_x2(const void* x, const void* w2, const void* bias, const
 int odet_pointwise_dual_x2(const void* x1, int cin1, const void* x2, int cin2, int H2, int W2, int stride2,
                            const void* w2, const void* bias, void* y, int batch, int cout, int relu, int w_exp,
                            void* workspace, size_t workspace_bytes, odet_stream_t stream);
-/* LIMB PLANES OF ACTIVATIONS (csrc/conv_x3.hip, PRE).  In the entry points above a layer's float32 input is split into limbs inside
- * the K loop -- once per tap and per channel tile, by the vector units, between the matrix instructions.  These forms move the split
- * to where an activation is PRODUCED: a layer's epilogue leaves its float32 result ALSO as limb planes `y_limbs` ([nl][M][cout] of
- * 2-byte limbs: nl = 3 bfloat16 limbs, a = p0 + p1 + p2 exactly; nl = 2 float16 limbs h, l with a ~ h + l * 2^-11; nullable), and
- * the 3x3 form takes its input from the planes its producer left (`x_limbs` [nl][batch * H * W][cin]; used when EVERY level brings
- * them, else every level's float32 `x` is read and split in the loop): both operands then travel global -> LDS by LDS-DMA and the
- * K loop is copies, fragment reads, matrix instructions and one counted wait per step.  Same arithmetic, same results bit for bit
- * as the *_x3 / *_x2 entry points (the limbs of a value do not depend on where it is split).  `wplanes` = the weights' limb planes
- * (odet_split_bf16x3 / odet_split_f16x2), `w_exp` as in the *_x2 forms (ignored for nl = 3); everything else as above.
- * odet_split_activation: float32 [n] -> planes [nl][n] for an activation no split-precision layer produced (n even). */
-typedef struct {
-  const void* x_limbs;           /* input limb planes of the level, or NULL */
-  void* y_limbs;                 /* where to leave the output's limb planes, or NULL */
-} odet_conv_limbs_t;
-int odet_conv3x3_xl_levels(int nl, const odet_conv_level_t* levels, const odet_conv_limbs_t* limbs, int num_levels,
-                           const void* wplanes, const void* bias, int batch, int cin, int cout, int relu, int w_exp,
-                           void* workspace, size_t workspace_bytes, odet_stream_t stream);
-int odet_pointwise_xl(int nl, const void* x, const void* wplanes, const void* bias, const void* residual, void* y,
-                      void* y_limbs, int batch, int H, int W, int stride, int cin, int cout, int relu, int w_exp,
-                      void* workspace, size_t workspace_bytes, odet_stream_t stream);
-int odet_lateral_merge_xl(int nl, const void* x, const void* wplanes, const void* bias, const void* top, int th, int tw,
-                          void* y, void* y_limbs, int batch, int H, int W, int cin, int cout, int w_exp,
-                          void* workspace, size_t workspace_bytes, odet_stream_t stream);
-int odet_split_activation(int nl, const float* x, void* planes, long long n, odet_stream_t stream);
 /* The stem's patch matrix in float32 mode: row (image, yo, xo) = the zero-padded 7 x 7 x 3 window of conv1_pad +
  * Conv2D(64, 7x7, strides 2, 'valid') (resnet_fpn.py:262-289) in (dy, dx, channel) order, padded from 147 to 160 floats;
  * images NHWC float32 [batch,H,W,3] -> patches [batch * Ho * Wo][160], Ho = (H - 1) / 2 + 1.  The convolution is then

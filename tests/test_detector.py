@@ -1772,60 +1772,3 @@ def test_split_precision_split_k_is_deterministic_exact_on_integers_and_leaves_i
         for ws in ops._X3_WS.values():
             assert int(ws.buf[:16384].max().item()) == 0                             # every ticket drawn back to zero
             assert ws.range_ok()                                                     # and nothing reported out of range
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('form', SPLIT_FORMS)
-def test_limb_plane_3x3_kernel_equals_the_in_loop_split_bit_for_bit(form):
-    """the operand split out of the K loop.  A split-precision 3x3 layer runs on its input's LIMB PLANES (left by
-    the producing layer's epilogue, or by the stand-alone split) with both operands travelling by LDS-DMA; the limbs of a value
-    do not depend on where it is split, so the results equal the in-loop-split kernel's bit for bit (shapes without a K split:
-    the tile choice never changes a sum's order, a K split would) -- borders, several tiles, batches, pyramid levels in one
-    launch; the planes a layer leaves are exactly the stand-alone split of its float32 result; a stale tag is never used."""
-    from tf_eager_object_detection_amd import ops
-    g = torch.Generator(device='cuda'); g.manual_seed(91)
-    nl = 3 if form == 'x3' else 2
-    with ops.f32_form(form):
-        for (B, H, W, cin, cout) in ((1, 5, 7, 32, 64), (2, 33, 47, 32, 128), (3, 64, 80, 32, 256), (2, 200, 334, 64, 64), (2, 50, 84, 32, 512)):
-            x = torch.randn((B, H, W, cin), device='cuda', generator=g)
-            w = (torch.randn((cout, cin, 3, 3), device='cuda', generator=g) * (9 * cin) ** -0.5).contiguous(memory_format=torch.channels_last)
-            b = torch.randn(cout, device='cuda', generator=g)
-            want = ops.conv3x3_f32(x, w, b, relu=True, inloop=True)               # float32 map, split inside the K loop
-            assert ops.limbs_of(x) is None
-            got = ops.conv3x3_f32(x, w, b, relu=True)                             # stand-alone split, then the limb-plane kernel
-            assert ops.limbs_of(x) is not None and torch.equal(got, want), (B, H, W, cin, cout)
-            # ... and the planes the layer leaves: the stand-alone split of its float32 result
-            got2 = ops.conv3x3_f32(x, w, b, relu=True, limbs=True)
-            planes = ops.limbs_of(got2)
-            assert torch.equal(got2, want) and planes is not None and tuple(planes.shape) == (nl,) + tuple(want.shape)
-            ref = ops.limbs_of(ops.split_activation(want.clone()))
-            assert torch.equal(planes, ref)
-            # a chain: 1x1 (leaves planes) -> 3x3 (reads them) == the same chain on float32 maps
-            w1 = (torch.randn((cin, cin), device='cuda', generator=g) * cin ** -0.5)
-            y1 = ops.pointwise(x, w1, None, None, True, limbs=True)
-            assert ops.limbs_of(y1) is not None
-            a = ops.conv3x3_f32(y1, w, b)
-            bb = ops.conv3x3_f32(ops.pointwise(x, w1, None, None, True), w, b, inloop=True)
-            assert torch.equal(a, bb)
-            # the tag dies with an in-place write torch sees, and with an out= write of this package
-            y1.add_(1.0)
-            assert ops.limbs_of(y1) is None
-            y2 = ops.pointwise(x, w1, None, None, True, limbs=True)
-            ops.pointwise(x, w1, None, None, False, out=y2)
-            assert ops.limbs_of(y2) is None
-        # all pyramid levels in one launch, planes on every level / on none / on some (then: stand-alone split of the others)
-        xs = [torch.randn((2, h, w_, 32), device='cuda', generator=g) for h, w_ in ((48, 64), (24, 32), (12, 16), (6, 8), (3, 4))]
-        w = (torch.randn((128, 32, 3, 3), device='cuda', generator=g) * 0.06).contiguous(memory_format=torch.channels_last)
-        b = torch.randn(128, device='cuda', generator=g)
-        want = ops.conv3x3_f32_levels(xs, w, b, relu=True, inloop=True)
-        ops.split_activation(xs[1])
-        got = ops.conv3x3_f32_levels(xs, w, b, relu=True, limbs=True)
-        assert all(torch.equal(a_, b_) for a_, b_ in zip(got, want)) and all(ops.limbs_of(t) is not None for t in got)
-        # integer data: exact, whatever the route
-        xi = torch.randint(-3, 4, (2, 19, 23, 64), device='cuda', generator=g).float()
-        wi = torch.randint(-2, 3, (64, 64, 3, 3), device='cuda', generator=g).float().contiguous(memory_format=torch.channels_last)
-        exact = F.conv2d(xi.permute(0, 3, 1, 2).double(), wi.double(), None, 1, 1).permute(0, 2, 3, 1)
-        assert torch.equal(ops.conv3x3_f32(xi, wi).double(), exact)
-    with ops.f32_form('exact'):                                                   # the exact form ignores all of it
-        y = ops.pointwise(x, w1, None, None, True, limbs=True)
-        assert ops.limbs_of(y) is None

@@ -54,7 +54,7 @@ def test_library_loads_and_exports_every_header_symbol():
     assert len(syms) >= 20
     for name in syms:
         assert hasattr(handle, name), 'libodet_hip.so does not export %s' % name
-    assert handle.odet_version() == 104
+    assert handle.odet_version() == 103
 
 
 def test_shipped_library_has_no_debug_hooks():

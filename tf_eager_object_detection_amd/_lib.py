@@ -11,7 +11,7 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libodet_hip.so')     # (tools/_diag.py points it at a diagnostic build; no environment switch)
-ODET_VERSION = 104                                   # include/odet.h
+ODET_VERSION = 103                                   # include/odet.h
 
 _lib = None
 
@@ -26,11 +26,6 @@ class OdetLevel(C.Structure):
 class OdetConvLevel(C.Structure):
     """odet_conv_level_t"""
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32)]
-
-
-class OdetConvLimbs(C.Structure):
-    """odet_conv_limbs_t"""
-    _fields_ = [('x_limbs', C.c_void_p), ('y_limbs', C.c_void_p)]
 
 
 MAX_LEVELS = 8
@@ -150,10 +145,6 @@ SIGNATURES = {
     'odet_pointwise_x2': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'odet_lateral_merge_x2': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'odet_pointwise_dual_x2': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
-    'odet_conv3x3_xl_levels': (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    'odet_pointwise_xl': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    'odet_lateral_merge_xl': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    'odet_split_activation': (_i, [_i, _vp, _vp, _i64, _vp]),
     'odet_stem_patches_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'odet_rgb_patches3x3_f32': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'odet_pointwise_dual_f16': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -307,7 +307,6 @@ static void f32_defaults(ConvF32Params* p) {
   p->stride = 1; p->Ho = p->Wo = 0; p->Min = 0; p->res = nullptr; p->top = nullptr; p->th = p->tw = 0; p->tys = p->txs = 0.0f;
   p->x2 = nullptr; p->cin2 = 0; p->k1steps = 0; p->Min2 = 0;
   p->ksplit = 0; p->part = nullptr; p->ticket = nullptr; p->acc_scale = 1.0f; p->status = nullptr;
-  for (int l = 0; l < ODET_MAX_LEVELS; ++l) { p->xl[l] = nullptr; p->yl[l] = nullptr; }
 }
 
 static int conv3x3_f32_launch(const odet_conv_level_t* levels, int num_levels, const void* w, const void* bias, int batch,

@@ -33,65 +33,10 @@ struct ConvF32Params {
   // limb, and every product with it is infinite or NaN: every sum it enters is non-finite BEFORE bias / shortcut / ReLU, whatever
   // the weights' signs -- the epilogue ORs 1 into the word when it sees one (a wave ballot, then at most one atomic per wave)
   unsigned* status;
-  // conv_x3.hip, LIMB PLANES of activations (both nullable per level): xl = the input already split by its producer, planes
-  // [NL][rows][cin] of 2-byte limbs (the 3x3 PRE kernels copy them global -> LDS by LDS-DMA: no split in the K loop);
-  // yl = where this launch's epilogue ALSO leaves its float32 result as limb planes [NL][M][cout] for the next layer
-  const void* xl[ODET_MAX_LEVELS]; void* yl[ODET_MAX_LEVELS];
 };
 
-typedef __bf16 c3b2 __attribute__((ext_vector_type(2)));
-typedef _Float16 c3h2 __attribute__((ext_vector_type(2)));
-typedef float c3f2 __attribute__((ext_vector_type(2)));
-typedef unsigned int c3u2 __attribute__((ext_vector_type(2)));
-
-// two float32 -> their three bfloat16 limbs, packed (low half = first value): a = h + m + l exactly (round to nearest even)
-__device__ __forceinline__ void x3_split2(const c3f2 a, unsigned& h, unsigned& m, unsigned& l) {
-  const c3b2 hb = __builtin_convertvector(a, c3b2);
-  h = __builtin_bit_cast(unsigned, hb);
-  const c3f2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xFFFF0000u)};
-  const c3f2 r1 = a - hf;                                 // exact (the difference has at most 16 significant bits)
-  const c3b2 mb = __builtin_convertvector(r1, c3b2);
-  m = __builtin_bit_cast(unsigned, mb);
-  const c3f2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xFFFF0000u)};
-  const c3f2 r2 = r1 - mf;                                // exact (at most 8 significant bits are left)
-  const c3b2 lb = __builtin_convertvector(r2, c3b2);
-  l = __builtin_bit_cast(unsigned, lb);
-}
-
-// two float32 -> their two float16 limbs, packed: a ~ h + l * 2^-11, h = f16(a), l = f16((a - h) * 2^11) (the low limb scaled
-// into float16's normal range; |a| >= 65520 gives infinities -- and a non-finite result -- never a wrong finite number)
-__device__ __forceinline__ void x2_split2(const c3f2 a, unsigned& h, unsigned& l) {
-  const c3h2 hb = __builtin_convertvector(a, c3h2);
-  h = __builtin_bit_cast(unsigned, hb);
-  const c3f2 hf = __builtin_convertvector(hb, c3f2);
-  const c3f2 r = (a - hf) * 2048.0f;                      // exact (the difference has at most 13 significant bits)
-  const c3h2 lb = __builtin_convertvector(r, c3h2);
-  l = __builtin_bit_cast(unsigned, lb);
-}
-
-// four consecutive channels of one pixel -> 8 bytes in each of the NLO limb planes (plane = elements per plane)
-template <int NLO>
-__device__ __forceinline__ void conv_store_limbs(void* yl, long long plane, long long elem, const c3f4 o) {
-  unsigned short* dst = reinterpret_cast<unsigned short*>(yl) + elem;
-  if constexpr (NLO == 3) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    x3_split2((c3f2){o[0], o[1]}, h0, m0, l0);
-    x3_split2((c3f2){o[2], o[3]}, h1, m1, l1);
-    *reinterpret_cast<c3u2*>(dst) = (c3u2){h0, h1};
-    *reinterpret_cast<c3u2*>(dst + plane) = (c3u2){m0, m1};
-    *reinterpret_cast<c3u2*>(dst + 2 * plane) = (c3u2){l0, l1};
-  } else if constexpr (NLO == 2) {
-    unsigned h0, l0, h1, l1;
-    x2_split2((c3f2){o[0], o[1]}, h0, l0);
-    x2_split2((c3f2){o[2], o[3]}, h1, l1);
-    *reinterpret_cast<c3u2*>(dst) = (c3u2){h0, h1};
-    *reinterpret_cast<c3u2*>(dst + plane) = (c3u2){l0, l1};
-  }
-}
-
 // bias (+ shortcut | FPN top-down merge) (+ ReLU) and the stores of a wave's MT x 4 accumulator tiles
-// NLO: 0, or the limb count of the planes the launch may ALSO write (p.yl[lv], nullable at run time)
-template <int MT, int TAPS, int NLO = 0>
+template <int MT, int TAPS>
 __device__ __forceinline__ void conv_f32_epilogue(const ConvF32Params& p, c3f4 (&acc)[MT][4], long long tile_m, int TM, int TN,
                                                   int wm, int wn, int tn, int l15, int lq, int lv, long long M, int cout) {
   // lane = pixel l15 of every pixel tile; tile t of the wave's 64-channel group: channels c0 + 16 t .. + 3
@@ -117,8 +62,6 @@ __device__ __forceinline__ void conv_f32_epilogue(const ConvF32Params& p, c3f4 (
     const long long m = tile_m * TM + wm * 16 * MT + mt * 16 + l15;
     if (m < M) {
       float* dst = p.y[lv] + m * cout + c0;
-      void* ylimb = NLO ? p.yl[lv] : nullptr;
-      const long long lplane = M * cout, lelem = m * cout + c0;
       if constexpr (TAPS == 1) {
         if (p.top) {
           // the FPN top-down merge (neck.hip's arithmetic and operation order, float32 throughout: bit-identical to
@@ -149,7 +92,6 @@ __device__ __forceinline__ void conv_f32_epilogue(const ConvF32Params& p, c3f4 (
               o[j] = up * 0.5f + lat * 0.5f;
             }
             *reinterpret_cast<c3f4*>(dst + 16 * t) = o;
-            if constexpr (NLO != 0) { if (ylimb) conv_store_limbs<NLO>(ylimb, lplane, lelem + 16 * t, o); }
           }
           continue;
         }
@@ -167,7 +109,6 @@ __device__ __forceinline__ void conv_f32_epilogue(const ConvF32Params& p, c3f4 (
           o[j] = v;
         }
         *reinterpret_cast<c3f4*>(dst + 16 * t) = o;
-        if constexpr (NLO != 0) { if (ylimb) conv_store_limbs<NLO>(ylimb, lplane, lelem + 16 * t, o); }
       }
     }
   }

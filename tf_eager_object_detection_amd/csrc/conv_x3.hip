@@ -59,7 +59,30 @@ typedef __attribute__((address_space(3))) void* x3_lds_ptr;
 #define X3_NA(NS) (NS)
 #endif
 
-// (x3_split2 / x2_split2: conv_f32_common.h -- the producing layers' epilogues use them too)
+// two float32 -> their three bfloat16 limbs, packed (low half = first value)
+__device__ __forceinline__ void x3_split2(const x3f2 a, unsigned& h, unsigned& m, unsigned& l) {
+  const x3b2 hb = __builtin_convertvector(a, x3b2);
+  h = __builtin_bit_cast(unsigned, hb);
+  const x3f2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xFFFF0000u)};
+  const x3f2 r1 = a - hf;                                 // exact (the difference has at most 16 significant bits)
+  const x3b2 mb = __builtin_convertvector(r1, x3b2);
+  m = __builtin_bit_cast(unsigned, mb);
+  const x3f2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xFFFF0000u)};
+  const x3f2 r2 = r1 - mf;                                // exact (at most 8 significant bits are left)
+  const x3b2 lb = __builtin_convertvector(r2, x3b2);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
+// two float32 -> their two float16 limbs, packed: a ~ h + l * 2^-11, h = f16(a), l = f16((a - h) * 2^11) (the low limb scaled
+// into float16's normal range; |a| > 65504 gives infinities -- and a NaN result -- never a wrong finite number)
+__device__ __forceinline__ void x2_split2(const x3f2 a, unsigned& h, unsigned& l) {
+  const x2h2 hb = __builtin_convertvector(a, x2h2);
+  h = __builtin_bit_cast(unsigned, hb);
+  const x3f2 hf = __builtin_convertvector(hb, x3f2);
+  const x3f2 r = (a - hf) * 2048.0f;                      // exact (the difference has at most 13 significant bits)
+  const x2h2 lb = __builtin_convertvector(r, x2h2);
+  l = __builtin_bit_cast(unsigned, lb);
+}
 
 // ---- weights: float32 [n] -> planes [3][n] of bfloat16 (once per weight tensor) ------------------------------------------------
 __global__ void __launch_bounds__(256) k_split_bf16x3(const float* __restrict__ w, unsigned* __restrict__ planes, long long n2) {
@@ -108,13 +131,9 @@ extern "C" int odet_split_f16x2(const float* w, void* planes, long long n, int w
 // into a second one that joins it times 2^-11 at the end (dropped: l l <= 2^-22 |a b|): half the matrix work, for data inside
 // float16's RANGE.  Against float64 on the network's layers its error is no larger than the exact-float32 form's
 // (tools/r05/x3_layers.py --check: the accumulation's float32 rounding dominates both).
-// PRE (3x3 only): the pixel rows come from the input's LIMB PLANES p.xl (written by the producing layer's epilogue: the split
-// happens once per activation instead of once per tap and channel tile) by LDS-DMA, exactly like the weight rows -- the K
-// loop is copies, fragment reads, MFMAs and one counted wait per step; no vector work, no LDS stores.
-template <int MT, int WN, int TAPS, int NL, bool PRE = false>
+template <int MT, int WN, int TAPS, int NL>
 __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
   static_assert(NL == 2 || NL == 3, "two float16 or three bfloat16 limbs");
-  static_assert(!PRE || TAPS == 9, "limb-plane input: the 3x3 form");
   using frag_t = std::conditional_t<NL == 3, x3b8, x2h8>;
   constexpr int WM = 8 / WN;
   constexpr int TM = WM * 16 * MT;
@@ -211,42 +230,6 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
     // (the DMA writes lane-linear: LDS slot lane % 4 of row lane / 4 receives the K slot (lane % 4) ^ 2 [rows 8..15])
     voffW[i] = pi < WPIECES ? (uint32_t)limb * planeB + (uint32_t)ch * wrowB + (uint32_t)((lane & 3) ^ ((lane >> 5) << 1)) * 16u : OOB;
   }
-  // ---- PRE: this thread's rows of the input's limb planes.  A stage's pixel rows are NL * TM / 16 pieces of 16 rows x 64 B;
-  // piece wv + 8 i = limb i / RPL, rows 16 (wv + 8 (i % RPL)) + lane / 4, 16-byte slot lane % 4 -- stored swizzled like the
-  // weight rows (the DMA writes lane-linear: the swizzle is on the SOURCE slot)
-  constexpr int RPL = PRE ? TM / 128 : 1;                // pixel rows of a lane (per limb)
-  constexpr int XPWP = NL * RPL;                         // pixel copies per wave and K-step
-  static_assert(!PRE || TM % 128 == 0, "limb-plane input: every wave copies whole 16-row pieces of every limb");
-  uint32_t voffX[RPL], maskX[RPL];
-  x3_rsrc_t rxl[NL];
-  const uint32_t pixL = (uint32_t)cin * 2u;              // bytes of a pixel's row inside a limb plane
-  if constexpr (PRE) {
-    const uint32_t PADL = (uint32_t)(W + 1) * pixL;
-    const char* xb = reinterpret_cast<const char*>(p.xl[lv]);
-    const size_t planeX = (size_t)M * pixL;
-#pragma unroll
-    for (int l = 0; l < NL; ++l)
-      rxl[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb) + (size_t)l * planeX - PADL, 0,
-                                                 (int)((uint32_t)M * pixL + 2u * PADL), 0x00020000);
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-      const int row = (wv + 8 * r) * 16 + (lane >> 2);
-      const long long m = tile_m * TM + row;
-      uint32_t mk = 0;
-      if (m < M) {
-        const long long img = m / ((long long)H * W);
-        const int rem = (int)(m - img * H * W);
-        const int yy = rem / W, xx = rem - yy * W;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
-          if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) mk |= 1u << t;
-        }
-      }
-      maskX[r] = mk;
-      voffX[r] = (uint32_t)m * pixL + (uint32_t)((lane & 3) ^ ((lane >> 5) << 1)) * 16u;
-    }
-  }
   const int chunks = cin / X3_BK;
   const int ksteps_all = TAPS * chunks + (dual ? p.cin2 / X3_BK : 0);
   const int k1steps = dual ? p.k1steps : ksteps_all;
@@ -282,17 +265,6 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
       if (WPIECES % 8 == 0 || wv + 8 * i < WPIECES)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (x3_lds_ptr)(lds + stage + WBASE + (uint32_t)(wv + 8 * i) * 1024u), 16,
                                                  (int)voffW[i], (int)((uint32_t)ks * 64u), 0, 0);
-  };
-  auto issue_x = [&](int ks, uint32_t stage) {          // (PRE) the pixel rows of K-step ks: tap ks / chunks, 32 channels = 64 B per limb
-    const int tap = ks / chunks;
-    const int chunk = ks - tap * chunks;
-    const uint32_t so = (uint32_t)((tap / 3) * W + tap % 3) * pixL + (uint32_t)chunk * 64u;
-#pragma unroll
-    for (int i = 0; i < XPWP; ++i) {
-      const int l = i / RPL, r = i % RPL;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl[l], (x3_lds_ptr)(lds + stage + (uint32_t)l * XLIMB + (uint32_t)(wv + 8 * r) * 1024u), 16,
-                                               (int)(((maskX[r] >> tap) & 1u) ? voffX[r] : OOB), (int)so, 0, 0);
-    }
   };
   // split a loaded slot and write its three limb planes: 4 channels = 8 bytes per limb
   // (row = piece * 8 + sub, piece = wv + 8 i: rows 8..15 of a 16-row tile are the odd pieces = the odd waves)
@@ -467,41 +439,8 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
     for (; i + 2 * NA - 1 < ksteps; i += NA) round(steady);     // (the round's last step still has its slots of i + 2 NA - 1 to load)
     for (; i < ksteps; i += NA) round(guarded);
   };
-  // ---- PRE: both operands by LDS-DMA, NS - 1 K-steps ahead; every wave issues the same CP copies per step, in order, so the
-  // counted wait leaves exactly the youngest step's in flight (two stages: none)
-  auto kloop_pre = [&](auto early_c) {
-    constexpr bool EARLY = decltype(early_c)::value;
-    constexpr int CP = WPW + XPWP;
-    auto issue_all = [&](int ksr, uint32_t st) {
-      asm volatile("" ::: "memory");
-      issue_w(ks_lo + ksr, st * STAGE);
-      issue_x(ks_lo + ksr, st * STAGE);
-      asm volatile("" ::: "memory");
-    };
-#pragma unroll
-    for (int j = 0; j < NS - 1; ++j)
-      if (j < ksteps) issue_all(j, (uint32_t)j);
-    if (NS == 3 && ksteps > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    uint32_t si = 0;
-    for (int i = 0; i < ksteps; ++i) {
-      const bool more = i + NS - 1 < ksteps;
-      const uint32_t wst = si == 0 ? (uint32_t)(NS - 1) : si - 1;          // stage of K-step i + NS - 1 (read last in step i - 1)
-      compute(lds + si * STAGE, ra[0], 0u, false,
-              [&] { if constexpr (EARLY) { if (more) issue_all(i + NS - 1, wst); } },
-              [&] { if constexpr (!EARLY) { if (more) issue_all(i + NS - 1, wst); } });
-      if (NS == 3 && i + 2 < ksteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      si = si + 1 == NS ? 0u : si + 1;
-    }
-  };
-  if constexpr (PRE) {
-    if (wv < 4) kloop_pre(std::true_type{});
-    else kloop_pre(std::false_type{});
-  } else {
-    if (wv < 4) kloop(std::true_type{});
-    else kloop(std::false_type{});
-  }
+  if (wv < 4) kloop(std::true_type{});
+  else kloop(std::false_type{});
   if constexpr (NL == 2) {
     // the two accumulators joined, the weights' scale (a power of two) taken back out
     const float s2 = p.acc_scale * 0x1p-11f;
@@ -545,7 +484,7 @@ __device__ __forceinline__ void conv_tile_x3(const ConvF32Params& p) {
         acc[mt][t] = sum;
       }
   }
-  conv_f32_epilogue<MT, TAPS, NL>(p, acc, tile_m, TM, TN, wm, wn, tn, l15, lq, lv, M, cout);
+  conv_f32_epilogue<MT, TAPS>(p, acc, tile_m, TM, TN, wm, wn, tn, l15, lq, lv, M, cout);
 }
 
 template <int MT, int WN>
@@ -568,17 +507,6 @@ __global__ void __launch_bounds__(512) k_pointwise_x2(ConvF32Params p) {
   conv_tile_x3<MT, WN, 1, 2>(p);
 }
 
-// the 3x3 forms on the input's limb planes (PRE)
-template <int MT, int WN>
-__global__ void __launch_bounds__(512) k_conv3x3_x3p(ConvF32Params p) {
-  conv_tile_x3<MT, WN, 9, 3, true>(p);
-}
-
-template <int MT, int WN>
-__global__ void __launch_bounds__(512) k_conv3x3_x2p(ConvF32Params p) {
-  conv_tile_x3<MT, WN, 9, 2, true>(p);
-}
-
 // ---- host side --------------------------------------------------------------------------------------------------------------
 // tiles (MT, WN): 256 x 128, 128 x 128 | 128 x 256 | 256 x 64, 128 x 64, 64 x 64 (pixels x channels)
 // (the two-limb form keeps two accumulator sets: 256 x 128 would not fit the register file)
@@ -587,8 +515,8 @@ __global__ void __launch_bounds__(512) k_conv3x3_x2p(ConvF32Params p) {
 
 template <typename F>
 static void x3_for_each_kernel(F f) {
-#define X3_K(MT_, WN_) f((const void*)k_conv3x3_x3<MT_, WN_>); f((const void*)k_pointwise_x3<MT_, WN_>); f((const void*)k_conv3x3_x3p<MT_, WN_>);
-#define X2_K(MT_, WN_) f((const void*)k_conv3x3_x2<MT_, WN_>); f((const void*)k_pointwise_x2<MT_, WN_>); f((const void*)k_conv3x3_x2p<MT_, WN_>);
+#define X3_K(MT_, WN_) f((const void*)k_conv3x3_x3<MT_, WN_>); f((const void*)k_pointwise_x3<MT_, WN_>);
+#define X2_K(MT_, WN_) f((const void*)k_conv3x3_x2<MT_, WN_>); f((const void*)k_pointwise_x2<MT_, WN_>);
   X3_FOR_TILES(X3_K)
   X2_FOR_TILES(X2_K)
 #undef X3_K
@@ -632,7 +560,7 @@ extern "C" int odet_debug_x3_tile(int mt, int wn, int ksplit) {
 // a deep-K, few-row layer is a latency chain of its K-steps (conv5's 3 x 3 at batch 1: 144 steps of 1.5 us on 18 workgroups).
 #define X3_TICKETS 4096                                  // tiles of a split-K launch (the workspace's ticket words)
 struct X3Pick { int mt, wn, ksplit; };
-static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int ksteps, size_t part_bytes_max, int nl, bool pre = false) {
+static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int ksteps, size_t part_bytes_max, int nl) {
   static const int cand[][2] = {{4, 2}, {2, 2}, {4, 4}, {2, 1}, {1, 1}};       // (mt, wn)
   X3Pick best_pick{0, 0, 1};
   double best = 1e300;
@@ -646,8 +574,7 @@ static X3Pick x3_pick_tile(const long long* M, int num_levels, int cout, int kst
     const int occ = std::max(1, std::min(2, (int)(X3_LDS_MAX / x3_lds_bytes(tm, tn, nl))));
     // (two limbs: 3 products, two thirds of the weight rows' bytes, a shorter split)
     const double mfma = (double)tm * tn / 256.0 * (nl == 3 ? 6.0 : 3.0) * 16.0 / 4.0;
-    // (PRE: a pixel row is an LDS-DMA copy like a weight row -- no load / split / store by the vector units)
-    const double other = (pre ? (nl == 3 ? 0.8 : 0.55) : (nl == 3 ? 3.5 : 3.0)) * tm + (nl == 3 ? 0.8 : 0.55) * tn + 720.0;
+    const double other = (nl == 3 ? 3.5 : 3.0) * tm + (nl == 3 ? 0.8 : 0.55) * tn + 720.0;
     for (int S = 1; S <= 8; ++S) {
       // a split only where the tiles leave CUs idle (the parts of a launch that fills the chip would be HBM traffic of their
       // own: 1.1 GB for the RpnHead's P2 level at batch 1), every part at least 8 K-steps, tickets and parts inside the workspace
@@ -697,20 +624,17 @@ static size_t x3_part_bytes(const void* ws, size_t ws_bytes) {
 }
 
 
-// kind: 0 = 3x3, 1 = pointwise, 2 = 3x3 on the input's limb planes (PRE)
-template <int KIND>
+template <bool PW>
 static int x3_launch_tile(int nl, int wn, int mt, dim3 grid, unsigned lds_bytes, hipStream_t st, const ConvF32Params& p) {
 #define X3_L(MT_, WN_)                                                                                      \
   if (nl == 3 && mt == MT_ && wn == WN_) {                                                                  \
-    if (KIND == 1) hipLaunchKernelGGL((k_pointwise_x3<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);       \
-    else if (KIND == 2) hipLaunchKernelGGL((k_conv3x3_x3p<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);   \
+    if (PW) hipLaunchKernelGGL((k_pointwise_x3<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);              \
     else hipLaunchKernelGGL((k_conv3x3_x3<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);                   \
     return ODET_OK;                                                                                         \
   }
 #define X2_L(MT_, WN_)                                                                                      \
   if (nl == 2 && mt == MT_ && wn == WN_) {                                                                  \
-    if (KIND == 1) hipLaunchKernelGGL((k_pointwise_x2<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);       \
-    else if (KIND == 2) hipLaunchKernelGGL((k_conv3x3_x2p<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);   \
+    if (PW) hipLaunchKernelGGL((k_pointwise_x2<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);              \
     else hipLaunchKernelGGL((k_conv3x3_x2<MT_, WN_>), grid, dim3(512), lds_bytes, st, p);                   \
     return ODET_OK;                                                                                         \
   }
@@ -725,7 +649,6 @@ static void x3_defaults(ConvF32Params* p) {
   p->stride = 1; p->Ho = p->Wo = 0; p->Min = 0; p->res = nullptr; p->top = nullptr; p->th = p->tw = 0; p->tys = p->txs = 0.0f;
   p->x2 = nullptr; p->cin2 = 0; p->k1steps = 0; p->Min2 = 0;
   p->ksplit = 0; p->part = nullptr; p->ticket = nullptr; p->acc_scale = 1.0f; p->status = nullptr;
-  for (int l = 0; l < ODET_MAX_LEVELS; ++l) { p->xl[l] = nullptr; p->yl[l] = nullptr; }
 }
 
 // the limb form of a launch: 3 bfloat16 planes, or 2 float16 planes of w * 2^w_exp
@@ -736,8 +659,7 @@ static unsigned* x3_status_word(const X3Form& form, void* ws, size_t ws_bytes) {
 }
 
 static int conv3x3_x3_launch(const X3Form& form, const odet_conv_level_t* levels, int num_levels, const void* w3, const void* bias,
-                             int batch, int cin, int cout, int relu, void* ws, size_t ws_bytes, hipStream_t st,
-                             const odet_conv_limbs_t* limbs = nullptr) {
+                             int batch, int cin, int cout, int relu, void* ws, size_t ws_bytes, hipStream_t st) {
   ODET_REQUIRE(levels && w3, "odet_conv3x3_x3: null pointer");
   ODET_REQUIRE(x3_form_ok(form), "odet_conv3x3_x2: w_exp %d out of range", form.w_exp);
   ODET_REQUIRE(num_levels >= 1 && num_levels <= ODET_MAX_LEVELS, "odet_conv3x3_x3: num_levels %d out of range", num_levels);
@@ -751,22 +673,14 @@ static int conv3x3_x3_launch(const X3Form& form, const odet_conv_level_t* levels
   x3_defaults(&p);
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     const odet_conv_level_t& L = levels[l < num_levels ? l : 0];
-    const odet_conv_limbs_t* LL = limbs ? &limbs[l < num_levels ? l : 0] : nullptr;
-    ODET_REQUIRE((L.x || (LL && LL->x_limbs)) && L.y && L.H > 0 && L.W > 0, "odet_conv3x3_x3: bad level %d", l);
-    ODET_REQUIRE(((uintptr_t)L.x | (uintptr_t)L.y | (uintptr_t)(LL ? LL->x_limbs : nullptr) | (uintptr_t)(LL ? LL->y_limbs : nullptr)) % 16 == 0,
-                 "odet_conv3x3_x3: maps and limb planes must be 16-byte aligned");
-    p.xl[l] = LL ? LL->x_limbs : nullptr; p.yl[l] = LL ? LL->y_limbs : nullptr;
+    ODET_REQUIRE(L.x && L.y && L.H > 0 && L.W > 0, "odet_conv3x3_x3: bad level %d", l);
+    ODET_REQUIRE(((uintptr_t)L.x | (uintptr_t)L.y) % 16 == 0, "odet_conv3x3_x3: maps must be 16-byte aligned");
     const long long M = (long long)batch * L.H * L.W;
     ODET_REQUIRE((unsigned long long)M * cin * 4ull + 2ull * (L.W + 1) * cin * 4ull < 0xFFFFFFF0ull,
                  "odet_conv3x3_x3: level %d input larger than 4 GiB", l);
     p.x[l] = (const float*)L.x; p.y[l] = (float*)L.y; p.M[l] = M; p.H[l] = L.H; p.W[l] = L.W;
   }
-  // the limb-plane form when EVERY level brings its input's planes (else every level reads its float32 map and splits in the loop)
-  bool pre = limbs != nullptr;
-  for (int l = 0; l < num_levels && pre; ++l) pre = limbs[l].x_limbs != nullptr;
-  for (int l = 0; l < num_levels; ++l)
-    ODET_REQUIRE(pre || levels[l].x, "odet_conv3x3_x3: level %d has neither a float32 map nor (on every level) limb planes", l);
-  const X3Pick pick = x3_pick_tile(p.M, num_levels, cout, 9 * (cin / X3_BK), x3_part_bytes(ws, ws_bytes), form.nl, pre);
+  const X3Pick pick = x3_pick_tile(p.M, num_levels, cout, 9 * (cin / X3_BK), x3_part_bytes(ws, ws_bytes), form.nl);
   p.acc_scale = form.nl == 2 ? ldexpf(1.0f, -form.w_exp) : 1.0f;
   p.status = x3_status_word(form, ws, ws_bytes);
   const int wn = pick.wn, mt = pick.mt;
@@ -784,9 +698,8 @@ static int conv3x3_x3_launch(const X3Form& form, const odet_conv_level_t* levels
   ODET_REQUIRE(blocks < (1ll << 28), "odet_conv3x3_x3: too many workgroups");
   const int rs = x3_apply_split(&p, pick, blocks, TMsel, ws, ws_bytes, "odet_conv3x3_x3");
   if (rs != ODET_OK) return rs;
-  const dim3 grid((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1)));
-  const int rc = pre ? x3_launch_tile<2>(form.nl, wn, mt, grid, x3_lds_bytes(TMsel, 64 * wn, form.nl), st, p)
-                     : x3_launch_tile<0>(form.nl, wn, mt, grid, x3_lds_bytes(TMsel, 64 * wn, form.nl), st, p);
+  const int rc = x3_launch_tile<false>(form.nl, wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))),
+                                       x3_lds_bytes(TMsel, 64 * wn, form.nl), st, p);
   if (rc != ODET_OK) return rc;
   ODET_LAUNCH_CHECK();
   return ODET_OK;
@@ -823,7 +736,7 @@ extern "C" int odet_conv3x3_x3_levels(const odet_conv_level_t* levels, int num_l
                            (hipStream_t)stream);
 }
 
-struct PwX3Epilogue { const void* res; const void* top; int th, tw; const void* x2; int cin2; void* y_limbs = nullptr; };
+struct PwX3Epilogue { const void* res; const void* top; int th, tw; const void* x2; int cin2; };
 
 static int pointwise_x3_launch(const char* who, const X3Form& form, const void* x, const void* w3, const void* bias, void* y,
                                int batch, int H, int W, int stride, int cin, int cout, int relu, const PwX3Epilogue& epi, void* ws,
@@ -850,8 +763,6 @@ static int pointwise_x3_launch(const char* who, const X3Form& form, const void* 
   for (int l = 0; l < ODET_MAX_LEVELS; ++l) {
     p.x[l] = (const float*)x; p.y[l] = (float*)y; p.M[l] = M; p.H[l] = H; p.W[l] = W;
   }
-  ODET_REQUIRE((uintptr_t)epi.y_limbs % 16 == 0, "%s: limb planes must be 16-byte aligned", who);
-  for (int l = 0; l < ODET_MAX_LEVELS; ++l) p.yl[l] = epi.y_limbs;
   p.res = (const float*)epi.res;
   p.top = (const float*)epi.top; p.th = epi.th; p.tw = epi.tw;
   p.tys = epi.top ? (float)epi.th / (float)Ho : 0.0f;
@@ -873,7 +784,7 @@ static int pointwise_x3_launch(const char* who, const X3Form& form, const void* 
   ODET_REQUIRE(blocks < (1ll << 28), "%s: too many workgroups", who);
   const int rs = x3_apply_split(&p, pick, blocks, TMsel, ws, ws_bytes, who);
   if (rs != ODET_OK) return rs;
-  const int rc = x3_launch_tile<1>(form.nl, wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))),
+  const int rc = x3_launch_tile<true>(form.nl, wn, mt, dim3((unsigned)(blocks * (p.ksplit > 1 ? p.ksplit : 1))),
                                       x3_lds_bytes(TMsel, 64 * wn, form.nl), st, p);
   if (rc != ODET_OK) return rc;
   ODET_LAUNCH_CHECK();
@@ -931,52 +842,4 @@ extern "C" int odet_pointwise_dual_x2(const void* x1, int cin1, const void* x2, 
   const PwX3Epilogue e{nullptr, nullptr, 0, 0, x2, cin2};
   return pointwise_x3_launch("odet_pointwise_dual_x2", X3Form{2, w_exp}, x1, w2, bias, y, batch, H2, W2, stride2, cin1, cout, relu,
                              e, workspace, workspace_bytes, (hipStream_t)stream);
-}
-
-// ---- the limb-plane entry points: `nl` = 3 (bfloat16 limbs; w_exp ignored) or 2 (float16 limbs of w * 2^w_exp); the layer ALSO
-// leaves its float32 result as limb planes (y_limbs [nl][M][cout], nullable), and the 3x3 form takes its input from the planes
-// its producer left (x_limbs on every level) -------------------------------------------------------------------------------------
-static bool xl_form(int nl, int w_exp, X3Form* f) {
-  if (nl == 3) { *f = X3Form{3, 0}; return true; }
-  if (nl == 2) { *f = X3Form{2, w_exp}; return true; }
-  return false;
-}
-
-extern "C" int odet_conv3x3_xl_levels(int nl, const odet_conv_level_t* levels, const odet_conv_limbs_t* limbs, int num_levels,
-                                      const void* wplanes, const void* bias, int batch, int cin, int cout, int relu, int w_exp,
-                                      void* workspace, size_t workspace_bytes, odet_stream_t stream) {
-  X3Form f;
-  ODET_REQUIRE(xl_form(nl, w_exp, &f), "odet_conv3x3_xl_levels: nl must be 3 or 2");
-  return conv3x3_x3_launch(f, levels, num_levels, wplanes, bias, batch, cin, cout, relu, workspace, workspace_bytes,
-                           (hipStream_t)stream, limbs);
-}
-
-extern "C" int odet_pointwise_xl(int nl, const void* x, const void* wplanes, const void* bias, const void* residual, void* y,
-                                 void* y_limbs, int batch, int H, int W, int stride, int cin, int cout, int relu, int w_exp,
-                                 void* workspace, size_t workspace_bytes, odet_stream_t stream) {
-  X3Form f;
-  ODET_REQUIRE(xl_form(nl, w_exp, &f), "odet_pointwise_xl: nl must be 3 or 2");
-  PwX3Epilogue e{residual, nullptr, 0, 0, nullptr, 0};
-  e.y_limbs = y_limbs;
-  return pointwise_x3_launch("odet_pointwise_xl", f, x, wplanes, bias, y, batch, H, W, stride, cin, cout, relu, e, workspace,
-                             workspace_bytes, (hipStream_t)stream);
-}
-
-extern "C" int odet_lateral_merge_xl(int nl, const void* x, const void* wplanes, const void* bias, const void* top, int th, int tw,
-                                     void* y, void* y_limbs, int batch, int H, int W, int cin, int cout, int w_exp,
-                                     void* workspace, size_t workspace_bytes, odet_stream_t stream) {
-  X3Form f;
-  ODET_REQUIRE(xl_form(nl, w_exp, &f), "odet_lateral_merge_xl: nl must be 3 or 2");
-  ODET_REQUIRE(top, "odet_lateral_merge_xl: null pointer");
-  PwX3Epilogue e{nullptr, top, th, tw, nullptr, 0};
-  e.y_limbs = y_limbs;
-  return pointwise_x3_launch("odet_lateral_merge_xl", f, x, wplanes, bias, y, batch, H, W, 1, cin, cout, 0, e, workspace,
-                             workspace_bytes, (hipStream_t)stream);
-}
-
-// float32 [rows][c] -> its limb planes [nl][rows][c] (an activation that no split-precision layer produced: the image side of a
-// chain, max-pooled maps); n = rows * c values, even
-extern "C" int odet_split_activation(int nl, const float* x, void* planes, long long n, odet_stream_t stream) {
-  ODET_REQUIRE(nl == 3 || nl == 2, "odet_split_activation: nl must be 3 or 2");
-  return nl == 3 ? odet_split_bf16x3(x, planes, n, stream) : odet_split_f16x2(x, planes, n, 0, stream);
 }

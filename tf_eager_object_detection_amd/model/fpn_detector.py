@@ -179,22 +179,20 @@ def _conv_relu_pool(conv, x, kernel, stride, pool_pad=0, ceil_mode=False):
     return ops.bias_relu_maxpool(yn, conv.bias, kernel, stride, pool_pad, ceil_mode).permute(0, 3, 1, 2)
 
 
-def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None, limbs=False):
+def _conv_epi(conv, x, relu=False, residual=None, extra_bias=None):
     """conv -> + bias (+ extra_bias) (+ residual) -> ReLU in ONE launch of this package's kernels; x / residual / result are
-    channels_last [B,C,H,W] tensors (= NHWC in memory).  limbs: (float32 split-precision forms) the layer's epilogue also leaves
-    the result as limb planes -- set where the consumer is a 3x3 convolution (ops.limbs_of)."""
+    channels_last [B,C,H,W] tensors (= NHWC in memory)."""
     bias = conv.bias if extra_bias is None else conv.bias + extra_bias
     if tuple(conv.kernel_size) == (1, 1):
         res = None if residual is None else _nhwc(residual)
         xn = _nhwc(x)
         if _route_1x1(conv, x) == 'mfma':
             return ops.conv1x1_f16(xn, conv.weight, bias, res, relu).permute(0, 3, 1, 2)
-        return ops.pointwise(xn, conv.weight, bias, res, relu, conv.stride[0], limbs=limbs).permute(0, 3, 1, 2)
+        return ops.pointwise(xn, conv.weight, bias, res, relu, conv.stride[0]).permute(0, 3, 1, 2)
     if residual is None and _own_conv3x3(conv, x):
         # the implicit GEMM with bias (+ ReLU) in its epilogue
-        if x.dtype == torch.float32:
-            return ops.conv3x3_f32(_nhwc(x), conv.weight, bias, relu=relu, limbs=limbs).permute(0, 3, 1, 2)
-        return ops.conv3x3_f16(_nhwc(x), conv.weight, bias, relu=relu).permute(0, 3, 1, 2)
+        fn = ops.conv3x3_f32 if x.dtype == torch.float32 else ops.conv3x3_f16
+        return fn(_nhwc(x), conv.weight, bias, relu=relu).permute(0, 3, 1, 2)
     raise _no_kernel('convolution', conv, x)
 
 
@@ -228,7 +226,7 @@ class _Block(nn.Module):
         return c[1], c[2]
 
     def forward(self, x):
-        y = _conv_epi(self.c1, x, relu=True, limbs=True)             # (c2 is a 3x3: it reads c1's limb planes in the split forms)
+        y = _conv_epi(self.c1, x, relu=True)
         if self.short is not None:
             # a stage's first block: the last 1x1 convolution AND the convolutional shortcut + Add + ReLU as ONE contraction
             # over [c2's output | the block's (strided) input] with the weights concatenated along K (ops.pointwise_dual) --
@@ -606,14 +604,12 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
     def neck(self, c_list):
         """(C2..C5) -> (P2..P6) (ResnetFpnNeck.call, resnet_fpn.py:378-407)."""
         c2, c3, c4, c5 = c_list
-        # (limbs: every map here feeds a 3x3 convolution -- the smoothing convolutions, then the RpnHead's)
-        p5 = _conv_epi(self.p5, c5, limbs=True)
+        p5 = _conv_epi(self.p5, c5)
         p6 = p5[:, :, ::2, ::2]                                                  # MaxPooling2D(1x1, stride 2)
         p4 = self._lateral_merge(p5, self.l4, c4)
         p3 = self._lateral_merge(p4, self.l3, c3)
         p2 = self._lateral_merge(p3, self.l2, c2)
-        return (_conv_epi(self.s2, p2, limbs=True), _conv_epi(self.s3, p3, limbs=True), _conv_epi(self.s4, p4, limbs=True),
-                p5, p6)
+        return _conv_epi(self.s2, p2), _conv_epi(self.s3, p3), _conv_epi(self.s4, p4), p5, p6
 
     def _lateral_merge(self, top, conv, c):
         """P_k = 0.5 * resize_bilinear(P_{k+1}) + 0.5 * lateral(C_k) (resnet_fpn.py:385-398) in ONE launch: the merge rides in
@@ -621,7 +617,7 @@ class ResNetFpnDetector(_NmsCompleteness, _FinalLayer, nn.Module):
         P2 at batch 8)."""
         if not _pw_ok(conv, c) or tuple(conv.stride) != (1, 1) or top.dtype != c.dtype:
             raise _no_kernel('lateral convolution + top-down merge', conv, c)
-        return ops.lateral_merge(_nhwc(c), conv.weight, conv.bias, _nhwc(top), limbs=True).permute(0, 3, 1, 2)
+        return ops.lateral_merge(_nhwc(c), conv.weight, conv.bias, _nhwc(top)).permute(0, 3, 1, 2)
 
     @staticmethod
     def _merge(top, lateral):

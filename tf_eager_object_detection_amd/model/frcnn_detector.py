@@ -298,7 +298,7 @@ class Vgg16Detector(ResNetC4Detector):
             # (32-bit byte offsets into the patch matrix: groups of images that keep it below 4 GiB)
             Bn, Hn, Wn = (int(v) for v in images_nhwc.shape[:3])
             step = max(1, min(Bn, fpn._PATCH_BYTES_MAX // (Hn * Wn * 64 * 4)))
-            parts = [ops.pointwise(ops.rgb_patches3x3_f32(images_nhwc[i:i + step]), packed[1], first.bias, None, True, limbs=True)
+            parts = [ops.pointwise(ops.rgb_patches3x3_f32(images_nhwc[i:i + step]), packed[1], first.bias, None, True)
                      for i in range(0, Bn, step)]
             x = (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).permute(0, 3, 1, 2)
         else:
@@ -313,7 +313,7 @@ class Vgg16Detector(ResNetC4Detector):
                     # the stage's last convolution: bias + ReLU + MaxPooling2D((2,2), 2, padding='same') in one pass
                     x = _conv_relu_pool(self.convs[i], x, 2, 2, ceil_mode=True)
                 else:
-                    x = _conv_epi(self.convs[i], x, relu=True, limbs=True)     # (every consumer here is a 3x3 convolution)
+                    x = _conv_epi(self.convs[i], x, relu=True)
                 i += 1
         return x
 

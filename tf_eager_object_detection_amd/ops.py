@@ -214,78 +214,9 @@ def _f32_call(sym, *args):
     try:
         L.call(sym, *args)
     except L.OdetError:
-        if sym.endswith(('_x3', '_x2', '_x3_levels', '_x2_levels', '_xl', '_xl_levels')):
+        if sym.endswith(('_x3', '_x2', '_x3_levels', '_x2_levels')):
             _x3_workspace(torch.device('cuda', torch.cuda.current_device())).reset()
         raise
-
-
-# ---- limb planes of ACTIVATIONS (include/odet.h: odet_*_xl).  A split-precision layer can leave its float32 result ALSO as limb
-# planes (`limbs=True`); the planes hang on the result's BASE tensor object (views -- the detectors pass NCHW / NHWC views of one
-# buffer around -- keep their base alive), tagged with the form, the buffer's address and its version counter.  A 3x3 layer whose
-# input carries valid planes of the current form runs the limb-plane kernel (both operands by LDS-DMA, no split in the K loop);
-# anything else -- another form, a tensor modified since (in-place ops bump the version), a slice -- reads the float32 map and
-# splits in the loop, as before: same limbs, same results bit for bit.
-def _limb_count():
-    return {'x3': 3, 'x2': 2}.get(_F32_CTX.get()[0], 0)
-
-
-def _limbs_new(out):
-    """uninitialised limb planes [nl, *out.shape] (int16) for the float32 tensor `out` in the current form"""
-    return torch.empty((_limb_count(),) + tuple(out.shape), dtype=torch.int16, device=out.device)
-
-
-def _limbs_tag(out, planes):
-    out.__dict__['_odet_limbs'] = (_F32_CTX.get()[0], planes, out._version, out.data_ptr(), out.numel())
-
-
-def limbs_drop(t):
-    """forget the limb planes of `t`'s buffer.  The tag is checked against the buffer's address and torch's version counter; a
-    writer torch does not see (this package's kernels writing an `out=` tensor; anything else through a raw pointer) must drop
-    it -- the ops that take `out=` do."""
-    if t is not None:
-        (t._base if t._base is not None else t).__dict__.pop('_odet_limbs', None)
-    return t
-
-
-def limbs_of(x):
-    """the limb planes the producing layer left for the contiguous float32 tensor `x` (or a whole-buffer view of it) in the
-    CURRENT form, or None"""
-    form = _F32_CTX.get()[0]
-    if form == 'exact' or not x.is_contiguous():
-        return None
-    base = x._base if x._base is not None else x
-    rec = base.__dict__.get('_odet_limbs')
-    if rec is None:
-        return None
-    try:
-        ver = base._version
-    except RuntimeError:
-        return None
-    if rec[0] != form or rec[2] != ver or rec[3] != x.data_ptr() or rec[4] != x.numel():
-        return None
-    return rec[1]
-
-
-def split_activation(x):
-    """limb planes of the contiguous float32 tensor `x` in the current form, by a stand-alone kernel (odet_split_activation) --
-    for an activation no split-precision layer produced (pooled maps); tags `x` like a producing layer would.  -> x"""
-    if _limb_count() == 0:
-        return x
-    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or x.numel() % 2:
-        raise ValueError('split_activation: needs a contiguous float32 GPU tensor with an even element count')
-    planes = _limbs_new(x)
-    L.call('odet_split_activation', _limb_count(), L.dptr(x), C.c_void_p(planes.data_ptr()), x.numel(), L.stream())
-    base = x._base if x._base is not None else x
-    base.__dict__['_odet_limbs'] = (_F32_CTX.get()[0], planes, base._version, x.data_ptr(), x.numel())
-    return x
-
-
-def _xl_weight(w, holder):
-    """(nl, weight planes pointer, w_exp) of the current split-precision form"""
-    if _F32_CTX.get()[0] == 'x3':
-        return 3, C.c_void_p(_x3_planes(w if holder is None else holder, w).data_ptr()), 0
-    planes, w_exp = _x2_planes(w if holder is None else holder, w)
-    return 2, C.c_void_p(planes.data_ptr()), w_exp
 
 
 def _boxes(t, name):
@@ -605,7 +536,7 @@ def fpn_topdown_merge(top, lateral, out=None):
         out = torch.empty_like(lateral)
     L.call('odet_fpn_topdown_merge', L.dptr(top), h, w, L.dptr(lateral), H, W, B, Cc, L.dptr(out),
            1 if top.dtype == torch.float16 else 0, L.stream())
-    return limbs_drop(out)
+    return out
 
 
 def bias_act_(x, bias, residual=None, relu=True):
@@ -620,7 +551,7 @@ def bias_act_(x, bias, residual=None, relu=True):
         raise ValueError('bias must have %d elements' % Cc)
     L.call('odet_bias_act', L.dptr(x), L.dptr(bias), L.dptr(residual), x.numel() // Cc, Cc, 1 if relu else 0,
            1 if x.dtype == torch.float16 else 0, L.stream())
-    return limbs_drop(x)                      # (in place through a raw pointer: torch's version counter does not see it)
+    return x
 
 
 def rpn_pack(level_out, bias, out, out_offset):
@@ -704,9 +635,7 @@ def _conv3x3_weight(weight, cin, cout, dtype, name):
     return w if w.is_contiguous() else w.contiguous()
 
 
-def _conv3x3(dtype, x, weight, bias, relu, out, limbs=False, inloop=False):
-    if dtype == torch.float32 and _limb_count() and not inloop:
-        return _conv3x3_levels(dtype, [x], weight, bias, relu, None if out is None else [out], limbs)[0]
+def _conv3x3(dtype, x, weight, bias, relu, out):
     sym, name, _ = _CONV3X3_FORMS[dtype]
     if x.dtype != dtype or not x.is_cuda or x.dim() != 4 or not x.is_contiguous():
         raise ValueError('x must be a contiguous NHWC %s GPU tensor [B,H,W,cin]' % name)
@@ -720,7 +649,6 @@ def _conv3x3(dtype, x, weight, bias, relu, out, limbs=False, inloop=False):
         out = torch.empty(shape, dtype=dtype, device=x.device)
     elif out.dtype != dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous %s tensor [B,H,W,cout]' % name)
-    limbs_drop(out)
     wp, extra = L.dptr(w), ()
     if dtype == torch.float32:
         sym, wp, extra = _f32_sym(sym, w, weight)
@@ -729,7 +657,7 @@ def _conv3x3(dtype, x, weight, bias, relu, out, limbs=False, inloop=False):
     return out
 
 
-def _conv3x3_levels(dtype, xs, weight, bias, relu, outs, limbs=False, inloop=False):
+def _conv3x3_levels(dtype, xs, weight, bias, relu, outs):
     sym, name, _ = _CONV3X3_FORMS[dtype]
     if not 1 <= len(xs) <= MAX_LEVELS:
         raise ValueError('between 1 and %d maps expected' % MAX_LEVELS)
@@ -748,32 +676,7 @@ def _conv3x3_levels(dtype, xs, weight, bias, relu, outs, limbs=False, inloop=Fal
         if y.dtype != dtype or tuple(y.shape) != tuple(x.shape[:3]) + (cout,) or not y.is_contiguous():
             raise ValueError('outs must be contiguous %s tensors [B,H,W,cout]' % name)
         lv[i].x, lv[i].y, lv[i].H, lv[i].W = x.data_ptr(), y.data_ptr(), int(x.shape[1]), int(x.shape[2])
-        limbs_drop(y)
     wp, extra = L.dptr(w), ()
-    if dtype == torch.float32 and _limb_count():
-        # split-precision forms: the 3x3 layer runs on its input's LIMB PLANES -- the ones the producing layer left, or (a level
-        # nobody split: a pooled map, a caller's own tensor) the stand-alone split's, one pass over the map instead of a split per
-        # tap and channel tile inside the K loop.  inloop=True keeps the float32 input and the in-loop split (same results).
-        xl = [None] * len(xs) if inloop else [limbs_of(x) for x in xs]
-        if not inloop:
-            for i, x in enumerate(xs):
-                if xl[i] is None and x.numel() % 2 == 0:
-                    xl[i] = limbs_of(split_activation(x))
-        if limbs or all(p_ is not None for p_ in xl):
-            # the limb-plane entry point: input planes when EVERY level brings them, output planes on request
-            ll = (L.OdetConvLimbs * len(xs))()
-            yl = [_limbs_new(y) if limbs else None for y in outs]
-            use_in = all(p_ is not None for p_ in xl)
-            for i in range(len(xs)):
-                ll[i].x_limbs = xl[i].data_ptr() if use_in else None
-                ll[i].y_limbs = yl[i].data_ptr() if limbs else None
-            nl, wpl, w_exp = _xl_weight(w, weight)
-            _f32_call('odet_conv3x3_xl_levels', nl, lv, ll, len(xs), wpl, L.dptr(bias) if bias is not None else None, B, cin, cout,
-                      1 if relu else 0, w_exp, *_x3_workspace(w.device).args(), L.stream())
-            if limbs:
-                for y, p_ in zip(outs, yl):
-                    _limbs_tag(y, p_)
-            return outs
     if dtype == torch.float32:
         sym, wp, extra = _f32_sym(sym, w, weight)
     _f32_call(sym + '_levels', lv, len(xs), wp, L.dptr(bias) if bias is not None else None, B, cin, cout,
@@ -950,18 +853,15 @@ def conv3x3_rgb(images_nhwc, packed_weight, bias, relu=True, out=None):
     return out
 
 
-def conv3x3_f32(x, weight, bias=None, relu=False, out=None, limbs=False, inloop=False):
+def conv3x3_f32(x, weight, bias=None, relu=False, out=None):
     """conv3x3_f16 in the reference's precision: float32 operands and result, exact-float32 matrix instructions
-    (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 64 == 0.
-    Split-precision forms (f32_form 'x3' / 'x2'): the layer runs on its input's limb planes -- those its producer left
-    (limbs_of), else a stand-alone split's; ``inloop=True``: on the float32 map with the split inside the K loop (the same
-    limbs, the same results); ``limbs=True`` leaves the RESULT's planes for a 3x3 layer that follows (ignored in 'exact')."""
-    return _conv3x3(torch.float32, x, weight, bias, relu, out, limbs, inloop)
+    (every product and sum rounded to float32 once, as a chain of fmaf).  cin % 32 == 0, cout % 64 == 0."""
+    return _conv3x3(torch.float32, x, weight, bias, relu, out)
 
 
-def conv3x3_f32_levels(xs, weight, bias=None, relu=False, outs=None, limbs=False, inloop=False):
+def conv3x3_f32_levels(xs, weight, bias=None, relu=False, outs=None):
     """conv3x3_f32 with shared weights over a list of NHWC float32 maps in ONE launch."""
-    return _conv3x3_levels(torch.float32, xs, weight, bias, relu, outs, limbs, inloop)
+    return _conv3x3_levels(torch.float32, xs, weight, bias, relu, outs)
 
 
 def conv1x1_f16(x, weight, bias, residual=None, relu=True, out=None, in_bias=None):
@@ -1022,7 +922,7 @@ def _pw_args(x, weight, bias, who, min_k=True):
     return w, cin, cout, sfx
 
 
-def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=None, limbs=False):
+def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=None):
     """A 1x1 convolution (stride 1 or 2, 'valid') or dense layer as the LDS-staged GEMM on the matrix cores
     (odet_pointwise_f16 / odet_pointwise_f32 by the dtype of ``x``): ``x`` [B,H,W,cin] NHWC contiguous, ``weight``
     [cout, cin(, 1, 1)], ``residual`` / ``out`` [B, ceil(H/stride), ceil(W/stride), cout];
@@ -1037,16 +937,6 @@ def pointwise(x, weight, bias=None, residual=None, relu=False, stride=1, out=Non
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    limbs_drop(out)
-    if limbs and sfx == 'f32' and _limb_count():
-        # (split-precision forms) the result ALSO as limb planes for a 3x3 layer that follows
-        nl, wpl, w_exp = _xl_weight(w, weight)
-        yl = _limbs_new(out)
-        _f32_call('odet_pointwise_xl', nl, L.dptr(x), wpl, L.dptr(bias) if bias is not None else None,
-                  L.dptr(residual) if residual is not None else None, L.dptr(out), C.c_void_p(yl.data_ptr()), B, H, W, stride, cin,
-                  cout, 1 if relu else 0, w_exp, *_x3_workspace(w.device).args(), L.stream())
-        _limbs_tag(out, yl)
-        return out
     sym, wp, extra = ('odet_pointwise_' + sfx, L.dptr(w), ()) if sfx != 'f32' else _f32_sym('odet_pointwise_f32', w, weight)
     _f32_call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None,
            L.dptr(residual) if residual is not None else None, L.dptr(out), B, H, W, stride, cin, cout, 1 if relu else 0,
@@ -1063,7 +953,7 @@ def dense(x, weight, bias=None, relu=False, out=None):
     return y.view(x.shape[0], -1)
 
 
-def lateral_merge(x, weight, bias, top, out=None, limbs=False):
+def lateral_merge(x, weight, bias, top, out=None):
     """The FPN neck's lateral 1x1 convolution with the top-down merge in its epilogue (odet_lateral_merge_f16 / _f32;
     resnet_fpn.py:385-398): 0.5 * resize_bilinear(top) + 0.5 * (x . w^T + bias); ``x`` [B,H,W,cin], ``top`` [B,h,w,cout]
     NHWC contiguous, float16 or float32."""
@@ -1077,15 +967,6 @@ def lateral_merge(x, weight, bias, top, out=None, limbs=False):
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
     elif out.dtype != x.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x\'s dtype' % (shape,))
-    limbs_drop(out)
-    if limbs and sfx == 'f32' and _limb_count():
-        nl, wpl, w_exp = _xl_weight(w, weight)
-        yl = _limbs_new(out)
-        _f32_call('odet_lateral_merge_xl', nl, L.dptr(x), wpl, L.dptr(bias) if bias is not None else None, L.dptr(top),
-                  int(top.shape[1]), int(top.shape[2]), L.dptr(out), C.c_void_p(yl.data_ptr()), B, H, W, cin, cout, w_exp,
-                  *_x3_workspace(w.device).args(), L.stream())
-        _limbs_tag(out, yl)
-        return out
     sym, wp, extra = ('odet_lateral_merge_' + sfx, L.dptr(w), ()) if sfx != 'f32' else _f32_sym('odet_lateral_merge_f32', w, weight)
     _f32_call(sym, L.dptr(x), wp, L.dptr(bias) if bias is not None else None, L.dptr(top),
            int(top.shape[1]), int(top.shape[2]), L.dptr(out), B, H, W, cin, cout, *extra, L.stream())
@@ -1120,7 +1001,6 @@ def pointwise_dual(x1, x2, weight, bias=None, stride=1, relu=True, out=None):
         out = torch.empty(shape, dtype=x1.dtype, device=x1.device)
     elif out.dtype != x1.dtype or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError('out must be a contiguous tensor %s of x1\'s dtype' % (shape,))
-    limbs_drop(out)
     sym, wp, extra = ('odet_pointwise_dual_' + sfx, L.dptr(weight), ()) if sfx != 'f32' else _f32_sym('odet_pointwise_dual_f32', weight)
     _f32_call(sym, L.dptr(x1), c1, L.dptr(x2), c2, H, W, stride, wp,
            L.dptr(bias) if bias is not None else None, L.dptr(out), B, cout, 1 if relu else 0, *extra, L.stream())

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Round 6: the split-precision 3x3 layers on their input's LIMB PLANES (csrc/conv_x3.hip PRE: both operands by LDS-DMA, no split
+"""(needs tools/exp/conv_x3_limb_planes.patch applied: measured and NOT adopted, round 6)
+Round 6: the split-precision 3x3 layers on their input's LIMB PLANES (csrc/conv_x3.hip PRE: both operands by LDS-DMA, no split
 in the K loop) against the in-loop split, on the ResNet-101-FPN 3x3 shapes of a `--batch`-image pass; the planes are in place
 before the timed launch (they are the producing layer's by-product) and the stand-alone split is timed beside it.
     python tools/r06/pre_layers.py [--batch 15] [--forms x3,x2] [--out file.json]"""
