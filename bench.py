@@ -319,7 +319,11 @@ def run_detail_child(args, t_main):
     cmd += ['--trace'] if args.trace else []
     env = {k: v for k, v in os.environ.items() if k not in _RENDEZVOUS_ENV}
     t0 = time.perf_counter()
-    proc = subprocess.Popen(cmd, stdout=sys.stderr, stderr=sys.stderr, env=env, start_new_session=True)
+    try:
+        proc = subprocess.Popen(cmd, stdout=sys.stderr, stderr=sys.stderr, env=env, start_new_session=True)
+    except Exception as ex:                               # (a box that refuses the child: the line does not depend on it)
+        return {'error': 'could not start the detail process: %s: %s' % (type(ex).__name__, ex), 'file': None, 'complete': False,
+                'child_rc': None, 'child_s': 0.0, 'legs_done_n': 0}
 
     def on_term(signum, frame):
         raise _Terminated()

@@ -16,18 +16,20 @@ import csv
 import json
 
 
-def mean_counter(path, counter, kernel_substr):
-    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
+def mean_counter(paths, counter, kernel_substr):
+    """(round 6: bench.py runs config 5 in a child process, which the profiler follows: one counter file per process)"""
+    paths = [paths] if isinstance(paths, str) else list(paths)
+    vals = [float(r['Counter_Value']) for path in paths for r in csv.DictReader(open(path))
             if r['Counter_Name'] == counter and kernel_substr in r['Kernel_Name']]
     if not vals:
-        raise SystemExit('no %s rows for %s in %s' % (counter, kernel_substr, path))
+        raise SystemExit('no %s rows for %s in %s' % (counter, kernel_substr, paths))
     return sum(vals) / len(vals), len(vals)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--fetch', required=True)
-    ap.add_argument('--write', required=True)
+    ap.add_argument('--fetch', required=True, nargs='+')
+    ap.add_argument('--write', required=True, nargs='+')
     ap.add_argument('--kernel', default='k_roi_pool')
     ap.add_argument('--workload', required=True)
     ap.add_argument('--images-per-launch', type=int, default=1, help='images sharing one launch in the profiled run (--batch)')
