@@ -327,7 +327,10 @@ def run_detail_child(args, t_main):
 
     def on_term(signum, frame):
         raise _Terminated()
-    old = signal.signal(signal.SIGTERM, on_term)
+    try:
+        old = signal.signal(signal.SIGTERM, on_term)
+    except (ValueError, OSError):                         # (not the main thread)
+        old = False
     try:
         rc = proc.wait(timeout=budget + HARD_LIMIT_EXTRA_S)
     except (subprocess.TimeoutExpired, _Terminated, KeyboardInterrupt) as ex:
@@ -341,7 +344,12 @@ def run_detail_child(args, t_main):
         except Exception:
             pass
     finally:
-        signal.signal(signal.SIGTERM, old)
+        # (a handler installed from C -- a profiler's -- reads back as None: nothing of Python's to restore then)
+        if old is not False:
+            try:
+                signal.signal(signal.SIGTERM, old if old is not None else signal.SIG_DFL)
+            except (TypeError, ValueError, OSError):
+                pass
     detail = {}
     try:
         detail = json.load(open(path))
@@ -966,7 +974,11 @@ def main():
             # ---- everything that is not the headline runs in a FRESH CHILD PROCESS (never an exec of this one, which holds the
             # GPU) under a timeout: a hang or a GPU fault in any of its legs costs that leg, not the line.  Its records go to
             # the side file (and its progress to stderr); this line keeps their headline figures in `summary`.
-            detail = run_detail_child(args, t_main)
+            try:
+                detail = run_detail_child(args, t_main)
+            except Exception as ex:                       # (whatever happens around the child: the line is printed)
+                detail = {'error': '%s: %s' % (type(ex).__name__, ex), 'file': None, 'complete': False, 'child_rc': None,
+                          'child_s': None, 'legs_done_n': 0}
             result['detail'] = {k_: detail.get(k_) for k_ in ('file', 'complete', 'child_rc', 'child_s', 'legs_done_n')}
             summarise_detail(summary, detail)
         mr = result['multi_rank']

@@ -1648,8 +1648,8 @@ def test_two_limb_overflow_that_a_relu_would_hide_still_sets_the_status_word():
 
 @pytest.mark.gpu
 def test_caller_object_on_two_limbs_repeats_an_out_of_range_pass():
-    """the reference-surface models take f32_form = 'x2' (VERDICT r5 #8): call() / im_detect on an image 3000 times brighter than
-    real ones equal the 'x3' model's results bit for bit, the dense part counts the repeated pass"""
+    """the reference-surface models take f32_form = 'x2' (VERDICT r5 #8): call() / im_detect on an image with a patch of pixels
+    beyond float16's range equal the 'x3' model's results bit for bit, the dense part counts the repeated pass"""
     from tf_eager_object_detection_amd.model.base_fpn_model import ResnetV1Fpn
     torch.manual_seed(3)
     kw = dict(depth=50, rpn_proposal_num_post_nms_test=64, prediction_score_threshold=0.0)
@@ -1660,7 +1660,8 @@ def test_caller_object_on_two_limbs_repeats_an_out_of_range_pass():
     img = torch.from_numpy((rng.uniform(0, 255, (1, 192, 256, 3)) - 110).astype(np.float32)).cuda()
     b(img, training=False)
     assert b._dense_ref.range_reruns == 0
-    big = img * 3000.0
+    big = img.clone()
+    big[0, 50:54, 60:64, :] = 70000.0                    # (a few inputs beyond 65504: everything else stays an ordinary image)
     oa, ob = a(big, training=False), b(big, training=False)
     assert b._dense_ref.range_reruns == 1 and b._dense_ref.f32_form == 'x2'
     for u, v in zip(oa, ob):
