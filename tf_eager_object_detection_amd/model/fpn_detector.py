@@ -490,9 +490,20 @@ class _NmsCompleteness:
 
     def run_range_checked(self, fn):
         """fn() -> result on this instance's float32 form; a two-limb pass that reported an out-of-range activation is repeated
-        on three limbs (`range_reruns`).  For composed passes (im_detect, the caller objects' call)."""
-        out = fn()
-        if getattr(self, 'f32_form', 'exact') == 'x2' and not self.range_ok():
+        on three limbs (`range_reruns`).  For composed passes (im_detect, the caller objects' call).  A composed pass may also
+        FAIL on the non-finite maps of such a pass (no proposal survives, the reference's own torch.cat / tf.concat of an empty
+        list raises): the error is the range's if the status word is set -- then the pass is repeated, else it is the caller's."""
+        if getattr(self, 'f32_form', 'exact') != 'x2':
+            return fn()
+        self.range_ok()                                    # (a word left set by an earlier, unchecked pass is not this pass's)
+        try:
+            out = fn()
+            bad = not self.range_ok()
+        except Exception:
+            if self.range_ok():
+                raise
+            bad = True
+        if bad:
             self.range_reruns += 1
             self.f32_form = 'x3'
             try:

@@ -75,18 +75,21 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_f16_v2(V2Params p) {
   }
   const int chunks = cin / V2_BK;
   const int ksteps = 9 * chunks;
+  // copy j (0..7) of a wave's 8 per K-step: 0..3 its pixel pieces, 4..7 its weight pieces
+  auto issue_piece = [&](int ks, uint32_t stage, int j) {
+    if (j < 4) {
+      const int tap = ks / chunks, chunk = ks - tap * chunks;
+      const uint32_t soX = (uint32_t)((tap / 3) * W + tap % 3) * pixB + (uint32_t)chunk * 64u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(lds + stage + (uint32_t)(wv + 4 * j) * 1024u), 16,
+                                               (int)(((maskX[j] >> tap) & 1u) ? voffX[j] : OOB), (int)soX, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + stage + (uint32_t)V2_TM * 64u + (uint32_t)(wv + 4 * (j - 4)) * 1024u), 16,
+                                               (int)voffW[j - 4], (int)((uint32_t)ks * 64u), 0, 0);
+    }
+  };
   auto issue = [&](int ks, uint32_t stage) {
-    const int tap = ks / chunks, chunk = ks - tap * chunks;
-    const uint32_t soX = (uint32_t)((tap / 3) * W + tap % 3) * pixB + (uint32_t)chunk * 64u;
-    const uint32_t soW = (uint32_t)ks * 64u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(lds + stage + (uint32_t)(wv + 4 * i) * 1024u), 16,
-                                               (int)(((maskX[i] >> tap) & 1u) ? voffX[i] : OOB), (int)soX, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(lds + stage + (uint32_t)V2_TM * 64u + (uint32_t)(wv + 4 * i) * 1024u), 16,
-                                               (int)voffW[i], (int)soW, 0, 0);
+    for (int j = 0; j < 8; ++j) issue_piece(ks, stage, j);
   };
   // ---- fragments
   const int l15 = lane & 15, lq = lane >> 4;
@@ -120,11 +123,26 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_f16_v2(V2Params p) {
   // step ks + 3 go into buffer (ks + 3) % 4 = (ks - 1) % 4, whose fragments were read during step ks - 2.
   auto step = [&](int ks, uint32_t sn, h8 (&wc)[8], h8 (&wn_)[8]) {
     const unsigned char* nb = lds + sn * (uint32_t)V2_STAGE;                    // stage of step ks + 1
+#ifdef V2_DIAG_NOREAD
+    const bool more = false;
+#else
     const bool more = ks + 1 < ksteps;
+#endif
+#ifdef V2_DIAG_NODMA
+    const bool dma = false;
+#else
     const bool dma = ks + 3 < ksteps;
+#endif
+#ifdef V2_BURST
     if (dma) issue(ks + 3, ((sn + 2u) & 3u) * (uint32_t)V2_STAGE);
+#endif
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
+#ifndef V2_BURST
+      // one copy behind every pixel tile's MFMAs: a wave never queues more than one 1-KB piece at the texture path at a time
+      // (all 8 at the top of the step stalled the wave's issue -- and with one wave per SIMD the matrix pipe -- behind them)
+      if (dma) issue_piece(ks + 3, ((sn + 2u) & 3u) * (uint32_t)V2_STAGE, mt);
+#endif
 #pragma unroll
       for (int t = 0; t < 8; ++t)      // accumulators pinned to the accumulator file ("a"): the compiler's own MFMA form keeps them in
                                         // VGPRs and shuttles them to AGPRs and back inside the loop once there are 256 of them
@@ -135,8 +153,14 @@ __global__ void __launch_bounds__(256, 1) k_conv3x3_f16_v2(V2Params p) {
       }
     }
     // stage ks + 2 landed (the copies of ks + 3, issued at the top of this step, may stay in flight)
+#if defined(V2_DIAG_NOBAR)
+    if (dma) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#elif defined(V2_DIAG_NOSYNC)
+#else
     if (dma) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
   };
   int ks = 0;
   uint32_t sn = 1u;                                                              // (ks + 1) % 4
