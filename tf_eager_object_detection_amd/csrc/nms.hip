@@ -542,6 +542,11 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const u64 mine = (i < cnt) ? cand[i] : ~0ull;
+  // the candidate's box does not depend on its rank: wave 0 requests its deltas NOW (decode + clip: a dependent global round trip
+  // and a float64 exp pair) so that they travel while all 16 waves count, instead of after the count (round 6: the latency
+  // arrangement's chain is one round trip shorter)
+  float4 bx = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (w == 0 && i < cnt) bx = d_candidate_box(prep, mode, blockIdx.y, (int)(uint32_t)mine);
   int c = 0;
   for (int t0 = 0; t0 < cnt; t0 += NMS_CHUNK) {          // the pair list goes through LDS a tile at a time
     const int tc = min(NMS_CHUNK, cnt - t0);
@@ -562,7 +567,6 @@ __global__ void __launch_bounds__(RANK_THREADS) k_sel_rank(PerImg<NmsHeader*> hd
     sel_idx[r] = idx;
     // invalid scores (key 0xFFFFFFFF) sort last; rows >= chunk_m are never read
     if (r < cap0) {
-      const float4 bx = d_candidate_box(prep, mode, blockIdx.y, (int)idx);
       sboxes[r] = d_norm_box(bx);
       sorig[r] = bx;
     }
