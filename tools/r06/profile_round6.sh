@@ -24,9 +24,11 @@ python3 tools/pmc_traffic.py --fetch $out/pmc_fetch/*/*_counter_collection.csv -
 # 5. the accuracy gates at full size (4096 / 6144 / 8192 scenes; the default run cuts them to its time budget)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --time-budget 900 --detail-out $out/bench_detail_full_gates.json > $out/bench_full_gates.json 2> $out/bench_full_gates.err
 # only the summaries travel back
-for d in stats_driver stats_s1b1; do
-  i=0; for f in $(find $out/$d -name "*_kernel_stats.csv" | sort); do cp "$f" $out/kernel_stats_${d#stats_}_$i.csv; i=$((i+1)); done
+# (the driver's command: one stats file per process -- the parent's holds the isolated RoI launches k_roi_pool<1, 1, float, 1>)
+for f in $(find $out/stats_driver -name "*_kernel_stats.csv" | sort); do
+  if grep -q "k_roi_pool<1, 1, float, 1>" "$f"; then cp "$f" $out/kernel_stats_driver_cmd.csv; else cp "$f" $out/kernel_stats_driver_cmd_child.csv; fi
 done
+for f in $(find $out/stats_s1b1 -name "*_kernel_stats.csv" | sort | head -1); do cp "$f" $out/kernel_stats_streams1_batch1.csv; done
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*_agent_info.csv" -delete; find $out -name "*_counter_collection.csv" -delete
 ls -la $out | head -40
 cut -c1-400 $out/bench_driver_cmd.json; echo; tail -c 1200 $out/bench_full_gates.json
