@@ -450,6 +450,8 @@ class _NmsCompleteness:
         """image b of the last pass again from the RPN head's outputs: exact proposals -> RoI features -> RoI head ->
         post-ops, into the buffers the pass handed out"""
         rpn_scores, rpn_deltas, maps, heads = self._last_pass
+        if maps is None:
+            raise RuntimeError('image %d flagged incomplete after its pass was checked and its maps released' % b)
         hot = self._hot[b]
         hot.stage_proposals(rpn_scores[b], rpn_deltas[b], exact=True)
         feats = hot.stage_roi(self._maps_of(maps, b))
@@ -472,6 +474,11 @@ class _NmsCompleteness:
             if getattr(self, 'f32_form', 'exact') == 'x2' and not self.range_ok(batch):
                 return False
             self.recover(batch)
+            # every image of the pass is complete: nothing is left to re-run, so the pass's pyramid (P2..P5: ~90 MB per image)
+            # is released here instead of staying pinned until the next pass ends; the RPN outputs and the heads' outputs stay
+            lp = self._last_pass
+            if lp is not None:
+                self._last_pass = (lp[0], lp[1], None, lp[3])
         return True
 
     # ---- the two-limb float32 form's RANGE (f32_form = 'x2': float16 limbs).  An activation beyond float16's range becomes an
