@@ -214,6 +214,33 @@ def test_nms_index_exact(n, k, thr, kind):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize('n,step,k', [(40, 1, 40), (200, 1, 200), (1500, 1, 1000), (1500, 1, 333), (1400, 7, 1000), (1536, 3, 100), (3000, 1, 2000)])
+def test_nms_chains_parallel_iteration_and_serial_walk(n, step, k):
+    """Round 6: the first chunk's greedy NMS runs as a parallel fixed-point iteration (k_nms_scan<true>) that settles a candidate
+    after depth + 1 rounds, depth = the longest chain of overlapping candidates in score order ending in it; a list that has not
+    settled after SCAN_FP_ROUNDS rounds is walked serially.  LADDERS make the depth what the test wants: box i overlaps box
+    i +- 1 (IoU 0.74 > 0.7) and nothing else (IoU 0.54 with i +- 2), so greedy NMS keeps every other box of a ladder and the
+    decision about its j-th box hangs on all j - 1 before it.  `step` ladders of n / step boxes interleaved in score order: depth
+    n / step -- a handful (the iteration settles), 200 .. 1500 (it gives up and the serial walk decides); K cuts inside a 64-block;
+    n > 1536 continues in further chunks.  Kept indices exact against the oracle in every case."""
+    rng = np.random.default_rng(n * 31 + step)
+    w_, h_ = np.float32(100.0), np.float32(60.0)
+    boxes = np.zeros((n, 4), np.float32)
+    for i in range(n):
+        lad, j = i % step, i // step
+        x0 = np.float32(15.0 * j)                             # shift 0.15 w: IoU(i, i + 1) = 0.85 / 1.15, IoU(i, i + 2) = 0.7 / 1.3
+        y0 = np.float32(200.0 * lad)                          # ladders far apart
+        boxes[i] = [x0, y0, x0 + w_, y0 + h_]
+    scores = np.linspace(0.99, 0.01, n).astype(np.float32)    # score order = index order
+    perm = rng.permutation(n)                                 # memory order is not score order
+    boxes, scores = boxes[perm], scores[perm]
+    want, _ = co.nms(boxes, scores, k, 0.7, True)
+    got = _nms_gpu(boxes, scores, k, 0.7)
+    np.testing.assert_array_equal(got, want)
+    # (greedy keeps every other box of each ladder until K are kept)
+    assert len(want) == min(k, sum((n - lad + step - 1) // step // 2 + ((n - lad + step - 1) // step) % 2 for lad in range(step)))
+
+
 def test_nms_dense_suppression_many_chunks():
     # nearly identical boxes: almost everything is suppressed, the scan has to walk many 4096-chunks
     rng = np.random.default_rng(5)

@@ -21,6 +21,11 @@ P="--no-cpu-baseline --no-e2e --no-config5 --no-second-distribution --streams 1 
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py $P > $out/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 bench.py $P > $out/pmc_write.log 2>&1
 python3 tools/pmc_traffic.py --fetch $out/pmc_fetch/*/*_counter_collection.csv --write $out/pmc_write/*/*_counter_collection.csv --kernel "k_roi_pool<1, 1, float" --workload fpn_hot_path_800x1333_r101fpn_distinct --images-per-launch 8 --out $out/roi_pool_traffic.json > /dev/null
+# 4b. the same for config 5's float16 launch: the detail process alone (it IS bench.py's config-5 code), no e2e legs
+C5="--detail-child /tmp/r06_c5_detail.json --no-e2e --time-budget 120 --streams 1 --batch 8 --rounds-per-step 4 --steps 8 --warmup 2"
+timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch_c5 --output-format csv -- python3 bench.py $C5 > $out/pmc_fetch_c5.log 2>&1
+timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write_c5 --output-format csv -- python3 bench.py $C5 > $out/pmc_write_c5.log 2>&1
+python3 tools/pmc_traffic.py --fetch $out/pmc_fetch_c5/*/*_counter_collection.csv --write $out/pmc_write_c5/*/*_counter_collection.csv --kernel "k_roi_pool<1, 1, __half" --workload fpn_hot_path_1333x1333_r101fpn_81cls_f16maps --images-per-launch 8 --out $out/roi_pool_traffic_config5.json > /dev/null
 # 5. the accuracy gates at full size (4096 / 6144 / 8192 scenes; the default run cuts them to its time budget)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --time-budget 900 --detail-out $out/bench_detail_full_gates.json > $out/bench_full_gates.json 2> $out/bench_full_gates.err
 # only the summaries travel back
