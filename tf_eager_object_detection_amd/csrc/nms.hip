@@ -668,10 +668,9 @@ __global__ void __launch_bounds__(256) k_nms_mask(PerImg<const NmsState*> st_, P
     const u64 word = (u64)part[0][lane] | ((u64)part[1][lane] << 16) | ((u64)part[2][lane] << 32) |
                      ((u64)part[3][lane] << 48);
     if (cb == rb) {
-      // diagonal tile, row-wise, the WHOLE word: bits j > lane = later candidates this row suppresses when kept (the serial walk's
-      // view), bits j < lane = earlier candidates of the block that suppress this row (the parallel iteration's); bit lane is
-      // the row against itself.  k_nms_scan masks what it needs.
-      diag_up[row] = word;
+      // diagonal tile, row-wise: later candidates (bit j > lane) this row suppresses when kept
+      const u64 later = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+      diag_up[row] = word & later;
     } else {
       // earlier candidates of block cb that suppress `row`; packed = the LDS image of k_nms_scan<true>
       if (packed) Lt[SCAN_MAT_OFF(cb, (m + 63) >> 6) + row - (cb + 1) * 64] = word;
@@ -695,9 +694,6 @@ struct AssignOut {      // optional fused _assign_levels (base_fpn_model.py:303-
 #define SCAN_Q 8      // candidates per thread: wave w owns candidates [512w, 512w+512) = blocks 8w..8w+7
 #define SCAN_RING 4   // <false> path: column words of this many blocks are in flight per wave (registers)
 #define SCAN_STAGE_ITEMS ((SCAN_LDS_WORDS / 2 + SCAN_THREADS - 1) / SCAN_THREADS)   // 16-B units per thread
-#ifndef SCAN_FP_ROUNDS
-#define SCAN_FP_ROUNDS 24      // rounds of the parallel iteration before the chunk is walked serially (k_nms_scan<true>)
-#endif
 
 __device__ __forceinline__ u64 rfl64(u64 v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -836,7 +832,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     u64 sm = __ballot(j >= m);
     if (use_init && b_own + q < nblk) sm |= removed_init[b_own + q];
     supm[q] = sm;
-    dg[q] = (j < m) ? (diag_up[j] & ((lane == 63) ? 0ull : (~0ull << (lane + 1)))) : 0ull;
+    dg[q] = (j < m) ? diag_up[j] : 0ull;
   }
   if (threadIdx.x < NMS_WORDS) { keepw[threadIdx.x] = 0ull; nkeptw[threadIdx.x] = -1; }
   int nk = nk0;
@@ -874,83 +870,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
       }
     }
     __syncthreads();
-    // ---- (round 6) the chunk's greedy NMS as a PARALLEL fixed-point iteration before the serial walk is tried.  The greedy
-    // result is the unique solution of  kept[j] = present[j] and no earlier i with kept[i] and S[i][j]  (a candidate's decision
-    // depends on earlier candidates only), and iterating that equation from ANY start settles candidate j after at most
-    // depth(j) + 1 rounds (depth = the longest chain of overlapping candidates in score order that ends in j): every round all
-    // candidates re-evaluate themselves against the kept words of the previous round -- 24 words of the LDS-resident matrix per
-    // candidate at most -- instead of 24 blocks resolving one after the other (0.8 us each, whatever the boxes).  Proposal lists
-    // settle in a handful of rounds; a list that has not settled after SCAN_FP_ROUNDS (a long chain: adversarial) is walked
-    // serially below, from scratch.  Identical kept bits either way: the truncation at K survivors is applied to the settled
-    // words in order.
-    bool settled = false;
-    if (nblk >= 2) {
-      __shared__ u64 fpw[2][SCAN_LDS_BLOCKS];                  // kept words, ping-pong
-      __shared__ int fp_changed[2];
-      // thread t: candidates t + 512 r (r < 3) = lane (t & 63) of blocks (t >> 6) + 8 r
-      constexpr int FPQ = SCAN_LDS_CAND / SCAN_THREADS;
-      static_assert(FPQ * SCAN_THREADS == SCAN_LDS_CAND && SCAN_WAVES * FPQ == SCAN_LDS_BLOCKS, "iteration ownership");
-      u64 fe[FPQ];                                             // earlier candidates of my block that suppress me
-      bool fpres[FPQ];
-#pragma unroll
-      for (int r = 0; r < FPQ; ++r) {
-        const int c = threadIdx.x + SCAN_THREADS * r, b = w + SCAN_WAVES * r;
-        bool pres = c < m;
-        if (use_init && b < nblk) pres = pres && !((removed_init[b] >> lane) & 1ull);
-        fpres[r] = pres;
-        fe[r] = (c < m) ? (diag_up[c] & lt_lane) : 0ull;
-        const u64 w0 = __ballot(pres);
-        if (lane == 0 && b < SCAN_LDS_BLOCKS) fpw[0][b] = w0;
-      }
-      if (threadIdx.x < 2) fp_changed[threadIdx.x] = 0;
-      __syncthreads();
-      int cur = 0;
-      for (int round = 0; round < SCAN_FP_ROUNDS; ++round) {
-        bool changed = false;
-#pragma unroll
-        for (int r = 0; r < FPQ; ++r) {
-          const int c = threadIdx.x + SCAN_THREADS * r, b = w + SCAN_WAVES * r;
-          if (b < nblk) {                                      // (wave-uniform)
-            bool sup = (fe[r] & fpw[cur][b]) != 0ull;
-            const u64* col = mat + (c - 64);                   // + SCAN_MAT_OFF(bb, nblk) - 64 bb: the word (block bb -> candidate c)
-            for (int bb = 0; bb < b; ++bb) sup = sup || ((col[SCAN_MAT_OFF(bb, nblk) - 64 * bb] & fpw[cur][bb]) != 0ull);
-            const u64 nw = __ballot(fpres[r] && !sup);
-            if (lane == 0) fpw[cur ^ 1][b] = nw;
-            changed = changed || (nw != fpw[cur][b]);
-          }
-        }
-        if (changed && lane == 0) fp_changed[cur] = 1;         // (any wave; same value)
-        __syncthreads();
-        const int ch = fp_changed[cur];
-        cur ^= 1;
-        if (threadIdx.x == 0) fp_changed[cur] = 0;             // (the flag of the NEXT round but one: nobody reads it before the next barrier)
-        if (!ch) { settled = true; break; }
-        __syncthreads();
-      }
-      if (settled) {
-        // the settled words in order, truncated at K survivors: what the serial walk would have published
-        if (w == 0) {
-          const u64 kwd = (lane < nblk) ? fpw[cur][lane] : 0ull;
-          const int pc = (int)__popcll(kwd);
-          const int inc = wave_incl_scan(pc);
-          const int before = nk0 + inc - pc;                   // kept before this block
-          u64 outw = 0ull;
-          if (before < K) {
-            outw = kwd;
-            if (before + pc > K) {                             // the block in which K is reached: its first K - before survivors
-              int room = K - before;
-              u64 rest = kwd;
-              outw = 0ull;
-              while (room > 0) { const u64 low = rest & (~rest + 1ull); outw |= low; rest ^= low; --room; }
-            }
-          }
-          keepw[lane] = outw;
-        }
-        stop = true;                                           // (skips the serial walk below)
-      }
-      __syncthreads();
-    }
-    if (!settled && b_own < nblk) {
+    if (b_own < nblk) {
       for (int b = 0; b < b_own; ++b) {
         if (stop) break;
         // words of (source block b -> own blocks); reads past nblk hit the slack, their masks are unused
