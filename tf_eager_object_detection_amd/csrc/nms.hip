@@ -821,6 +821,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
   const int b_own = SCAN_Q * w;               // first block of this wave
   const int jbase = w * (64 * SCAN_Q) + lane; // candidate of (q, lane) = jbase + 64 q
   const u64 lt_lane = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // Who writes which candidate's outputs.  The walk needs a wave to own 8 CONSECUTIVE blocks; the output tail does not, and with
+  // the LDS-resident chunk (<= 1536 candidates = the first three waves' blocks) that ownership left five of the eight waves idle
+  // through the tail (round 6: outputs 5.6 us, level assignment + order 4.5 us of an 18 us launch).  LDSMAT: thread t writes
+  // candidates t + 512 q (q < 3) = lane t & 63 of blocks (t >> 6) + 8 q -- every wave, a third of the work each.
+  constexpr int TQ = LDSMAT ? SCAN_LDS_CAND / SCAN_THREADS : SCAN_Q;
+  static_assert(!LDSMAT || TQ * SCAN_THREADS == SCAN_LDS_CAND, "tail ownership covers the LDS-resident chunk");
+  auto tblk = [&](int q) { return LDSMAT ? w + SCAN_WAVES * q : b_own + q; };
+  auto tcand = [&](int q) { return LDSMAT ? (int)threadIdx.x + SCAN_THREADS * q : jbase + 64 * q; };
 
   u64 supm[SCAN_Q];                           // wave-uniform: candidates of own block q suppressed / absent
   u64 dg[SCAN_Q];
@@ -835,6 +843,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     dg[q] = (j < m) ? diag_up[j] : 0ull;
   }
   if (threadIdx.x < NMS_WORDS) { keepw[threadIdx.x] = 0ull; nkeptw[threadIdx.x] = -1; }
+  // (the tail's level counts: every (level, block) entry is read by the partition's scan, the LDS-resident chunk writes 24 blocks)
+  static_assert(ODET_MAX_LEVELS * NMS_WORDS == SCAN_THREADS, "one level-count entry per thread");
+  (&lvl_cnt[0][0])[threadIdx.x] = 0;
   int nk = nk0;
   bool stop = false;
 
@@ -847,8 +858,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
   if (LDSMAT) {
     // output rows, fetched now (independent of every decision) and written after the walk
 #pragma unroll
-    for (int q = 0; q < SCAN_Q; ++q) {
-      const int j = jbase + 64 * q;
+    for (int q = 0; q < TQ; ++q) {
+      const int j = tcand(q);
       oidx[q] = (j < m) ? sorted_idx[pos0 + j] : 0u;
       obox[q] = (j < m) ? sorig[j] : make_float4(0, 0, 0, 0);
     }
@@ -967,23 +978,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
   const bool want_assign = ao.rois && done && out_boxes;
   const bool fused_lv = want_assign && nk0 == 0;
   const int nl = ao.max_level - ao.min_level + 1;
-  // every block of the chunk is covered: wave w handles blocks 8w..8w+7 (rows past m are not kept)
+  // every block of the chunk is covered by the tail's ownership (rows past m are not kept)
   int myp[SCAN_Q], mylv[SCAN_Q], myrank[SCAN_Q];
   bool iskept[SCAN_Q];
 #pragma unroll
-  for (int q = 0; q < SCAN_Q; ++q) {
-    const int c = jbase + 64 * q;
-    const u64 kbits = keepw[b_own + q];
+  for (int q = 0; q < TQ; ++q) {
+    const int c = tcand(q);
+    const u64 kbits = keepw[tblk(q)];
     iskept[q] = (c < m) && ((kbits >> lane) & 1ull);
-    myp[q] = iskept[q] ? keptpre[b_own + q] + (int)__popcll(kbits & lt_lane) : -1;
+    myp[q] = iskept[q] ? keptpre[tblk(q)] + (int)__popcll(kbits & lt_lane) : -1;
     if (!LDSMAT) {
       oidx[q] = iskept[q] ? sorted_idx[pos0 + c] : 0u;
       obox[q] = iskept[q] ? sorig[c] : make_float4(0, 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int q = 0; q < SCAN_Q; ++q) {
-    const int c = jbase + 64 * q;
+  for (int q = 0; q < TQ; ++q) {
     mylv[q] = -1;
     myrank[q] = 0;
     if (iskept[q]) {
@@ -999,7 +1009,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
         if (L < nl) {
           const u64 bal = __ballot(mylv[q] == L);
           if (mylv[q] == L) myrank[q] = (int)__popcll(bal & lt_lane);
-          if (lane == 0) lvl_cnt[L][b_own + q] = (int)__popcll(bal);
+          if (lane == 0) lvl_cnt[L][tblk(q)] = (int)__popcll(bal);
         }
       }
     }
@@ -1028,14 +1038,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < SCAN_Q; ++q) {
+    for (int q = 0; q < TQ; ++q) {
       if (mylv[q] >= 0) {
         int base = 0;
         for (int L = 0; L < mylv[q]; ++L) base += lvl_tot[L];
-        const int pos = base + lvl_cnt[mylv[q]][b_own + q] + myrank[q];
+        const int pos = base + lvl_cnt[mylv[q]][tblk(q)] + myrank[q];
         ao.rois[pos] = obox[q];
         ao.level[pos] = mylv[q];
         ao.perm[pos] = myp[q];
+        myrank[q] = pos;                       // (from here on: the RoI's row in the assigned list, for the order below)
       }
     }
   } else if (want_assign) {
@@ -1054,7 +1065,41 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_nms_scan(ScanParams sp) {
   // Without an assignment (job not finished yet / reported empty) the order is the identity, so that the RoI kernel
   // visits -- and zero-fills -- every row.
   int32_t* __restrict__ order = sp.as_order.v[img];
-  if (order) {
+  if (order && fused_lv) {
+    // (round 6) the common case -- one chunk finished the job: every kept candidate still holds its box, its level and its row
+    // of the assigned list in registers, so the counting sort runs on those instead of re-reading ao.rois / ao.level from
+    // memory behind the stores above (a store -> load round trip through L2 in the middle of a one-workgroup launch)
+    __syncthreads();                               // (lvl_cnt / lvl_tot were read above; they become the buckets now)
+    const int tid = threadIdx.x;
+    int* ocnt = &lvl_cnt[0][0];                    // [256]
+    int* obase = ocnt + 256;                       // [256]
+    for (int i = tid; i < 256; i += SCAN_THREADS) ocnt[i] = 0;
+    __syncthreads();
+    int bktq[SCAN_Q], slotq[SCAN_Q];
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      bktq[q] = -1;
+      if (mylv[q] >= 0) {
+        const float4 bx = obox[q];
+        const int l = min(max(mylv[q], 0), 7);
+        const int qy = min(max((int)((bx.y + bx.w) * 0.5f * sp.ord_inv_h * 4096.0f), 0), 4095);
+        bktq[q] = l * 32 + (qy >> 7);
+        slotq[q] = atomicAdd(&ocnt[bktq[q]], 1);
+      }
+    }
+    for (int r = nkf + tid; r < K; r += SCAN_THREADS) order[r] = r;     // padded rows stay behind the valid ones
+    __syncthreads();
+    {
+      int total;
+      const int v = (tid < 256) ? ocnt[tid] : 0;
+      const int ex = block_excl_scan(v, keptpre, &total);
+      if (tid < 256) obase[tid] = ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TQ; ++q)
+      if (bktq[q] >= 0) order[obase[bktq[q]] + slotq[q]] = myrank[q];
+  } else if (order) {
     __threadfence_block();
     __syncthreads();
     const int tid = threadIdx.x;
