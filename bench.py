@@ -966,9 +966,13 @@ def main():
                    'roi_kernel_us': round(result['roofline']['kernel_ms'] * 1e3, 1),
                    'roi_vs_calibration': round(result['roofline']['calibration']['roi_kernel_vs_calibration'], 3)}
         if not args.no_cpu_baseline and world == 1:
-            result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
-            cb = result['cpu_baseline']
-            summary['cpu_port_img_s'] = [round(cb['value'], 1), cb['cores']]
+            try:
+                result['cpu_baseline'] = cpu_baseline(host, IMAGE_SHAPE)
+                cb = result['cpu_baseline']
+                summary['cpu_port_img_s'] = [round(cb['value'], 1), cb['cores']]
+            except Exception as ex:                       # (the headline does not depend on the host leg)
+                result['cpu_baseline'] = {'error': '%s: %s' % (type(ex).__name__, ex), 'kind': 'port', 'value': None, 'unit': 'img/s',
+                                          'cores': None, 'sample': None}
             mark('cpu baseline done')
         if world == 1 and not (args.no_e2e and args.no_config5):
             # ---- everything that is not the headline runs in a FRESH CHILD PROCESS (never an exec of this one, which holds the
@@ -980,7 +984,10 @@ def main():
                 detail = {'error': '%s: %s' % (type(ex).__name__, ex), 'file': None, 'complete': False, 'child_rc': None,
                           'child_s': None, 'legs_done_n': 0}
             result['detail'] = {k_: detail.get(k_) for k_ in ('file', 'complete', 'child_rc', 'child_s', 'legs_done_n')}
-            summarise_detail(summary, detail)
+            try:
+                summarise_detail(summary, detail)
+            except Exception as ex:
+                summary['detail'] = 'summary failed: %s: %s' % (type(ex).__name__, ex)
         mr = result['multi_rank']
         summary['ranks'] = [mr['rccl_world'], round(mr['per_rank_img_s_min'], 1), round(mr['per_rank_img_s_max'], 1), mr['allgathers_in_timed_region']]
         summary['run_s'] = round(time.perf_counter() - t_main, 1)
